@@ -1,0 +1,195 @@
+"""Pins the CPU oracle (oracle/) to every golden vector / known-answer test the reference holds
+for the hot path.  CPU only.  Citations relative to /root/reference/."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _rust_exp(v):
+    """format like Rust's {:.2e} (no zero padding / sign in the exponent)"""
+    s = "%.2e" % v
+    mant, ex = s.split("e")
+    return "%se%d" % (mant, int(ex))
+
+
+def test_log_qemu_golden_trace():
+    # examples/nostd_cortex-m/log_qemu.txt:1-26 -- every logged residual triple, the iteration
+    # count and the solution to all 16 printed digits
+    g = json.load(open(os.path.join(HERE, "golden", "log_qemu.json")))
+    pb = g["problem"]
+    assert O.lib().oc_query_worklen(3, 2) == g["query_worklen"] == 48
+    par = O.param(max_iter=pb["max_iter"], log_period=pb["log_period"])
+    r = O.solve_matop_cones(par, pb["vec_c"], pb["mat_a_colmajor"], pb["vec_b"], [O.CONE_RPOS], [pb["m"]],
+                            trace_cap=4096)
+    assert r.status == O.OK
+    assert r.iters == g["trace"][-1]["iter"] == 159
+    by_iter = {t[0]: t for t in r.trace}
+    for rec in g["trace"]:
+        t = by_iter[rec["iter"]]
+        assert t[1] == 0
+        assert [_rust_exp(v) for v in t[2:5]] == rec["text"], rec
+    assert [repr(float(v)) for v in r.x] == g["x_text"]
+
+
+def test_core_solver_psd_kat():
+    # totsu_core/tests/solver.rs:14-53 (and totsu_f64lapack/tests/solver.rs:17-55 for the QL flavour)
+    for use_ql in (False, True):
+        par = O.param(max_iter=100000)
+        r = O.solve_matop_cones(par, [1.0], [0.0, -1.0 * 1.41421356, -3.0], [1.0, 0.0 * 1.41421356, 10.0],
+                                [O.CONE_PSD], [3], use_ql=use_ql)
+        assert r.status == O.OK
+        assert abs(r.x[0] - (-2.0)) <= 1e-3
+
+
+def test_lp1_infeasible():
+    # totsu/tests/lp.rs:13-45
+    par = O.param(max_iter=100000)
+    r = O.solve_lp(par, [1.0], np.array([[1.0], [-1.0]]), [-5.0, -10.0], np.zeros((0, 1)), [])
+    assert r.status == O.INFEASIBLE
+
+
+def test_lp2_unbounded():
+    # totsu/tests/lp.rs:50-82
+    par = O.param(max_iter=100000)
+    r = O.solve_lp(par, [1.0], np.array([[1.0], [1.0]]), [5.0, 10.0], np.zeros((0, 1)), [])
+    assert r.status == O.UNBOUNDED
+
+
+def test_socp1():
+    # totsu/tests/socp.rs:14-46 (default params: max_iter None)
+    par = O.param()
+    G = np.eye(2)
+    r = O.solve_socp(par, [1.0, 1.0], [G], [[0.0, 0.0]], [[0.0, 0.0]], [np.sqrt(2.0)], np.zeros((0, 2)), [])
+    assert r.status == O.OK
+    assert np.allclose(r.x, [-1.0, -1.0], atol=1e-3)
+
+
+def test_socp2_zero_row_cone():
+    # totsu/tests/socp.rs:52-93 -- includes a General(0, n) block
+    par = O.param(max_iter=100000)
+    r = O.solve_socp(par, [0.0, 1.0],
+                     [np.zeros((0, 2)), np.array([[-1.0, 0.0]])],
+                     [[], [2.0]],
+                     [[0.0, -1.0], [0.0, 1.0]],
+                     [50.0, 0.0], np.zeros((0, 2)), [])
+    assert r.status == O.OK
+    assert np.allclose(r.x, [2.0, 0.0], atol=1e-3)
+
+
+def test_sdp1():
+    # totsu/tests/sdp.rs:14-50 ; SymPack set_iter_rowmaj of a symmetric 2x2 -> packed [a00, a01, a11]
+    for use_ql in (False, True):
+        par = O.param(max_iter=100000)
+        syms = [[-1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [3.0, 0.0, 4.0]]
+        r = O.solve_sdp(par, [1.0, 1.0], syms, np.zeros((0, 2)), [], par.eps_zero, use_ql=use_ql)
+        assert r.status == O.OK
+        assert np.allclose(r.x, [3.0, 4.0], atol=1e-3)
+
+
+def test_cone_psd_unit_kat():
+    # totsu_core/src/cone_psd.rs:90-110
+    for use_ql in (False, True):
+        x = O.proj(O.CONE_PSD, [5.0, 0.0, -5.0], eps_zero=1e-12, use_ql=use_ql)
+        assert np.allclose(x, [5.0, 0.0, 0.0], atol=1e-6)
+
+
+def test_matop_sympack_kat():
+    # totsu_core/src/matop.rs:180-212
+    array = [1., 2., 3., 4., 5., 6., 7., 8., 9., 10., 11., 12., 13., 14., 15.]
+    ref = np.array([[1., 2., 4., 7., 11.], [2., 3., 5., 8., 12.], [4., 5., 6., 9., 13.],
+                    [7., 8., 9., 10., 14.], [11., 12., 13., 14., 15.]])
+    for i in range(5):
+        x = np.zeros(5)
+        x[i] = 1.0
+        y = O.transform_sp(5, 1.0, array, x, 0.0, np.zeros(5))
+        assert np.allclose(y, ref[i], atol=1e-3)
+
+
+def test_vec_to_mat_kat():
+    # totsu_f64lapack/src/f64lapack.rs:262-287
+    ref_v = np.array([1. * 0.7, 2., 3. * 0.7, 4., 5., 6. * 0.7, 7., 8., 9., 10. * 0.7,
+                      11., 12., 13., 14., 15. * 0.7])
+    ref_m = np.array([1., 0, 0, 0, 0, 2., 3., 0, 0, 0, 4., 5., 6., 0, 0, 7., 8., 9., 10., 0,
+                      11., 12., 13., 14., 15.])
+    m = O.vec_to_mat(ref_v, scale=np.sqrt(2.0))
+    assert np.all(np.abs(m - ref_m) <= 0.5)
+    v, _ = O.mat_to_vec(m, scale=np.sqrt(2.0))
+    assert np.allclose(v, ref_v, atol=1e-6)
+
+
+def test_scale_nondiag_kat():
+    # totsu/src/matbuild/mod.rs:305-333
+    packed = [1., 2., 3., 4., 5., 6., 7., 8., 9., 10., 11., 12., 13., 14., 15.]
+    ref = [1., 2. * 1.4, 3., 4. * 1.4, 5. * 1.4, 6., 7. * 1.4, 8. * 1.4, 9. * 1.4, 10.,
+           11. * 1.4, 12. * 1.4, 13. * 1.4, 14. * 1.4, 15.]
+    assert np.allclose(O.scale_nondiag_sympack(packed, 1.4), ref, atol=1e-3)
+
+
+def test_abssum_striding():
+    # floatgeneric.rs:62-74 / f64lapack.rs:51-59: chunks(incx) semantics incl. ragged tail and incx 0
+    x = np.array([1., -2., 3., -4., 5., -6., 7.])
+    assert O.abssum(x, 1) == 28.0
+    assert O.abssum(x, 2) == 1 + 3 + 5 + 7
+    assert O.abssum(x, 3) == 1 + 4 + 7
+    assert O.abssum(x, 7) == 1
+    assert O.abssum(x, 100) == 1
+    assert O.abssum(x, 0) == 0.0
+    assert O.abssum(np.zeros(0), 1) == 0.0
+
+
+def test_transform_ge_matches_numpy():
+    rng = np.random.default_rng(0)
+    for (nr, nc) in [(1, 1), (3, 2), (7, 13), (64, 65), (300, 17)]:
+        a = rng.standard_normal((nr, nc))
+        for tr in (False, True):
+            x = rng.standard_normal(nr if tr else nc)
+            y0 = rng.standard_normal(nc if tr else nr)
+            y = O.transform_ge(tr, nr, nc, 0.7, a.ravel(order="F"), x, -0.3, y0)
+            ref = 0.7 * ((a.T if tr else a) @ x) - 0.3 * y0
+            assert np.allclose(y, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_map_eig_jacobi_vs_ql_vs_numpy():
+    rng = np.random.default_rng(1)
+    for k in (1, 2, 3, 8, 25):
+        b = rng.standard_normal((k, k))
+        s = (b + b.T) / 2
+        iu = [(r, c) for c in range(k) for r in range(c + 1)]
+        packed = np.array([s[r, c] * (np.sqrt(2.0) if r != c else 1.0) for (r, c) in iu])
+        w, v = np.linalg.eigh(s)
+        ref = (v * np.maximum(w, 0)) @ v.T
+        ref_p = np.array([ref[r, c] * (np.sqrt(2.0) if r != c else 1.0) for (r, c) in iu])
+        pj = O.proj(O.CONE_PSD, packed, use_ql=False)
+        pq = O.proj(O.CONE_PSD, packed, use_ql=True)
+        assert np.allclose(pj, ref_p, atol=1e-9)
+        assert np.allclose(pq, ref_p, atol=1e-9)
+
+
+def test_soc_rotsoc_branches():
+    # cone_soc.rs:38-65: the three branches + empty + length 1
+    assert O.proj(O.CONE_SOC, []).size == 0
+    assert np.array_equal(O.proj(O.CONE_SOC, [-1.0]), [0.0])            # |v|=0 <= 1 -> zero
+    assert np.array_equal(O.proj(O.CONE_SOC, [2.0]), [2.0])
+    assert np.array_equal(O.proj(O.CONE_SOC, [-5.0, 3.0, 4.0]), [0.0, 0.0, 0.0])
+    assert np.array_equal(O.proj(O.CONE_SOC, [5.0, 3.0, 4.0]), [5.0, 3.0, 4.0])
+    y = O.proj(O.CONE_SOC, [1.0, 3.0, 4.0])
+    assert np.allclose(y, [3.0, 3.0 * 0.6, 4.0 * 0.6])
+    # cone_rotsoc.rs:38-65
+    assert np.array_equal(O.proj(O.CONE_ROTSOC, [-3.0]), [0.0])
+    z = O.proj(O.CONE_ROTSOC, [1.0, 1.0, 0.5])          # 2rs >= |v|^2 : inside
+    assert np.allclose(z, [1.0, 1.0, 0.5])
+
+
+def test_rng_is_deterministic_and_sane():
+    u = np.array([O.rng_uniform(0, 1, i) for i in range(4000)])
+    g = np.array([O.rng_normal(0, 2, i) for i in range(4000)])
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.03
+    assert abs(g.mean()) < 0.06 and abs(g.std() - 1.0) < 0.05
+    assert O.rng_uniform(0, 1, 17) == O.rng_uniform(0, 1, 17)
+    assert O.rng_uniform(0, 1, 17) != O.rng_uniform(1, 1, 17)
