@@ -1,0 +1,202 @@
+/*
+ * totsu_f32hip.h -- C ABI of libtotsu_f32hip.so, the MI355X (gfx950) linear-algebra backend for
+ * Totsu's first-order conic solver.  This is the drop-in boundary: a Rust `totsu_f32hip` crate
+ * (`F32HIP: LinAlgEx`, `F32HIPSlice: SliceLike`) binds exactly these entry points,
+ * the way `totsu_f32cuda` binds cuBLAS / cuSOLVER.
+ *
+ * Conventions
+ *   - every `float *` / `const float *` is a DEVICE pointer unless the name starts with `host_`;
+ *   - every call enqueues on the context stream (thip_set_stream) and returns without
+ *     synchronising, except the ones that return a host scalar (marked SYNC);
+ *   - return value: 0 = ok, otherwise a hipError_t (or THIP_E_* below); thip_last_error() gives text.
+ *     The reference backends assert on library status (f32cuda.rs:38 etc.): a binding should
+ *     `assert_eq!(rc, 0)`;
+ *   - zero-length vectors and zero-sized matrices are legal everywhere (matop.rs:83-85);
+ *   - citations are relative to /root/reference/solver_rust_conic/.
+ */
+#ifndef TOTSU_F32HIP_H
+#define TOTSU_F32HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THIP_E_INVALID   10001   /* bad argument */
+#define THIP_E_NOTINIT   10002
+#define THIP_E_NOGPU     10003   /* no HIP device: the product path fails loudly, there is no CPU fallback */
+#define THIP_E_WORK      10004   /* work buffer too short */
+#define THIP_E_NOCONV    10005   /* eigen iteration did not converge */
+
+/* ---------------------------------------------------------------------------------------------
+ * Context.  Replaces totsu_f32cuda/src/cuda_mgr.rs:24-111 (context + cuBLAS/cuSOLVER handles,
+ * device 0 only there; any device here).
+ * ------------------------------------------------------------------------------------------- */
+int  thip_init(int device);                        /* cuda_mgr.rs:30-60 */
+int  thip_shutdown(void);
+int  thip_device_count(int *host_count);
+int  thip_set_stream(void *hip_stream);            /* NULL = the context's own stream */
+void *thip_get_stream(void);
+int  thip_sync(void);                              /* SYNC */
+const char *thip_last_error(void);
+const char *thip_version(void);
+
+/* device memory: replaces cuda_mgr.rs:119-138 (buf_from_slice / buf_zeroes) and
+ * f32cuda_slice.rs:343-355 (sync_from_dev / sync_from_host) */
+int thip_alloc(size_t n, float **out);             /* n floats, 256-byte aligned, NOT zeroed */
+int thip_alloc_zeroed(size_t n, float **out);
+int thip_free(float *p);
+int thip_h2d(float *dst, const float *host_src, size_t n);     /* async on the stream (pageable src: staged) */
+int thip_d2h(float *host_dst, const float *src, size_t n);     /* SYNC */
+int thip_get(const float *x, size_t idx, float *host_out);     /* SYNC; SliceLike::get, slicelike.rs:54-59 */
+int thip_set(float *x, size_t idx, float val);                 /*       SliceLike::set, slicelike.rs:62-69 */
+
+/* ---------------------------------------------------------------------------------------------
+ * LinAlg (totsu_core/src/solver/linalg.rs:10-68); CUDA counterparts f32cuda.rs:27-136
+ * ------------------------------------------------------------------------------------------- */
+int thip_norm(size_t n, const float *x, float *host_out);                       /* SYNC  linalg.rs:22  (cublasSnrm2, f32cuda.rs:27-42) */
+int thip_copy(size_t n, const float *x, float *y);                              /*       linalg.rs:29  (f32cuda.rs:44-57) */
+int thip_scale(size_t n, float alpha, float *x);                                /*       linalg.rs:35  (f32cuda.rs:59-69) */
+int thip_add(size_t n, float alpha, const float *x, float *y);                  /*       linalg.rs:42  (f32cuda.rs:71-84) */
+int thip_adds(size_t n, float s, float *y);                                     /*       linalg.rs:49  (f32cuda.rs:86-99) */
+int thip_abssum(size_t len, const float *x, size_t incx, float *host_out);      /* SYNC  linalg.rs:56  (f32cuda.rs:101-121); sums |x[0]|,|x[incx]|,.. < len */
+int thip_transform_di(size_t n, float alpha, const float *d, const float *x,
+                      float beta, float *y);                                    /*       linalg.rs:67  (cublasSsbmv k=0, f32cuda.rs:123-136) */
+
+/* ---------------------------------------------------------------------------------------------
+ * LinAlgEx (totsu_core/src/linalg_ex.rs:7-66); CUDA counterparts f32cuda.rs:144-370
+ * ------------------------------------------------------------------------------------------- */
+/* y = alpha * G^(T) x + beta * y, G column-major n_row x n_col, lda = n_row.
+ * linalg_ex.rs:23 (cublasSgemv, f32cuda.rs:144-171) */
+int thip_transform_ge(int transpose, size_t n_row, size_t n_col, float alpha, const float *mat,
+                      const float *x, float beta, float *y);
+/* y = alpha * S x + beta * y, S symmetric, packed upper by columns.  linalg_ex.rs:37 (cublasSspmv, f32cuda.rs:174-187) */
+int thip_transform_sp(size_t n, float alpha, const float *mat, const float *x, float beta, float *y);
+/* linalg_ex.rs:44 (f32cuda.rs:243-251) */
+size_t thip_map_eig_worklen(size_t n);
+/* linalg_ex.rs:64-65 with the two closures that exist in the reference, evaluated on the device:
+ *   map_kind 0: e > 0 -> e            (cone_psd.rs:69-76)
+ *   map_kind 1: e > 0 -> sqrt(e)      (totsu/src/matbuild/mod.rs:231-238)
+ * mat: packed upper by columns, length n(n+1)/2, in/out; scale_diag applied as f64lapack.rs:195-255. */
+int thip_map_eig(size_t n, float *mat, int has_scale, float scale_diag, float eps_zero,
+                 float *work, size_t worklen, int map_kind);
+/* arbitrary host closure, two phases (keeps the `M: Fn(F)->Option<F>` contract of linalg_ex.rs:64-65):
+ *   1) decompose: eigenvalues -> host_w[n] (SYNC), eigenvectors stay in work;
+ *   2) the host applies its closure: host_e[i] = mapped value, host_keep[i] = 1 for Some, 0 for None;
+ *   3) rebuild: mat <- sum_i keep_i * e_i z_i z_i^T, diag scaled back, repacked. */
+int thip_eig_decompose(size_t n, float *mat, int has_scale, float scale_diag, float eps_zero,
+                       float *work, size_t worklen, float *host_w);
+int thip_eig_rebuild(size_t n, float *mat, int has_scale, float scale_diag,
+                     float *work, size_t worklen, const float *host_e, const uint8_t *host_keep);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident variants used by the fused path (no host round trip).  They replace host loops
+ * in totsu_core that a generic backend cannot intercept ("hard parts").
+ * ------------------------------------------------------------------------------------------- */
+int thip_norm_dev(size_t n, const float *x, float *dev_out);                    /* ||x||_2 -> *dev_out */
+int thip_dot_dev(size_t n, const float *x, const float *y, float *dev_out);     /* x.y -> *dev_out */
+int thip_abssum_dev(size_t len, const float *x, size_t incx, float *dev_out);
+
+/* MatOp::absadd_impl for General (matop.rs:98-117) in one pass each: tau[c] += sum_r |G(r,c)|,
+ * sigma[r] += sum_c |G(r,c)| -- replaces n + m blocking cublasSasum calls */
+int thip_absadd_cols(size_t n_row, size_t n_col, const float *mat, float *tau);
+int thip_absadd_rows(size_t n_row, size_t n_col, const float *mat, float *sigma);
+/* SymPack arm, matop.rs:119-136 */
+int thip_absadd_sympack(size_t n, const float *mat, float *y);
+/* calc_precond host loops, solver.rs:501-506: x[i] = 1 / max(x[i], eps_zero) */
+int thip_recip_max(size_t n, float eps_zero, float *x);
+
+/* Cone projections (totsu_core/src/cone_*.rs) on device-resident vectors */
+enum { THIP_CONE_ZERO = 0, THIP_CONE_RPOS = 1, THIP_CONE_SOC = 2, THIP_CONE_ROTSOC = 3, THIP_CONE_PSD = 4 };
+int thip_proj_zero(int dual_cone, size_t n, float *x);          /* cone_zero.rs:38-44 */
+int thip_proj_rpos(size_t n, float *x);                         /* cone_rpos.rs:38-45 (host loop in the reference) */
+int thip_proj_soc(size_t n, float *x);                          /* cone_soc.rs:38-65, one cone */
+int thip_proj_rotsoc(size_t n, float *x);                       /* cone_rotsoc.rs:38-65, one cone */
+/* many cones in one launch: cone i occupies x[host_offs[i] .. host_offs[i+1]); rotated != 0 -> ConeRotSOC.
+ * Replaces the per-cone loop of ProbSOCPCone::proj (totsu/src/problem/socp.rs:296-313). */
+int thip_proj_soc_batched(float *x, const int64_t *dev_offs, size_t n_cones, int rotated, size_t max_len);
+/* ConePSD::proj, cone_psd.rs:56-79: returns THIP_E_WORK on work shortage (-> Err(())) */
+int thip_proj_psd(size_t sn, float *x, float eps_zero, float *work, size_t worklen);
+/* the `group` closure of solver.rs:509-520 applied to many blocks at once (product_group) */
+int thip_group_min_batched(float *dp_tau, const int64_t *dev_offs, size_t n_groups, size_t max_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused conic iteration on the device.  Native restatement of
+ * totsu_core/src/solver/solver.rs:340-657 (SolverCore) for operators that are dense matrices:
+ * all per-iteration arithmetic, the projections and the termination test run on the GPU; the host
+ * only polls a status word.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct thip_solver thip_solver;
+
+typedef struct thip_param {           /* solver.rs:13-41 */
+    int64_t max_iter;                 /* < 0: None */
+    float   eps_acc, eps_inf, eps_zero;
+    int64_t log_period;               /* 0: no periodic log */
+} thip_param;
+
+enum { THIP_ST_RUNNING = -1,
+       THIP_ST_OK = 0, THIP_ST_UNBOUNDED = 1, THIP_ST_INFEASIBLE = 2, THIP_ST_EXCESS_ITER = 3,
+       THIP_ST_INVALID_OP = 4, THIP_ST_WORK_SHORTAGE = 5, THIP_ST_CONE_FAILURE = 6 };   /* solver_error.rs:3-17 */
+
+enum { THIP_SCHED_REFERENCE = 0,   /* 6 single GEMVs per iteration, the reference's op sequence (solver.rs:122-597) */
+       THIP_SCHED_FUSED     = 1,   /* 3 passes over A: N and T products of one stage share a tile read */
+       THIP_SCHED_CARRIED   = 2 }; /* 2 passes: K*rx obtained by linearity from the criteria products */
+
+typedef struct thip_problem {
+    size_t n, m;                      /* A is m x n (local rows if sharded) */
+    const float *mat_a;               /* device, column-major, lda = m */
+    const float *vec_b;               /* device, m */
+    const float *vec_c;               /* device, n */
+    const float *vec_b_rowabs;        /* device, m, or NULL: what op_b.absadd_rows adds per row (default |b|).
+                                         ProbSOCPOpB adds scl_d, not |scl_d| (socp.rs:259-279) */
+    size_t n_seg;                     /* product cone over consecutive segments of the m rows */
+    const int32_t *host_seg_type;     /* THIP_CONE_* */
+    const int64_t *host_seg_len;
+} thip_problem;
+
+typedef struct thip_status {
+    int32_t state;                    /* THIP_ST_* */
+    int64_t iter;                     /* index i of the last executed iteration */
+    int32_t kind;                     /* 0: pri_dual_gap valid, 1: unbdd_infeas valid */
+    float   cri[3];
+    float   tau, kappa;
+    float   norm_b, norm_c;
+} thip_status;
+
+/* collective hook for a row-sharded A: sum-all-reduce `n` floats in place on the
+ * given stream.  NULL = single GPU. */
+typedef int (*thip_allreduce_fn)(void *ctx, float *dev_buf, size_t n, void *hip_stream);
+
+int thip_solver_create(const thip_problem *prob, const thip_param *par, int schedule, thip_solver **out);
+int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
+int thip_solver_init(thip_solver *s);                                 /* calc_norms + init_vecs + calc_precond, solver.rs:460-524 */
+/* enqueue up to max_steps iterations (the device stops by itself on termination), poll every
+ * `poll_every` iterations; returns when terminated or after max_steps.  SYNC. */
+int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_status *host_status);
+int thip_solver_status(thip_solver *s, thip_status *host_status);     /* SYNC */
+/* solver.rs:317-320: x = work[0..n], y = work[n..n+m] */
+int thip_solver_solution(thip_solver *s, float *host_x, float *host_y);
+/* raw iterate (x: n+2m+1, y: n+m+1, reference layout solver.rs:349-355), for parity tests */
+int thip_solver_iterate(thip_solver *s, float *host_x, float *host_y);
+int thip_solver_precond(thip_solver *s, float *host_dp_tau, float *host_dp_sigma);
+int thip_solver_destroy(thip_solver *s);
+/* physical passes over A per iteration of the schedule in use, and bytes one pass reads */
+int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_bytes_per_pass);
+
+/* ---------------------------------------------------------------------------------------------
+ * Synthetic data on the device (bench / tests): counter-based generator keyed by
+ * (seed, stream, index), bit-identical to oracle/totsu_oracle.c:oc_rng_*.
+ * kind 0: U[0,1) ; kind 1: approx N(0,1) (Irwin-Hall 4).  out[i] = scale * g(idx0 + i) + shift.
+ * For a column-major block: index of element (r,c) is (row0 + r) + (col0 + c) * ld_index.
+ * ------------------------------------------------------------------------------------------- */
+int thip_gen_vector(float *out, size_t n, uint64_t seed, uint64_t stream, uint64_t idx0,
+                    int kind, float scale, float shift);
+int thip_gen_matrix(float *out, size_t n_row, size_t n_col, size_t lda, uint64_t seed, uint64_t stream,
+                    uint64_t row0, uint64_t col0, uint64_t ld_index, int kind, float scale, float shift);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOTSU_F32HIP_H */

@@ -1,0 +1,218 @@
+"""GPU parity tests, primitive level: every LinAlg / LinAlgEx / Cone entry point of the C ABI against the CPU
+oracle (oracle/) on the same seeded inputs.  Tolerances are f32 round-off of the operation, stated per test.
+Edge cases follow the reference: zero-length and length-1 vectors, odd lengths, unaligned sub-slices (the
+solver hands out slices at offsets n, n+m, n+2m: solver.rs:116-118), strided abssum (matop.rs:110-114),
+zero-sized matrices (matop.rs:83-85)."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LENS = [0, 1, 2, 3, 63, 64, 65, 255, 1000, 4097, 100003]
+
+
+@pytest.fixture(scope="module")
+def L():
+    from totsu_amd import F32HIP, _lib
+    _lib.init()
+    return F32HIP
+
+
+def _sl(L, a, off=0):
+    """device slice of `a` that starts `off` floats into a bigger allocation (unaligned base)"""
+    a = np.asarray(a, dtype=np.float32)
+    buf = np.zeros(a.size + off, dtype=np.float32)
+    buf[off:] = a
+    root = L.Sl.new_mut(buf)
+    _, s = root.split(off)
+    return root, s
+
+
+@pytest.mark.parametrize("n", LENS)
+@pytest.mark.parametrize("off", [0, 1, 3])
+def test_level1(L, n, off):
+    rng = np.random.default_rng(n * 7 + off)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    d = rng.standard_normal(n).astype(np.float32)
+    rx, sx = _sl(L, x, off)
+    ry, sy = _sl(L, y, off)
+    rd, sd = _sl(L, d, off)
+    x64, y64, d64 = x.astype(np.float64), y.astype(np.float64), d.astype(np.float64)
+
+    # norm / abssum: relative 1e-5 (f32 tree sums, f64 final stage)
+    assert abs(L.norm(sx) - O.norm(x64)) <= 1e-5 * max(O.norm(x64), 1e-30)
+    for inc in (1, 2, 3, 7):
+        assert abs(L.abssum(sx, inc) - O.abssum(x64, inc)) <= 1e-5 * max(O.abssum(x64, inc), 1e-30)
+    assert L.abssum(sx, 0) == 0.0
+
+    L.copy(sx, sy)
+    assert np.array_equal(sy.get_ref(), x)
+    L.scale(-1.5, sy)
+    assert np.array_equal(sy.get_ref(), (np.float32(-1.5) * x))
+    L.add(0.25, sx, sy)
+    assert np.allclose(sy.get_ref(), -1.25 * x64, rtol=1e-6, atol=1e-7)
+    L.adds(2.0, sy)
+    assert np.allclose(sy.get_ref(), -1.25 * x64 + 2.0, rtol=1e-6, atol=1e-6)
+    ref = O.transform_di(0.7, d64, x64, -0.3, sy.get_ref().astype(np.float64))
+    L.transform_di(0.7, sd, sx, -0.3, sy)
+    assert np.allclose(sy.get_ref(), ref, rtol=1e-5, atol=1e-6)
+    L.scale(0.0, sy)
+    assert not sy.get_ref().any()
+    if n:
+        sy.set(n - 1, 3.5)
+        assert sy.get(n - 1) == 3.5
+    for r in (rx, ry, rd):
+        r.drop()
+
+
+SHAPES = [(1, 1), (3, 2), (4, 4), (99, 50), (100, 64), (256, 33), (1024, 17), (1028, 300), (4096, 129),
+          (5000, 1030), (20000, 37), (8, 5000), (33000, 70)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_transform_ge(L, shape):
+    nr, nc = shape
+    rng = np.random.default_rng(nr * 131 + nc)
+    a = rng.standard_normal((nr, nc)).astype(np.float32)
+    am = L.Sl.new_ref(a.ravel(order="F"))
+    for tr in (False, True):
+        for off in (0, 1):
+            x = rng.standard_normal(nr if tr else nc).astype(np.float32)
+            y0 = rng.standard_normal(nc if tr else nr).astype(np.float32)
+            rx, sx = _sl(L, x, off)
+            ry, sy = _sl(L, y0, off)
+            for alpha, beta in ((1.0, 0.0), (-0.7, 1.0), (0.5, -0.25)):
+                ry2, sy2 = _sl(L, y0, off)
+                L.transform_ge(tr, nr, nc, alpha, am, sx, beta, sy2)
+                got = sy2.get_ref().astype(np.float64)
+                ref = O.transform_ge(tr, nr, nc, alpha, a.astype(np.float64).ravel(order="F"), x, beta, y0)
+                scale = np.abs(alpha) * (np.abs(a.T if tr else a).astype(np.float64) @ np.abs(x)) + np.abs(beta * y0)
+                # f32 dot of length K: error <= ~K eps sum|a||x| worst case, sqrt(K) typical: 2e-6 * scale * 8
+                assert np.all(np.abs(got - ref) <= 2e-5 * scale + 1e-6), (tr, off, alpha, beta)
+                ry2.drop()
+            rx.drop()
+            ry.drop()
+    am.drop()
+
+
+def test_transform_ge_zero_sized_is_scale(L):
+    # matop.rs:83-85
+    from totsu_amd import MatOp, MatType
+    y = np.arange(5, dtype=np.float32)
+    ry, sy = _sl(L, y)
+    m = MatOp(L, MatType.General(0, 5), np.zeros(0, dtype=np.float32))
+    x0 = L.Sl.new_ref(np.zeros(0, dtype=np.float32))
+    m.trans_op(2.0, x0, 0.5, sy)
+    assert np.array_equal(sy.get_ref(), 0.5 * y)
+    ry.drop()
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 130])
+def test_transform_sp_and_absadd(L, n):
+    rng = np.random.default_rng(n)
+    sp = rng.standard_normal(n * (n + 1) // 2).astype(np.float32)
+    x = rng.standard_normal(n).astype(np.float32)
+    y0 = rng.standard_normal(n).astype(np.float32)
+    sm = L.Sl.new_ref(sp)
+    rx, sx = _sl(L, x)
+    ry, sy = _sl(L, y0)
+    L.transform_sp(n, 0.7, sm, sx, -0.3, sy)
+    ref = O.transform_sp(n, 0.7, sp, x, -0.3, y0)
+    assert np.allclose(sy.get_ref(), ref, rtol=1e-4, atol=1e-4)
+    ry2, sy2 = _sl(L, y0)
+    L.absadd_sympack(n, sm, sy2)
+    ref = O.matop_absadd(1, n, n, sp, True, y0)   # typ 1 = SymPack
+    assert np.allclose(sy2.get_ref(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(3, 2), (100, 64), (1000, 333), (4100, 257)])
+def test_absadd_general(L, shape):
+    # MatOp::absadd_impl, matop.rs:98-117
+    nr, nc = shape
+    rng = np.random.default_rng(nr + nc)
+    a = rng.standard_normal((nr, nc)).astype(np.float32)
+    am = L.Sl.new_ref(a.ravel(order="F"))
+    t0 = rng.uniform(0, 1, nc).astype(np.float32)
+    s0 = rng.uniform(0, 1, nr).astype(np.float32)
+    rt, st = _sl(L, t0, 1)
+    rs, ss = _sl(L, s0, 1)
+    L.absadd_cols(nr, nc, am, st)
+    L.absadd_rows(nr, nc, am, ss)
+    reft = O.matop_absadd(0, nr, nc, a.astype(np.float64).ravel(order="F"), True, t0)
+    refs = O.matop_absadd(0, nr, nc, a.astype(np.float64).ravel(order="F"), False, s0)
+    assert np.allclose(st.get_ref(), reft, rtol=2e-5)
+    assert np.allclose(ss.get_ref(), refs, rtol=2e-5)
+
+
+def test_cones_single(L):
+    from totsu_amd import ConeRPos, ConeRotSOC, ConeSOC, ConeZero
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 3, 100, 2049, 5000):
+        x = rng.standard_normal(n).astype(np.float32)
+        for cone, typ in ((ConeRPos(L), O.CONE_RPOS), (ConeSOC(L), O.CONE_SOC), (ConeRotSOC(L), O.CONE_ROTSOC),
+                          (ConeZero(L), O.CONE_ZERO)):
+            for dual in (False, True):
+                for shift in (-3.0, 0.0, 3.0):       # force each branch of cone_soc.rs:49-61
+                    xx = x.copy()
+                    if n:
+                        xx[0] += shift * max(np.linalg.norm(x), 1.0)
+                    if typ == O.CONE_ROTSOC and n > 1:
+                        xx[1] += shift * max(np.linalg.norm(x), 1.0)
+                    r, s = _sl(L, xx, 1)
+                    assert cone.proj(dual, s)
+                    ref = O.proj(typ, xx.astype(np.float64), dual_cone=dual)
+                    assert np.allclose(s.get_ref(), ref, rtol=2e-5, atol=2e-5 * max(np.abs(xx).max() if n else 0, 1)), (n, typ, dual, shift)
+                    r.drop()
+
+
+def test_soc_batched_ragged(L):
+    import ctypes as C
+    from totsu_amd._lib import lib
+    from totsu_amd.fused import DeviceBuffer
+    rng = np.random.default_rng(11)
+    lens = [1, 100, 0, 2, 65, 3000, 7, 64, 1]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for rot in (0, 1):
+        x = rng.standard_normal(offs[-1]).astype(np.float32)
+        for i, ln in enumerate(lens):      # alternate inside / outside / polar
+            if ln:
+                x[offs[i]] += (i % 3 - 1) * 2.0 * np.linalg.norm(x[offs[i]:offs[i + 1]])
+        d = DeviceBuffer.from_host(x)
+        od = DeviceBuffer(2 * len(offs))
+        lib.thip_h2d(od.ptr, offs.ctypes.data, 2 * len(offs))      # int64 as pairs of floats
+        lib.thip_proj_soc_batched(d.ptr, od.ptr, len(lens), rot, max(lens))
+        got = d.to_host()
+        ref = x.astype(np.float64).copy()
+        for i in range(len(lens)):
+            ref[offs[i]:offs[i + 1]] = O.proj(O.CONE_ROTSOC if rot else O.CONE_SOC, ref[offs[i]:offs[i + 1]])
+        assert np.allclose(got, ref, rtol=2e-5, atol=1e-4)
+        # group-min over the same ragged groups (solver.rs:509-520)
+        t = rng.uniform(0.1, 1, offs[-1]).astype(np.float32)
+        dt = DeviceBuffer.from_host(t)
+        lib.thip_group_min_batched(dt.ptr, od.ptr, len(lens), max(lens))
+        gt = dt.to_host()
+        for i in range(len(lens)):
+            if lens[i]:
+                assert np.all(gt[offs[i]:offs[i + 1]] == t[offs[i]:offs[i + 1]].min())
+        d.free(); od.free(); dt.free()
+
+
+def test_rng_matches_oracle_bitwise(L):
+    from totsu_amd._lib import lib
+    from totsu_amd.fused import DeviceBuffer
+    d = DeviceBuffer(1000)
+    lib.thip_gen_vector(d.ptr, 1000, 7, 3, 12345, 0, 1.0, 0.0)
+    u = d.to_host()
+    lib.thip_gen_vector(d.ptr, 1000, 7, 3, 12345, 1, 1.0, 0.0)
+    g = d.to_host()
+    for i in (0, 1, 17, 999):
+        assert u[i] == np.float32(O.rng_uniform(7, 3, 12345 + i))
+        assert g[i] == np.float32(O.rng_normal(7, 3, 12345 + i))
+    m = DeviceBuffer(12 * 5)
+    lib.thip_gen_matrix(m.ptr, 12, 5, 12, 1, 2, 100, 10, 1000, 1, 0.5, 0.0)
+    mm = m.to_host().reshape((5, 12)).T
+    assert mm[3, 2] == np.float32(0.5) * np.float32(O.rng_normal(1, 2, (10 + 2) * 1000 + 100 + 3))
+    d.free(); m.free()

@@ -1,0 +1,273 @@
+"""GPU parity tests, solver level: the reference's known-answer tests through the trait-level `Solver(F32HIP)`
+and through the fused device loop, iterate-level agreement with the CPU oracle on seeded LP / SOCP / SDP
+instances, agreement of the three schedules, and size-independent properties at BASELINE.json's LP size."""
+import numpy as np
+import pytest
+
+import oracle as O
+from problems import benchmark_lp, random_sdp, random_socp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import totsu_amd
+    from totsu_amd import _lib
+    _lib.init()
+    return totsu_amd
+
+
+def _mb(T, typ):
+    return T.MatBuild(T.F32HIP, typ)
+
+
+def _par(s, **kw):
+    for k, v in kw.items():
+        setattr(s.param, k, v)
+    return s
+
+
+# ---- known-answer tests (f32: eps_acc 1e-4 like-for-like with the reference's own f32 tolerance 1e-3,
+# experimental/benchmark_lp/src/main.rs:62-65; answers asserted to abs 1e-3 like totsu/tests/*.rs) -----------
+
+def test_kat_nostd_lp_trait_level(T):
+    # examples/nostd_cortex-m/src/main.rs:57-99 on F32HIP
+    L = T.F32HIP
+    op_c = T.MatOp(L, T.MatType.General(2, 1), np.array([-1., 0.], np.float32))
+    op_a = T.MatOp(L, T.MatType.General(3, 2), np.array([4., -1., -1., -1., 4., -1.], np.float32))
+    op_b = T.MatOp(L, T.MatType.General(3, 1), np.array([6., 6., 1.], np.float32))
+    s = _par(T.Solver(L), max_iter=100_000, eps_acc=1e-5)
+    s.trace = []
+    work = np.zeros(48, dtype=np.float32)
+    x, y = s.solve((op_c, op_a, op_b, T.ConeRPos(L), work))
+    assert np.allclose(x, [2.0, 2.0], atol=1e-3)
+    # the f64 golden trace converges at iteration 159 with eps 1e-6; f32 at 1e-5 must be in the same regime
+    assert 100 < s.trace[-1][0] < 200
+    ro = O.solve_matop_cones(O.param(max_iter=100000, eps_acc=1e-5), [-1., 0.], [4., -1., -1., -1., 4., -1.],
+                             [6., 6., 1.], [O.CONE_RPOS], [3], trace_cap=400)
+    assert abs(s.trace[-1][0] - ro.iters) <= 2
+    for a, b in zip(s.trace[:100], ro.trace[:100]):
+        assert np.allclose(a[2:], b[2:], rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("schedule", ["reference", "fused", "carried"])
+def test_kat_nostd_lp_fused(T, schedule):
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 100_000, 1e-5
+    fs = T.FusedSolver(2, 3, [4., -1., -1., -1., 4., -1.], [6., 6., 1.], [-1., 0.], [1], [3], p, schedule)
+    x, y = fs.solve()
+    r = fs.status()
+    assert np.allclose(x, [2.0, 2.0], atol=1e-3)
+    ro = O.solve_matop_cones(O.param(max_iter=100000, eps_acc=1e-5), [-1., 0.], [4., -1., -1., -1., 4., -1.],
+                             [6., 6., 1.], [O.CONE_RPOS], [3])
+    assert abs(r.iters - ro.iters) <= 2
+    assert np.allclose(y, ro.y, atol=1e-3)
+    fs.destroy()
+
+
+def _lp(T, c, g_rowmaj, h, n, m):
+    return T.ProbLP(_mb(T, T.MatType.General(n, 1)).iter_colmaj(c), _mb(T, T.MatType.General(m, n)).iter_rowmaj(g_rowmaj),
+                    _mb(T, T.MatType.General(m, 1)).iter_colmaj(h), _mb(T, T.MatType.General(0, n)),
+                    _mb(T, T.MatType.General(0, 1)))
+
+
+@pytest.mark.parametrize("path", ["trait", "reference", "fused", "carried"])
+def test_kat_lp_infeasible_unbounded(T, path):
+    # totsu/tests/lp.rs:13-82
+    for g, h, want in (([1., -1.], [-5., -10.], T.SolverError.Infeasible), ([1., 1.], [5., 10.], T.SolverError.Unbounded)):
+        lp = _lp(T, [1.], g, h, 1, 2)
+        with pytest.raises(T.SolverError) as e:
+            if path == "trait":
+                _par(T.Solver(T.F32HIP), max_iter=100_000).solve(lp.problem())
+            else:
+                p = T.SolverParam()
+                p.max_iter = 100_000
+                T.FusedSolver.from_dense(lp.dense(), p, path).solve()
+        assert e.value.kind == want
+        lp.drop()
+
+
+def _socp_kats(T):
+    n = 2
+    vec_f = _mb(T, T.MatType.General(n, 1)).by_fn(lambda r, c: 1.0)
+    g = _mb(T, T.MatType.General(2, n))
+    g[(0, 0)] = 1.0
+    g[(1, 1)] = 1.0
+    s1 = T.ProbSOCP(vec_f, [g], [_mb(T, T.MatType.General(2, 1))], [_mb(T, T.MatType.General(n, 1))], [np.sqrt(2.0)],
+                    _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+    vec_f = _mb(T, T.MatType.General(n, 1)).iter_colmaj([0., 1.])
+    mats_g = [_mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(1, n)).iter_rowmaj([-1., 0.])]
+    vecs_h = [_mb(T, T.MatType.General(0, 1)), _mb(T, T.MatType.General(1, 1)).iter_colmaj([2.])]
+    vecs_c = [_mb(T, T.MatType.General(2, 1)).iter_colmaj([0., -1.]), _mb(T, T.MatType.General(2, 1)).iter_colmaj([0., 1.])]
+    s2 = T.ProbSOCP(vec_f, mats_g, vecs_h, vecs_c, [50., 0.], _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+    return (s1, [-1., -1.]), (s2, [2., 0.])
+
+
+@pytest.mark.parametrize("path", ["trait", "reference", "fused", "carried"])
+def test_kat_socp(T, path):
+    # totsu/tests/socp.rs:14-93 (second one has a zero-row cone)
+    for socp, want in _socp_kats(T):
+        if path == "trait":
+            x, _ = _par(T.Solver(T.F32HIP), max_iter=100_000, eps_acc=1e-5).solve(socp.problem())
+        else:
+            p = T.SolverParam()
+            p.max_iter, p.eps_acc = 100_000, 1e-5
+            x, _ = T.FusedSolver.from_dense(socp.dense(), p, path).solve()
+        assert np.allclose(x, want, atol=1e-3), (path, x)
+        socp.drop()
+
+
+@pytest.mark.parametrize("path", ["trait", "fused", "carried"])
+def test_kat_psd(T, path):
+    # totsu_core/tests/solver.rs:14-53 == totsu_f32cuda/tests/solver.rs:16-54, and totsu/tests/sdp.rs:14-50
+    L = T.F32HIP
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 100_000, 1e-5
+    if path == "trait":
+        op_c = T.MatOp(L, T.MatType.General(1, 1), np.array([1.], np.float32))
+        op_a = T.MatOp(L, T.MatType.General(3, 1), np.array([0., -1. * 1.41421356, -3.], np.float32))
+        op_b = T.MatOp(L, T.MatType.General(3, 1), np.array([1., 0., 10.], np.float32))
+        s = _par(T.Solver(L), max_iter=100_000, eps_acc=1e-5)
+        cone_w = np.zeros(T.ConePSD.query_worklen(L, 3), dtype=np.float32)
+        cone = T.ConePSD(L, cone_w, s.param.eps_zero)
+        work = np.zeros(T.Solver.query_worklen(op_a.size()), dtype=np.float32)
+        x, _ = s.solve((op_c, op_a, op_b, cone, work))
+    else:
+        x, _ = T.FusedSolver(1, 3, [0., -1. * 1.41421356, -3.], [1., 0., 10.], [1.], [4], [3], p, path).solve()
+    assert abs(x[0] + 2.0) <= 1e-3
+
+    n, k = 2, 2
+    vec_c = _mb(T, T.MatType.General(n, 1)).iter_colmaj([1., 1.])
+    syms = [_mb(T, T.MatType.SymPack(k)) for _ in range(n + 1)]
+    syms[0].set_iter_rowmaj([-1., 0., 0., 0.])
+    syms[1].set_iter_rowmaj([0., 0., 0., -1.])
+    syms[2].set_iter_rowmaj([3., 0., 0., 4.])
+    sdp = T.ProbSDP(vec_c, syms, _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)), 1e-12)
+    if path == "trait":
+        x, _ = _par(T.Solver(L), max_iter=100_000, eps_acc=1e-5).solve(sdp.problem())
+    else:
+        x, _ = T.FusedSolver.from_dense(sdp.dense(), p, path).solve()
+    assert np.allclose(x, [3., 4.], atol=1e-3)
+    sdp.drop()
+
+
+# ---- iterate-level parity with the oracle on seeded instances ------------------------------------------
+
+def _oracle_snaps(dense, iters):
+    par = O.param(max_iter=max(iters) + 2, eps_acc=1e-30)
+    return O.solve_matop_cones(par, dense.vec_c, dense.mat_a, dense.vec_b, dense.seg_type, dense.seg_len,
+                               snap_iters=iters, trace_cap=max(iters) + 3, use_ql=True)
+
+
+def _check_iterates(T, dense, schedule, iters, tols):
+    ro = _oracle_snaps(dense, iters)
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    fs = T.FusedSolver.from_dense(dense, p, schedule)
+    t, s = fs.precond()
+    N = dense.n + 2 * dense.m + 1
+    done = 0
+    for q, (it, tol) in enumerate(zip(iters, tols)):
+        fs.run(it + 1 - done, poll_every=64)
+        done = it + 1
+        x, y = fs.iterate()
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        sx = max(np.abs(rx).max(), 1e-6)
+        sy = max(np.abs(ry).max(), 1e-6)
+        assert np.abs(x - rx).max() <= tol * sx, (schedule, it, np.abs(x - rx).max() / sx)
+        assert np.abs(y - ry).max() <= tol * sy, (schedule, it, np.abs(y - ry).max() / sy)
+        st = fs.status()
+        assert st.iters == it + 1 or st.iters == it       # running: next index
+        tr = ro.trace[it]
+        assert np.allclose(st.cri, tr[2:], rtol=max(50 * tol, 1e-3), atol=1e-5), (it, st.cri, tr)
+    fs.destroy()
+
+
+@pytest.mark.parametrize("schedule", ["reference", "fused", "carried"])
+def test_iterates_lp(T, schedule):
+    c, G, h = benchmark_lp(40, seed=1)
+    lp = T.ProbLP(_mb(T, T.MatType.General(40, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(80, 40)).set_array(G),
+                  _mb(T, T.MatType.General(80, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, 40)),
+                  _mb(T, T.MatType.General(0, 1)))
+    # f32 round-off accumulates over iterations: 1e-5 after 1-2, 1e-4 after 10, 2e-3 after 100
+    _check_iterates(T, lp.dense(), schedule, [0, 1, 9, 99], [2e-5, 2e-5, 1e-4, 2e-3])
+
+
+@pytest.mark.parametrize("schedule", ["reference", "fused", "carried"])
+def test_iterates_socp(T, schedule):
+    n, cones = 30, [5, 1, 0, 17, 99, 3]
+    f, Gs, hs, cs, d = random_socp(n, cones, seed=2)
+    socp = T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(f.reshape(-1, 1)),
+                      [_mb(T, T.MatType.General(G.shape[0], n)).set_array(G) for G in Gs],
+                      [_mb(T, T.MatType.General(len(h_), 1)).set_array(h_.reshape(-1, 1)) for h_ in hs],
+                      [_mb(T, T.MatType.General(n, 1)).set_array(c_.reshape(-1, 1)) for c_ in cs], d,
+                      _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+    _check_iterates(T, socp.dense(), schedule, [0, 1, 9, 99], [2e-5, 2e-5, 1e-4, 2e-3])
+
+
+@pytest.mark.parametrize("schedule", ["fused", "carried"])
+def test_iterates_sdp(T, schedule):
+    n, k = 6, 9
+    c, syms = random_sdp(n, k, seed=3)
+    sdp = T.ProbSDP(_mb(T, T.MatType.General(n, 1)).set_array(c.reshape(-1, 1)),
+                    [_mb(T, T.MatType.SymPack(k)).set_array(s) for s in syms],
+                    _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)), 1e-12)
+    _check_iterates(T, sdp.dense(), schedule, [0, 1, 9, 49], [5e-5, 5e-5, 3e-4, 3e-3])
+
+
+def test_trait_level_equals_fused_on_lp(T):
+    c, G, h = benchmark_lp(25, seed=4)
+    mk = lambda: T.ProbLP(_mb(T, T.MatType.General(25, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(50, 25)).set_array(G),
+                          _mb(T, T.MatType.General(50, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, 25)),
+                          _mb(T, T.MatType.General(0, 1)))
+    lp = mk()
+    s = _par(T.Solver(T.F32HIP), max_iter=100_000, eps_acc=1e-4)
+    s.trace = []
+    x1, y1 = s.solve(lp.problem())
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 100_000, 1e-4
+    fs = T.FusedSolver.from_dense(lp.dense(), p, "reference")
+    x2, y2 = fs.solve()
+    ro = O.solve_lp(O.param(max_iter=100000, eps_acc=1e-4), c, G, h, np.zeros((0, 25)), [])
+    assert ro.status == O.OK
+    # same objective as the f64 CPU path within 1e-4 relative (BASELINE.json north_star)
+    pobj = float(c.astype(np.float64) @ ro.x)
+    for x in (x1, x2):
+        assert abs(float(c.astype(np.float64) @ x) - pobj) <= 1e-3 * (1 + abs(pobj))
+    assert abs(s.trace[-1][0] - ro.iters) <= max(5, 0.02 * ro.iters)
+    assert abs(fs.status().iters - ro.iters) <= max(5, 0.02 * ro.iters)
+    lp.drop()
+
+
+# ---- size-independent properties at BASELINE.json's LP size (n = 10k, m = 20k, 800 MB of A) ------------
+
+def test_gemv_properties_full_lp_size(T):
+    import ctypes as C
+    from totsu_amd._lib import lib
+    D = T.DeviceBuffer
+    n, m = 10_000, 20_000
+    A = D(n * m)
+    lib.thip_gen_matrix(A.ptr, m, n, m, 0, 1, 0, 0, m, 0, 1.0, 0.0)
+    x, y = D(n), D(m)
+    lib.thip_gen_vector(x.ptr, n, 0, 2, 0, 1, 1.0, 0.0)
+    lib.thip_gen_vector(y.ptr, m, 0, 3, 0, 1, 1.0, 0.0)
+    Ax, Aty = D(m), D(n)
+    lib.thip_transform_ge(0, m, n, 1.0, A.ptr, x.ptr, 0.0, Ax.ptr)
+    lib.thip_transform_ge(1, m, n, 1.0, A.ptr, y.ptr, 0.0, Aty.ptr)
+    hx, hy, hAx, hAty = x.to_host().astype(np.float64), y.to_host().astype(np.float64), Ax.to_host().astype(np.float64), Aty.to_host().astype(np.float64)
+    # adjointness <A x, y> == <x, A^T y>, relative to the size of the terms (f32 sums of 2e8 products)
+    lhs, rhs = hAx @ hy, hx @ hAty
+    assert abs(lhs - rhs) <= 1e-5 * (np.abs(hAx) @ np.abs(hy))
+    # spot rows / columns against f64 sums of the regenerated entries (counter-based generator)
+    for r in (0, 1, 7777, m - 1):
+        row = np.array([O.rng_uniform(0, 1, r + cc * m) for cc in range(n)], dtype=np.float64)
+        assert abs(hAx[r] - row @ hx) <= 2e-5 * (np.abs(row) @ np.abs(hx))
+    for cc in (0, 5, n - 1):
+        col = np.array([O.rng_uniform(0, 1, r + cc * m) for r in range(m)], dtype=np.float64)
+        assert abs(hAty[cc] - col @ hy) <= 2e-5 * (np.abs(col) @ np.abs(hy))
+    # linearity: A(2x) == 2 A x bitwise-close, and beta accumulation
+    lib.thip_transform_ge(0, m, n, 2.0, A.ptr, x.ptr, -1.0, Ax.ptr)       # 2Ax - Ax = Ax
+    assert np.allclose(Ax.to_host(), hAx, rtol=1e-5, atol=1e-3)
+    for d in (A, x, y, Ax, Aty):
+        d.free()

@@ -1,0 +1,191 @@
+"""CPU tests of the host-side mirror (totsu_amd.solver / matop / cone / problem) on a numpy backend: the same
+known-answer tests the reference runs on FloatGeneric<f64> (totsu/tests/*.rs, totsu_core/tests/solver.rs),
+and agreement of the generic Python loop with the C oracle iteration for iteration."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from np_backend import F64NP as La
+from totsu_amd.cone import ConePSD, ConeRPos
+from totsu_amd.matbuild import MatBuild
+from totsu_amd.matop import MatOp, MatType
+from totsu_amd.problem import ProbLP, ProbSDP, ProbSOCP
+from totsu_amd.solver import Solver, SolverError
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_log_qemu_trace_through_python_loop():
+    g = json.load(open(os.path.join(HERE, "golden", "log_qemu.json")))
+    pb = g["problem"]
+    op_c = MatOp(La, MatType.General(2, 1), np.array(pb["vec_c"]))
+    op_a = MatOp(La, MatType.General(3, 2), np.array(pb["mat_a_colmajor"]))
+    op_b = MatOp(La, MatType.General(3, 1), np.array(pb["vec_b"]))
+    s = Solver(La).par(lambda p: (setattr(p, "max_iter", 100_000), setattr(p, "log_period", 10)))
+    s.trace = []
+    assert Solver.query_worklen(op_a.size()) == 48
+    work = np.zeros(48)
+    x, _ = s.solve((op_c, op_a, op_b, ConeRPos(La), work))
+    assert s.trace[-1][0] == 159
+    assert abs(x[0] - 1.9999994251590176) < 1e-12 and abs(x[1] - 2.0000004472430635) < 1e-12
+    by = {t[0]: t for t in s.trace}
+    for rec in g["trace"]:
+        t = by[rec["iter"]]
+        for v, txt in zip(t[2:5], rec["text"]):
+            assert abs(v - float(txt)) <= 0.006 * max(abs(float(txt)), 1e-300)
+
+
+def test_core_solver_psd():
+    # totsu_core/tests/solver.rs:14-53
+    op_c = MatOp(La, MatType.General(1, 1), np.array([1.0]))
+    op_a = MatOp(La, MatType.General(3, 1), np.array([0.0, -1.0 * 1.41421356, -3.0]))
+    op_b = MatOp(La, MatType.General(3, 1), np.array([1.0, 0.0 * 1.41421356, 10.0]))
+    s = Solver(La).par(lambda p: setattr(p, "max_iter", 100_000))
+    cone_w = np.zeros(ConePSD.query_worklen(La, 3))
+    cone = ConePSD(La, cone_w, s.param.eps_zero)
+    work = np.zeros(Solver.query_worklen(op_a.size()))
+    x, _ = s.solve((op_c, op_a, op_b, cone, work))
+    assert abs(x[0] - (-2.0)) <= 1e-3
+
+
+def _mb(typ):
+    return MatBuild(La, typ)
+
+
+def test_lp1_infeasible_lp2_unbounded():
+    # totsu/tests/lp.rs:13-82
+    for g, h, want in (([1.0, -1.0], [-5.0, -10.0], SolverError.Infeasible),
+                       ([1.0, 1.0], [5.0, 10.0], SolverError.Unbounded)):
+        vec_c = _mb(MatType.General(1, 1)).iter_colmaj([1.0])
+        mat_g = _mb(MatType.General(2, 1)).iter_rowmaj(g)
+        vec_h = _mb(MatType.General(2, 1)).iter_colmaj(h)
+        mat_a = _mb(MatType.General(0, 1))
+        vec_b = _mb(MatType.General(0, 1))
+        s = Solver(La).par(lambda p: setattr(p, "max_iter", 100_000))
+        lp = ProbLP(vec_c, mat_g, vec_h, mat_a, vec_b)
+        with pytest.raises(SolverError) as e:
+            s.solve(lp.problem())
+        assert e.value.kind == want
+
+
+def test_socp1_socp2():
+    # totsu/tests/socp.rs:14-93
+    n = 2
+    vec_f = _mb(MatType.General(n, 1)).by_fn(lambda r, c: 1.0)
+    g = _mb(MatType.General(2, n))
+    g[(0, 0)] = 1.0
+    g[(1, 1)] = 1.0
+    socp = ProbSOCP(vec_f, [g], [_mb(MatType.General(2, 1))], [_mb(MatType.General(n, 1))], [np.sqrt(2.0)],
+                    _mb(MatType.General(0, n)), _mb(MatType.General(0, 1)))
+    x, _ = Solver(La).solve(socp.problem())
+    assert np.allclose(x, [-1.0, -1.0], atol=1e-3)
+
+    vec_f = _mb(MatType.General(n, 1)).iter_colmaj([0.0, 1.0])
+    mats_g = [_mb(MatType.General(0, n)), _mb(MatType.General(1, n)).iter_rowmaj([-1.0, 0.0])]
+    vecs_h = [_mb(MatType.General(0, 1)), _mb(MatType.General(1, 1)).iter_colmaj([2.0])]
+    vecs_c = [_mb(MatType.General(2, 1)).iter_colmaj([0.0, -1.0]), _mb(MatType.General(2, 1)).iter_colmaj([0.0, 1.0])]
+    socp = ProbSOCP(vec_f, mats_g, vecs_h, vecs_c, [50.0, 0.0], _mb(MatType.General(0, n)), _mb(MatType.General(0, 1)))
+    s = Solver(La).par(lambda p: setattr(p, "max_iter", 100_000))
+    x, _ = s.solve(socp.problem())
+    assert np.allclose(x, [2.0, 0.0], atol=1e-3)
+
+
+def test_sdp1():
+    # totsu/tests/sdp.rs:14-50
+    n, k = 2, 2
+    vec_c = _mb(MatType.General(n, 1)).iter_colmaj([1.0, 1.0])
+    syms = [_mb(MatType.SymPack(k)) for _ in range(n + 1)]
+    syms[0].set_iter_rowmaj([-1.0, 0.0, 0.0, 0.0])
+    syms[1].set_iter_rowmaj([0.0, 0.0, 0.0, -1.0])
+    syms[2].set_iter_rowmaj([3.0, 0.0, 0.0, 4.0])
+    s = Solver(La).par(lambda p: setattr(p, "max_iter", 100_000))
+    sdp = ProbSDP(vec_c, syms, _mb(MatType.General(0, n)), _mb(MatType.General(0, 1)), s.param.eps_zero)
+    x, _ = s.solve(sdp.problem())
+    assert np.allclose(x, [3.0, 4.0], atol=1e-3)
+
+
+def test_matop_sympack_and_scale_nondiag():
+    # matop.rs:180-212, matbuild/mod.rs:305-333
+    array = np.arange(1.0, 16.0)
+    ref = np.array([[1., 2., 4., 7., 11.], [2., 3., 5., 8., 12.], [4., 5., 6., 9., 13.],
+                    [7., 8., 9., 10., 14.], [11., 12., 13., 14., 15.]])
+    m = MatOp(La, MatType.SymPack(5), array)
+    for i in range(5):
+        x = np.zeros(5)
+        x[i] = 1.0
+        y = np.zeros(5)
+        m.op(1.0, La.Sl.new_ref(x), 0.0, La.Sl.new_mut(y))
+        assert np.allclose(y, ref[i], atol=1e-3)
+    full = [1., 0, 0, 0, 0, 2., 3., 0, 0, 0, 4., 5., 6., 0, 0, 7., 8., 9., 10., 0, 11., 12., 13., 14., 15.]
+    mb = _mb(MatType.SymPack(5)).iter_colmaj(full).scale_nondiag(1.4)
+    want = [1., 2. * 1.4, 3., 4. * 1.4, 5. * 1.4, 6., 7. * 1.4, 8. * 1.4, 9. * 1.4, 10.,
+            11. * 1.4, 12. * 1.4, 13. * 1.4, 14. * 1.4, 15.]
+    assert np.allclose(mb.array, want, atol=1e-3)
+
+
+def _random_socp(rng, n, cones, p=0):
+    mats_g, vecs_h, vecs_c, d = [], [], [], []
+    x0 = rng.standard_normal(n)
+    for ni in cones:
+        G = rng.standard_normal((ni, n)) / np.sqrt(n)
+        h = rng.standard_normal(ni)
+        c = rng.standard_normal(n) / np.sqrt(n)
+        mats_g.append(G)
+        vecs_h.append(h)
+        vecs_c.append(c)
+        d.append(np.linalg.norm(G @ x0 + h) - c @ x0 + rng.uniform(0.1, 1.1))
+    f = np.zeros(n)
+    for G, c in zip(mats_g, vecs_c):
+        t = rng.uniform(0.5, 1.5)
+        w = rng.standard_normal(G.shape[0])
+        w *= 0.9 * t * rng.uniform(0, 1) / max(np.linalg.norm(w), 1e-9)
+        f += t * c + G.T @ w
+    return f, mats_g, vecs_h, vecs_c, d
+
+
+def test_python_loop_matches_oracle_on_random_socp_and_dense_stacking():
+    rng = np.random.default_rng(3)
+    n, cones = 12, [3, 0, 5, 1]
+    f, Gs, hs, cs, d = _random_socp(rng, n, cones)
+    par = O.param(max_iter=3000, eps_acc=1e-7)
+    ro = O.solve_socp(par, f, Gs, hs, cs, d, np.zeros((0, n)), [], trace_cap=4000)
+
+    vec_f = _mb(MatType.General(n, 1)).set_array(f.reshape(n, 1))
+    mats_g = [_mb(MatType.General(G.shape[0], n)).set_array(G) for G in Gs]
+    vecs_h = [_mb(MatType.General(len(h), 1)).set_array(np.reshape(h, (-1, 1))) for h in hs]
+    vecs_c = [_mb(MatType.General(n, 1)).set_array(c.reshape(n, 1)) for c in cs]
+    socp = ProbSOCP(vec_f, mats_g, vecs_h, vecs_c, d, _mb(MatType.General(0, n)), _mb(MatType.General(0, 1)))
+    s = Solver(La).par(lambda p: (setattr(p, "max_iter", 3000), setattr(p, "eps_acc", 1e-7)))
+    s.trace = []
+    try:
+        x, y = s.solve(socp.problem())
+        status = O.OK
+    except SolverError as e:
+        status = e.kind
+        x = socp.w_solver[:n]
+    assert status == ro.status
+    assert s.trace[-1][0] == ro.iters
+    for a, b_ in zip(s.trace[:50], ro.trace[:50]):
+        assert a[0] == b_[0] and a[1] == b_[1]
+        assert np.allclose(a[2:], b_[2:], rtol=1e-9, atol=1e-12)
+    assert np.allclose(x, ro.x, rtol=1e-8, atol=1e-10)
+
+    # dense stacking used by the fused device loop == the block operators (socp.rs:77-130)
+    dn = socp.dense()
+    A = dn.mat_a.reshape((n, dn.m)).T
+    xx = rng.standard_normal(n)
+    yy = np.zeros(dn.m)
+    op_c, op_a, op_b, cone, work = socp.problem()
+    op_a.op(1.0, La.Sl.new_ref(xx), 0.0, La.Sl.new_mut(yy))
+    assert np.allclose(A @ xx, yy, rtol=1e-12, atol=1e-12)
+    one = np.ones(1)
+    bb = np.zeros(dn.m)
+    op_b.op(1.0, La.Sl.new_ref(one), 0.0, La.Sl.new_mut(bb))
+    assert np.allclose(dn.vec_b, bb)
+    # oracle on the stacked form gives the same iterates as on the block form
+    r2 = O.solve_matop_cones(par, dn.vec_c, dn.mat_a, dn.vec_b, dn.seg_type, dn.seg_len, trace_cap=4000)
+    assert r2.status == ro.status and r2.iters == ro.iters
+    assert np.allclose(r2.x, ro.x, rtol=1e-7, atol=1e-9)

@@ -1,0 +1,174 @@
+// thip_common.h -- internal helpers shared by the gfx950 kernels of libtotsu_f32hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "totsu_f32hip.h"
+
+namespace thip {
+
+struct Ctx {
+    bool         inited = false;
+    int          device = 0;
+    hipStream_t  own_stream = nullptr;
+    hipStream_t  stream = nullptr;       // the stream every entry point enqueues on
+    float       *scratch = nullptr;      // partial sums of the two-stage reductions / GEMV partials
+    size_t       scratch_n = 0;
+    float       *dev_scalar = nullptr;   // 64 floats of device scalars for SYNC calls
+    float       *pinned = nullptr;       // 64 floats, host-pinned
+    void        *stage = nullptr;        // pinned staging for pageable h2d
+    size_t       stage_bytes = 0;
+    int          num_cu = 256;
+};
+
+Ctx &ctx();
+int  fail(int code, const char *what, const char *file, int line);
+int  need_init();
+// returns a scratch buffer of at least n floats (grows with hipMalloc; not inside graph capture)
+int  scratch(size_t n, float **out);
+
+#define THIP_TRY(expr)                                                            \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) return ::thip::fail((int)e__, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define THIP_RC(expr)                                                             \
+    do {                                                                          \
+        int rc__ = (expr);                                                        \
+        if (rc__ != 0) return rc__;                                               \
+    } while (0)
+
+#define THIP_NEED_INIT()                                                          \
+    do {                                                                          \
+        if (!::thip::ctx().inited) return ::thip::need_init();                    \
+    } while (0)
+
+#define THIP_LAUNCH_CHECK() THIP_TRY(hipGetLastError())
+
+// ---- device helpers ---------------------------------------------------------------------
+
+// sum over the 64 lanes of a wave; result valid in every lane
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `sh` holds >= 16 floats; result in all threads
+__device__ __forceinline__ float block_sum(float v, float *sh)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float t = (lane < nw) ? sh[lane] : 0.0f;
+    t = wave_sum(t);
+    return t;
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double *sh)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum_d(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double t = (lane < nw) ? sh[lane] : 0.0;
+    t = wave_sum_d(t);
+    return t;
+}
+
+__device__ __forceinline__ float block_min(float v, float *sh)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_min(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float t = (lane < nw) ? sh[lane] : __builtin_inff();
+    t = wave_min(t);
+    return t;
+}
+
+static inline unsigned grid_for(size_t n, unsigned block, unsigned max_blocks)
+{
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (unsigned)g;
+}
+
+// ---- internal entry points shared between translation units (device pointers, stream given) ----
+// dual GEMV: optional N product (xn: n_col -> hN: n_row) and T product (xt: n_row -> gT: n_col) from
+// one pass over the column-major matrix.  Results are written as finished vectors:
+//   outN[r] = alphaN * (A xn)[r] + betaN * outN[r]      (betaN == 0: outN not read)
+//   outT[c] = alphaT * (A^T xt)[c] + betaT * outT[c]
+// abs_mode: use |A| (for absadd_*), x vectors ignored (taken as all-ones).
+int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
+              const float *xn, float alphaN, float betaN, float *outN,
+              const float *xt, float alphaT, float betaT, float *outT,
+              bool abs_mode, const int *stop_flag);
+// raw form: leaves per-chunk / per-tile partial sums in scratch and reports their geometry so that a
+// consumer kernel can fold the second reduction stage into its own pass
+struct GemvPartials {
+    const float *partN; int nN; size_t strideN;   // outN[r] = sum_{k<nN} partN[k*strideN + r]
+    const float *partT; int nT; size_t strideT;   // outT[c] = sum_{k<nT} partT[k*strideT + c]
+};
+int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
+                       const float *xn, const float *xt, bool do_n, bool do_t, bool abs_mode,
+                       float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag);
+size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col);
+
+int reduce_to_dev(hipStream_t st, int op, size_t n, const float *x, const float *y, size_t incx, float *dev_out);
+enum { RED_SUMSQ_SQRT = 0, RED_ABSSUM = 1, RED_DOT = 2 };
+
+int soc_batched(hipStream_t st, float *x, const int64_t *dev_begs, const int64_t *dev_ends, size_t n_cones,
+                int rotated, size_t max_len, const int *stop);
+int group_min_batched(hipStream_t st, float *t, const int64_t *dev_begs, const int64_t *dev_ends, size_t n_groups,
+                      size_t max_len);
+
+int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale_diag, float eps_zero,
+                    float *work, size_t worklen, int map_kind, const int *stop);
+
+// counter-based generator, identical integer function to oracle/totsu_oracle.c:oc_rng_hash
+__host__ __device__ __forceinline__ uint64_t rng_hash(uint64_t seed, uint64_t stream, uint64_t idx)
+{
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + stream * 0xD1B54A32D192ED03ull + idx * 0xBF58476D1CE4E5B9ull
+                 + 0x94D049BB133111EBull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return z;
+}
+__host__ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t stream, uint64_t idx)
+{
+    return (float)(rng_hash(seed, stream, idx) >> 40) * (1.0f / 16777216.0f);
+}
+__host__ __device__ __forceinline__ float rng_normal(uint64_t seed, uint64_t stream, uint64_t idx)
+{
+    const uint64_t h = rng_hash(seed, stream, idx);
+    const uint32_t s = (uint32_t)(h & 0xFFFF) + (uint32_t)((h >> 16) & 0xFFFF)
+                     + (uint32_t)((h >> 32) & 0xFFFF) + (uint32_t)((h >> 48) & 0xFFFF);
+    return ((float)((int32_t)s - 131070) * (1.0f / 65536.0f)) * 1.7320508f;
+}
+
+}  // namespace thip

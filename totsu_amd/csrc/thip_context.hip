@@ -1,0 +1,198 @@
+// thip_context.hip -- context, stream, device memory and host<->device transfers.
+// Replaces totsu_f32cuda/src/cuda_mgr.rs (context + library handles) and the host/device mirroring
+// primitives of totsu_f32cuda/src/f32cuda_slice.rs:343-355.
+#include "thip_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+namespace thip {
+
+static Ctx g_ctx;
+static char g_err[512] = "";
+
+Ctx &ctx() { return g_ctx; }
+
+int fail(int code, const char *what, const char *file, int line)
+{
+    const char *hs = (code > 0 && code < 10000) ? hipGetErrorString((hipError_t)code) : "thip error";
+    snprintf(g_err, sizeof(g_err), "%s:%d: %s -> %d (%s)", file, line, what, code, hs);
+    return code;
+}
+
+int need_init()
+{
+    return fail(THIP_E_NOTINIT, "thip_init() has not been called (or found no GPU)", __FILE__, __LINE__);
+}
+
+int scratch(size_t n, float **out)
+{
+    Ctx &c = ctx();
+    if (n > c.scratch_n) {
+        // grow geometrically; callers size the scratch before entering a hot loop
+        size_t want = n + n / 4 + 1024;
+        float *p = nullptr;
+        THIP_TRY(hipStreamSynchronize(c.stream));
+        THIP_TRY(hipMalloc((void **)&p, want * sizeof(float)));
+        if (c.scratch) THIP_TRY(hipFree(c.scratch));
+        c.scratch = p;
+        c.scratch_n = want;
+    }
+    *out = c.scratch;
+    return 0;
+}
+
+}  // namespace thip
+
+using namespace thip;
+
+extern "C" {
+
+const char *thip_last_error(void) { return g_err; }
+const char *thip_version(void) { return "totsu_f32hip 0.1 (gfx950)"; }
+
+int thip_device_count(int *host_count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (host_count) *host_count = n;
+    return 0;
+}
+
+int thip_init(int device)
+{
+    Ctx &c = ctx();
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(THIP_E_NOGPU, "no HIP device visible: totsu_f32hip has no CPU fallback", __FILE__, __LINE__);
+    if (device < 0 || device >= n) return fail(THIP_E_INVALID, "device index out of range", __FILE__, __LINE__);
+    if (c.inited && c.device == device) return 0;
+    if (c.inited) thip_shutdown();
+    THIP_TRY(hipSetDevice(device));
+    c.device = device;
+    THIP_TRY(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    c.stream = c.own_stream;
+    THIP_TRY(hipMalloc((void **)&c.dev_scalar, 64 * sizeof(float)));
+    THIP_TRY(hipHostMalloc((void **)&c.pinned, 64 * sizeof(float), hipHostMallocDefault));
+    c.stage_bytes = 8u << 20;
+    THIP_TRY(hipHostMalloc(&c.stage, c.stage_bytes, hipHostMallocDefault));
+    hipDeviceProp_t prop;
+    THIP_TRY(hipGetDeviceProperties(&prop, device));
+    c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c.inited = true;
+    return 0;
+}
+
+int thip_shutdown(void)
+{
+    Ctx &c = ctx();
+    if (!c.inited) return 0;
+    hipSetDevice(c.device);
+    hipStreamSynchronize(c.stream);
+    if (c.scratch) hipFree(c.scratch);
+    if (c.dev_scalar) hipFree(c.dev_scalar);
+    if (c.pinned) hipHostFree(c.pinned);
+    if (c.stage) hipHostFree(c.stage);
+    if (c.own_stream) hipStreamDestroy(c.own_stream);
+    c = Ctx();
+    return 0;
+}
+
+int thip_set_stream(void *hip_stream)
+{
+    THIP_NEED_INIT();
+    Ctx &c = ctx();
+    c.stream = hip_stream ? (hipStream_t)hip_stream : c.own_stream;
+    return 0;
+}
+
+void *thip_get_stream(void) { return (void *)ctx().stream; }
+
+int thip_sync(void)
+{
+    THIP_NEED_INIT();
+    THIP_TRY(hipStreamSynchronize(ctx().stream));
+    return 0;
+}
+
+int thip_alloc(size_t n, float **out)
+{
+    THIP_NEED_INIT();
+    if (!out) return fail(THIP_E_INVALID, "out == NULL", __FILE__, __LINE__);
+    *out = nullptr;
+    // never hand out a NULL for n == 0: zero-length slices are legal and may be offset
+    THIP_TRY(hipMalloc((void **)out, (n ? n : 1) * sizeof(float)));
+    return 0;
+}
+
+int thip_alloc_zeroed(size_t n, float **out)
+{
+    THIP_RC(thip_alloc(n, out));
+    THIP_TRY(hipMemsetAsync(*out, 0, (n ? n : 1) * sizeof(float), ctx().stream));
+    return 0;
+}
+
+int thip_free(float *p)
+{
+    THIP_NEED_INIT();
+    if (!p) return 0;
+    THIP_TRY(hipStreamSynchronize(ctx().stream));
+    THIP_TRY(hipFree(p));
+    return 0;
+}
+
+int thip_h2d(float *dst, const float *host_src, size_t n)
+{
+    THIP_NEED_INIT();
+    if (n == 0) return 0;
+    Ctx &c = ctx();
+    // pageable source: stage through pinned memory in chunks so the call is safe to return from
+    const char *src = (const char *)host_src;
+    char *d = (char *)dst;
+    size_t bytes = n * sizeof(float);
+    while (bytes) {
+        const size_t b = bytes < c.stage_bytes ? bytes : c.stage_bytes;
+        THIP_TRY(hipStreamSynchronize(c.stream));   // staging buffer reuse
+        memcpy(c.stage, src, b);
+        THIP_TRY(hipMemcpyAsync(d, c.stage, b, hipMemcpyHostToDevice, c.stream));
+        src += b; d += b; bytes -= b;
+    }
+    THIP_TRY(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+int thip_d2h(float *host_dst, const float *src, size_t n)
+{
+    THIP_NEED_INIT();
+    if (n == 0) return 0;
+    Ctx &c = ctx();
+    THIP_TRY(hipMemcpyAsync(host_dst, src, n * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    THIP_TRY(hipStreamSynchronize(c.stream));
+    return 0;
+}
+
+int thip_get(const float *x, size_t idx, float *host_out)
+{
+    THIP_NEED_INIT();
+    Ctx &c = ctx();
+    THIP_TRY(hipMemcpyAsync(c.pinned, x + idx, sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    THIP_TRY(hipStreamSynchronize(c.stream));
+    *host_out = c.pinned[0];
+    return 0;
+}
+
+__global__ void set_kernel(float *x, float v) { x[0] = v; }
+
+int thip_set(float *x, size_t idx, float val)
+{
+    THIP_NEED_INIT();
+    hipLaunchKernelGGL(set_kernel, dim3(1), dim3(1), 0, ctx().stream, x + idx, val);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,407 @@
+// thip_gemv.hip -- dense GEMV on a column-major matrix for gfx950: the >99 %-of-bytes kernel of the
+// conic iteration.  Replaces cublasSgemv at totsu_f32cuda/src/f32cuda.rs:144-171
+// (semantic spec totsu_core/src/floatgeneric.rs:331-353) and MatOp::absadd_impl's per-column / per-row
+// asum loops (totsu_core/src/matop.rs:98-117).
+//
+// One kernel template does y_N = A x_N and y_T = A^T x_T from ONE read of A ("dual GEMV"): the two
+// products of SelfDualEmbed::op / ::trans_op / criteria_conv take independent inputs
+// (solver.rs:122 vs 125, 146 vs 149, 594 vs 597), so a tile fetched for one is reused for the other.
+//
+// Tiling (HBM-bound: 0.5 flop/byte, so no LDS staging of A and no MFMA -- A streams straight to VGPRs):
+//   block = 256 threads (4 waves); a block owns TILE = 256*VW*NJ consecutive rows and a chunk of columns;
+//   lane t holds rows r0 + j*256*VW + t*VW + k  (k < VW, j < NJ): a wave-load is 64 x 16 B = 1 KiB
+//   contiguous, the 4 waves cover 4 KiB contiguous of one column, KU columns are in flight (>= 8 loads
+//   of 16 B per lane before the first use);
+//   N: per-lane accumulators over the chunk's columns -> partial vector per chunk (float4 stores);
+//   T: per-column partial dot over the lane's rows, KU columns reduced across the wave with a
+//      transpose-reduce butterfly (K values on 64 lanes -> K sums in K+3 shuffles instead of 6K),
+//      4 waves combined through LDS -> partial vector per row tile.
+// The second reduction stage (over chunks / tiles) is deterministic: a finalize kernel, or folded into
+// the consumer kernel of the fused iteration (thip_solver.hip).
+#include "thip_common.h"
+
+using namespace thip;
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int MAXCW = 1024;   // max columns per chunk (LDS: 4 waves x MAXCW floats = 16 KiB)
+
+template <int K, int O>
+__device__ __forceinline__ void halve(float *v, int lane)
+{
+    const bool hi = (lane & O) != 0;
+#pragma unroll
+    for (int i = 0; i < K / 2; ++i) {
+        const float send = hi ? v[i] : v[i + K / 2];
+        const float keep = hi ? v[i + K / 2] : v[i];
+        v[i] = keep + __shfl_xor(send, O, 64);
+    }
+}
+
+// K per-lane values on 64 lanes -> the K wave-wide sums; the lanes with (lane & (64/K - 1)) == 0 and
+// (lane >> (6 - log2 K)) == c hold sum c (in fact every lane of that group does)
+template <int K>
+__device__ __forceinline__ float multi_reduce(float *v, int lane)
+{
+    if constexpr (K == 8) {
+        halve<8, 32>(v, lane); halve<4, 16>(v, lane); halve<2, 8>(v, lane);
+        float r = v[0];
+        r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
+        return r;
+    } else if constexpr (K == 4) {
+        halve<4, 32>(v, lane); halve<2, 16>(v, lane);
+        float r = v[0];
+        r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
+        return r;
+    } else if constexpr (K == 2) {
+        halve<2, 32>(v, lane);
+        float r = v[0];
+        r += __shfl_xor(r, 16, 64); r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 4, 64);
+        r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
+        return r;
+    } else {
+        return wave_sum(v[0]);
+    }
+}
+
+template <int K> struct Log2;
+template <> struct Log2<1> { static constexpr int v = 0; };
+template <> struct Log2<2> { static constexpr int v = 1; };
+template <> struct Log2<4> { static constexpr int v = 2; };
+template <> struct Log2<8> { static constexpr int v = 3; };
+
+template <int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS>
+__device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, int m, int r_first, int c, int cc,
+                                     const float *__restrict__ xn, const float (&xtv)[NJ][VW],
+                                     float (&accN)[NJ][VW], float *ldsT_wave, int lane)
+{
+    float av[K][NJ][VW];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const float *col = A + (size_t)(c + u) * lda;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = r_first + j * (BLK * VW);
+            if constexpr (VW == 4) {
+                if (r + 4 <= m) {
+                    const float4 q = *reinterpret_cast<const float4 *>(col + r);
+                    av[u][j][0] = q.x; av[u][j][1] = q.y; av[u][j][2] = q.z; av[u][j][3] = q.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) av[u][j][k] = (r + k < m) ? col[r + k] : 0.0f;
+                }
+            } else {
+                av[u][j][0] = (r < m) ? col[r] : 0.0f;
+            }
+        }
+    }
+    if constexpr (ABS) {
+#pragma unroll
+        for (int u = 0; u < K; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < VW; ++k) av[u][j][k] = fabsf(av[u][j][k]);
+    }
+    if constexpr (DO_N) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const float xs = ABS ? 1.0f : xn[c + u];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < VW; ++k) accN[j][k] = fmaf(av[u][j][k], xs, accN[j][k]);
+        }
+    }
+    if constexpr (DO_T) {
+        float p[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int k = 0; k < VW; ++k) s = fmaf(av[u][j][k], xtv[j][k], s);
+            p[u] = s;
+        }
+        const float r = multi_reduce<K>(p, lane);
+        constexpr int SH = 6 - Log2<K>::v;
+        if ((lane & ((64 >> Log2<K>::v) - 1)) == 0) ldsT_wave[cc + (lane >> SH)] = r;
+    }
+}
+
+template <int VW, int NJ, int KU, bool DO_N, bool DO_T, bool ABS>
+__global__ __launch_bounds__(BLK) void dual_gemv_k(const float *__restrict__ A, size_t lda, int m, int n,
+                                                   const float *__restrict__ xn, const float *__restrict__ xt,
+                                                   float *__restrict__ partN, size_t strideN,
+                                                   float *__restrict__ partT, size_t strideT,
+                                                   int cols_per_chunk, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    __shared__ float ldsT[DO_T ? 4 * MAXCW : 4];
+
+    constexpr int TILE = BLK * VW * NJ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, chunk = blockIdx.y;
+    const int r_first = tile * TILE + tid * VW;
+    const int c0 = chunk * cols_per_chunk;
+    const int c1 = min(n, c0 + cols_per_chunk);
+
+    float xtv[NJ][VW];
+    float accN[NJ][VW];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+            const int r = r_first + j * (BLK * VW) + k;
+            accN[j][k] = 0.0f;
+            xtv[j][k] = (DO_T && r < m) ? (ABS ? 1.0f : xt[r]) : 0.0f;
+        }
+
+    float *ldsT_wave = ldsT + wave * (DO_T ? MAXCW : 1);
+    int c = c0;
+    for (; c + KU <= c1; c += KU)
+        step<VW, NJ, KU, DO_N, DO_T, ABS>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+    for (; c < c1; ++c)
+        step<VW, NJ, 1, DO_N, DO_T, ABS>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+
+    if constexpr (DO_N) {
+        float *dst = partN + (size_t)chunk * strideN;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = r_first + j * (BLK * VW);
+            if constexpr (VW == 4) {
+                if (r + 4 <= m) {
+                    *reinterpret_cast<float4 *>(dst + r) = make_float4(accN[j][0], accN[j][1], accN[j][2], accN[j][3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (r + k < m) dst[r + k] = accN[j][k];
+                }
+            } else {
+                if (r < m) dst[r] = accN[j][0];
+            }
+        }
+    }
+    if constexpr (DO_T) {
+        __syncthreads();
+        float *dst = partT + (size_t)tile * strideT + c0;
+        for (int t = tid; t < c1 - c0; t += BLK)
+            dst[t] = (ldsT[t] + ldsT[MAXCW + t]) + (ldsT[2 * MAXCW + t] + ldsT[3 * MAXCW + t]);
+    }
+}
+
+// second stage: y[i] = alpha * sum_k part[k*stride + i] + beta * y[i]
+__global__ void finalize_k(size_t n, const float *__restrict__ part, int np, size_t stride, float alpha, float beta,
+                           float *__restrict__ y, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+        float s = 0.0f;
+        for (int k = 0; k < np; ++k) s += part[(size_t)k * stride + i];
+        y[i] = (beta == 0.0f) ? alpha * s : alpha * s + beta * y[i];
+    }
+}
+
+// y = alpha * S x + beta * y, S packed upper by columns (floatgeneric.rs:356-376).  One wave per row.
+__global__ void spmv_k(int n, float alpha, const float *__restrict__ sp, const float *__restrict__ x, float beta,
+                       float *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float s = 0.0f;
+    // c <= r: element (c, r) of column r: idx = r(r+1)/2 + c  (contiguous)
+    const size_t base = (size_t)r * (r + 1) / 2;
+    for (int c = lane; c <= r; c += 64) s = fmaf(sp[base + c], x[c], s);
+    // c > r: element (r, c) of column c: idx = c(c+1)/2 + r
+    for (int c = r + 1 + lane; c < n; c += 64) s = fmaf(sp[(size_t)c * (c + 1) / 2 + r], x[c], s);
+    s = wave_sum(s);
+    if (lane == 0) y[r] = (beta == 0.0f) ? alpha * s : alpha * s + beta * y[r];
+}
+
+// SymPack absadd (matop.rs:119-136): y[i] += sum_j |S(i,j)| over the full symmetric matrix
+__global__ void sp_absadd_k(int n, const float *__restrict__ sp, float *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float s = 0.0f;
+    const size_t base = (size_t)r * (r + 1) / 2;
+    for (int c = lane; c <= r; c += 64) s += fabsf(sp[base + c]);
+    for (int c = r + 1 + lane; c < n; c += 64) s += fabsf(sp[(size_t)c * (c + 1) / 2 + r]);
+    s = wave_sum(s);
+    if (lane == 0) y[r] = y[r] + s;
+}
+
+struct Plan {
+    int vw, nj, ku;
+    int tiles, chunks, cols_per_chunk;
+    size_t strideN, strideT;
+};
+
+static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+Plan make_plan(size_t n_row, size_t n_col, bool vec_ok)
+{
+    Plan p;
+    p.vw = vec_ok ? 4 : 1;
+    if (vec_ok) {
+        if (n_row >= (size_t)BLK * 16 * 6) { p.nj = 4; p.ku = 2; }
+        else if (n_row >= (size_t)BLK * 8 * 4) { p.nj = 2; p.ku = 4; }
+        else { p.nj = 1; p.ku = 8; }
+    } else {
+        if (n_row >= (size_t)BLK * 4 * 4) { p.nj = 4; p.ku = 4; }
+        else { p.nj = 1; p.ku = 8; }
+    }
+    const size_t tile = (size_t)BLK * p.vw * p.nj;
+    p.tiles = (int)((n_row + tile - 1) / tile);
+    // aim at ~8 blocks per CU over 256 CUs, chunk width in [KU, MAXCW]
+    const int target_blocks = 2048;
+    int chunks = (target_blocks + p.tiles - 1) / p.tiles;
+    int cpc = (int)((n_col + chunks - 1) / chunks);
+    if (cpc < 32) cpc = 32;
+    if (cpc > MAXCW) cpc = MAXCW;
+    cpc = (int)round_up(cpc, 8);
+    if (cpc > MAXCW) cpc = MAXCW;
+    p.cols_per_chunk = cpc;
+    p.chunks = (int)((n_col + cpc - 1) / cpc);
+    p.strideN = round_up(n_row, 4);
+    p.strideT = round_up(n_col, 4);
+    return p;
+}
+
+template <bool DO_N, bool DO_T, bool ABS>
+void launch_cfg(const Plan &p, hipStream_t st, const float *A, size_t lda, int m, int n, const float *xn,
+                const float *xt, float *partN, float *partT, const int *stop)
+{
+    dim3 g(p.tiles, p.chunks), b(BLK);
+#define THIP_GEMV_LAUNCH(VW, NJ, KU)                                                                      \
+    hipLaunchKernelGGL((dual_gemv_k<VW, NJ, KU, DO_N, DO_T, ABS>), g, b, 0, st, A, lda, m, n, xn, xt, partN, \
+                       p.strideN, partT, p.strideT, p.cols_per_chunk, stop)
+    if (p.vw == 4) {
+        if (p.nj == 4) THIP_GEMV_LAUNCH(4, 4, 2);
+        else if (p.nj == 2) THIP_GEMV_LAUNCH(4, 2, 4);
+        else THIP_GEMV_LAUNCH(4, 1, 8);
+    } else {
+        if (p.nj == 4) THIP_GEMV_LAUNCH(1, 4, 4);
+        else THIP_GEMV_LAUNCH(1, 1, 8);
+    }
+#undef THIP_GEMV_LAUNCH
+}
+
+}  // namespace
+
+namespace thip {
+
+size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col)
+{
+    const Plan a = make_plan(n_row, n_col, true), b = make_plan(n_row, n_col, false);
+    const size_t fa = (size_t)a.chunks * a.strideN + (size_t)a.tiles * a.strideT;
+    const size_t fb = (size_t)b.chunks * b.strideN + (size_t)b.tiles * b.strideT;
+    return (fa > fb ? fa : fb) + 64;
+}
+
+int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
+                       const float *xn, const float *xt, bool do_n, bool do_t, bool abs_mode,
+                       float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag)
+{
+    if (n_row == 0 || n_col == 0 || (!do_n && !do_t)) {
+        out->partN = out->partT = nullptr; out->nN = out->nT = 0; out->strideN = out->strideT = 0;
+        return 0;
+    }
+    if (n_row > 0x7fffffffull || n_col > 0x7fffffffull) return fail(THIP_E_INVALID, "matrix dimension > 2^31", __FILE__, __LINE__);
+    const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (lda % 4 == 0);
+    const Plan p = make_plan(n_row, n_col, vec_ok);
+    const size_t needN = do_n ? (size_t)p.chunks * p.strideN : 0;
+    const size_t needT = do_t ? (size_t)p.tiles * p.strideT : 0;
+    if (needN + needT > scratch_floats) return fail(THIP_E_WORK, "gemv scratch too small", __FILE__, __LINE__);
+    float *partN = scratch_base;
+    float *partT = scratch_base + needN;
+    const int m = (int)n_row, n = (int)n_col;
+    if (abs_mode) {
+        if (do_n && do_t) launch_cfg<true, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        else if (do_n)    launch_cfg<true, false, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        else              launch_cfg<false, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+    } else {
+        if (do_n && do_t) launch_cfg<true, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        else if (do_n)    launch_cfg<true, false, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        else              launch_cfg<false, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+    }
+    THIP_LAUNCH_CHECK();
+    out->partN = do_n ? partN : nullptr; out->nN = do_n ? p.chunks : 0; out->strideN = p.strideN;
+    out->partT = do_t ? partT : nullptr; out->nT = do_t ? p.tiles : 0;  out->strideT = p.strideT;
+    return 0;
+}
+
+int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
+              const float *xn, float alphaN, float betaN, float *outN,
+              const float *xt, float alphaT, float betaT, float *outT,
+              bool abs_mode, const int *stop_flag)
+{
+    const bool do_n = outN != nullptr, do_t = outT != nullptr;
+    float *scr = nullptr;
+    const size_t need = dual_gemv_scratch_floats(n_row, n_col);
+    THIP_RC(scratch(need, &scr));
+    GemvPartials gp;
+    THIP_RC(dual_gemv_partials(st, n_row, n_col, mat, lda, xn, xt, do_n, do_t, abs_mode, scr, need, &gp, stop_flag));
+    if (do_n && n_row)
+        hipLaunchKernelGGL(finalize_k, dim3(grid_for(n_row, BLK, 2048)), dim3(BLK), 0, st, n_row, gp.partN, gp.nN,
+                           gp.strideN, alphaN, betaN, outN, stop_flag);
+    if (do_t && n_col)
+        hipLaunchKernelGGL(finalize_k, dim3(grid_for(n_col, BLK, 2048)), dim3(BLK), 0, st, n_col, gp.partT, gp.nT,
+                           gp.strideT, alphaT, betaT, outT, stop_flag);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace thip
+
+extern "C" {
+
+int thip_transform_ge(int transpose, size_t n_row, size_t n_col, float alpha, const float *mat, const float *x,
+                      float beta, float *y)
+{
+    THIP_NEED_INIT();
+    // zero-sized operands: MatOp::op_impl never calls transform_ge then (matop.rs:79-85); be lenient anyway
+    const size_t ylen = transpose ? n_col : n_row;
+    if (ylen == 0) return 0;
+    if (n_row == 0 || n_col == 0) return thip_scale(ylen, beta, y);
+    if (transpose)
+        return dual_gemv(ctx().stream, n_row, n_col, mat, n_row, nullptr, 0.f, 0.f, nullptr, x, alpha, beta, y, false, nullptr);
+    return dual_gemv(ctx().stream, n_row, n_col, mat, n_row, x, alpha, beta, y, nullptr, 0.f, 0.f, nullptr, false, nullptr);
+}
+
+int thip_absadd_cols(size_t n_row, size_t n_col, const float *mat, float *tau)
+{
+    THIP_NEED_INIT();
+    if (n_row == 0 || n_col == 0) return 0;
+    return dual_gemv(ctx().stream, n_row, n_col, mat, n_row, nullptr, 0.f, 0.f, nullptr, nullptr, 1.0f, 1.0f, tau, true, nullptr);
+}
+
+int thip_absadd_rows(size_t n_row, size_t n_col, const float *mat, float *sigma)
+{
+    THIP_NEED_INIT();
+    if (n_row == 0 || n_col == 0) return 0;
+    return dual_gemv(ctx().stream, n_row, n_col, mat, n_row, nullptr, 1.0f, 1.0f, sigma, nullptr, 0.f, 0.f, nullptr, true, nullptr);
+}
+
+int thip_transform_sp(size_t n, float alpha, const float *mat, const float *x, float beta, float *y)
+{
+    THIP_NEED_INIT();
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(spmv_k, dim3((unsigned)((n + 3) / 4)), dim3(BLK), 0, ctx().stream, (int)n, alpha, mat, x, beta, y);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int thip_absadd_sympack(size_t n, const float *mat, float *y)
+{
+    THIP_NEED_INIT();
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sp_absadd_k, dim3((unsigned)((n + 3) / 4)), dim3(BLK), 0, ctx().stream, (int)n, mat, y);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

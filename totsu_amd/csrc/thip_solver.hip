@@ -1,0 +1,793 @@
+// thip_solver.hip -- the conic iteration resident on the GPU.
+//
+// Native restatement of totsu_core/src/solver/solver.rs:340-657 (SolverCore::{solve, calc_norms, init_vecs,
+// calc_precond, update_vecs, criteria_conv, criteria_inf}) and of SelfDualEmbed::{op, trans_op, abssum}
+// (solver.rs:109-183) for operators that are dense column-major matrices (MatOp, matop.rs) and a product
+// cone of zero / nonneg / second-order / rotated second-order / PSD blocks (cone_*.rs).
+//
+// Differences from the reference are of SCHEDULE only:
+//   * state vectors, tau, kappa, the dots and norms and the termination test stay on the device; the host
+//     enqueues iterations back to back and polls a status word (the reference reads >= 8 scalars per
+//     iteration through SliceLike::get, solver.rs:551-567,599-608).  Once the device has decided to stop,
+//     every later kernel returns immediately, so the result is that of stopping at exactly that iteration;
+//   * THIP_SCHED_FUSED: the A x and A^T y products of one stage come from one read of A (dual GEMV);
+//   * THIP_SCHED_CARRIED: K*rx is obtained from the criteria products by linearity, rx = x_k - 2 x_{k+1}
+//     (solver.rs:555) => A rx_x = (A x_k) - 2 (A x_{k+1}); both right-hand products are recomputed from the
+//     iterate every iteration (no recursion, no drift);
+//   * THIP_SCHED_REFERENCE issues the reference's six single GEMVs.
+// Row-sharded A (one process per GPU): every m-length vector is sharded like the rows, every n-length
+// vector is replicated; the only exchange is a sum-all-reduce of the n-vector A_g^T y_g (with the sharded
+// scalars riding in its tail) per transposed product.
+#include "thip_common.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace thip;
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int TAIL = 8;          // scalars riding behind an n-vector through the all-reduce
+constexpr unsigned EG = 512;     // max blocks of the elementwise kernels (block partials per quantity)
+
+// device status block (copied whole to the host when polling)
+struct DevStatus {
+    int       stop;              // != 0: every kernel returns at entry
+    int       state;             // THIP_ST_*
+    int       kind;
+    int       pad;
+    long long iter;              // index of the iteration being / last executed
+    float     cri[3];
+    float     tau, kappa;
+    float     norm_b, norm_c;
+    float     t_tau, s_kappa;    // preconditioner entries of tau / kappa
+    float     r_tau;             // rx_tau
+    float     pad2[2];
+};
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+
+// sum of `np` block partials of `nq` quantities (part[q*np + k]) -> out[q]; one block
+__global__ void sum_partials_k(int nq, int np, const float *__restrict__ part, float *__restrict__ out,
+                               const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    __shared__ double shd[16];
+    for (int q = 0; q < nq; ++q) {
+        double acc = 0.0;
+        for (int k = threadIdx.x; k < np; k += blockDim.x) acc += (double)part[(size_t)q * np + k];
+        acc = block_sum_d(acc, shd);
+        if (threadIdx.x == 0) out[q] = (float)acc;
+        __syncthreads();
+    }
+}
+
+// two dot products in one launch: q0 = a0.b0 over n0 (block partials part[0..G)), q1 = a1.b1 over n1
+__global__ void dots2_k(size_t n0, const float *__restrict__ a0, const float *__restrict__ b0,
+                        size_t n1, const float *__restrict__ a1, const float *__restrict__ b1,
+                        float *__restrict__ part, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    __shared__ float sh[16];
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    float s0 = 0.0f, s1 = 0.0f;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n0; i += gstride) s0 = fmaf(a0[i], b0[i], s0);
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n1; i += gstride) s1 = fmaf(a1[i], b1[i], s1);
+    s0 = block_sum(s0, sh);
+    s1 = block_sum(s1, sh);
+    if (threadIdx.x == 0) { part[blockIdx.x] = s0; part[gridDim.x + blockIdx.x] = s1; }
+}
+
+// x-update, solver.rs:538-552 without the block cones:
+//   rx <- x ; x += T o tx with tx = -K^T y (solver.rs:541-542, SelfDualEmbed::trans_op solver.rs:133-157):
+//   x_x += Tx o ( gT + c kappa)        gT = A^T v   (after the all-reduce)
+//   x_y += Ty o (-hN + b kappa)        hN = A u
+//   x_s += Ts o ( v )
+//   tau += Ttau (-c.u - b.v) ; tau <- max(tau, 0)
+// and the element-wise cones folded in: cls 0 = zero cone (dual: identity, primal: 0; cone_zero.rs:38-44),
+// cls 1 = nonneg (max(.,0) for both; cone_rpos.rs:38-45), cls 2 = member of a block cone (projected later).
+__global__ void xupdate_k(int n, int m, const float *__restrict__ gT, const float *__restrict__ hN,
+                          const float *__restrict__ c, const float *__restrict__ b,
+                          const float *__restrict__ v, const float *__restrict__ Tx, const float *__restrict__ Ty,
+                          const float *__restrict__ Ts, const unsigned char *__restrict__ cls,
+                          float *__restrict__ xx, float *__restrict__ xy, float *__restrict__ xs,
+                          float *__restrict__ rxx, float *__restrict__ rxy, float *__restrict__ rxs,
+                          const float *__restrict__ dot_c, const float *__restrict__ dot_b, DevStatus *st)
+{
+    if (st->stop != 0) return;
+    const float kappa = st->kappa;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
+        const float old = xx[i];
+        rxx[i] = old;
+        xx[i] = old + Tx[i] * (gT[i] + c[i] * kappa);
+    }
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
+        const unsigned char k = cls[i];
+        const float oy = xy[i], os = xs[i];
+        rxy[i] = oy;
+        rxs[i] = os;
+        float ny = oy + Ty[i] * (b[i] * kappa - hN[i]);
+        float ns = os + Ts[i] * v[i];
+        if (k == 1) { ny = fmaxf(ny, 0.0f); ns = fmaxf(ns, 0.0f); }
+        else if (k == 0) { ns = 0.0f; }
+        xy[i] = ny;
+        xs[i] = ns;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // every other block only reads st->kappa / st->stop; tau is written by this thread alone
+        const float old = st->tau;
+        float t = old + st->t_tau * (-(dot_c[0]) - dot_b[0]);
+        t = fmaxf(t, 0.0f);               // solver.rs:551-552
+        st->r_tau = old;
+        st->tau = t;
+    }
+}
+
+// rx <- rx - 2 x  (solver.rs:555), after the projections
+__global__ void rx_k(int n, int m, const float *__restrict__ xx, const float *__restrict__ xy,
+                     const float *__restrict__ xs, float *__restrict__ rxx, float *__restrict__ rxy,
+                     float *__restrict__ rxs, DevStatus *st)
+{
+    if (st->stop != 0) return;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) rxx[i] = rxx[i] - 2.0f * xx[i];
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
+        rxy[i] = rxy[i] - 2.0f * xy[i];
+        rxs[i] = rxs[i] - 2.0f * xs[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->r_tau = st->r_tau - 2.0f * st->tau;
+}
+
+// carried schedule: h2 = hP - 2 h3, g2 = gP - 2 g3 (then the new criteria products become the previous)
+__global__ void carried_k(int n, int m, const float *__restrict__ g3, const float *__restrict__ h3,
+                          float *__restrict__ gP, float *__restrict__ hP, float *__restrict__ g2,
+                          float *__restrict__ h2, const DevStatus *st)
+{
+    if (st->stop != 0) return;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
+        const float nw = g3[i];
+        g2[i] = gP[i] - 2.0f * nw;
+        gP[i] = nw;
+    }
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
+        const float nw = h3[i];
+        h2[i] = hP[i] - 2.0f * nw;
+        hP[i] = nw;
+    }
+}
+
+// y-update, solver.rs:557-567 with ty = -K rx (SelfDualEmbed::op solver.rs:109-131):
+//   u += Su o (-g2 - c rtau)          g2 = A^T rx_y (after the all-reduce)
+//   v += Sv o ( h2 + rx_s - b rtau)   h2 = A rx_x
+//   kappa += Skappa (c.rx_x + b.rx_y) ; kappa <- min(kappa, 0)
+__global__ void yupdate_k(int n, int m, const float *__restrict__ g2, const float *__restrict__ h2,
+                          const float *__restrict__ c, const float *__restrict__ b, const float *__restrict__ rxs,
+                          const float *__restrict__ Su, const float *__restrict__ Sv, float *__restrict__ u,
+                          float *__restrict__ v, const float *__restrict__ dot_c, const float *__restrict__ dot_b,
+                          DevStatus *st)
+{
+    if (st->stop != 0) return;
+    const float rtau = st->r_tau;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride)
+        u[i] = u[i] + Su[i] * (-g2[i] - c[i] * rtau);
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride)
+        v[i] = v[i] + Sv[i] * (h2[i] + rxs[i] - b[i] * rtau);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float k = st->kappa + st->s_kappa * (dot_c[0] + dot_b[0]);
+        st->kappa = fminf(k, 0.0f);       // solver.rs:566-567
+    }
+}
+
+// criteria, m-part (sharded): block partials of ||p||^2 and b.x_y
+//   tau > eps_zero: p = x_s/tau - b + (A x_x)/tau  (solver.rs:592-594) ; else p = x_s + A x_x (solver.rs:631-632)
+__global__ void crit_m_k(int m, const float *__restrict__ h3, const float *__restrict__ xs,
+                         const float *__restrict__ xy, const float *__restrict__ b, float eps_zero,
+                         float *__restrict__ part, const DevStatus *st)
+{
+    if (st->stop != 0) return;
+    __shared__ float sh[16];
+    const float tau = st->tau;
+    const bool conv = tau > eps_zero;
+    const float rt = conv ? 1.0f / tau : 1.0f;
+    float pp = 0.0f, by = 0.0f;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
+        const float bi = b[i];
+        float p;
+        if (conv) { p = xs[i] * rt - bi; p = fmaf(rt, h3[i], p); }
+        else p = xs[i] + h3[i];
+        pp = fmaf(p, p, pp);
+        by = fmaf(bi, xy[i], by);
+    }
+    pp = block_sum(pp, sh);
+    by = block_sum(by, sh);
+    if (threadIdx.x == 0) { part[blockIdx.x] = pp; part[gridDim.x + blockIdx.x] = by; }
+}
+
+// criteria, n-part (replicated): ||d||^2 and c.x_x ;  d = c + (A^T x_y)/tau (solver.rs:596-597) or A^T x_y (:634)
+__global__ void crit_n_k(int n, const float *__restrict__ g3, const float *__restrict__ xx,
+                         const float *__restrict__ c, float eps_zero, float *__restrict__ part, const DevStatus *st)
+{
+    if (st->stop != 0) return;
+    __shared__ float sh[16];
+    const float tau = st->tau;
+    const bool conv = tau > eps_zero;
+    const float rt = conv ? 1.0f / tau : 1.0f;
+    float dd = 0.0f, cx = 0.0f;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
+        const float ci = c[i];
+        const float d = conv ? fmaf(rt, g3[i], ci) : g3[i];
+        dd = fmaf(d, d, dd);
+        cx = fmaf(ci, xx[i], cx);
+    }
+    dd = block_sum(dd, sh);
+    cx = block_sum(cx, sh);
+    if (threadIdx.x == 0) { part[blockIdx.x] = dd; part[gridDim.x + blockIdx.x] = cx; }
+}
+
+// the termination test, solver.rs:381-451 + the tails of criteria_conv / criteria_inf (solver.rs:599-611,
+// 636-655).  One thread.  sums: pp_by[0] = ||p||^2, pp_by[1] = b.x_y (all-reduced), dd_cx[0] = ||d||^2,
+// dd_cx[1] = c.x_x.
+__global__ void status_k(const float *__restrict__ pp_by, const float *__restrict__ dd_cx, float eps_acc,
+                         float eps_inf, float eps_zero, long long max_iter, DevStatus *st)
+{
+    if (st->stop != 0) return;
+    const long long i = st->iter;
+    const bool excess_iter = (max_iter >= 0) ? (i + 1 >= max_iter) : false;
+    const float tau = st->tau;
+    const float norm_p = sqrtf(pp_by[0]), norm_d = sqrtf(dd_cx[0]);
+    int state = THIP_ST_RUNNING;
+    if (tau > eps_zero) {
+        const float rt = 1.0f / tau;
+        const float g_x = rt * dd_cx[1];
+        const float g_y = rt * pp_by[1];
+        const float g = g_x + g_y;
+        const float cri_pri = norm_p / (1.0f + st->norm_b);
+        const float cri_dual = norm_d / (1.0f + st->norm_c);
+        const float cri_gap = fabsf(g) / (1.0f + fabsf(g_x) + fabsf(g_y));
+        st->kind = 0; st->cri[0] = cri_pri; st->cri[1] = cri_dual; st->cri[2] = cri_gap;
+        const bool term_conv = (cri_pri <= eps_acc) && (cri_dual <= eps_acc) && (cri_gap <= eps_acc);
+        if (term_conv) state = THIP_ST_OK;
+        else if (excess_iter) state = THIP_ST_EXCESS_ITER;
+    } else {
+        const float m_cx = -dd_cx[1];
+        const float m_by = -pp_by[1];
+        const float cri_unbdd = (m_cx > eps_zero) ? norm_p * st->norm_c / m_cx : __builtin_inff();
+        const float cri_infeas = (m_by > eps_zero) ? norm_d * st->norm_b / m_by : __builtin_inff();
+        st->kind = 1; st->cri[0] = cri_unbdd; st->cri[1] = cri_infeas; st->cri[2] = 0.0f;
+        const bool term_unbdd = cri_unbdd <= eps_inf, term_infeas = cri_infeas <= eps_inf;
+        if (term_unbdd) state = THIP_ST_UNBOUNDED;
+        else if (term_infeas) state = THIP_ST_INFEASIBLE;
+        else if (excess_iter) state = THIP_ST_EXCESS_ITER;
+    }
+    if (state == THIP_ST_RUNNING) {
+        st->iter = i + 1;
+    } else {
+        st->state = state;
+        // stop is raised by final_scale_k, which still has to run for this iteration
+    }
+}
+
+// solver.rs:397-400: on Converged / ExcessIter in the tau > eps_zero branch, x_x and x_y are scaled by 1/tau.
+// Runs after status_k in every iteration; a no-op unless status_k has just decided to terminate.
+__global__ void final_scale_k(int n, int m, float eps_zero, float *__restrict__ xx, float *__restrict__ xy,
+                              DevStatus *st, int *done_count)
+{
+    if (st->stop != 0) return;
+    if (st->state == THIP_ST_RUNNING) return;
+    const bool scale = (st->kind == 0) && (st->state == THIP_ST_OK || st->state == THIP_ST_EXCESS_ITER);
+    if (scale) {
+        const float rt = 1.0f / st->tau;
+        const size_t gstride = (size_t)gridDim.x * BLK;
+        for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) xx[i] = rt * xx[i];
+        for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) xy[i] = rt * xy[i];
+    }
+    // the last block to finish raises the stop flag (every block must have read state/stop before that)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int prev = atomicAdd(done_count, 1);
+        if (prev == (int)gridDim.x - 1) {
+            *done_count = 0;
+            __threadfence();
+            atomicExch(&st->stop, 1);
+        }
+    }
+}
+
+__global__ void init_status_k(DevStatus *st, float norm_b_sq_dummy)
+{
+    (void)norm_b_sq_dummy;
+    st->stop = 0; st->state = THIP_ST_RUNNING; st->kind = 0; st->iter = 0;
+    st->cri[0] = st->cri[1] = st->cri[2] = 0.0f;
+    st->tau = 1.0f; st->kappa = 0.0f; st->r_tau = 0.0f;
+}
+
+// norms + scalar preconditioner entries (solver.rs:460-481, 159-183, 501-506)
+//   sums[0] = sum b^2 (all-reduced), sums[1] = sum |b| (all-reduced), loc[0] = sum c^2, loc[1] = sum |c|
+__global__ void init_scalars_k(const float *__restrict__ sums, const float *__restrict__ loc, float eps_zero,
+                               DevStatus *st)
+{
+    // fr_norm (solver.rs:85-107): n = norm(col); sq_norm += n*n; sqrt(sq_norm)
+    const float nb = sqrtf(sums[0]), nc = sqrtf(loc[0]);
+    st->norm_b = sqrtf(nb * nb);
+    st->norm_c = sqrtf(nc * nc);
+    const float tau_tau = loc[1] + sums[1];            // c.absadd_cols + b.absadd_cols (solver.rs:171-172)
+    st->t_tau = 1.0f / fmaxf(tau_tau, eps_zero);
+    st->s_kappa = 1.0f / fmaxf(tau_tau, eps_zero);     // sigma_1 = tau_tau (solver.rs:182)
+}
+
+// block partials of sum b^2, sum |b| (q0,q1 over m) and sum c^2, sum |c| (q2,q3 over n)
+__global__ void init_sums_k(int m, const float *__restrict__ b, int n, const float *__restrict__ c,
+                            float *__restrict__ part)
+{
+    __shared__ float sh[16];
+    float b2 = 0.0f, b1 = 0.0f, c2 = 0.0f, c1 = 0.0f;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) { const float t = b[i]; b2 = fmaf(t, t, b2); b1 += fabsf(t); }
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) { const float t = c[i]; c2 = fmaf(t, t, c2); c1 += fabsf(t); }
+    b2 = block_sum(b2, sh); b1 = block_sum(b1, sh); c2 = block_sum(c2, sh); c1 = block_sum(c1, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = b2; part[gridDim.x + blockIdx.x] = b1;
+        part[2 * gridDim.x + blockIdx.x] = c2; part[3 * gridDim.x + blockIdx.x] = c1;
+    }
+}
+
+// vector preconditioners (solver.rs:159-183 then 501-506):
+//   tau_x = colabs(A) + |c| ; tau_y = rowabs(A) + rowabs(b) ; tau_s = 1
+//   sigma_n = tau_x ; sigma_m = tau_y + tau_s
+__global__ void precond_k(int n, int m, const float *__restrict__ colabs, const float *__restrict__ rowabs,
+                          const float *__restrict__ c, const float *__restrict__ b, const float *__restrict__ b_rowabs,
+                          float eps_zero, float *__restrict__ Tx, float *__restrict__ Ty, float *__restrict__ Ts,
+                          float *__restrict__ Su, float *__restrict__ Sv)
+{
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
+        const float t = colabs[i] + fabsf(c[i]);
+        const float r = 1.0f / fmaxf(t, eps_zero);
+        Tx[i] = r; Su[i] = r;
+    }
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
+        const float t = rowabs[i] + (b_rowabs ? b_rowabs[i] : fabsf(b[i]));
+        Ty[i] = 1.0f / fmaxf(t, eps_zero);
+        Ts[i] = 1.0f / fmaxf(1.0f, eps_zero);
+        Sv[i] = 1.0f / fmaxf(t + 1.0f, eps_zero);
+    }
+}
+
+}  // namespace
+
+// second reduction stage of the GEMV partials into a finished vector (used by products())
+namespace {
+__global__ void fin_k(size_t n, const float *__restrict__ part, int np, size_t stride, float *__restrict__ y,
+                      const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+        float s = 0.0f;
+        for (int k = 0; k < np; ++k) s += part[(size_t)k * stride + i];
+        y[i] = s;
+    }
+}
+}  // namespace
+static int thip_finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float *y, const int *stop)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fin_k, dim3(grid_for(n, BLK, 2048)), dim3(BLK), 0, st, n, part, np, stride, y, stop);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+
+struct thip_solver {
+    size_t n = 0, m = 0;
+    const float *A = nullptr, *b = nullptr, *c = nullptr, *b_rowabs = nullptr;
+    thip_param par{};
+    int schedule = THIP_SCHED_FUSED;
+
+    thip_allreduce_fn allreduce = nullptr;
+    void *allreduce_ctx = nullptr;
+
+    // cone structure
+    std::vector<int32_t> seg_type;
+    std::vector<int64_t> seg_len;
+    unsigned char *cls = nullptr;                 // per-row class for the element-wise cones
+    int64_t *soc_beg = nullptr, *soc_end = nullptr; size_t n_soc = 0, soc_max = 0;
+    int64_t *rot_beg = nullptr, *rot_end = nullptr; size_t n_rot = 0, rot_max = 0;
+    int64_t *grp_beg = nullptr, *grp_end = nullptr; size_t n_grp = 0, grp_max = 0;
+    std::vector<std::pair<int64_t, int64_t>> psd;  // (offset, packed length)
+    float *psd_work = nullptr; size_t psd_worklen = 0;
+
+    // device vectors (one arena)
+    float *arena = nullptr; size_t arena_n = 0;
+    float *xx, *xy, *xs, *u, *v, *Tx, *Ty, *Ts, *Su, *Sv, *rxx, *rxy, *rxs;
+    float *g1, *h1, *g2, *h2, *g3, *h3, *gP, *hP;   // n-vectors carry TAIL extra floats
+    float *part = nullptr;                           // block partials (4 * EG)
+    float *dotc = nullptr;                           // local scalars: [0] c.u, [1] c.rx_x, [2..3] dd,cx
+    float *gemv_scr = nullptr; size_t gemv_scr_n = 0;
+    DevStatus *dst = nullptr;
+    DevStatus *hst = nullptr;                        // pinned
+    int *done_count = nullptr;
+    bool inited = false;
+};
+
+namespace {
+
+size_t pad64(size_t v) { return (v + 63) / 64 * 64; }
+
+int do_allreduce(thip_solver *s, float *buf, size_t count)
+{
+    if (!s->allreduce) return 0;
+    const int rc = s->allreduce(s->allreduce_ctx, buf, count, (void *)ctx().stream);
+    if (rc != 0) return fail(rc, "all-reduce callback failed", __FILE__, __LINE__);
+    return 0;
+}
+
+unsigned egrid(size_t n) { return grid_for(n, BLK, EG); }
+
+// one stage's products: hN = A xn (m), gT = A^T xt (n), honouring the schedule
+int products(thip_solver *s, const float *xn, const float *xt, float *hN, float *gT)
+{
+    hipStream_t st = ctx().stream;
+    const int *stop = &s->dst->stop;
+    if (s->m == 0 || s->n == 0) {
+        // zero-sized operator: MatOp degenerates to scale(beta=0, y) (matop.rs:83-85)
+        if (s->m) THIP_TRY(hipMemsetAsync(hN, 0, s->m * sizeof(float), st));
+        if (s->n) THIP_TRY(hipMemsetAsync(gT, 0, s->n * sizeof(float), st));
+        return 0;
+    }
+    GemvPartials gp;
+    if (s->schedule == THIP_SCHED_REFERENCE) {
+        // two passes over A, like the reference's separate cublasSgemv calls
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, nullptr, xt, false, true, false, s->gemv_scr, s->gemv_scr_n, &gp, stop));
+        THIP_RC(thip_finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, gT, stop));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, nullptr, true, false, false, s->gemv_scr, s->gemv_scr_n, &gp, stop));
+        THIP_RC(thip_finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, hN, stop));
+    } else {
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, &gp, stop));
+        THIP_RC(thip_finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, gT, stop));
+        THIP_RC(thip_finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, hN, stop));
+    }
+    return 0;
+}
+
+int project_blocks(thip_solver *s, float *x, bool dual_cone)
+{
+    (void)dual_cone;   // SOC / RotSOC / PSD are self-dual (cone_soc.rs:38, cone_psd.rs:56)
+    hipStream_t st = ctx().stream;
+    const int *stop = &s->dst->stop;
+    THIP_RC(soc_batched(st, x, s->soc_beg, s->soc_end, s->n_soc, 0, s->soc_max, stop));
+    THIP_RC(soc_batched(st, x, s->rot_beg, s->rot_end, s->n_rot, 1, s->rot_max, stop));
+    for (auto &pr : s->psd) {
+        const size_t sn = (size_t)pr.second;
+        const size_t k = (size_t)((std::sqrt((double)(8 * sn + 1)) - 1.0) / 2.0 + 0.5);
+        THIP_RC(eig_psd_project(st, k, x + pr.first, 1, std::sqrt(2.0f), s->par.eps_zero, s->psd_work, s->psd_worklen, 0, stop));
+    }
+    return 0;
+}
+
+int one_iteration(thip_solver *s)
+{
+    hipStream_t st = ctx().stream;
+    const int n = (int)s->n, m = (int)s->m;
+    const int *stop = &s->dst->stop;
+    const unsigned g = egrid(s->n > s->m ? s->n : s->m);
+    float *const part = s->part;
+
+    // ---- stage 1: x update ------------------------------------------------------------------
+    THIP_RC(products(s, s->u, s->v, s->h1, s->g1));
+    hipLaunchKernelGGL(dots2_k, dim3(g), dim3(BLK), 0, st, s->n, s->c, s->u, s->m, s->b, s->v, part, stop);
+    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part, s->dotc + 0, stop);
+    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part + g, s->g1 + s->n, stop);
+    THIP_RC(do_allreduce(s, s->g1, s->n + 1));
+    hipLaunchKernelGGL(xupdate_k, dim3(g), dim3(BLK), 0, st, n, m, s->g1, s->h1, s->c, s->b, s->v, s->Tx, s->Ty, s->Ts,
+                       s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dotc + 0, s->g1 + s->n, s->dst);
+    THIP_RC(project_blocks(s, s->xy, true));
+    THIP_RC(project_blocks(s, s->xs, false));
+    hipLaunchKernelGGL(rx_k, dim3(g), dim3(BLK), 0, st, n, m, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dst);
+
+    // ---- stage 2 / 3 ------------------------------------------------------------------------
+    if (s->schedule == THIP_SCHED_CARRIED) {
+        // criteria products of the new iterate first, K*rx from them by linearity
+        THIP_RC(products(s, s->xx, s->xy, s->h3, s->g3));
+        hipLaunchKernelGGL(crit_m_k, dim3(g), dim3(BLK), 0, st, m, s->h3, s->xs, s->xy, s->b, s->par.eps_zero, part, s->dst);
+        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 2, (int)g, part, s->g3 + s->n, stop);
+        THIP_RC(do_allreduce(s, s->g3, s->n + 2));
+        hipLaunchKernelGGL(carried_k, dim3(g), dim3(BLK), 0, st, n, m, s->g3, s->h3, s->gP, s->hP, s->g2, s->h2, s->dst);
+    } else {
+        THIP_RC(products(s, s->rxx, s->rxy, s->h2, s->g2));
+    }
+    hipLaunchKernelGGL(dots2_k, dim3(g), dim3(BLK), 0, st, s->n, s->c, s->rxx, s->m, s->b, s->rxy, part, stop);
+    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part, s->dotc + 1, stop);
+    if (s->schedule == THIP_SCHED_CARRIED) {
+        // b.rx_y is sharded: its own small all-reduce buffer (g2 tail), g2 itself is already global
+        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part + g, s->g2 + s->n, stop);
+        THIP_RC(do_allreduce(s, s->g2 + s->n, 1));
+    } else {
+        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part + g, s->g2 + s->n, stop);
+        THIP_RC(do_allreduce(s, s->g2, s->n + 1));
+    }
+    hipLaunchKernelGGL(yupdate_k, dim3(g), dim3(BLK), 0, st, n, m, s->g2, s->h2, s->c, s->b, s->rxs, s->Su, s->Sv, s->u,
+                       s->v, s->dotc + 1, s->g2 + s->n, s->dst);
+
+    if (s->schedule != THIP_SCHED_CARRIED) {
+        THIP_RC(products(s, s->xx, s->xy, s->h3, s->g3));
+        hipLaunchKernelGGL(crit_m_k, dim3(g), dim3(BLK), 0, st, m, s->h3, s->xs, s->xy, s->b, s->par.eps_zero, part, s->dst);
+        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 2, (int)g, part, s->g3 + s->n, stop);
+        THIP_RC(do_allreduce(s, s->g3, s->n + 2));
+    }
+    hipLaunchKernelGGL(crit_n_k, dim3(g), dim3(BLK), 0, st, n, s->g3, s->xx, s->c, s->par.eps_zero, part, s->dst);
+    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 2, (int)g, part, s->dotc + 2, stop);
+    hipLaunchKernelGGL(status_k, dim3(1), dim3(1), 0, st, s->g3 + s->n, s->dotc + 2, s->par.eps_acc, s->par.eps_inf,
+                       s->par.eps_zero, (long long)s->par.max_iter, s->dst);
+    hipLaunchKernelGGL(final_scale_k, dim3(g), dim3(BLK), 0, st, n, m, s->par.eps_zero, s->xx, s->xy, s->dst, s->done_count);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int poll(thip_solver *s, thip_status *out)
+{
+    hipStream_t st = ctx().stream;
+    THIP_TRY(hipMemcpyAsync(s->hst, s->dst, sizeof(DevStatus), hipMemcpyDeviceToHost, st));
+    THIP_TRY(hipStreamSynchronize(st));
+    if (out) {
+        out->state = s->hst->state; out->iter = s->hst->iter; out->kind = s->hst->kind;
+        out->cri[0] = s->hst->cri[0]; out->cri[1] = s->hst->cri[1]; out->cri[2] = s->hst->cri[2];
+        out->tau = s->hst->tau; out->kappa = s->hst->kappa;
+        out->norm_b = s->hst->norm_b; out->norm_c = s->hst->norm_c;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int thip_solver_create(const thip_problem *prob, const thip_param *par, int schedule, thip_solver **out)
+{
+    THIP_NEED_INIT();
+    if (!prob || !par || !out) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    if (schedule < 0 || schedule > 2) return fail(THIP_E_INVALID, "bad schedule", __FILE__, __LINE__);
+    int64_t tot = 0;
+    for (size_t i = 0; i < prob->n_seg; ++i) {
+        if (prob->host_seg_len[i] < 0 || prob->host_seg_type[i] < 0 || prob->host_seg_type[i] > THIP_CONE_PSD)
+            return fail(THIP_E_INVALID, "bad cone segment", __FILE__, __LINE__);
+        tot += prob->host_seg_len[i];
+    }
+    if ((size_t)tot != prob->m) return fail(THIP_E_INVALID, "cone segments do not cover m rows", __FILE__, __LINE__);
+
+    thip_solver *s = new thip_solver();
+    s->n = prob->n; s->m = prob->m;
+    s->A = prob->mat_a; s->b = prob->vec_b; s->c = prob->vec_c; s->b_rowabs = prob->vec_b_rowabs;
+    s->par = *par; s->schedule = schedule;
+    s->seg_type.assign(prob->host_seg_type, prob->host_seg_type + prob->n_seg);
+    s->seg_len.assign(prob->host_seg_len, prob->host_seg_len + prob->n_seg);
+    hipStream_t st = ctx().stream;
+    const size_t n = s->n, m = s->m;
+
+    // ---- cone tables ----
+    std::vector<unsigned char> cls(m ? m : 1, 2);
+    std::vector<int64_t> sb, se, rb, re, gb, ge;
+    int64_t off = 0;
+    size_t psd_kmax = 0;
+    for (size_t i = 0; i < s->seg_type.size(); ++i) {
+        const int64_t l = s->seg_len[i];
+        switch (s->seg_type[i]) {
+        case THIP_CONE_ZERO: for (int64_t r = 0; r < l; ++r) cls[off + r] = 0; break;
+        case THIP_CONE_RPOS: for (int64_t r = 0; r < l; ++r) cls[off + r] = 1; break;
+        case THIP_CONE_SOC:
+            sb.push_back(off); se.push_back(off + l); gb.push_back(off); ge.push_back(off + l);
+            if ((size_t)l > s->soc_max) s->soc_max = (size_t)l;
+            break;
+        case THIP_CONE_ROTSOC:
+            rb.push_back(off); re.push_back(off + l); gb.push_back(off); ge.push_back(off + l);
+            if ((size_t)l > s->rot_max) s->rot_max = (size_t)l;
+            break;
+        case THIP_CONE_PSD: {
+            const size_t k = (size_t)((std::sqrt((double)(8 * l + 1)) - 1.0) / 2.0 + 0.5);
+            if ((int64_t)(k * (k + 1) / 2) != l) { delete s; return fail(THIP_E_INVALID, "PSD segment is not triangular", __FILE__, __LINE__); }
+            s->psd.push_back({off, l});
+            gb.push_back(off); ge.push_back(off + l);
+            if (k > psd_kmax) psd_kmax = k;
+            break; }
+        }
+        if ((size_t)l > s->grp_max && s->seg_type[i] >= THIP_CONE_SOC) s->grp_max = (size_t)l;
+        off += l;
+    }
+    s->n_soc = sb.size(); s->n_rot = rb.size(); s->n_grp = gb.size();
+    auto up64 = [&](const std::vector<int64_t> &h, int64_t **d) -> int {
+        *d = nullptr;
+        if (h.empty()) return 0;
+        THIP_TRY(hipMalloc((void **)d, h.size() * sizeof(int64_t)));
+        THIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        return 0;
+    };
+    THIP_RC(up64(sb, &s->soc_beg)); THIP_RC(up64(se, &s->soc_end));
+    THIP_RC(up64(rb, &s->rot_beg)); THIP_RC(up64(re, &s->rot_end));
+    THIP_RC(up64(gb, &s->grp_beg)); THIP_RC(up64(ge, &s->grp_end));
+    THIP_TRY(hipMalloc((void **)&s->cls, cls.size()));
+    THIP_TRY(hipMemcpy(s->cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
+    if (psd_kmax) {
+        s->psd_worklen = thip_map_eig_worklen(psd_kmax);
+        THIP_TRY(hipMalloc((void **)&s->psd_work, s->psd_worklen * sizeof(float)));
+    }
+
+    // ---- vectors ----
+    const size_t pn = pad64(n + TAIL), pm = pad64(m + 1);
+    const size_t total = 7 * pn /*xx u Tx Su rxx + g1 g2 g3 gP = 9*/ + 2 * pn + 13 * pm + 64;
+    THIP_TRY(hipMalloc((void **)&s->arena, total * sizeof(float)));
+    THIP_TRY(hipMemsetAsync(s->arena, 0, total * sizeof(float), st));
+    s->arena_n = total;
+    float *p = s->arena;
+    auto take = [&](size_t k) { float *r = p; p += k; return r; };
+    s->xx = take(pn); s->u = take(pn); s->Tx = take(pn); s->Su = take(pn); s->rxx = take(pn);
+    s->g1 = take(pn); s->g2 = take(pn); s->g3 = take(pn); s->gP = take(pn);
+    s->xy = take(pm); s->xs = take(pm); s->v = take(pm); s->Ty = take(pm); s->Ts = take(pm); s->Sv = take(pm);
+    s->rxy = take(pm); s->rxs = take(pm); s->h1 = take(pm); s->h2 = take(pm); s->h3 = take(pm); s->hP = take(pm);
+    (void)take(pm);
+    s->dotc = take(64);
+
+    THIP_TRY(hipMalloc((void **)&s->part, 4 * EG * sizeof(float)));
+    s->gemv_scr_n = dual_gemv_scratch_floats(m, n);
+    THIP_TRY(hipMalloc((void **)&s->gemv_scr, s->gemv_scr_n * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&s->dst, sizeof(DevStatus)));
+    THIP_TRY(hipMemsetAsync(s->dst, 0, sizeof(DevStatus), st));
+    THIP_TRY(hipHostMalloc((void **)&s->hst, sizeof(DevStatus), hipHostMallocDefault));
+    THIP_TRY(hipMalloc((void **)&s->done_count, sizeof(int)));
+    THIP_TRY(hipMemsetAsync(s->done_count, 0, sizeof(int), st));
+    *out = s;
+    return 0;
+}
+
+int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *c)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    s->allreduce = fn; s->allreduce_ctx = c;
+    return 0;
+}
+
+int thip_solver_init(thip_solver *s)
+{
+    THIP_NEED_INIT();
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    hipStream_t st = ctx().stream;
+    const size_t n = s->n, m = s->m;
+    const unsigned g = egrid(n > m ? n : m);
+
+    // init_vecs (solver.rs:483-494): x = 0, y = 0, tau = 1
+    THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
+    hipLaunchKernelGGL(init_status_k, dim3(1), dim3(1), 0, st, s->dst, 0.0f);
+
+    // calc_norms (solver.rs:460-481) + scalar parts of abssum (solver.rs:171-172)
+    hipLaunchKernelGGL(init_sums_k, dim3(g), dim3(BLK), 0, st, (int)m, s->b, (int)n, s->c, s->part);
+    float *sums = s->g1 + n;        // [0] sum b^2, [1] sum |b|  (sharded -> all-reduce)
+    float *loc = s->dotc + 8;       // [0] sum c^2, [1] sum |c|
+    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 2, (int)g, s->part, sums, (const int *)nullptr);
+    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 2, (int)g, s->part + 2 * g, loc, (const int *)nullptr);
+
+    // |A| column sums (sharded partial -> all-reduce with the two scalars in the tail) and row sums
+    float *colabs = s->g1, *rowabs = s->h1;
+    if (n && m) {
+        THIP_RC(dual_gemv(st, m, n, s->A, m, nullptr, 1.0f, 0.0f, rowabs, nullptr, 1.0f, 0.0f, colabs, true, nullptr));
+    }
+    THIP_RC(do_allreduce(s, s->g1, n + 2));
+    hipLaunchKernelGGL(init_scalars_k, dim3(1), dim3(1), 0, st, sums, loc, s->par.eps_zero, s->dst);
+    hipLaunchKernelGGL(precond_k, dim3(g), dim3(BLK), 0, st, (int)n, (int)m, colabs, rowabs, s->c, s->b, s->b_rowabs,
+                       s->par.eps_zero, s->Tx, s->Ty, s->Ts, s->Su, s->Sv);
+    // product_group (solver.rs:521-523): per block cone, dp_tau's x_y and x_s parts <- their minimum
+    THIP_RC(group_min_batched(st, s->Ty, s->grp_beg, s->grp_end, s->n_grp, s->grp_max));
+    THIP_RC(group_min_batched(st, s->Ts, s->grp_beg, s->grp_end, s->n_grp, s->grp_max));
+    // scratch vectors used above must read as zero again for the carried products (A x_0 = 0)
+    THIP_TRY(hipMemsetAsync(s->g1, 0, (n + TAIL) * sizeof(float), st));
+    THIP_TRY(hipMemsetAsync(s->h1, 0, (m ? m : 1) * sizeof(float), st));
+    THIP_LAUNCH_CHECK();
+    s->inited = true;
+    return 0;
+}
+
+int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_status *host_status)
+{
+    THIP_NEED_INIT();
+    if (!s || !s->inited) return fail(THIP_E_INVALID, "solver not initialised", __FILE__, __LINE__);
+    if (poll_every <= 0) poll_every = 16;
+    int64_t done = 0;
+    THIP_RC(poll(s, host_status));
+    while (s->hst->state == THIP_ST_RUNNING && (max_steps < 0 || done < max_steps)) {
+        int64_t batch = poll_every;
+        if (max_steps >= 0 && done + batch > max_steps) batch = max_steps - done;
+        for (int64_t k = 0; k < batch; ++k) THIP_RC(one_iteration(s));
+        done += batch;
+        THIP_RC(poll(s, host_status));
+    }
+    return 0;
+}
+
+int thip_solver_status(thip_solver *s, thip_status *host_status)
+{
+    THIP_NEED_INIT();
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    return poll(s, host_status);
+}
+
+int thip_solver_solution(thip_solver *s, float *host_x, float *host_y)
+{
+    THIP_NEED_INIT();
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (host_x) THIP_RC(thip_d2h(host_x, s->xx, s->n));
+    if (host_y) THIP_RC(thip_d2h(host_y, s->xy, s->m));
+    return 0;
+}
+
+int thip_solver_iterate(thip_solver *s, float *host_x, float *host_y)
+{
+    THIP_NEED_INIT();
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    const size_t n = s->n, m = s->m;
+    THIP_RC(poll(s, nullptr));
+    if (host_x) {
+        THIP_RC(thip_d2h(host_x, s->xx, n));
+        THIP_RC(thip_d2h(host_x + n, s->xy, m));
+        THIP_RC(thip_d2h(host_x + n + m, s->xs, m));
+        host_x[n + m + m] = s->hst->tau;
+    }
+    if (host_y) {
+        THIP_RC(thip_d2h(host_y, s->u, n));
+        THIP_RC(thip_d2h(host_y + n, s->v, m));
+        host_y[n + m] = s->hst->kappa;
+    }
+    return 0;
+}
+
+int thip_solver_precond(thip_solver *s, float *host_dp_tau, float *host_dp_sigma)
+{
+    THIP_NEED_INIT();
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    const size_t n = s->n, m = s->m;
+    THIP_RC(poll(s, nullptr));
+    if (host_dp_tau) {
+        THIP_RC(thip_d2h(host_dp_tau, s->Tx, n));
+        THIP_RC(thip_d2h(host_dp_tau + n, s->Ty, m));
+        THIP_RC(thip_d2h(host_dp_tau + n + m, s->Ts, m));
+        host_dp_tau[n + m + m] = s->hst->t_tau;
+    }
+    if (host_dp_sigma) {
+        THIP_RC(thip_d2h(host_dp_sigma, s->Su, n));
+        THIP_RC(thip_d2h(host_dp_sigma + n, s->Sv, m));
+        host_dp_sigma[n + m] = s->hst->s_kappa;
+    }
+    return 0;
+}
+
+int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_bytes_per_pass)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : 2);
+    if (host_bytes_per_pass) *host_bytes_per_pass = s->m * s->n * sizeof(float);
+    return 0;
+}
+
+int thip_solver_destroy(thip_solver *s)
+{
+    if (!s) return 0;
+    if (ctx().inited) hipStreamSynchronize(ctx().stream);
+    hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
+    hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
+    hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->done_count);
+    if (s->hst) hipHostFree(s->hst);
+    delete s;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+"""`FusedSolver`: the device-resident conic iteration (thip_solver_* in include/totsu_f32hip.h) for problems whose
+operators are dense matrices -- what `Solver::solve` (solver.rs:285-321) does, with every per-iteration step,
+the projections and the termination test on the GPU.  Takes the stacked dense description produced by
+`ProbLP/ProbSOCP/ProbSDP.dense()` or device buffers generated in place (bench)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+from .solver import SolverError, SolverParam
+
+SCHEDULES = {"reference": _lib.SCHED_REFERENCE, "fused": _lib.SCHED_FUSED, "carried": _lib.SCHED_CARRIED}
+
+
+class DeviceBuffer:
+    """float32 device array owned through the C ABI"""
+
+    def __init__(self, n, zero=False):
+        _lib.ensure_init()
+        self.n = int(n)
+        p = C.c_void_p()
+        (lib.thip_alloc_zeroed if zero else lib.thip_alloc)(self.n, C.byref(p))
+        self.ptr = p.value
+
+    @staticmethod
+    def from_host(a):
+        a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+        d = DeviceBuffer(a.size)
+        if a.size:
+            lib.thip_h2d(d.ptr, a.ctypes.data, a.size)
+        return d
+
+    def to_host(self):
+        out = np.empty(self.n, dtype=np.float32)
+        if self.n:
+            lib.thip_d2h(out.ctypes.data, self.ptr, self.n)
+        return out
+
+    def free(self):
+        if self.ptr is not None:
+            lib.thip_free(self.ptr)
+            self.ptr = None
+
+
+class FusedResult:
+    def __init__(self, st):
+        self.state = st.state
+        self.iters = st.iter
+        self.kind = st.kind
+        self.cri = (st.cri[0], st.cri[1], st.cri[2])
+        self.tau, self.kappa = st.tau, st.kappa
+        self.norm_b, self.norm_c = st.norm_b, st.norm_c
+
+
+class FusedSolver:
+    def __init__(self, n, m, mat_a, vec_b, vec_c, seg_type, seg_len, param=None, schedule="fused",
+                 vec_b_rowabs=None, allreduce=None):
+        """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded)."""
+        _lib.ensure_init()
+        self.n, self.m = int(n), int(m)
+        self._owned = []
+        self.mat_a = self._dev(mat_a, self.n * self.m)
+        self.vec_b = self._dev(vec_b, self.m)
+        self.vec_c = self._dev(vec_c, self.n)
+        self.vec_b_rowabs = None if vec_b_rowabs is None else self._dev(vec_b_rowabs, self.m)
+        self.param = param or SolverParam()
+        self._st = np.ascontiguousarray(seg_type, dtype=np.int32)
+        self._sl = np.ascontiguousarray(seg_len, dtype=np.int64)
+        prob = _lib.Problem(self.n, self.m, self.mat_a.ptr, self.vec_b.ptr, self.vec_c.ptr,
+                            None if self.vec_b_rowabs is None else self.vec_b_rowabs.ptr, len(self._st),
+                            self._st.ctypes.data_as(C.POINTER(C.c_int32)),
+                            self._sl.ctypes.data_as(C.POINTER(C.c_int64)))
+        p = self.param
+        par = _lib.Param(-1 if p.max_iter is None else int(p.max_iter), p.eps_acc, p.eps_inf, p.eps_zero,
+                         int(p.log_period))
+        h = C.c_void_p()
+        lib.thip_solver_create(C.byref(prob), C.byref(par), SCHEDULES[schedule], C.byref(h))
+        self.h = h
+        self.schedule = schedule
+        self._cb = None
+        if allreduce is not None:
+            self._cb = _lib.ALLREDUCE_FN(allreduce)
+            lib.thip_solver_set_allreduce(self.h, self._cb, None)
+        lib.thip_solver_init(self.h)
+
+    @staticmethod
+    def from_dense(d, param=None, schedule="fused"):
+        return FusedSolver(d.n, d.m, d.mat_a, d.vec_b, d.vec_c, d.seg_type, d.seg_len, param, schedule,
+                           d.vec_b_rowabs)
+
+    def _dev(self, a, n):
+        if isinstance(a, DeviceBuffer):
+            assert a.n >= n
+            return a
+        d = DeviceBuffer.from_host(a)
+        assert d.n == n, (d.n, n)
+        self._owned.append(d)
+        return d
+
+    def run(self, max_steps=-1, poll_every=16):
+        st = _lib.Status()
+        lib.thip_solver_run(self.h, int(max_steps), int(poll_every), C.byref(st))
+        return FusedResult(st)
+
+    def status(self):
+        st = _lib.Status()
+        lib.thip_solver_status(self.h, C.byref(st))
+        return FusedResult(st)
+
+    def solution(self):
+        x = np.empty(self.n, dtype=np.float32)
+        y = np.empty(self.m, dtype=np.float32)
+        lib.thip_solver_solution(self.h, x.ctypes.data, y.ctypes.data)
+        return x, y
+
+    def iterate(self):
+        x = np.empty(self.n + 2 * self.m + 1, dtype=np.float32)
+        y = np.empty(self.n + self.m + 1, dtype=np.float32)
+        lib.thip_solver_iterate(self.h, x.ctypes.data, y.ctypes.data)
+        return x, y
+
+    def precond(self):
+        t = np.empty(self.n + 2 * self.m + 1, dtype=np.float32)
+        s = np.empty(self.n + self.m + 1, dtype=np.float32)
+        lib.thip_solver_precond(self.h, t.ctypes.data, s.ctypes.data)
+        return t, s
+
+    def passes(self):
+        p, b = C.c_int(), C.c_size_t()
+        lib.thip_solver_passes(self.h, C.byref(p), C.byref(b))
+        return p.value, b.value
+
+    def solve(self, poll_every=16):
+        """Solver::solve semantics: returns (x, y) or raises SolverError (solver.rs:285-321)."""
+        r = self.run(-1, poll_every)
+        if r.state != _lib.ST_OK:
+            raise SolverError(r.state)
+        return self.solution()
+
+    def destroy(self):
+        if self.h is not None:
+            lib.thip_solver_destroy(self.h)
+            self.h = None
+        for d in self._owned:
+            d.free()
+        self._owned = []
