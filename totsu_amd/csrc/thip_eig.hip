@@ -1,32 +1,480 @@
-// thip_eig.hip -- LinAlgEx::map_eig (totsu_core/src/linalg_ex.rs:44-65) on the device.  PLACEHOLDER: filled in
-// after the LP / SOCP path is measured.
+// thip_eig.hip -- LinAlgEx::map_eig (totsu_core/src/linalg_ex.rs:44-65) and ConePSD::proj
+// (totsu_core/src/cone_psd.rs:56-79) on the device.
+//
+// Contract (F64LAPACK recipe, totsu_f64lapack/src/f64lapack.rs:172-255; CUDA: f32cuda.rs:196-370):
+//   packed upper (by columns) --vec_to_mat, diag*scale--> M ; M = Z diag(w) Z^T ; R = sum_i map(w_i) z_i z_i^T ;
+//   R --diag/scale, pack upper--> packed.
+//
+// Two engines:
+//  (1) eigen-decomposition by parallel one-sided Jacobi (Hestenes) on the definite shift M + sigma I,
+//      sigma > ||M||_F: for a positive definite matrix the right singular vectors ARE the eigenvectors and no
+//      +/-lambda pair can mix.  Round-robin ordering gives n/2 independent column-pair rotations per step, one
+//      wavefront per pair (3 width-64 shuffle-tree dots, then a rotation of two G and two V columns).  n <= 64
+//      runs as one workgroup with G and V in LDS; larger n as one launch per step.  This engine serves the
+//      arbitrary-closure contract (thip_eig_decompose / thip_eig_rebuild) and map_kind 1 (sqrt).
+//  (2) PSD projection without eigenvectors: P = (M + M sign(M)) / 2, sign(M) by an odd matrix polynomial
+//      iteration -- a chain of n x n x n f32 GEMMs on v_mfma_f32_32x32x2_f32.  This is where the matrix cores
+//      are a real dense contraction; a Householder/QR chain at k = 500 is O(k) dependent latency-bound
+//      steps while this is ~40 GEMMs.  Used by ConePSD::proj for n > 64.
 #include "thip_common.h"
+
+#include <cmath>
 
 using namespace thip;
 
-namespace thip {
-int eig_psd_project(hipStream_t, size_t, float *, int, float, float, float *, size_t, int, const int *)
+namespace {
+
+constexpr int BLK = 256;
+constexpr int SMALL_N = 64;
+constexpr int MAX_SWEEPS = 18;
+
+__host__ __device__ inline size_t np_of(size_t n) { return (n + 63) / 64 * 64; }
+
+// round-robin (circle method) pairing on n_even players: step in [0, n_even-1), k in [0, n_even/2)
+__device__ __forceinline__ void rr_pair(int n_even, int step, int k, int &p, int &q)
 {
-    return fail(THIP_E_INVALID, "map_eig: not implemented yet", __FILE__, __LINE__);
+    const int n1 = n_even - 1;
+    if (k == 0) { p = step; q = n1; }
+    else { p = (step + k) % n1; q = (step - k + n1) % n1; }
+    if (p > q) { const int t = p; p = q; q = t; }
 }
+
+// one wave orthogonalises columns p, q of G (and applies the same rotation to V); returns 1 if it rotated
+__device__ __forceinline__ int rotate_pair(float *G, float *V, int ld, int n, int p, int q, int lane)
+{
+    float *gp = G + (size_t)p * ld, *gq = G + (size_t)q * ld;
+    float a = 0.0f, b = 0.0f, g = 0.0f;
+    for (int r = lane; r < n; r += 64) {
+        const float x = gp[r], y = gq[r];
+        a = fmaf(x, x, a); b = fmaf(y, y, b); g = fmaf(x, y, g);
+    }
+    a = wave_sum(a); b = wave_sum(b); g = wave_sum(g);
+    // rotate when the columns are not orthogonal to working precision
+    const float thr = 1.0e-7f;
+    if (!(g * g > thr * thr * a * b) || !(g * g > 1.0e-37f)) return 0;
+    const float zeta = (b - a) / (2.0f * g);
+    const float t = (zeta > 0.0f ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+    const float c = 1.0f / sqrtf(1.0f + t * t);
+    const float s = c * t;
+    float *vp = V + (size_t)p * ld, *vq = V + (size_t)q * ld;
+    for (int r = lane; r < n; r += 64) {
+        const float x = gp[r], y = gq[r];
+        gp[r] = c * x - s * y;
+        gq[r] = s * x + c * y;
+        const float u = vp[r], w = vq[r];
+        vp[r] = c * u - s * w;
+        vq[r] = s * u + c * w;
+    }
+    return 1;
+}
+
+// packed upper (by columns) -> full symmetric G (ld x ld, zero padded), diag * scale ; V = I ; block partials of
+// the squared Frobenius norm
+__global__ void unpack_k(int n, int ld, const float *__restrict__ packed, int has_scale, float scale,
+                         float *__restrict__ G, float *__restrict__ V, float *__restrict__ part,
+                         const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    __shared__ float sh[16];
+    float acc = 0.0f;
+    const size_t tot = (size_t)ld * ld;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) {
+        const int r = (int)(i % ld), c = (int)(i / ld);
+        float v = 0.0f;
+        if (r < n && c < n) {
+            const int lo = r < c ? r : c, hi = r < c ? c : r;
+            v = packed[(size_t)hi * (hi + 1) / 2 + lo];
+            if (r == c && has_scale) v *= scale;
+            acc = fmaf(v, v, acc);
+        }
+        G[i] = v;
+        if (V) V[i] = (r == c && r < n) ? 1.0f : 0.0f;
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// sc[0] = ||M||_F, sc[1] = sigma = 1.01 ||M||_F + tiny ; G += sigma I (when shift != 0)
+__global__ void shift_k(int n, int ld, int np, const float *__restrict__ part, float *__restrict__ G,
+                        float *__restrict__ sc, int shift, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    __shared__ double shd[16];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < np; k += blockDim.x) acc += (double)part[k];
+    acc = block_sum_d(acc, shd);
+    const float fro = (float)sqrt(acc);
+    const float sigma = 1.01f * fro + 1.0e-30f;
+    if (threadIdx.x == 0) { sc[0] = fro; sc[1] = sigma; sc[2] = 0.0f; }
+    if (shift)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) G[(size_t)i * ld + i] += sigma;
+}
+
+// n <= 64: whole decomposition in one workgroup, G and V staged in LDS
+__global__ __launch_bounds__(BLK) void jacobi_small_k(int n, int ld, float *__restrict__ Gg, float *__restrict__ Vg,
+                                                     const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    __shared__ float G[SMALL_N * SMALL_N];
+    __shared__ float V[SMALL_N * SMALL_N];
+    __shared__ int rotated;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n * n; i += BLK) {
+        const int r = i % n, c = i / n;
+        G[c * n + r] = Gg[(size_t)c * ld + r];
+        V[c * n + r] = (r == c) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    const int n_even = (n + 1) & ~1;
+    for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
+        if (tid == 0) rotated = 0;
+        __syncthreads();
+        for (int step = 0; step < n_even - 1; ++step) {
+            int cnt = 0;
+            for (int k = wave; k < n_even / 2; k += 4) {
+                int p, q;
+                rr_pair(n_even, step, k, p, q);
+                if (q < n) cnt += rotate_pair(G, V, n, n, p, q, lane);
+            }
+            if (lane == 0 && cnt) atomicAdd(&rotated, cnt);
+            __syncthreads();
+        }
+        const int r = rotated;
+        __syncthreads();
+        if (r == 0) break;
+    }
+    for (int i = tid; i < n * n; i += BLK) {
+        const int r = i % n, c = i / n;
+        Gg[(size_t)c * ld + r] = G[c * n + r];
+        Vg[(size_t)c * ld + r] = V[c * n + r];
+    }
+}
+
+// n > 64: one launch per round-robin step, one wave per pair
+__global__ __launch_bounds__(BLK) void jacobi_step_k(int n, int ld, float *__restrict__ G, float *__restrict__ V,
+                                                    int step, int *__restrict__ counters, int sweep,
+                                                    const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    // counters[s] = rotations of sweep s ; a sweep without rotations ends the decomposition
+    if (sweep > 0 && counters[sweep - 1] == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_even = (n + 1) & ~1;
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= n_even / 2) return;
+    int p, q;
+    rr_pair(n_even, step, k, p, q);
+    if (q >= n) return;
+    const int c = rotate_pair(G, V, ld, n, p, q, lane);
+    if (lane == 0 && c) atomicAdd(&counters[sweep], 1);
+}
+
+__global__ void zero_counters_k(int *counters, int n) { for (int i = threadIdx.x; i < n; i += blockDim.x) counters[i] = 0; }
+
+// w[i] = v_i . g_i - sigma (g_i = (M + sigma I) v_i) ; e[i], keep[i] from the built-in maps
+__global__ __launch_bounds__(BLK) void eigvals_k(int n, int ld, const float *__restrict__ G, const float *__restrict__ V,
+                                                const float *__restrict__ sc, int map_kind, float *__restrict__ w,
+                                                float *__restrict__ e, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    float acc = 0.0f, nv = 0.0f;
+    for (int r = lane; r < n; r += 64) {
+        const float v = V[(size_t)i * ld + r];
+        acc = fmaf(v, G[(size_t)i * ld + r], acc);
+        nv = fmaf(v, v, nv);
+    }
+    acc = wave_sum(acc); nv = wave_sum(nv);
+    if (lane == 0) {
+        const float lam = acc / nv - sc[1];
+        w[i] = lam;
+        // map_kind 0: e > 0 -> e (cone_psd.rs:69-76); 1: e > 0 -> sqrt(e) (matbuild/mod.rs:231-238); < 0: host-supplied
+        if (map_kind == 0) e[i] = lam > 0.0f ? lam : 0.0f;
+        else if (map_kind == 1) e[i] = lam > 0.0f ? sqrtf(lam) : 0.0f;
+    }
+}
+
+// packed(r,c) = sum_i e_i V(r,i) V(c,i), r <= c ; diag / scale (f64lapack.rs:96-107, 226-255).  One thread per
+// output entry, consecutive threads -> consecutive r of one column (coalesced V reads).
+__global__ __launch_bounds__(BLK) void rebuild_k(int n, int ld, const float *__restrict__ V, const float *__restrict__ e,
+                                                int has_scale, float scale, float *__restrict__ packed,
+                                                const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    const int c = blockIdx.y;
+    for (int r = blockIdx.x * BLK + threadIdx.x; r <= c; r += gridDim.x * BLK) {
+        float s = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            const float ei = e[i];
+            if (ei != 0.0f) s = fmaf(ei * V[(size_t)i * ld + c], V[(size_t)i * ld + r], s);
+        }
+        if (r == c && has_scale) s = s / scale;
+        packed[(size_t)c * (c + 1) / 2 + r] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// engine (2): f32 GEMM on the matrix cores for the sign-function chain.  All operands are ld x ld with
+// ld a multiple of 64 (zero padded: a block-diagonal [S 0; 0 0] stays block-diagonal under products).
+//   C = alpha * A * B + beta * D      (A, B, C, D column-major ld x ld; D may alias C or be null)
+// Workgroup = 256 threads = 4 waves, tile 64 x 64, each wave one 32 x 32 accumulator on
+// v_mfma_f32_32x32x2_f32 (A operand: lane l holds A[i = l & 31][k = l >> 5]; B: B[k = l >> 5][j = l & 31];
+// C/D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)).  K is staged through LDS in slabs of 16.
+// ---------------------------------------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int GT = 64, GK = 16;
+
+__global__ __launch_bounds__(BLK) void gemm64_k(int ld, float alpha, const float *__restrict__ A,
+                                               const float *__restrict__ B, float beta, const float *D,
+                                               float *C, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    __shared__ float As[GK][GT + 1];     // As[k][i]
+    __shared__ float Bs[GK][GT + 1];     // Bs[k][j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * GT, j0 = blockIdx.y * GT;
+    const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    for (int k0 = 0; k0 < ld; k0 += GK) {
+        // A tile: 64 rows x 16 k (column-major: consecutive i contiguous) ; 1024 elements, 4 per thread
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = tid + t * BLK;
+            const int i = idx & 63, k = idx >> 6;
+            As[k][i] = A[(size_t)(k0 + k) * ld + i0 + i];
+        }
+        // B tile: 16 k x 64 cols ; element (k, j) at B[(j0 + j) * ld + k0 + k]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = tid + t * BLK;
+            const int k = idx & 15, j = idx >> 4;
+            Bs[k][j] = B[(size_t)(j0 + j) * ld + k0 + k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wi + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wj + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = j0 + wj + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const size_t o = (size_t)col * ld + row;
+        float v = alpha * acc[r];
+        if (beta != 0.0f) v = fmaf(beta, D[o], v);
+        C[o] = v;
+    }
+}
+
+// S = M / ||M||_F  (sc[0] = ||M||_F); exact zero matrix stays zero
+__global__ void scale_by_fro_k(size_t tot, const float *__restrict__ M, const float *__restrict__ sc,
+                               float *__restrict__ S, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    const float f = sc[0];
+    const float inv = f > 0.0f ? 1.0f / f : 0.0f;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) S[i] = M[i] * inv;
+}
+
+// T = a I + b Y + c Z  (quintic step polynomial in Y = S^2, Z = S^4); identity only on the leading n x n block
+__global__ void poly_k(int n, int ld, float a, float b, float c, const float *__restrict__ Y,
+                       const float *__restrict__ Z, float *__restrict__ T, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    const size_t tot = (size_t)ld * ld;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) {
+        const int r = (int)(i % ld), cc = (int)(i / ld);
+        float v = b * Y[i] + (Z ? c * Z[i] : 0.0f);
+        if (r == cc && r < n) v += a;
+        T[i] = v;
+    }
+}
+
+// packed(r,c) = (M + MS)(r,c) / 2 symmetrised, diag / scale
+__global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const float *__restrict__ MS, int has_scale,
+                            float scale, float *__restrict__ packed, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    const int c = blockIdx.y;
+    for (int r = blockIdx.x * BLK + threadIdx.x; r <= c; r += gridDim.x * BLK) {
+        const size_t o1 = (size_t)c * ld + r, o2 = (size_t)r * ld + c;
+        float v = 0.5f * (M[o1] + 0.5f * (MS[o1] + MS[o2]));
+        if (r == c && has_scale) v = v / scale;
+        packed[(size_t)c * (c + 1) / 2 + r] = v;
+    }
+}
+
+int gemm(hipStream_t st, int ld, float alpha, const float *A, const float *B, float beta, const float *D, float *C,
+         const int *stop)
+{
+    dim3 g(ld / GT, ld / GT);
+    hipLaunchKernelGGL(gemm64_k, g, dim3(BLK), 0, st, ld, alpha, A, B, beta, D, C, stop);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+struct Work {
+    float *G, *V, *S, *Y, *Z;      // ld x ld each
+    float *w, *e;                  // ld each
+    float *sc;                     // 16 scalars
+    float *part;                   // 512 block partials
+    int   *counters;               // MAX_SWEEPS + 2 ints
+};
+
+Work carve(float *work, size_t n)
+{
+    const size_t ld = np_of(n), sq = ld * ld;
+    Work k;
+    k.G = work; k.V = k.G + sq; k.S = k.V + sq; k.Y = k.S + sq; k.Z = k.Y + sq;
+    k.w = k.Z + sq; k.e = k.w + ld; k.sc = k.e + ld; k.part = k.sc + 16;
+    k.counters = reinterpret_cast<int *>(k.part + 512);
+    return k;
+}
+
+int decompose(hipStream_t st, size_t n, const float *packed, int has_scale, float scale, const Work &k,
+              int map_kind, const int *stop)
+{
+    const int ni = (int)n, ld = (int)np_of(n);
+    const unsigned g = grid_for((size_t)ld * ld, BLK, 512);
+    hipLaunchKernelGGL(unpack_k, dim3(g), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, k.G, k.V, k.part, stop);
+    hipLaunchKernelGGL(shift_k, dim3(1), dim3(BLK), 0, st, ni, ld, (int)g, k.part, k.G, k.sc, 1, stop);
+    if (n <= SMALL_N) {
+        hipLaunchKernelGGL(jacobi_small_k, dim3(1), dim3(BLK), 0, st, ni, ld, k.G, k.V, stop);
+    } else {
+        hipLaunchKernelGGL(zero_counters_k, dim3(1), dim3(64), 0, st, k.counters, MAX_SWEEPS + 2);
+        const int n_even = (ni + 1) & ~1;
+        const unsigned blocks = (unsigned)((n_even / 2 + 3) / 4);
+        for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep)
+            for (int step = 0; step < n_even - 1; ++step)
+                hipLaunchKernelGGL(jacobi_step_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, k.G, k.V, step, k.counters,
+                                   sweep, stop);
+    }
+    hipLaunchKernelGGL(eigvals_k, dim3((unsigned)((n + 3) / 4)), dim3(BLK), 0, st, ni, ld, k.G, k.V, k.sc, map_kind, k.w,
+                       k.e, stop);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int rebuild(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop)
+{
+    const int ni = (int)n, ld = (int)np_of(n);
+    dim3 g((unsigned)((n + BLK - 1) / BLK), (unsigned)n);
+    hipLaunchKernelGGL(rebuild_k, g, dim3(BLK), 0, st, ni, ld, k.V, k.e, has_scale, scale, packed, stop);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// P = (M + M sign(M)) / 2 through the matrix cores
+int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop)
+{
+    const int ni = (int)n, ld = (int)np_of(n);
+    const size_t tot = (size_t)ld * ld;
+    const unsigned g = grid_for(tot, BLK, 512);
+    float *M = k.G, *S = k.S, *Y = k.Y, *Z = k.Z, *T = k.V;
+    hipLaunchKernelGGL(unpack_k, dim3(g), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, M, (float *)nullptr, k.part, stop);
+    hipLaunchKernelGGL(shift_k, dim3(1), dim3(BLK), 0, st, ni, ld, (int)g, k.part, M, k.sc, 0, stop);
+    hipLaunchKernelGGL(scale_by_fro_k, dim3(g), dim3(BLK), 0, st, tot, M, k.sc, S, stop);
+    // phase 1: quintic with a steep slope at 0 (3.4445 x - 4.7750 x^3 + 2.0315 x^5 maps (0, 1] into ~[0.7, 1.2] and
+    // multiplies tiny singular values by 3.44 per step): 13 steps lift relative eigenvalues >= 1e-7 into the band
+    for (int it = 0; it < 13; ++it) {
+        THIP_RC(gemm(st, ld, 1.0f, S, S, 0.0f, nullptr, Y, stop));
+        THIP_RC(gemm(st, ld, 1.0f, Y, Y, 0.0f, nullptr, Z, stop));
+        hipLaunchKernelGGL(poly_k, dim3(g), dim3(BLK), 0, st, ni, ld, 3.4445f, -4.7750f, 2.0315f, Y, Z, T, stop);
+        THIP_RC(gemm(st, ld, 1.0f, S, T, 0.0f, nullptr, Y, stop));       // S <- S T (into Y, then swap)
+        float *tmp = S; S = Y; Y = tmp;
+    }
+    // phase 2: Newton-Schulz x (3 - x^2) / 2, quadratic convergence to exactly +-1 from the band
+    for (int it = 0; it < 5; ++it) {
+        THIP_RC(gemm(st, ld, 1.0f, S, S, 0.0f, nullptr, Y, stop));
+        hipLaunchKernelGGL(poly_k, dim3(g), dim3(BLK), 0, st, ni, ld, 1.5f, -0.5f, 0.0f, Y, (const float *)nullptr, T, stop);
+        THIP_RC(gemm(st, ld, 1.0f, S, T, 0.0f, nullptr, Y, stop));
+        float *tmp = S; S = Y; Y = tmp;
+    }
+    THIP_RC(gemm(st, ld, 1.0f, M, S, 0.0f, nullptr, Z, stop));           // M sign(M)
+    dim3 gp((unsigned)((n + BLK - 1) / BLK), (unsigned)n);
+    hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+namespace thip {
+
+int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale_diag, float eps_zero,
+                    float *work, size_t worklen, int map_kind, const int *stop)
+{
+    (void)eps_zero;   // F32CUDA ignores eps_zero as well (f32cuda.rs:196); f32 round-off is the floor
+    if (n == 0) return 0;
+    if (worklen < thip_map_eig_worklen(n)) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
+    const Work k = carve(work, n);
+    if (map_kind == 0 && n > SMALL_N) return polar_project(st, n, packed, has_scale, scale_diag, k, stop);
+    THIP_RC(decompose(st, n, packed, has_scale, scale_diag, k, map_kind, stop));
+    return rebuild(st, n, packed, has_scale, scale_diag, k, stop);
+}
+
 }  // namespace thip
 
 extern "C" {
-size_t thip_map_eig_worklen(size_t n) { return 3 * n * n + 4 * n + 64; }
-int thip_map_eig(size_t n, float *mat, int has_scale, float scale_diag, float eps_zero, float *work, size_t worklen, int map_kind)
+
+size_t thip_map_eig_worklen(size_t n)
+{
+    const size_t ld = np_of(n);
+    return 5 * ld * ld + 2 * ld + 16 + 512 + 64;
+}
+
+int thip_map_eig(size_t n, float *mat, int has_scale, float scale_diag, float eps_zero, float *work, size_t worklen,
+                 int map_kind)
 {
     THIP_NEED_INIT();
-    if (worklen < thip_map_eig_worklen(n)) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
+    if (map_kind != 0 && map_kind != 1) return fail(THIP_E_INVALID, "map_kind", __FILE__, __LINE__);
     return eig_psd_project(ctx().stream, n, mat, has_scale, scale_diag, eps_zero, work, worklen, map_kind, nullptr);
 }
-int thip_eig_decompose(size_t, float *, int, float, float, float *, size_t, float *) { return fail(THIP_E_INVALID, "not implemented", __FILE__, __LINE__); }
-int thip_eig_rebuild(size_t, float *, int, float, float *, size_t, const float *, const uint8_t *) { return fail(THIP_E_INVALID, "not implemented", __FILE__, __LINE__); }
+
+int thip_eig_decompose(size_t n, float *mat, int has_scale, float scale_diag, float eps_zero, float *work,
+                       size_t worklen, float *host_w)
+{
+    THIP_NEED_INIT();
+    (void)eps_zero;
+    if (n == 0) return 0;
+    if (worklen < thip_map_eig_worklen(n)) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
+    const Work k = carve(work, n);
+    THIP_RC(decompose(ctx().stream, n, mat, has_scale, scale_diag, k, -1, nullptr));
+    return thip_d2h(host_w, k.w, n);
+}
+
+int thip_eig_rebuild(size_t n, float *mat, int has_scale, float scale_diag, float *work, size_t worklen,
+                     const float *host_e, const uint8_t *host_keep)
+{
+    THIP_NEED_INIT();
+    if (n == 0) return 0;
+    if (worklen < thip_map_eig_worklen(n)) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
+    const Work k = carve(work, n);
+    // None -> contributes nothing; a kept value of exactly 0 contributes nothing either
+    float *tmp = (float *)malloc(sizeof(float) * n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = host_keep[i] ? host_e[i] : 0.0f;
+    const int rc = thip_h2d(k.e, tmp, n);
+    free(tmp);
+    THIP_RC(rc);
+    return rebuild(ctx().stream, n, mat, has_scale, scale_diag, k, nullptr);
+}
+
 int thip_proj_psd(size_t sn, float *x, float eps_zero, float *work, size_t worklen)
 {
     THIP_NEED_INIT();
-    const size_t n = (size_t)((__builtin_sqrt((double)(8 * sn + 1)) - 1.0) / 2.0 + 0.5);
+    const size_t n = (size_t)((std::sqrt((double)(8 * sn + 1)) - 1.0) / 2.0 + 0.5);
     if (n * (n + 1) / 2 != sn) return fail(THIP_E_INVALID, "not a triangular number", __FILE__, __LINE__);
     if (worklen < thip_map_eig_worklen(n)) return fail(THIP_E_WORK, "ConePSD work shortage", __FILE__, __LINE__);
-    return eig_psd_project(ctx().stream, n, x, 1, 1.41421356237f, eps_zero, work, worklen, 0, nullptr);
+    return eig_psd_project(ctx().stream, n, x, 1, std::sqrt(2.0f), eps_zero, work, worklen, 0, nullptr);
 }
-}
+
+}  // extern "C"
