@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""bench.py -- solver iterations/sec of the device-resident conic loop on the dense random SOCP of
+BASELINE.json (configs[2]: n = 50 000, 1000 second-order cones of 1 + 99 rows => A is 100 000 x 50 000 f32,
+20 GB), row-sharded over N GPUs (one process per GPU; the A^T y partial sums are all-reduced over RCCL).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one solver iteration (SolverCore::solve loop body, totsu_core/src/solver/solver.rs:364-457:
+update_vecs + criteria).  Inputs are generated on the device before the timed region.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="socp", choices=["socp", "lp"])
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--cones", type=int, default=1000)
+    ap.add_argument("--schedule", default="carried", choices=["reference", "fused", "carried"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--force-collective", action="store_true", help="install the all-reduce hook even at N = 1")
+    ap.add_argument("--to-eps", type=float, default=None, help="also solve to this eps_acc and report time-to-eps")
+    ap.add_argument("--cpu-cones", type=int, default=20)
+    return ap.parse_args()
+
+
+class _CAI:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class TorchAllreduce:
+    """thip_allreduce_fn over torch.distributed (backend nccl == RCCL on ROCm): sums `n` floats in place."""
+
+    def __init__(self, torch, dist):
+        self.torch, self.dist, self.cache, self.calls = torch, dist, {}, 0
+
+    def __call__(self, ctx, ptr, n, stream):
+        try:
+            key = (ptr, n)
+            t = self.cache.get(key)
+            if t is None:
+                t = self.torch.as_tensor(_CAI(ptr, n), device="cuda")
+                self.cache[key] = t
+            self.dist.all_reduce(t)
+            self.calls += 1
+            return 0
+        except Exception as e:      # an exception must not unwind through the C frame
+            sys.stderr.write("all-reduce hook failed: %r\n" % (e,))
+            return 1
+
+
+def cpu_baseline(n, n_cones_full, ni, seed, cones_sub, budget_s=25.0):
+    """Times the CPU oracle (f64, OpenMP) on a BOUNDED sample: the first `cones_sub` cones of the same
+    instance (identical matrix entries), a few iterations; iteration cost is linear in the number of rows, so
+    the full-size rate is the measured rate * cones_sub / n_cones_full."""
+    import oracle as O
+    from totsu_amd import synth as S
+    rows = 1 + ni
+    m = cones_sub * rows
+    m_total = n_cones_full * rows
+    A = O.gen_matrix(m, n, seed, S.STREAM_A, 0, 0, m_total, 1, -1.0 / math.sqrt(n))
+    x0 = O.gen_vector(n, seed, S.STREAM_X0, 0, 1)
+    w = O.transform_ge(False, m, n, 1.0, A, x0, 0.0, np.zeros(m)).reshape(cones_sub, rows)
+    h = O.gen_vector(m, seed, S.STREAM_H, 0, 1).reshape(cones_sub, rows)
+    margin = O.gen_vector(cones_sub, seed, S.STREAM_D, 0, 0, 1.0, 0.1)
+    b = h.copy()
+    b[:, 0] = np.linalg.norm(h[:, 1:] - w[:, 1:], axis=1) + w[:, 0] + margin
+    t = O.gen_vector(cones_sub, seed, S.STREAM_T, 0, 0, 1.0, 0.5)
+    wd = O.gen_vector(m, seed, S.STREAM_W, 0, 1).reshape(cones_sub, rows)[:, 1:]
+    ws = O.gen_vector(cones_sub, seed, S.STREAM_WS, 0, 0)
+    wd = wd * (0.9 * t * ws / np.maximum(np.linalg.norm(wd, axis=1), 1e-9))[:, None]
+    z = np.concatenate([t[:, None], wd], axis=1).reshape(-1)
+    f = O.transform_ge(True, m, n, -1.0, A, z, 0.0, np.zeros(n))
+    seg_t, seg_l = [O.CONE_SOC] * cones_sub, [rows] * cones_sub
+
+    def run(k):
+        par = O.param(max_iter=k, eps_acc=1e-300)
+        t0 = time.perf_counter()
+        r = O.solve_matop_cones(par, f, A, b.reshape(-1), seg_t, seg_l)
+        return time.perf_counter() - t0, r
+
+    t1, _ = run(2)                      # init (norms, preconditioner) + 2 iterations
+    per_iter_guess = max(t1 / 4.0, 1e-3)
+    k2 = int(max(4, min(200, budget_s / per_iter_guess)))
+    t2, r2 = run(2 + k2)
+    rate_sub = k2 / max(t2 - t1, 1e-9)
+    return {
+        "value": rate_sub * cones_sub / n_cones_full,
+        "unit": "iter/s",
+        "cores": O.num_threads(),
+        "kind": "port",
+        "sample": ("oracle (C, f64, OpenMP %d threads) on the first %d of %d cones of the same instance "
+                   "(A_sub %d x %d f64), %d timed iterations at %.3f iter/s, scaled by rows %d/%d"
+                   % (O.num_threads(), cones_sub, n_cones_full, m, n, k2, rate_sub, cones_sub, n_cones_full)),
+        "measured_sub_instance_iter_per_s": rate_sub,
+        "host_cpu_count": os.cpu_count(),
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or a.force_collective
+    if use_dist and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import totsu_amd as T
+    from totsu_amd import _lib, synth
+    from totsu_amd._lib import lib
+    _lib.init(local_rank)
+    lib.thip_set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def allreduce_host(v):
+        if not use_dist:
+            return v
+        t = torch.from_numpy(np.ascontiguousarray(v)).cuda()
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    t_gen0 = time.perf_counter()
+    if a.workload == "socp":
+        n = a.n or 50_000
+        inst = synth.SocpInstance(n, a.cones, 99, seed=0, rank=rank, world=world, allreduce_host=allreduce_host)
+        wl = "random dense SOCP n=%d, %d second-order cones of 1+99 rows (m=%d), f32" % (n, a.cones, inst.m_total)
+    else:
+        n = a.n or 10_000
+        inst = synth.LpInstance(n, seed=0, rank=rank, world=world)
+        wl = "benchmark_lp dense LP n=%d m=%d, f32" % (n, inst.m_total)
+    lib.thip_sync()
+    t_gen = time.perf_counter() - t_gen0
+
+    p = T.SolverParam()
+    p.max_iter = None
+    p.eps_acc = 0.0            # never terminates inside the timed region: every step does full work
+    p.eps_inf = 0.0
+    hook = TorchAllreduce(torch, dist) if use_dist else None
+    fs = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, a.schedule,
+                       allreduce=hook)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fs.run(a.warmup, poll_every=max(a.warmup, 1))
+    barrier()
+    lib.thip_prof_enable(1)
+    t0 = time.perf_counter()
+    r = fs.run(a.steps, poll_every=a.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    import ctypes as C
+    nl, tot_ms = C.c_int64(), C.c_double()
+    lib.thip_prof_read(C.byref(nl), C.byref(tot_ms))
+    lib.thip_prof_enable(0)
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert r.state == _lib.ST_RUNNING and r.iters == a.warmup + a.steps, (r.state, r.iters)
+    assert math.isfinite(r.tau) and math.isfinite(r.cri[0]), "iterate blew up"
+
+    passes, bytes_per_pass = fs.passes()
+    iters_per_s = a.steps / elapsed
+    avg_ms = tot_ms.value / max(nl.value, 1)
+    achieved = bytes_per_pass / (avg_ms * 1e-3) / 1e9 if nl.value else 0.0
+    m_total = inst.m_total
+    b_iter = 24.0 * m_total * n                              # 6 GEMVs x 4 m n bytes
+    roofline = {
+        "bound": "hbm",
+        "kernel": "dual_gemv_k (one pass over the local A: y_N = A x_N and y_T = A^T x_T)",
+        "achieved": achieved,                                # physical bytes of one pass / avg launch duration
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None,
+        "bytes_per_launch": bytes_per_pass,
+        "avg_launch_ms": avg_ms,
+        "launches_timed": nl.value,
+        "passes_over_A_per_iter": passes,
+        # reference op sequence = 6 GEMVs/iter (B_iter = 24 m n): rate the whole job sustains in those terms
+        "algorithmic_GBps_per_gpu": b_iter * iters_per_s / 1e9 / world,
+        "algorithmic_frac": b_iter * iters_per_s / 1e9 / world / HBM_PEAK_GBPS,
+    }
+    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(prof):
+        try:
+            tr = json.load(open(prof))
+            key = "%s_n%d_m%d_%s" % (a.workload, n, inst.m, a.schedule)
+            if key in tr:
+                roofline["traffic"] = tr[key]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+
+    out = {
+        "metric": "solver iterations/sec, dense SOCP n=50k (time-to-eps with --to-eps)" if a.workload == "socp"
+                  else "solver iterations/sec, dense LP",
+        "value": iters_per_s,
+        "unit": "iter/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (counter-based generator on device, seed 0)",
+        "config": {"workload": wl, "schedule": a.schedule, "passes_over_A_per_iter": passes,
+                   "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world,
+                   "gen_seconds": round(t_gen, 3)},
+        "roofline": roofline,
+    }
+
+    if a.to_eps is not None:
+        p2 = T.SolverParam()
+        p2.eps_acc = a.to_eps
+        fs2 = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
+                            a.schedule, allreduce=hook)
+        barrier()
+        t0 = time.perf_counter()
+        r2 = fs2.run(-1, poll_every=64)
+        barrier()
+        out["time_to_eps"] = {"eps_acc": a.to_eps, "seconds": time.perf_counter() - t0, "iterations": r2.iters + 1,
+                              "state": r2.state, "cri": list(r2.cri)}
+        x, y = fs2.solution()
+        pobj = float(inst.vec_c_host.astype(np.float64) @ x.astype(np.float64))
+        dloc = -float(inst.vec_b_host.astype(np.float64) @ y.astype(np.float64))
+        dobj = float(allreduce_host(np.array([dloc], dtype=np.float32))[0]) if use_dist else dloc
+        out["time_to_eps"].update({"primal_obj": pobj, "dual_obj": dobj})
+        fs2.destroy()
+
+    if rank == 0 and world == 1 and not a.no_cpu and a.workload == "socp":
+        out["cpu_baseline"] = cpu_baseline(n, a.cones, 99, 0, min(a.cpu_cones, a.cones))
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    fs.destroy()
+    inst.free()
+    if rank == 0:
+        print(json.dumps(out))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

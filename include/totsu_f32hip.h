@@ -185,6 +185,11 @@ int thip_solver_destroy(thip_solver *s);
 /* physical passes over A per iteration of the schedule in use, and bytes one pass reads */
 int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_bytes_per_pass);
 
+/* per-launch timing of the GEMV kernels of the fused loop (HIP events on the launch stream): enable, run,
+ * then read the number of timed launches and their summed duration.  Used by bench.py's roofline. */
+int thip_prof_enable(int on);
+int thip_prof_read(int64_t *host_launches, double *host_total_ms);     /* SYNC */
+
 /* ---------------------------------------------------------------------------------------------
  * Synthetic data on the device (bench / tests): counter-based generator keyed by
  * (seed, stream, index), bit-identical to oracle/totsu_oracle.c:oc_rng_*.

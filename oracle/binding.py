@@ -344,3 +344,19 @@ def rng_normal(seed, stream, idx):
 
 def num_threads():
     return int(lib().oc_num_threads())
+
+
+def gen_matrix(n_row, n_col, seed, stream, row0, col0, ld_index, kind, scale, shift=0.0):
+    """column-major (n_row x n_col) block of the synthetic matrix, f64 holding the exact f32 entries"""
+    out = np.empty(n_row * n_col, dtype=np.float64)
+    lib().oc_gen_matrix(out.ctypes.data_as(_dp), _sz(n_row), _sz(n_col), _sz(n_row), C.c_uint64(seed),
+                        C.c_uint64(stream), C.c_uint64(row0), C.c_uint64(col0), C.c_uint64(ld_index),
+                        C.c_int(kind), C.c_float(scale), C.c_float(shift))
+    return out
+
+
+def gen_vector(n, seed, stream, idx0, kind, scale=1.0, shift=0.0):
+    out = np.empty(n, dtype=np.float64)
+    lib().oc_gen_vector(out.ctypes.data_as(_dp), _sz(n), C.c_uint64(seed), C.c_uint64(stream), C.c_uint64(idx0),
+                        C.c_int(kind), C.c_float(scale), C.c_float(shift))
+    return out

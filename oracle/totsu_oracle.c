@@ -1272,3 +1272,26 @@ float oc_rng_normal(uint64_t seed, uint64_t stream, uint64_t idx)
     /* mean of the sum = 4 * 32767.5 = 131070 */
     return ((float)((int32_t)s - 131070) * (1.0f / 65536.0f)) * 1.7320508f;
 }
+
+/* column-major block of the synthetic matrix: out(r,c) = scale * g(idx) + shift with
+ * idx = (row0 + r) + (col0 + c) * ld_index, evaluated in f32 like thip_gen_matrix, stored as f64 */
+void oc_gen_matrix(double *out, size_t n_row, size_t n_col, size_t lda, uint64_t seed, uint64_t stream,
+                   uint64_t row0, uint64_t col0, uint64_t ld_index, int kind, float scale, float shift)
+{
+    #pragma omp parallel for schedule(static)
+    for (ptrdiff_t c = 0; c < (ptrdiff_t)n_col; ++c) {
+        const uint64_t cbase = (col0 + (uint64_t)c) * ld_index + row0;
+        for (size_t r = 0; r < n_row; ++r) {
+            const float g = kind ? oc_rng_normal(seed, stream, cbase + r) : oc_rng_uniform(seed, stream, cbase + r);
+            out[(size_t)c * lda + r] = (double)(scale * g + shift);
+        }
+    }
+}
+
+void oc_gen_vector(double *out, size_t n, uint64_t seed, uint64_t stream, uint64_t idx0, int kind, float scale, float shift)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const float g = kind ? oc_rng_normal(seed, stream, idx0 + i) : oc_rng_uniform(seed, stream, idx0 + i);
+        out[i] = (double)(scale * g + shift);
+    }
+}

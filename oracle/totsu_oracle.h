@@ -153,6 +153,10 @@ uint64_t oc_rng_hash(uint64_t seed, uint64_t stream, uint64_t idx);
 float    oc_rng_uniform(uint64_t seed, uint64_t stream, uint64_t idx);   /* [0,1) on a 2^-24 grid */
 float    oc_rng_normal(uint64_t seed, uint64_t stream, uint64_t idx);    /* Irwin-Hall(4), unit variance */
 
+void oc_gen_matrix(double *out, size_t n_row, size_t n_col, size_t lda, uint64_t seed, uint64_t stream,
+                   uint64_t row0, uint64_t col0, uint64_t ld_index, int kind, float scale, float shift);
+void oc_gen_vector(double *out, size_t n, uint64_t seed, uint64_t stream, uint64_t idx0, int kind, float scale, float shift);
+
 int oc_num_threads(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,108 @@
+"""GPU parity: LinAlgEx::map_eig / ConePSD::proj (linalg_ex.rs:44-65, cone_psd.rs:56-79) against the oracle
+(Householder+QL in f64, itself cross-checked against the reference's Jacobi and numpy.eigh in
+tests/test_oracle_golden.py).  Tolerance: 2e-5 * ||X||_F absolute on every packed entry -- f32 round-off of an
+order-k symmetric eigenproblem (the CUDA backend's f32 syevdx gives the same order)."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from totsu_amd import F32HIP, _lib
+    _lib.init()
+    return F32HIP
+
+
+def _packed(s):
+    k = s.shape[0]
+    return np.array([s[r, c] * (np.sqrt(2.0) if r != c else 1.0) for c in range(k) for r in range(c + 1)], dtype=np.float32)
+
+
+def _rand_sym(k, seed, rank_def=False):
+    rng = np.random.default_rng(seed)
+    b = rng.standard_normal((k, k))
+    s = (b + b.T) / 2
+    if rank_def and k > 3:
+        # complementary-slackness-like spectrum: a few large eigenvalues of both signs, many exact zeros
+        q, _ = np.linalg.qr(b)
+        w = np.zeros(k)
+        w[: k // 4] = rng.uniform(0.5, 2.0, k // 4)
+        w[k // 4: k // 2] = -rng.uniform(0.5, 2.0, k // 2 - k // 4)
+        s = (q * w) @ q.T
+    return s
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 9, 33, 64, 65, 100, 200, 500])
+@pytest.mark.parametrize("rank_def", [False, True])
+def test_psd_projection(L, k, rank_def):
+    from totsu_amd import ConePSD
+    s = _rand_sym(k, k + 17 * rank_def, rank_def)
+    x = _packed(s)
+    ref = O.proj(O.CONE_PSD, x.astype(np.float64), use_ql=True)
+    w = np.zeros(ConePSD.query_worklen(L, x.size), dtype=np.float32)
+    cone = ConePSD(L, w, 1e-12)
+    buf = x.copy()
+    sl = L.Sl.new_mut(buf)
+    assert cone.proj(False, sl)
+    got = sl.get_ref().copy()
+    sl.drop()
+    cone.drop()
+    assert np.abs(got - ref).max() <= 2e-5 * np.linalg.norm(x), np.abs(got - ref).max() / np.linalg.norm(x)
+    # idempotence: projecting the projection changes nothing (size-independent property)
+    sl = L.Sl.new_mut(got.copy())
+    cone = ConePSD(L, w, 1e-12)
+    cone.proj(True, sl)
+    again = sl.get_ref().copy()
+    sl.drop()
+    cone.drop()
+    assert np.abs(again - got).max() <= 2e-5 * np.linalg.norm(x)
+
+
+def test_cone_psd_kat(L):
+    # totsu_core/src/cone_psd.rs:90-110
+    from totsu_amd import ConePSD
+    x = np.array([5.0, 0.0, -5.0], dtype=np.float32)
+    w = np.zeros(ConePSD.query_worklen(L, 3), dtype=np.float32)
+    c = ConePSD(L, w, 1e-12)
+    sl = L.Sl.new_mut(x)
+    c.proj(False, sl)
+    assert np.allclose(sl.get_ref(), [5.0, 0.0, 0.0], atol=1e-6)
+    # work shortage -> Err(()) (cone_psd.rs:58-61)
+    c2 = ConePSD(L, np.zeros(4, dtype=np.float32), 1e-12)
+    assert c2.proj(False, sl) is False
+
+
+@pytest.mark.parametrize("k", [2, 5, 40, 64, 65, 130])
+def test_map_eig_sqrt_and_closure(L, k):
+    # MatBuild::sqrt (matbuild/mod.rs:219-245) and an arbitrary host closure through the two-phase path
+    rng = np.random.default_rng(k)
+    b = rng.standard_normal((k, k))
+    s = b @ b.T / k + 0.05 * np.eye(k)
+    packed = np.array([s[r, c] for c in range(k) for r in range(c + 1)], dtype=np.float32)
+    ref = O.map_eig(packed.astype(np.float64), None, 1e-12, map_kind=1, use_ql=True)
+    work = L.Sl.new_mut(np.zeros(L.map_eig_worklen(k), dtype=np.float32))
+    sl = L.Sl.new_mut(packed.copy())
+    L.map_eig(sl, None, 1e-12, work, "sqrt_pos")
+    got = sl.get_ref().copy()
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    # sqrt squared gives the matrix back
+    r = np.zeros((k, k))
+    for c in range(k):
+        for rr in range(c + 1):
+            r[rr, c] = r[c, rr] = got[c * (c + 1) // 2 + rr]
+    assert np.abs(r @ r - s).max() <= 1e-4 * np.abs(s).max() * np.sqrt(k)
+    sl.drop()
+    # closure e -> 2e for e > 0.1, None otherwise, vs numpy
+    sl = L.Sl.new_mut(packed.copy())
+    L.map_eig(sl, None, 1e-12, work, lambda e: 2.0 * e if e > 0.1 else None)
+    got = sl.get_ref().copy()
+    w, z = np.linalg.eigh(s)
+    want = (z * np.where(w > 0.1, 2 * w, 0.0)) @ z.T
+    wp = np.array([want[rr, c] for c in range(k) for rr in range(c + 1)])
+    assert np.abs(got - wp).max() <= 1e-4 * np.abs(w).max()
+    sl.drop()
+    work.drop()

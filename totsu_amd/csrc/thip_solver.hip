@@ -427,6 +427,31 @@ namespace {
 
 size_t pad64(size_t v) { return (v + 63) / 64 * 64; }
 
+// optional per-launch timing of the dominant kernel (bench.py roofline): HIP event pairs recorded on the
+// launch stream around every GEMV kernel of products()
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;     // pairs
+    size_t used = 0;
+    double total_ms = 0.0;
+    long long launches = 0;
+} g_prof;
+
+void prof_begin(hipStream_t st)
+{
+    if (!g_prof.on) return;
+    if (g_prof.used + 2 > g_prof.ev.size()) {
+        for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); g_prof.ev.push_back(e); }
+    }
+    hipEventRecord(g_prof.ev[g_prof.used], st);
+}
+void prof_end(hipStream_t st)
+{
+    if (!g_prof.on) return;
+    hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+    g_prof.used += 2;
+}
+
 int do_allreduce(thip_solver *s, float *buf, size_t count)
 {
     if (!s->allreduce) return 0;
@@ -451,12 +476,18 @@ int products(thip_solver *s, const float *xn, const float *xt, float *hN, float 
     GemvPartials gp;
     if (s->schedule == THIP_SCHED_REFERENCE) {
         // two passes over A, like the reference's separate cublasSgemv calls
+        prof_begin(st);
         THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, nullptr, xt, false, true, false, s->gemv_scr, s->gemv_scr_n, &gp, stop));
+        prof_end(st);
         THIP_RC(thip_finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, gT, stop));
+        prof_begin(st);
         THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, nullptr, true, false, false, s->gemv_scr, s->gemv_scr_n, &gp, stop));
+        prof_end(st);
         THIP_RC(thip_finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, hN, stop));
     } else {
+        prof_begin(st);
         THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, &gp, stop));
+        prof_end(st);
         THIP_RC(thip_finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, gT, stop));
         THIP_RC(thip_finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, hN, stop));
     }
@@ -775,6 +806,30 @@ int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_byte
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
     if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : 2);
     if (host_bytes_per_pass) *host_bytes_per_pass = s->m * s->n * sizeof(float);
+    return 0;
+}
+
+int thip_prof_enable(int on)
+{
+    THIP_NEED_INIT();
+    g_prof.on = on != 0;
+    g_prof.used = 0; g_prof.total_ms = 0.0; g_prof.launches = 0;
+    return 0;
+}
+
+int thip_prof_read(int64_t *host_launches, double *host_total_ms)
+{
+    THIP_NEED_INIT();
+    THIP_TRY(hipStreamSynchronize(ctx().stream));
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float ms = 0.0f;
+        THIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+        g_prof.total_ms += ms;
+        g_prof.launches += 1;
+    }
+    g_prof.used = 0;
+    if (host_launches) *host_launches = g_prof.launches;
+    if (host_total_ms) *host_total_ms = g_prof.total_ms;
     return 0;
 }
 

@@ -1,0 +1,129 @@
+"""Synthetic instances generated on the device from a counter-based generator keyed by (seed, stream, index)
+(SURVEY.md 8d): every GPU shard -- and the CPU baseline through oracle.gen_matrix -- regenerates bit-identical
+f32 entries without shipping the matrix.
+
+SOCP (BASELINE.json configs[2]): n variables, `n_cones` second-order cones of 1 + `ni` rows each; in the
+stacked conic form  min f^T x  s.t.  A x + s = b, s in prod SOC  the rows of cone i are [-c_i^T ; -G_i]
+(totsu/src/problem/socp.rs:88-93), b = [d_i ; h_i]:
+    G_i, c_i ~ N(0, 1/n),  h_i ~ N(0, 1),
+    d_i = ||G_i x0 + h_i|| - c_i^T x0 + U(0.1, 1.1)      strictly feasible at x0 ~ N(0, I)
+    f   = sum_i (t_i c_i + G_i^T w_i), t_i ~ U(0.5, 1.5), ||w_i|| < 0.9 t_i   strictly dual feasible => bounded
+LP (configs[1], experimental/benchmark_lp/src/main.rs:14-57): c = -U(0,1), G = [-I ; U(0,1)], h = [0 ; U(0,1)].
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+from .fused import DeviceBuffer
+
+STREAM_A, STREAM_X0, STREAM_H, STREAM_D, STREAM_T, STREAM_W, STREAM_WS, STREAM_C = 1, 2, 3, 4, 5, 6, 7, 8
+
+
+def shard_cones(n_cones, world, rank):
+    """contiguous, cone-aligned row blocks (no cone straddles a boundary)"""
+    base, rem = divmod(n_cones, world)
+    c0 = rank * base + min(rank, rem)
+    c1 = c0 + base + (1 if rank < rem else 0)
+    return c0, c1
+
+
+def _gen(n, seed, stream, idx0, kind, scale=1.0, shift=0.0):
+    d = DeviceBuffer(n)
+    lib.thip_gen_vector(d.ptr, n, seed, stream, idx0, kind, scale, shift)
+    h = d.to_host()
+    d.free()
+    return h
+
+
+class SocpInstance:
+    """device-resident row shard of the synthetic SOCP"""
+
+    def __init__(self, n, n_cones, ni=99, seed=0, rank=0, world=1, allreduce_host=None):
+        _lib.ensure_init()
+        self.n, self.n_cones, self.ni, self.seed = n, n_cones, ni, seed
+        rows = 1 + ni
+        c0, c1 = shard_cones(n_cones, world, rank)
+        self.c0, self.c1 = c0, c1
+        self.m_total = n_cones * rows
+        self.m = (c1 - c0) * rows
+        row0 = c0 * rows
+        m = self.m
+        self.mat_a = DeviceBuffer(max(m * n, 1))
+        lib.thip_gen_matrix(self.mat_a.ptr, m, n, m, seed, STREAM_A, row0, 0, self.m_total, 1, -1.0 / math.sqrt(n), 0.0)
+        # strictly feasible point and the right-hand side
+        x0 = DeviceBuffer(n)
+        lib.thip_gen_vector(x0.ptr, n, seed, STREAM_X0, 0, 1, 1.0, 0.0)
+        w = DeviceBuffer(max(m, 1))
+        lib.thip_transform_ge(0, m, n, 1.0, self.mat_a.ptr, x0.ptr, 0.0, w.ptr)
+        wh = w.to_host()[:m].astype(np.float64).reshape(c1 - c0, rows)
+        hh = _gen(max(m, 1), seed, STREAM_H, row0, 1)[:m].astype(np.float64).reshape(c1 - c0, rows)
+        margin = _gen(max(c1 - c0, 1), seed, STREAM_D, c0, 0, 1.0, 0.1)[:c1 - c0].astype(np.float64)
+        d = np.linalg.norm(hh[:, 1:] - wh[:, 1:], axis=1) + wh[:, 0] + margin
+        b = hh.copy()
+        b[:, 0] = d
+        self.vec_b_host = b.reshape(-1).astype(np.float32)
+        self.vec_b = DeviceBuffer.from_host(self.vec_b_host) if m else DeviceBuffer(1)
+        # objective from a strictly dual-feasible point z = [t_i ; w_i]
+        t = _gen(max(c1 - c0, 1), seed, STREAM_T, c0, 0, 1.0, 0.5)[:c1 - c0].astype(np.float64)
+        wd = _gen(max(m, 1), seed, STREAM_W, row0, 1)[:m].astype(np.float64).reshape(c1 - c0, rows)[:, 1:]
+        ws = _gen(max(c1 - c0, 1), seed, STREAM_WS, c0, 0)[:c1 - c0].astype(np.float64)
+        wd = wd * (0.9 * t * ws / np.maximum(np.linalg.norm(wd, axis=1), 1e-9))[:, None]
+        z = np.concatenate([t[:, None], wd], axis=1).reshape(-1).astype(np.float32)
+        zd = DeviceBuffer.from_host(z) if m else DeviceBuffer(1)
+        f = DeviceBuffer(n)
+        lib.thip_transform_ge(1, m, n, -1.0, self.mat_a.ptr, zd.ptr, 0.0, f.ptr)
+        fh = f.to_host()
+        if allreduce_host is not None:
+            fh = allreduce_host(fh)          # sum over the row shards
+            lib.thip_h2d(f.ptr, fh.ctypes.data, n)
+        self.vec_c_host = fh
+        self.vec_c = f
+        self.seg_type = [_lib.CONE_SOC] * (c1 - c0)
+        self.seg_len = [rows] * (c1 - c0)
+        for d_ in (x0, w, zd):
+            d_.free()
+
+    def free(self):
+        for d in (self.mat_a, self.vec_b, self.vec_c):
+            d.free()
+
+
+class LpInstance:
+    """device-resident row shard of the benchmark_lp construction (rows split evenly; nonneg cone is separable)"""
+
+    def __init__(self, n, seed=0, rank=0, world=1):
+        _lib.ensure_init()
+        self.n = n
+        self.m_total = 2 * n
+        base, rem = divmod(self.m_total, world)
+        r0 = rank * base + min(rank, rem)
+        r1 = r0 + base + (1 if rank < rem else 0)
+        self.r0, self.r1 = r0, r1
+        m = self.m = r1 - r0
+        self.mat_a = DeviceBuffer(max(m * n, 1))
+        lib.thip_gen_matrix(self.mat_a.ptr, m, n, m, seed, STREAM_A, r0, 0, self.m_total, 0, 1.0, 0.0)
+        # rows r < n of the full matrix are -I: overwrite that part of the shard (host round trip of the identity
+        # block only when the shard intersects it)
+        if r0 < n:
+            k = min(n, r1) - r0
+            blk = np.zeros((k, n), dtype=np.float32)
+            blk[np.arange(k), r0 + np.arange(k)] = -1.0
+            full = self.mat_a.to_host().reshape(n, m)      # column-major (n columns of m)
+            full[:, :k] = blk.T
+            lib.thip_h2d(self.mat_a.ptr, full.ctypes.data, full.size)
+        h = _gen(max(m, 1), seed, STREAM_H, r0, 0)[:m]
+        h[np.arange(r0, r1) < n] = 0.0
+        self.vec_b_host = h
+        self.vec_b = DeviceBuffer.from_host(h) if m else DeviceBuffer(1)
+        c = -_gen(n, seed, STREAM_C, 0, 0)
+        self.vec_c_host = c
+        self.vec_c = DeviceBuffer.from_host(c)
+        self.seg_type = [_lib.CONE_RPOS]
+        self.seg_len = [m]
+
+    def free(self):
+        for d in (self.mat_a, self.vec_b, self.vec_c):
+            d.free()
