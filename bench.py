@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--force-collective", action="store_true", help="install the all-reduce hook even at N = 1")
     ap.add_argument("--to-eps", type=float, default=None, help="also solve to this eps_acc and report time-to-eps")
-    ap.add_argument("--cpu-cones", type=int, default=20)
+    ap.add_argument("--cpu-cones", type=int, default=0, help="cones in the CPU sample (0: pick from the thread count)")
     return ap.parse_args()
 
 
@@ -258,7 +258,10 @@ def main():
         fs2.destroy()
 
     if rank == 0 and world == 1 and not a.no_cpu and a.workload == "socp":
-        out["cpu_baseline"] = cpu_baseline(n, a.cones, 99, 0, min(a.cpu_cones, a.cones))
+        import oracle as O
+        # enough rows to give every OpenMP thread row blocks (256 rows each), A_sub capped at 16 GB of f64
+        cc = a.cpu_cones or max(20, min(int(2.56 * O.num_threads()) + 1, int(16e9 / (8.0 * n * 100))))
+        out["cpu_baseline"] = cpu_baseline(n, a.cones, 99, 0, min(cc, a.cones))
     elif rank == 0:
         out["cpu_baseline"] = None
 

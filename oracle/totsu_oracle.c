@@ -101,13 +101,13 @@ void oc_transform_ge(int transpose, size_t n_row, size_t n_col, double alpha,
         }
     } else {
         /* y has n_row entries; accumulate column by column into row blocks kept in cache */
-        const size_t RB = 2048;
+        const size_t RB = 256;
         const ptrdiff_t nblk = (ptrdiff_t)((n_row + RB - 1) / RB);
         #pragma omp parallel for schedule(static) if (n_row * n_col > 65536)
         for (ptrdiff_t b = 0; b < nblk; ++b) {
             const size_t r0 = (size_t)b * RB;
             const size_t r1 = (r0 + RB < n_row) ? r0 + RB : n_row;
-            double acc[2048];
+            double acc[256];
             for (size_t r = r0; r < r1; ++r) acc[r - r0] = 0.0;
             for (size_t c = 0; c < n_col; ++c) {
                 const double xc = x[c];

@@ -1,0 +1,59 @@
+"""Turns rocprofv3 result databases (gpurun_out/*/…_results.db) into the text summaries committed here.
+
+  python profiles/summarize.py stats gpurun_out/prof_r01/bench_results.db > profiles/r01_socp_carried_kernel_stats.txt
+  python profiles/summarize.py pmc gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db KEY
+
+`pmc` prints per-kernel averages of FETCH_SIZE / WRITE_SIZE (KiB as rocprofv3 reports them) and updates
+profiles/hbm_traffic.json[KEY] with the corrected HBM bytes per launch of the dominant kernel: on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM section) => read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is taken
+as reported (uncalibrated, and < 0.2 % of the traffic here).
+"""
+import json
+import os
+import sqlite3
+import sys
+
+
+def stats(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    print("# rocprofv3 --kernel-trace --stats  (durations in microseconds)   source: %s" % db)
+    print("%-8s %-14s %-12s %-8s  %s" % ("calls", "total_us", "avg_us", "pct", "kernel"))
+    for name, calls, tot, avg, pct in rows:
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "")
+        short = short.split("(")[0]
+        print("%-8d %-14.1f %-12.2f %-8.3f  %s" % (calls, tot, avg, pct, short))
+
+
+def pmc(fetch_db, write_db, key):
+    out = {}
+    for label, db in (("FETCH_SIZE", fetch_db), ("WRITE_SIZE", write_db)):
+        cur = sqlite3.connect(db).cursor()
+        q = ("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
+             "where counter_name = ? group by kernel_name order by avg(value) * count(*) desc")
+        print("# rocprofv3 --pmc %s   source: %s" % (label, db))
+        print("%-6s %-16s %-12s %s" % ("calls", "avg_KiB", "avg_us", "kernel"))
+        for name, calls, val, dur in cur.execute(q, (label,)):
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            print("%-6d %-16.1f %-12.1f %s" % (calls, val, dur / 1e3, short))
+            if short.startswith("dual_gemv_k<") and ", true, true, false>" in short:
+                out[label] = val
+        print()
+    if "FETCH_SIZE" in out:
+        rd = 2.0 * out["FETCH_SIZE"] * 1024.0
+        wr = out.get("WRITE_SIZE", 0.0) * 1024.0
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hbm_traffic.json")
+        d = json.load(open(path)) if os.path.exists(path) else {}
+        d[key] = {"kernel": "dual_gemv_k<DO_N, DO_T>", "fetch_size_KiB_raw": out["FETCH_SIZE"],
+                  "write_size_KiB_raw": out.get("WRITE_SIZE"), "read_bytes_corrected_x2": rd, "write_bytes": wr,
+                  "hbm_bytes_per_launch": rd + wr}
+        json.dump(d, open(path, "w"), indent=1)
+        print("# %s: corrected HBM bytes per launch = 2*FETCH + WRITE = %.4g" % (key, rd + wr))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
