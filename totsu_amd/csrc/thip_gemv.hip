@@ -20,6 +20,8 @@
 // the consumer kernel of the fused iteration (thip_solver.hip).
 #include "thip_common.h"
 
+#include <cstdlib>
+
 using namespace thip;
 
 namespace {
@@ -71,7 +73,7 @@ template <> struct Log2<2> { static constexpr int v = 1; };
 template <> struct Log2<4> { static constexpr int v = 2; };
 template <> struct Log2<8> { static constexpr int v = 3; };
 
-template <int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS>
+template <int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS, bool NT>
 __device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, int m, int r_first, int c, int cc,
                                      const float *__restrict__ xn, const float (&xtv)[NJ][VW],
                                      float (&accN)[NJ][VW], float *ldsT_wave, int lane)
@@ -85,8 +87,10 @@ __device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, in
             const int r = r_first + j * (BLK * VW);
             if constexpr (VW == 4) {
                 if (r + 4 <= m) {
-                    const float4 q = *reinterpret_cast<const float4 *>(col + r);
-                    av[u][j][0] = q.x; av[u][j][1] = q.y; av[u][j][2] = q.z; av[u][j][3] = q.w;
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    const f32x4_t *src = reinterpret_cast<const f32x4_t *>(col + r);
+                    const f32x4_t q = NT ? __builtin_nontemporal_load(src) : *src;
+                    av[u][j][0] = q[0]; av[u][j][1] = q[1]; av[u][j][2] = q[2]; av[u][j][3] = q[3];
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) av[u][j][k] = (r + k < m) ? col[r + k] : 0.0f;
@@ -131,7 +135,7 @@ __device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, in
     }
 }
 
-template <int VW, int NJ, int KU, bool DO_N, bool DO_T, bool ABS>
+template <int VW, int NJ, int KU, bool DO_N, bool DO_T, bool ABS, bool NT>
 __global__ __launch_bounds__(BLK) void dual_gemv_k(const float *__restrict__ A, size_t lda, int m, int n,
                                                    const float *__restrict__ xn, const float *__restrict__ xt,
                                                    float *__restrict__ partN, size_t strideN,
@@ -162,9 +166,9 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const float *__restrict__ A, 
     float *ldsT_wave = ldsT + wave * (DO_T ? MAXCW : 1);
     int c = c0;
     for (; c + KU <= c1; c += KU)
-        step<VW, NJ, KU, DO_N, DO_T, ABS>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+        step<VW, NJ, KU, DO_N, DO_T, ABS, NT>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
     for (; c < c1; ++c)
-        step<VW, NJ, 1, DO_N, DO_T, ABS>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+        step<VW, NJ, 1, DO_N, DO_T, ABS, NT>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
 
     if constexpr (DO_N) {
         float *dst = partN + (size_t)chunk * strideN;
@@ -235,30 +239,51 @@ __global__ void sp_absadd_k(int n, const float *__restrict__ sp, float *__restri
 }
 
 struct Plan {
-    int vw, nj, ku;
+    int vw, nj, ku, nt;
     int tiles, chunks, cols_per_chunk;
     size_t strideN, strideT;
 };
 
 static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// tuning knobs (experiments only): THIP_GEMV_NJ = 1|2|4, THIP_GEMV_BLOCKS = target grid size, THIP_GEMV_NT = 0|1
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 Plan make_plan(size_t n_row, size_t n_col, bool vec_ok)
 {
+    static const int env_nj = env_int("THIP_GEMV_NJ", 0);
+    static const int env_blocks = env_int("THIP_GEMV_BLOCKS", 0);
+    static const int env_nt = env_int("THIP_GEMV_NT", -1);
     Plan p;
     p.vw = vec_ok ? 4 : 1;
     if (vec_ok) {
-        if (n_row >= (size_t)BLK * 16 * 6) { p.nj = 4; p.ku = 2; }
-        else if (n_row >= (size_t)BLK * 8 * 4) { p.nj = 2; p.ku = 4; }
-        else { p.nj = 1; p.ku = 8; }
+        // measured on MI355X (gpurun_out/sweep_*.txt): 1 float4 row group per lane, 8 columns in
+        // flight, is as fast as taller tiles once the grid is fine enough, and keeps partial sums small
+        p.nj = 1; p.ku = 8;
+        if (env_nj == 1) { p.nj = 1; p.ku = 8; }
+        if (env_nj == 2) { p.nj = 2; p.ku = 4; }
+        if (env_nj == 4) { p.nj = 4; p.ku = 2; }
     } else {
         if (n_row >= (size_t)BLK * 4 * 4) { p.nj = 4; p.ku = 4; }
         else { p.nj = 1; p.ku = 8; }
     }
+    // A is read exactly once per launch: non-temporal loads (+6-8 % on MI355X: 6.0 -> 6.5 TB/s)
+    p.nt = env_nt >= 0 ? env_nt : 1;
     const size_t tile = (size_t)BLK * p.vw * p.nj;
     p.tiles = (int)((n_row + tile - 1) / tile);
-    // aim at ~8 blocks per CU over 256 CUs, chunk width in [KU, MAXCW]
-    const int target_blocks = 2048;
-    int chunks = (target_blocks + p.tiles - 1) / p.tiles;
+    // ~1.5 MB of A per workgroup, between 4 and 32 workgroups per CU: fine enough that the tail of the last
+    // round of workgroups is small (8192 beat 2048 by 2-4 % at 20 GB), coarse enough that the partial-sum
+    // traffic (chunks x m + tiles x n floats) stays < 1 % of A (1024-2048 was best at 0.8 GB)
+    int target_blocks = (int)((double)n_row * (double)n_col * 4.0 / 1.5e6);
+    if (target_blocks < 1024) target_blocks = 1024;
+    if (target_blocks > 8192) target_blocks = 8192;
+    if (env_blocks > 0) target_blocks = env_blocks;
+    int chunks = target_blocks / p.tiles;
+    if (chunks < 1) chunks = 1;
     int cpc = (int)((n_col + chunks - 1) / chunks);
     if (cpc < 32) cpc = 32;
     if (cpc > MAXCW) cpc = MAXCW;
@@ -276,9 +301,15 @@ void launch_cfg(const Plan &p, hipStream_t st, const float *A, size_t lda, int m
                 const float *xt, float *partN, float *partT, const int *stop)
 {
     dim3 g(p.tiles, p.chunks), b(BLK);
-#define THIP_GEMV_LAUNCH(VW, NJ, KU)                                                                      \
-    hipLaunchKernelGGL((dual_gemv_k<VW, NJ, KU, DO_N, DO_T, ABS>), g, b, 0, st, A, lda, m, n, xn, xt, partN, \
-                       p.strideN, partT, p.strideT, p.cols_per_chunk, stop)
+#define THIP_GEMV_LAUNCH(VW, NJ, KU)                                                                          \
+    do {                                                                                                      \
+        if (p.nt)                                                                                             \
+            hipLaunchKernelGGL((dual_gemv_k<VW, NJ, KU, DO_N, DO_T, ABS, true>), g, b, 0, st, A, lda, m, n, xn, xt, \
+                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop);                   \
+        else                                                                                                  \
+            hipLaunchKernelGGL((dual_gemv_k<VW, NJ, KU, DO_N, DO_T, ABS, false>), g, b, 0, st, A, lda, m, n, xn, xt, \
+                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop);                   \
+    } while (0)
     if (p.vw == 4) {
         if (p.nj == 4) THIP_GEMV_LAUNCH(4, 4, 2);
         else if (p.nj == 2) THIP_GEMV_LAUNCH(4, 2, 4);
