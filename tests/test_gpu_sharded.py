@@ -1,0 +1,152 @@
+"""GPU: the row-sharded fused loop.  Two ranks are emulated inside one process -- one thread per
+rank, each driving its own FusedSolver over its cone-aligned row block, with an all-reduce hook that meets at a
+barrier and sums the two device buffers on the shared stream.  This exercises exactly the product code that runs
+under torch.distributed (hook placement, tail scalars, replicated / sharded vectors) and must reproduce the
+unsharded solve: same status, same iteration count (+-1), same iterates to f32 round-off."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle as O
+from problems import benchmark_lp, random_socp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import totsu_amd
+    from totsu_amd import _lib
+    _lib.init()
+    return totsu_amd
+
+
+def _split_rows(dense, T, cut_seg):
+    """split the stacked problem after `cut_seg` cone segments"""
+    n, m = dense.n, dense.m
+    A = dense.mat_a.reshape((n, m)).T
+    r = int(sum(dense.seg_len[:cut_seg]))
+    parts = []
+    for lo, hi, st, sl in ((0, r, dense.seg_type[:cut_seg], dense.seg_len[:cut_seg]),
+                           (r, m, dense.seg_type[cut_seg:], dense.seg_len[cut_seg:])):
+        parts.append(dict(n=n, m=hi - lo, mat_a=np.asfortranarray(A[lo:hi]).ravel(order="F"), vec_b=dense.vec_b[lo:hi],
+                          vec_c=dense.vec_c, seg_type=list(st), seg_len=list(sl),
+                          rowabs=None if dense.vec_b_rowabs is None else dense.vec_b_rowabs[lo:hi]))
+    return parts
+
+
+def _run_sharded(T, parts, param, schedule, max_steps=-1):
+    from totsu_amd._lib import lib
+    from totsu_amd.fused import DeviceBuffer
+    # pre-grow the library's shared scratch so that no thread reallocates it under the other one
+    big = max(p["m"] for p in parts)
+    n = parts[0]["n"]
+    a = DeviceBuffer(big * n, zero=True)
+    t = DeviceBuffer(n, zero=True)
+    lib.thip_absadd_cols(big, n, a.ptr, t.ptr)
+    lib.thip_sync()
+    a.free(); t.free()
+
+    barrier = threading.Barrier(len(parts))
+    bufs = [None] * len(parts)
+    out = [None] * len(parts)
+    errs = []
+
+    def make_hook(rank):
+        def hook(ctx, ptr, cnt, stream):
+            try:
+                bufs[rank] = ptr
+                barrier.wait(timeout=60)
+                if rank == 0:
+                    for r in range(1, len(parts)):
+                        lib.thip_add(cnt, 1.0, bufs[r], bufs[0])
+                    for r in range(1, len(parts)):
+                        lib.thip_copy(cnt, bufs[0], bufs[r])
+                barrier.wait(timeout=60)
+                return 0
+            except Exception as e:      # noqa
+                errs.append(e)
+                return 1
+        return hook
+
+    def worker(rank):
+        try:
+            p = parts[rank]
+            fs = T.FusedSolver(p["n"], p["m"], p["mat_a"], p["vec_b"], p["vec_c"], p["seg_type"], p["seg_len"], param,
+                               schedule, vec_b_rowabs=p["rowabs"], allreduce=make_hook(rank))
+            r = fs.run(max_steps, poll_every=32)
+            x, y = fs.solution()
+            out[rank] = (r, x, y, fs.iterate())
+            fs.destroy()
+        except Exception as e:          # noqa
+            errs.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(len(parts))]
+    [t_.start() for t_ in th]
+    [t_.join() for t_ in th]
+    assert not errs, errs
+    return out
+
+
+def _mb(T, typ):
+    return T.MatBuild(T.F32HIP, typ)
+
+
+@pytest.mark.parametrize("schedule", ["reference", "fused", "carried"])
+def test_sharded_socp_matches_unsharded(T, schedule):
+    n, cones = 40, [9, 30, 0, 5, 64, 12]
+    f, Gs, hs, cs, d = random_socp(n, cones, seed=5)
+    socp = T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(f.reshape(-1, 1)),
+                      [_mb(T, T.MatType.General(g.shape[0], n)).set_array(g) for g in Gs],
+                      [_mb(T, T.MatType.General(len(v), 1)).set_array(v.reshape(-1, 1)) for v in hs],
+                      [_mb(T, T.MatType.General(n, 1)).set_array(v.reshape(-1, 1)) for v in cs], d,
+                      _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+    dense = socp.dense()
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 200_000, 1e-4
+    fs = T.FusedSolver.from_dense(dense, p, schedule)
+    x1, y1 = fs.solve()
+    r1 = fs.status()
+    fs.destroy()
+    parts = _split_rows(dense, T, 3)
+    out = _run_sharded(T, parts, p, schedule)
+    (ra, xa, ya, _), (rb, xb, yb, _) = out
+    assert ra.state == rb.state == 0
+    assert ra.iters == rb.iters and abs(ra.iters - r1.iters) <= max(2, 0.01 * r1.iters)
+    assert np.array_equal(xa, xb)                         # replicated n-vectors stay bitwise identical across ranks
+    assert np.allclose(xa, x1, rtol=2e-3, atol=2e-4)
+    assert np.allclose(np.concatenate([ya, yb]), y1, rtol=2e-3, atol=2e-4)
+    ro = O.solve_matop_cones(O.param(max_iter=200000, eps_acc=1e-4), dense.vec_c, dense.mat_a, dense.vec_b,
+                             dense.seg_type, dense.seg_len)
+    pobj = float(dense.vec_c.astype(np.float64) @ ro.x)
+    assert abs(float(dense.vec_c.astype(np.float64) @ xa) - pobj) <= 1e-3 * (1 + abs(pobj))
+
+
+def test_sharded_lp_first_iterates(T):
+    c, G, h = benchmark_lp(48, seed=6)
+    lp = T.ProbLP(_mb(T, T.MatType.General(48, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(96, 48)).set_array(G),
+                  _mb(T, T.MatType.General(96, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, 48)),
+                  _mb(T, T.MatType.General(0, 1)))
+    dense = lp.dense()
+    # nonneg cone is separable: split its rows 60 / 36 (+ the empty zero cone on the second shard)
+    n, m = dense.n, dense.m
+    A = dense.mat_a.reshape((n, m)).T
+    parts = [dict(n=n, m=60, mat_a=np.asfortranarray(A[:60]).ravel(order="F"), vec_b=dense.vec_b[:60], vec_c=dense.vec_c,
+                  seg_type=[1], seg_len=[60], rowabs=None),
+             dict(n=n, m=36, mat_a=np.asfortranarray(A[60:]).ravel(order="F"), vec_b=dense.vec_b[60:], vec_c=dense.vec_c,
+                  seg_type=[1, 0], seg_len=[36, 0], rowabs=None)]
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    ro = O.solve_matop_cones(O.param(max_iter=52, eps_acc=1e-300), dense.vec_c, dense.mat_a, dense.vec_b, dense.seg_type,
+                             dense.seg_len, snap_iters=[49], trace_cap=60)
+    out = _run_sharded(T, parts, p, "carried", max_steps=50)
+    N = n + 2 * m + 1
+    rx, ry = ro.snaps[0][:N], ro.snaps[0][N:]
+    (_, _, _, (xa, ya)), (_, _, _, (xb, yb)) = out
+    x = np.concatenate([xa[:n], xa[n:n + 60], xb[n:n + 36], xa[n + 60:n + 120], xb[n + 36:n + 72], xa[-1:]])
+    y = np.concatenate([ya[:n], ya[n:n + 60], yb[n:n + 36], ya[-1:]])
+    assert np.abs(x - rx).max() <= 1e-3 * max(np.abs(rx).max(), 1e-6)
+    assert np.abs(y - ry).max() <= 1e-3 * max(np.abs(ry).max(), 1e-6)
+    assert xa[-1] == xb[-1] and ya[-1] == yb[-1]          # tau, kappa replicated

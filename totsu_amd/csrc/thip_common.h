@@ -143,6 +143,8 @@ enum { RED_SUMSQ_SQRT = 0, RED_ABSSUM = 1, RED_DOT = 2 };
 
 int soc_batched(hipStream_t st, float *x, const int64_t *dev_begs, const int64_t *dev_ends, size_t n_cones,
                 int rotated, size_t max_len, const int *stop);
+int soc_batched2(hipStream_t st, float *x0, float *x1, float *rx0, float *rx1, const int64_t *dev_begs,
+                 const int64_t *dev_ends, size_t n_cones, int rotated, size_t max_len, const int *stop);
 int group_min_batched(hipStream_t st, float *t, const int64_t *dev_begs, const int64_t *dev_ends, size_t n_groups,
                       size_t max_len);
 

@@ -21,18 +21,23 @@ __global__ void rpos_k(size_t n, float *__restrict__ x)
         x[i] = fmaxf(x[i], 0.0f);
 }
 
-// BLOCKWISE = false: 4 cones per 256-thread block, one wave each; true: one cone per block
+// BLOCKWISE = false: 4 cones per 256-thread block, one wave each; true: one cone per block.
+// Optional second vector x1 (the fused loop projects x_y and x_s in one launch: grid covers 2 * n_cones) and
+// optional rx0 / rx1: after the projection rx <- rx - 2 x over the cone's rows (solver.rs:555 folded in).
 template <bool BLOCKWISE>
-__global__ __launch_bounds__(BLK) void soc_k(float *__restrict__ x, const int64_t *__restrict__ begs,
+__global__ __launch_bounds__(BLK) void soc_k(float *__restrict__ x0, float *__restrict__ x1, float *__restrict__ rx0,
+                                             float *__restrict__ rx1, const int64_t *__restrict__ begs,
                                              const int64_t *__restrict__ ends, int64_t n_cones,
                                              int rotated, int64_t single_len, const int *__restrict__ stop)
 {
     if (stop != nullptr && *stop != 0) return;
     __shared__ float sh[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t cone = BLOCKWISE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
-    const bool active = cone < n_cones;
-    if (!BLOCKWISE && !active) return;     // whole wave leaves together
+    const int64_t total = x1 ? 2 * n_cones : n_cones;
+    int64_t cone = BLOCKWISE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
+    if (!BLOCKWISE && cone >= total) return;     // whole wave leaves together
+    float *x = x0, *rx = rx0;
+    if (cone >= n_cones) { cone -= n_cones; x = x1; rx = rx1; }
     const int64_t beg = begs ? begs[cone] : 0;
     const int64_t end = ends ? ends[cone] : single_len;
     const int64_t len = end - beg;
@@ -42,7 +47,11 @@ __global__ __launch_bounds__(BLK) void soc_k(float *__restrict__ x, const int64_
     const float fsqrt2 = sqrtf(2.0f);
 
     if (rotated && len == 1) {             // cone_rotsoc.rs:46-49
-        if (gid == 0) x[beg] = fmaxf(x[beg], 0.0f);
+        if (gid == 0) {
+            const float v = fmaxf(x[beg], 0.0f);
+            x[beg] = v;
+            if (rx) rx[beg] = rx[beg] - 2.0f * v;
+        }
         return;
     }
 
@@ -71,15 +80,28 @@ __global__ __launch_bounds__(BLK) void soc_k(float *__restrict__ x, const int64_
     else { f = (1.0f + s0 / norm_v) / 2.0f; s_new = (norm_v + s0) / 2.0f; }
 
     if (!rotated) {
-        if (f == 1.0f) return;
-        if (gid == 0) x[beg] = s_new;
-        for (int64_t i = beg + 1 + gid; i < end; i += gsz) x[i] = f * x[i];
+        if (f == 1.0f && rx == nullptr) return;
+        if (gid == 0) {
+            x[beg] = s_new;
+            if (rx) rx[beg] = rx[beg] - 2.0f * s_new;
+        }
+        for (int64_t i = beg + 1 + gid; i < end; i += gsz) {
+            const float nv = (f == 1.0f) ? x[i] : f * x[i];
+            x[i] = nv;
+            if (rx) rx[i] = rx[i] - 2.0f * nv;
+        }
     } else {
         const float v1n = f * v1;
-        for (int64_t i = beg + 2 + gid; i < end; i += gsz) x[i] = f * x[i];
+        for (int64_t i = beg + 2 + gid; i < end; i += gsz) {
+            const float nv = (f == 1.0f) ? x[i] : f * x[i];
+            x[i] = nv;
+            if (rx) rx[i] = rx[i] - 2.0f * nv;
+        }
         if (gid == 0) {                    // cone_rotsoc.rs:58-61
-            x[beg] = (s_new + v1n) / fsqrt2;
-            x[beg + 1] = (s_new - v1n) / fsqrt2;
+            const float a = (s_new + v1n) / fsqrt2, b = (s_new - v1n) / fsqrt2;
+            x[beg] = a;
+            x[beg + 1] = b;
+            if (rx) { rx[beg] = rx[beg] - 2.0f * a; rx[beg + 1] = rx[beg + 1] - 2.0f * b; }
         }
     }
 }
@@ -106,18 +128,25 @@ __global__ __launch_bounds__(BLK) void group_min_k(float *__restrict__ t, const 
 
 namespace thip {
 // internal: batched SOC with a stop flag (fused iteration)
+int soc_batched2(hipStream_t st, float *x0, float *x1, float *rx0, float *rx1, const int64_t *dev_begs,
+                 const int64_t *dev_ends, size_t n_cones, int rotated, size_t max_len, const int *stop)
+{
+    if (n_cones == 0) return 0;
+    const size_t total = x1 ? 2 * n_cones : n_cones;
+    if (max_len > 2048)
+        hipLaunchKernelGGL(soc_k<true>, dim3((unsigned)total), dim3(BLK), 0, st, x0, x1, rx0, rx1, dev_begs, dev_ends,
+                           (int64_t)n_cones, rotated, (int64_t)0, stop);
+    else
+        hipLaunchKernelGGL(soc_k<false>, dim3((unsigned)((total + 3) / 4)), dim3(BLK), 0, st, x0, x1, rx0, rx1, dev_begs,
+                           dev_ends, (int64_t)n_cones, rotated, (int64_t)0, stop);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int soc_batched(hipStream_t st, float *x, const int64_t *dev_begs, const int64_t *dev_ends, size_t n_cones,
                 int rotated, size_t max_len, const int *stop)
 {
-    if (n_cones == 0) return 0;
-    if (max_len > 2048)
-        hipLaunchKernelGGL(soc_k<true>, dim3((unsigned)n_cones), dim3(BLK), 0, st, x, dev_begs, dev_ends,
-                           (int64_t)n_cones, rotated, (int64_t)0, stop);
-    else
-        hipLaunchKernelGGL(soc_k<false>, dim3((unsigned)((n_cones + 3) / 4)), dim3(BLK), 0, st, x, dev_begs, dev_ends,
-                           (int64_t)n_cones, rotated, (int64_t)0, stop);
-    THIP_LAUNCH_CHECK();
-    return 0;
+    return soc_batched2(st, x, nullptr, nullptr, nullptr, dev_begs, dev_ends, n_cones, rotated, max_len, stop);
 }
 
 int group_min_batched(hipStream_t st, float *t, const int64_t *dev_begs, const int64_t *dev_ends, size_t n_groups,
@@ -158,11 +187,13 @@ static int soc_single(size_t n, float *x, int rotated)
     THIP_NEED_INIT();
     if (n == 0) return 0;
     if (n > 2048)
-        hipLaunchKernelGGL(soc_k<true>, dim3(1), dim3(BLK), 0, ctx().stream, x, (const int64_t *)nullptr,
-                           (const int64_t *)nullptr, (int64_t)1, rotated, (int64_t)n, (const int *)nullptr);
+        hipLaunchKernelGGL(soc_k<true>, dim3(1), dim3(BLK), 0, ctx().stream, x, (float *)nullptr, (float *)nullptr,
+                           (float *)nullptr, (const int64_t *)nullptr, (const int64_t *)nullptr, (int64_t)1, rotated,
+                           (int64_t)n, (const int *)nullptr);
     else
-        hipLaunchKernelGGL(soc_k<false>, dim3(1), dim3(BLK), 0, ctx().stream, x, (const int64_t *)nullptr,
-                           (const int64_t *)nullptr, (int64_t)1, rotated, (int64_t)n, (const int *)nullptr);
+        hipLaunchKernelGGL(soc_k<false>, dim3(1), dim3(BLK), 0, ctx().stream, x, (float *)nullptr, (float *)nullptr,
+                           (float *)nullptr, (const int64_t *)nullptr, (const int64_t *)nullptr, (int64_t)1, rotated,
+                           (int64_t)n, (const int *)nullptr);
     THIP_LAUNCH_CHECK();
     return 0;
 }

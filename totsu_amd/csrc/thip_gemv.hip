@@ -275,11 +275,11 @@ Plan make_plan(size_t n_row, size_t n_col, bool vec_ok)
     p.nt = env_nt >= 0 ? env_nt : 1;
     const size_t tile = (size_t)BLK * p.vw * p.nj;
     p.tiles = (int)((n_row + tile - 1) / tile);
-    // ~1.5 MB of A per workgroup, between 4 and 32 workgroups per CU: fine enough that the tail of the last
-    // round of workgroups is small (8192 beat 2048 by 2-4 % at 20 GB), coarse enough that the partial-sum
-    // traffic (chunks x m + tiles x n floats) stays < 1 % of A (1024-2048 was best at 0.8 GB)
-    int target_blocks = (int)((double)n_row * (double)n_col * 4.0 / 1.5e6);
-    if (target_blocks < 1024) target_blocks = 1024;
+    // 8 to 32 workgroups per CU (0.2 MB of A each at the low end): a fine grid shortens the ramp and the tail of
+    // the last round of workgroups (MI355X sweep: 8192 beat 2048 by 2-4 % at 20 GB, 4096 beat 1024 by 30 % at
+    // 0.8 GB); the partial-sum traffic (chunks x m + tiles x n floats) stays at 1-2 % of A
+    int target_blocks = (int)((double)n_row * (double)n_col * 4.0 / 2.0e5);
+    if (target_blocks < 2048) target_blocks = 2048;
     if (target_blocks > 8192) target_blocks = 8192;
     if (env_blocks > 0) target_blocks = env_blocks;
     int chunks = target_blocks / p.tiles;

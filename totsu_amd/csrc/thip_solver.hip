@@ -32,6 +32,7 @@ namespace {
 constexpr int BLK = 256;
 constexpr int TAIL = 8;          // scalars riding behind an n-vector through the all-reduce
 constexpr unsigned EG = 512;     // max blocks of the elementwise kernels (block partials per quantity)
+constexpr unsigned PG = 4096;    // max blocks of post_k (64 elements per block)
 
 // device status block (copied whole to the host when polling)
 struct DevStatus {
@@ -49,206 +50,243 @@ struct DevStatus {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// kernels
+// kernels.  One iteration of the carried schedule is 11 launches:
+//   gemv, post, sumfin, [all-reduce], xupdate, soc | gemv, post, sumfin, [all-reduce], ycrit, status, final_scale
 // ---------------------------------------------------------------------------------------------------
 
-// sum of `np` block partials of `nq` quantities (part[q*np + k]) -> out[q]; one block
-__global__ void sum_partials_k(int nq, int np, const float *__restrict__ part, float *__restrict__ out,
-                               const int *__restrict__ stop)
+// After a dual GEMV: second reduction stage of both products + the stage's sharded / replicated reductions.
+//   g[i] = sum_k partT[k][i] (n) ; h[i] = sum_k partN[k][i] (m)
+//   q0 = dn_a . dn_b over n (optional) ; q1 = dm_a . dm_b over m (optional)
+//   crit != 0: q2 = ||p||^2, q3 = b . x_y with
+//      tau > eps_zero: p = x_s/tau - b + h/tau (solver.rs:592-594) ; else p = x_s + h (solver.rs:631-632)
+// block partials -> part[q * gridDim.x + blockIdx.x]
+__global__ __launch_bounds__(BLK) void post_k(int n, int m,
+                                             const float *__restrict__ partT, int nT, size_t strideT, float *__restrict__ g,
+                                             const float *__restrict__ partN, int nN, size_t strideN, float *__restrict__ h,
+                                             const float *__restrict__ dn_a, const float *__restrict__ dn_b,
+                                             const float *__restrict__ dm_a, const float *__restrict__ dm_b,
+                                             int crit, const float *__restrict__ xs, const float *__restrict__ xy,
+                                             const float *__restrict__ b, float eps_zero,
+                                             float *__restrict__ part, const DevStatus *st)
+{
+    if (st->stop != 0) return;
+    // 256 threads = 64 elements x 4 partial-index lanes: the sum over the ~100 partials of one element is split
+    // four ways (4x the loads in flight), combined through LDS, and lane 0 of each element does the epilogue
+    __shared__ float sh[16];
+    __shared__ float comb[3][64];
+    const int e = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const size_t gstride = (size_t)gridDim.x * 64;
+    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+    const float tau = st->tau;
+    const bool conv = tau > eps_zero;
+    const float rt = conv ? 1.0f / tau : 1.0f;
+
+    for (size_t i0 = blockIdx.x * (size_t)64; i0 < (size_t)n; i0 += gstride) {
+        const size_t i = i0 + e;
+        float s = 0.0f;
+        if (i < (size_t)n)
+            for (int k = kq; k < nT; k += 4) s += partT[(size_t)k * strideT + i];
+        if (kq > 0) comb[kq - 1][e] = s;
+        __syncthreads();
+        if (kq == 0 && i < (size_t)n) {
+            s = (s + comb[0][e]) + (comb[1][e] + comb[2][e]);
+            g[i] = s;
+            if (dn_a) q0 = fmaf(dn_a[i], dn_b[i], q0);
+        }
+        __syncthreads();
+    }
+    for (size_t i0 = blockIdx.x * (size_t)64; i0 < (size_t)m; i0 += gstride) {
+        const size_t i = i0 + e;
+        float s = 0.0f;
+        if (i < (size_t)m)
+            for (int k = kq; k < nN; k += 4) s += partN[(size_t)k * strideN + i];
+        if (kq > 0) comb[kq - 1][e] = s;
+        __syncthreads();
+        if (kq == 0 && i < (size_t)m) {
+            s = (s + comb[0][e]) + (comb[1][e] + comb[2][e]);
+            h[i] = s;
+            if (dm_a) q1 = fmaf(dm_a[i], dm_b[i], q1);
+            if (crit) {
+                const float bi = b[i];
+                float p;
+                if (conv) { p = xs[i] * rt - bi; p = fmaf(rt, s, p); }
+                else p = xs[i] + s;
+                q2 = fmaf(p, p, q2);
+                q3 = fmaf(bi, xy[i], q3);
+            }
+        }
+        __syncthreads();
+    }
+    q0 = block_sum(q0, sh); q1 = block_sum(q1, sh);
+    if (threadIdx.x == 0) { part[blockIdx.x] = q0; part[gridDim.x + blockIdx.x] = q1; }
+    if (crit) {
+        q2 = block_sum(q2, sh); q3 = block_sum(q3, sh);
+        if (threadIdx.x == 0) { part[2 * gridDim.x + blockIdx.x] = q2; part[3 * gridDim.x + blockIdx.x] = q3; }
+    }
+}
+
+// sums of the block partials of up to 4 quantities -> their destinations (null = skip); one block
+__global__ __launch_bounds__(BLK) void sumfin_k(int np, const float *__restrict__ part, float *d0, float *d1, float *d2,
+                                               float *d3, const int *__restrict__ stop)
 {
     if (stop != nullptr && *stop != 0) return;
     __shared__ double shd[16];
-    for (int q = 0; q < nq; ++q) {
+    float *dst[4] = { d0, d1, d2, d3 };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (dst[q] == nullptr) continue;
         double acc = 0.0;
-        for (int k = threadIdx.x; k < np; k += blockDim.x) acc += (double)part[(size_t)q * np + k];
+        for (int k = threadIdx.x; k < np; k += BLK) acc += (double)part[(size_t)q * np + k];
         acc = block_sum_d(acc, shd);
-        if (threadIdx.x == 0) out[q] = (float)acc;
+        if (threadIdx.x == 0) *dst[q] = (float)acc;
         __syncthreads();
     }
 }
 
-// two dot products in one launch: q0 = a0.b0 over n0 (block partials part[0..G)), q1 = a1.b1 over n1
-__global__ void dots2_k(size_t n0, const float *__restrict__ a0, const float *__restrict__ b0,
-                        size_t n1, const float *__restrict__ a1, const float *__restrict__ b1,
-                        float *__restrict__ part, const int *__restrict__ stop)
-{
-    if (stop != nullptr && *stop != 0) return;
-    __shared__ float sh[16];
-    const size_t gstride = (size_t)gridDim.x * BLK;
-    float s0 = 0.0f, s1 = 0.0f;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n0; i += gstride) s0 = fmaf(a0[i], b0[i], s0);
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n1; i += gstride) s1 = fmaf(a1[i], b1[i], s1);
-    s0 = block_sum(s0, sh);
-    s1 = block_sum(s1, sh);
-    if (threadIdx.x == 0) { part[blockIdx.x] = s0; part[gridDim.x + blockIdx.x] = s1; }
-}
-
-// x-update, solver.rs:538-552 without the block cones:
-//   rx <- x ; x += T o tx with tx = -K^T y (solver.rs:541-542, SelfDualEmbed::trans_op solver.rs:133-157):
-//   x_x += Tx o ( gT + c kappa)        gT = A^T v   (after the all-reduce)
-//   x_y += Ty o (-hN + b kappa)        hN = A u
-//   x_s += Ts o ( v )
-//   tau += Ttau (-c.u - b.v) ; tau <- max(tau, 0)
-// and the element-wise cones folded in: cls 0 = zero cone (dual: identity, primal: 0; cone_zero.rs:38-44),
-// cls 1 = nonneg (max(.,0) for both; cone_rpos.rs:38-45), cls 2 = member of a block cone (projected later).
-__global__ void xupdate_k(int n, int m, const float *__restrict__ gT, const float *__restrict__ hN,
-                          const float *__restrict__ c, const float *__restrict__ b,
-                          const float *__restrict__ v, const float *__restrict__ Tx, const float *__restrict__ Ty,
-                          const float *__restrict__ Ts, const unsigned char *__restrict__ cls,
-                          float *__restrict__ xx, float *__restrict__ xy, float *__restrict__ xs,
-                          float *__restrict__ rxx, float *__restrict__ rxy, float *__restrict__ rxs,
-                          const float *__restrict__ dot_c, const float *__restrict__ dot_b, DevStatus *st)
+// x-update, solver.rs:538-555 (everything except the block cones):
+//   x += T o tx with tx = -K^T y (SelfDualEmbed::trans_op, solver.rs:133-157):
+//     x_x += Tx o ( gT + c kappa)        gT = A^T v   (after the all-reduce)
+//     x_y += Ty o (-hN + b kappa)        hN = A u
+//     x_s += Ts o ( v )
+//     tau += Ttau (-c.u - b.v) ; tau <- max(tau, 0)                       (solver.rs:551-552)
+//   element-wise cones folded in: cls 0 = zero cone (dual: identity, primal: 0; cone_zero.rs:38-44),
+//   cls 1 = nonneg (max(.,0) both; cone_rpos.rs:38-45), cls >= 2 = member of a block cone (projected by the
+//   next launch, which also finishes rx for those rows);
+//   rx = x_k - 2 x_{k+1} (solver.rs:538,555) for x_x, tau and the cls 0/1 rows; rx = x_k for block-cone rows.
+__global__ __launch_bounds__(BLK) void xupdate_k(int n, int m, const float *__restrict__ gT, const float *__restrict__ hN,
+                                                const float *__restrict__ c, const float *__restrict__ b,
+                                                const float *__restrict__ v, const float *__restrict__ Tx,
+                                                const float *__restrict__ Ty, const float *__restrict__ Ts,
+                                                const unsigned char *__restrict__ cls,
+                                                float *__restrict__ xx, float *__restrict__ xy, float *__restrict__ xs,
+                                                float *__restrict__ rxx, float *__restrict__ rxy, float *__restrict__ rxs,
+                                                const float *__restrict__ dot_c, const float *__restrict__ dot_b,
+                                                DevStatus *st)
 {
     if (st->stop != 0) return;
     const float kappa = st->kappa;
     const size_t gstride = (size_t)gridDim.x * BLK;
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
         const float old = xx[i];
-        rxx[i] = old;
-        xx[i] = old + Tx[i] * (gT[i] + c[i] * kappa);
+        const float nw = old + Tx[i] * (gT[i] + c[i] * kappa);
+        xx[i] = nw;
+        rxx[i] = old - 2.0f * nw;
     }
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
         const unsigned char k = cls[i];
         const float oy = xy[i], os = xs[i];
-        rxy[i] = oy;
-        rxs[i] = os;
         float ny = oy + Ty[i] * (b[i] * kappa - hN[i]);
         float ns = os + Ts[i] * v[i];
         if (k == 1) { ny = fmaxf(ny, 0.0f); ns = fmaxf(ns, 0.0f); }
         else if (k == 0) { ns = 0.0f; }
         xy[i] = ny;
         xs[i] = ns;
+        rxy[i] = (k < 2) ? oy - 2.0f * ny : oy;
+        rxs[i] = (k < 2) ? os - 2.0f * ns : os;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // every other block only reads st->kappa / st->stop; tau is written by this thread alone
+        // every other thread only reads st->kappa / st->stop; tau is written by this thread alone
         const float old = st->tau;
         float t = old + st->t_tau * (-(dot_c[0]) - dot_b[0]);
-        t = fmaxf(t, 0.0f);               // solver.rs:551-552
-        st->r_tau = old;
+        t = fmaxf(t, 0.0f);
         st->tau = t;
+        st->r_tau = old - 2.0f * t;
     }
 }
 
-// rx <- rx - 2 x  (solver.rs:555), after the projections
-__global__ void rx_k(int n, int m, const float *__restrict__ xx, const float *__restrict__ xy,
-                     const float *__restrict__ xs, float *__restrict__ rxx, float *__restrict__ rxy,
-                     float *__restrict__ rxs, DevStatus *st)
+// rx <- rx - 2 x on the rows of PSD blocks (cls 3), after their projection
+__global__ void rx_psd_k(int m, const unsigned char *__restrict__ cls, const float *__restrict__ xy,
+                         const float *__restrict__ xs, float *__restrict__ rxy, float *__restrict__ rxs,
+                         const DevStatus *st)
 {
     if (st->stop != 0) return;
-    const size_t gstride = (size_t)gridDim.x * BLK;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) rxx[i] = rxx[i] - 2.0f * xx[i];
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
-        rxy[i] = rxy[i] - 2.0f * xy[i];
-        rxs[i] = rxs[i] - 2.0f * xs[i];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->r_tau = st->r_tau - 2.0f * st->tau;
-}
-
-// carried schedule: h2 = hP - 2 h3, g2 = gP - 2 g3 (then the new criteria products become the previous)
-__global__ void carried_k(int n, int m, const float *__restrict__ g3, const float *__restrict__ h3,
-                          float *__restrict__ gP, float *__restrict__ hP, float *__restrict__ g2,
-                          float *__restrict__ h2, const DevStatus *st)
-{
-    if (st->stop != 0) return;
-    const size_t gstride = (size_t)gridDim.x * BLK;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
-        const float nw = g3[i];
-        g2[i] = gP[i] - 2.0f * nw;
-        gP[i] = nw;
-    }
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
-        const float nw = h3[i];
-        h2[i] = hP[i] - 2.0f * nw;
-        hP[i] = nw;
-    }
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += (size_t)gridDim.x * BLK)
+        if (cls[i] == 3) { rxy[i] = rxy[i] - 2.0f * xy[i]; rxs[i] = rxs[i] - 2.0f * xs[i]; }
 }
 
 // y-update, solver.rs:557-567 with ty = -K rx (SelfDualEmbed::op solver.rs:109-131):
-//   u += Su o (-g2 - c rtau)          g2 = A^T rx_y (after the all-reduce)
+//   u += Su o (-g2 - c rtau)          g2 = A^T rx_y
 //   v += Sv o ( h2 + rx_s - b rtau)   h2 = A rx_x
 //   kappa += Skappa (c.rx_x + b.rx_y) ; kappa <- min(kappa, 0)
-__global__ void yupdate_k(int n, int m, const float *__restrict__ g2, const float *__restrict__ h2,
-                          const float *__restrict__ c, const float *__restrict__ b, const float *__restrict__ rxs,
-                          const float *__restrict__ Su, const float *__restrict__ Sv, float *__restrict__ u,
-                          float *__restrict__ v, const float *__restrict__ dot_c, const float *__restrict__ dot_b,
-                          DevStatus *st)
+// carried != 0: g2 = gP - 2 g3, h2 = hP - 2 h3 from the criteria products of x_k (gP, hP) and x_{k+1} (g3, h3),
+//   which then become the previous ones;  carried == 0: g2 / h2 are given.
+// docrit != 0: also the n-part of the criteria: block partials of ||d||^2 and c.x_x,
+//   d = c + (A^T x_y)/tau (solver.rs:596-597) or A^T x_y (solver.rs:634)
+__global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carried, int docrit,
+                                              const float *__restrict__ g3, const float *__restrict__ h3,
+                                              float *__restrict__ gP, float *__restrict__ hP,
+                                              const float *__restrict__ g2in, const float *__restrict__ h2in,
+                                              const float *__restrict__ c, const float *__restrict__ b,
+                                              const float *__restrict__ rxs, const float *__restrict__ Su,
+                                              const float *__restrict__ Sv, float *__restrict__ u, float *__restrict__ v,
+                                              const float *__restrict__ xx, const float *__restrict__ dot_c,
+                                              const float *__restrict__ dot_b, float eps_zero, float *__restrict__ part,
+                                              DevStatus *st)
 {
     if (st->stop != 0) return;
+    __shared__ float sh[16];
     const float rtau = st->r_tau;
-    const size_t gstride = (size_t)gridDim.x * BLK;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride)
-        u[i] = u[i] + Su[i] * (-g2[i] - c[i] * rtau);
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride)
-        v[i] = v[i] + Sv[i] * (h2[i] + rxs[i] - b[i] * rtau);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float k = st->kappa + st->s_kappa * (dot_c[0] + dot_b[0]);
-        st->kappa = fminf(k, 0.0f);       // solver.rs:566-567
-    }
-}
-
-// criteria, m-part (sharded): block partials of ||p||^2 and b.x_y
-//   tau > eps_zero: p = x_s/tau - b + (A x_x)/tau  (solver.rs:592-594) ; else p = x_s + A x_x (solver.rs:631-632)
-__global__ void crit_m_k(int m, const float *__restrict__ h3, const float *__restrict__ xs,
-                         const float *__restrict__ xy, const float *__restrict__ b, float eps_zero,
-                         float *__restrict__ part, const DevStatus *st)
-{
-    if (st->stop != 0) return;
-    __shared__ float sh[16];
     const float tau = st->tau;
     const bool conv = tau > eps_zero;
     const float rt = conv ? 1.0f / tau : 1.0f;
-    float pp = 0.0f, by = 0.0f;
     const size_t gstride = (size_t)gridDim.x * BLK;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
-        const float bi = b[i];
-        float p;
-        if (conv) { p = xs[i] * rt - bi; p = fmaf(rt, h3[i], p); }
-        else p = xs[i] + h3[i];
-        pp = fmaf(p, p, pp);
-        by = fmaf(bi, xy[i], by);
-    }
-    pp = block_sum(pp, sh);
-    by = block_sum(by, sh);
-    if (threadIdx.x == 0) { part[blockIdx.x] = pp; part[gridDim.x + blockIdx.x] = by; }
-}
-
-// criteria, n-part (replicated): ||d||^2 and c.x_x ;  d = c + (A^T x_y)/tau (solver.rs:596-597) or A^T x_y (:634)
-__global__ void crit_n_k(int n, const float *__restrict__ g3, const float *__restrict__ xx,
-                         const float *__restrict__ c, float eps_zero, float *__restrict__ part, const DevStatus *st)
-{
-    if (st->stop != 0) return;
-    __shared__ float sh[16];
-    const float tau = st->tau;
-    const bool conv = tau > eps_zero;
-    const float rt = conv ? 1.0f / tau : 1.0f;
     float dd = 0.0f, cx = 0.0f;
-    const size_t gstride = (size_t)gridDim.x * BLK;
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
         const float ci = c[i];
-        const float d = conv ? fmaf(rt, g3[i], ci) : g3[i];
-        dd = fmaf(d, d, dd);
-        cx = fmaf(ci, xx[i], cx);
+        if (doy) {
+            float g2;
+            if (carried) { const float nw = g3[i]; g2 = gP[i] - 2.0f * nw; gP[i] = nw; }
+            else g2 = g2in[i];
+            u[i] = u[i] + Su[i] * (-g2 - ci * rtau);
+        }
+        if (docrit) {
+            const float d = conv ? fmaf(rt, g3[i], ci) : g3[i];
+            dd = fmaf(d, d, dd);
+            cx = fmaf(ci, xx[i], cx);
+        }
     }
-    dd = block_sum(dd, sh);
-    cx = block_sum(cx, sh);
-    if (threadIdx.x == 0) { part[blockIdx.x] = dd; part[gridDim.x + blockIdx.x] = cx; }
+    if (doy) {
+        for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
+            float h2;
+            if (carried) { const float nw = h3[i]; h2 = hP[i] - 2.0f * nw; hP[i] = nw; }
+            else h2 = h2in[i];
+            v[i] = v[i] + Sv[i] * (h2 + rxs[i] - b[i] * rtau);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const float k = st->kappa + st->s_kappa * (dot_c[0] + dot_b[0]);
+            st->kappa = fminf(k, 0.0f);       // solver.rs:566-567
+        }
+    }
+    if (docrit) {
+        dd = block_sum(dd, sh);
+        cx = block_sum(cx, sh);
+        if (threadIdx.x == 0) { part[blockIdx.x] = dd; part[gridDim.x + blockIdx.x] = cx; }
+    }
 }
 
 // the termination test, solver.rs:381-451 + the tails of criteria_conv / criteria_inf (solver.rs:599-611,
-// 636-655).  One thread.  sums: pp_by[0] = ||p||^2, pp_by[1] = b.x_y (all-reduced), dd_cx[0] = ||d||^2,
-// dd_cx[1] = c.x_x.
-__global__ void status_k(const float *__restrict__ pp_by, const float *__restrict__ dd_cx, float eps_acc,
-                         float eps_inf, float eps_zero, long long max_iter, DevStatus *st)
+// 636-655).  One block: sums the np block partials of ||d||^2 and c.x_x, then thread 0 decides.
+// pp_by[0] = ||p||^2, pp_by[1] = b.x_y (already all-reduced).
+__global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict__ part, const float *__restrict__ pp_by,
+                                               float eps_acc, float eps_inf, float eps_zero, long long max_iter,
+                                               DevStatus *st)
 {
     if (st->stop != 0) return;
+    __shared__ double shd[16];
+    double a0 = 0.0, a1 = 0.0;
+    for (int k = threadIdx.x; k < np; k += BLK) { a0 += (double)part[k]; a1 += (double)part[np + k]; }
+    a0 = block_sum_d(a0, shd);
+    a1 = block_sum_d(a1, shd);
+    if (threadIdx.x != 0) return;
+    const float dd = (float)a0, cx = (float)a1;
     const long long i = st->iter;
     const bool excess_iter = (max_iter >= 0) ? (i + 1 >= max_iter) : false;
     const float tau = st->tau;
-    const float norm_p = sqrtf(pp_by[0]), norm_d = sqrtf(dd_cx[0]);
+    const float norm_p = sqrtf(pp_by[0]), norm_d = sqrtf(dd);
     int state = THIP_ST_RUNNING;
     if (tau > eps_zero) {
         const float rt = 1.0f / tau;
-        const float g_x = rt * dd_cx[1];
+        const float g_x = rt * cx;
         const float g_y = rt * pp_by[1];
         const float g = g_x + g_y;
         const float cri_pri = norm_p / (1.0f + st->norm_b);
@@ -259,7 +297,7 @@ __global__ void status_k(const float *__restrict__ pp_by, const float *__restric
         if (term_conv) state = THIP_ST_OK;
         else if (excess_iter) state = THIP_ST_EXCESS_ITER;
     } else {
-        const float m_cx = -dd_cx[1];
+        const float m_cx = -cx;
         const float m_by = -pp_by[1];
         const float cri_unbdd = (m_cx > eps_zero) ? norm_p * st->norm_c / m_cx : __builtin_inff();
         const float cri_infeas = (m_by > eps_zero) ? norm_d * st->norm_b / m_by : __builtin_inff();
@@ -269,12 +307,8 @@ __global__ void status_k(const float *__restrict__ pp_by, const float *__restric
         else if (term_infeas) state = THIP_ST_INFEASIBLE;
         else if (excess_iter) state = THIP_ST_EXCESS_ITER;
     }
-    if (state == THIP_ST_RUNNING) {
-        st->iter = i + 1;
-    } else {
-        st->state = state;
-        // stop is raised by final_scale_k, which still has to run for this iteration
-    }
+    if (state == THIP_ST_RUNNING) st->iter = i + 1;
+    else st->state = state;      // stop is raised by final_scale_k, which still has to run for this iteration
 }
 
 // solver.rs:397-400: on Converged / ExcessIter in the tau > eps_zero branch, x_x and x_y are scaled by 1/tau.
@@ -301,6 +335,21 @@ __global__ void final_scale_k(int n, int m, float eps_zero, float *__restrict__ 
             __threadfence();
             atomicExch(&st->stop, 1);
         }
+    }
+}
+
+// sum of `np` block partials of `nq` quantities (part[q*np + k]) -> out[q]; one block (init only)
+__global__ void sum_partials_k(int nq, int np, const float *__restrict__ part, float *__restrict__ out,
+                               const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    __shared__ double shd[16];
+    for (int q = 0; q < nq; ++q) {
+        double acc = 0.0;
+        for (int k = threadIdx.x; k < np; k += blockDim.x) acc += (double)part[(size_t)q * np + k];
+        acc = block_sum_d(acc, shd);
+        if (threadIdx.x == 0) out[q] = (float)acc;
+        __syncthreads();
     }
 }
 
@@ -365,27 +414,6 @@ __global__ void precond_k(int n, int m, const float *__restrict__ colabs, const 
 }
 
 }  // namespace
-
-// second reduction stage of the GEMV partials into a finished vector (used by products())
-namespace {
-__global__ void fin_k(size_t n, const float *__restrict__ part, int np, size_t stride, float *__restrict__ y,
-                      const int *__restrict__ stop)
-{
-    if (stop != nullptr && *stop != 0) return;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
-        float s = 0.0f;
-        for (int k = 0; k < np; ++k) s += part[(size_t)k * stride + i];
-        y[i] = s;
-    }
-}
-}  // namespace
-static int thip_finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float *y, const int *stop)
-{
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(fin_k, dim3(grid_for(n, BLK, 2048)), dim3(BLK), 0, st, n, part, np, stride, y, stop);
-    THIP_LAUNCH_CHECK();
-    return 0;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // host side
@@ -462,49 +490,49 @@ int do_allreduce(thip_solver *s, float *buf, size_t count)
 
 unsigned egrid(size_t n) { return grid_for(n, BLK, EG); }
 
-// one stage's products: hN = A xn (m), gT = A^T xt (n), honouring the schedule
-int products(thip_solver *s, const float *xn, const float *xt, float *hN, float *gT)
+// one stage's products as partial sums: N partials of A xn (m), T partials of A^T xt (n).  The fused and carried
+// schedules read A once (dual launch); the reference schedule issues the reference's two single GEMVs.
+int products(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp)
 {
     hipStream_t st = ctx().stream;
     const int *stop = &s->dst->stop;
-    if (s->m == 0 || s->n == 0) {
-        // zero-sized operator: MatOp degenerates to scale(beta=0, y) (matop.rs:83-85)
-        if (s->m) THIP_TRY(hipMemsetAsync(hN, 0, s->m * sizeof(float), st));
-        if (s->n) THIP_TRY(hipMemsetAsync(gT, 0, s->n * sizeof(float), st));
-        return 0;
-    }
-    GemvPartials gp;
+    gp->partN = gp->partT = nullptr; gp->nN = gp->nT = 0; gp->strideN = gp->strideT = 0;
+    if (s->m == 0 || s->n == 0) return 0;     // zero-sized operator: products are 0 (matop.rs:83-85)
     if (s->schedule == THIP_SCHED_REFERENCE) {
-        // two passes over A, like the reference's separate cublasSgemv calls
+        GemvPartials a, b;
+        const size_t half = s->gemv_scr_n / 2;
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, nullptr, xt, false, true, false, s->gemv_scr, s->gemv_scr_n, &gp, stop));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, nullptr, xt, false, true, false, s->gemv_scr, half, &a, stop));
         prof_end(st);
-        THIP_RC(thip_finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, gT, stop));
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, nullptr, true, false, false, s->gemv_scr, s->gemv_scr_n, &gp, stop));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, nullptr, true, false, false, s->gemv_scr + half, half, &b, stop));
         prof_end(st);
-        THIP_RC(thip_finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, hN, stop));
+        gp->partT = a.partT; gp->nT = a.nT; gp->strideT = a.strideT;
+        gp->partN = b.partN; gp->nN = b.nN; gp->strideN = b.strideN;
     } else {
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, &gp, stop));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, gp, stop));
         prof_end(st);
-        THIP_RC(thip_finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, gT, stop));
-        THIP_RC(thip_finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, hN, stop));
     }
     return 0;
 }
 
-int project_blocks(thip_solver *s, float *x, bool dual_cone)
+int project_blocks(thip_solver *s)
 {
-    (void)dual_cone;   // SOC / RotSOC / PSD are self-dual (cone_soc.rs:38, cone_psd.rs:56)
     hipStream_t st = ctx().stream;
     const int *stop = &s->dst->stop;
-    THIP_RC(soc_batched(st, x, s->soc_beg, s->soc_end, s->n_soc, 0, s->soc_max, stop));
-    THIP_RC(soc_batched(st, x, s->rot_beg, s->rot_end, s->n_rot, 1, s->rot_max, stop));
-    for (auto &pr : s->psd) {
-        const size_t sn = (size_t)pr.second;
-        const size_t k = (size_t)((std::sqrt((double)(8 * sn + 1)) - 1.0) / 2.0 + 0.5);
-        THIP_RC(eig_psd_project(st, k, x + pr.first, 1, std::sqrt(2.0f), s->par.eps_zero, s->psd_work, s->psd_worklen, 0, stop));
+    // SOC / RotSOC / PSD are self-dual (cone_soc.rs:38, cone_psd.rs:56): x_y and x_s get the same projection
+    THIP_RC(soc_batched2(st, s->xy, s->xs, s->rxy, s->rxs, s->soc_beg, s->soc_end, s->n_soc, 0, s->soc_max, stop));
+    THIP_RC(soc_batched2(st, s->xy, s->xs, s->rxy, s->rxs, s->rot_beg, s->rot_end, s->n_rot, 1, s->rot_max, stop));
+    if (!s->psd.empty()) {
+        for (float *x : { s->xy, s->xs })
+            for (auto &pr : s->psd) {
+                const size_t sn = (size_t)pr.second;
+                const size_t k = (size_t)((std::sqrt((double)(8 * sn + 1)) - 1.0) / 2.0 + 0.5);
+                THIP_RC(eig_psd_project(st, k, x + pr.first, 1, std::sqrt(2.0f), s->par.eps_zero, s->psd_work,
+                                        s->psd_worklen, 0, stop));
+            }
+        hipLaunchKernelGGL(rx_psd_k, dim3(egrid(s->m)), dim3(BLK), 0, st, (int)s->m, s->cls, s->xy, s->xs, s->rxy, s->rxs, s->dst);
     }
     return 0;
 }
@@ -516,54 +544,52 @@ int one_iteration(thip_solver *s)
     const int *stop = &s->dst->stop;
     const unsigned g = egrid(s->n > s->m ? s->n : s->m);
     float *const part = s->part;
+    const bool carried = s->schedule == THIP_SCHED_CARRIED;
+    const float ez = s->par.eps_zero;
+    GemvPartials gp;
+    const unsigned gq = grid_for(s->n > s->m ? s->n : s->m, 64, PG);
 
-    // ---- stage 1: x update ------------------------------------------------------------------
-    THIP_RC(products(s, s->u, s->v, s->h1, s->g1));
-    hipLaunchKernelGGL(dots2_k, dim3(g), dim3(BLK), 0, st, s->n, s->c, s->u, s->m, s->b, s->v, part, stop);
-    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part, s->dotc + 0, stop);
-    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part + g, s->g1 + s->n, stop);
+    // ---- stage X: x update (solver.rs:538-555) ----------------------------------------------------
+    THIP_RC(products(s, s->u, s->v, &gp));
+    hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g1, gp.partN, gp.nN,
+                       gp.strideN, s->h1, s->c, s->u, s->b, s->v, 0, (const float *)nullptr, (const float *)nullptr,
+                       (const float *)nullptr, ez, part, s->dst);
+    hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, s->dotc + 0, s->g1 + s->n, (float *)nullptr,
+                       (float *)nullptr, stop);
     THIP_RC(do_allreduce(s, s->g1, s->n + 1));
     hipLaunchKernelGGL(xupdate_k, dim3(g), dim3(BLK), 0, st, n, m, s->g1, s->h1, s->c, s->b, s->v, s->Tx, s->Ty, s->Ts,
                        s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dotc + 0, s->g1 + s->n, s->dst);
-    THIP_RC(project_blocks(s, s->xy, true));
-    THIP_RC(project_blocks(s, s->xs, false));
-    hipLaunchKernelGGL(rx_k, dim3(g), dim3(BLK), 0, st, n, m, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dst);
+    THIP_RC(project_blocks(s));
 
-    // ---- stage 2 / 3 ------------------------------------------------------------------------
-    if (s->schedule == THIP_SCHED_CARRIED) {
-        // criteria products of the new iterate first, K*rx from them by linearity
-        THIP_RC(products(s, s->xx, s->xy, s->h3, s->g3));
-        hipLaunchKernelGGL(crit_m_k, dim3(g), dim3(BLK), 0, st, m, s->h3, s->xs, s->xy, s->b, s->par.eps_zero, part, s->dst);
-        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 2, (int)g, part, s->g3 + s->n, stop);
-        THIP_RC(do_allreduce(s, s->g3, s->n + 2));
-        hipLaunchKernelGGL(carried_k, dim3(g), dim3(BLK), 0, st, n, m, s->g3, s->h3, s->gP, s->hP, s->g2, s->h2, s->dst);
-    } else {
-        THIP_RC(products(s, s->rxx, s->rxy, s->h2, s->g2));
-    }
-    hipLaunchKernelGGL(dots2_k, dim3(g), dim3(BLK), 0, st, s->n, s->c, s->rxx, s->m, s->b, s->rxy, part, stop);
-    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part, s->dotc + 1, stop);
-    if (s->schedule == THIP_SCHED_CARRIED) {
-        // b.rx_y is sharded: its own small all-reduce buffer (g2 tail), g2 itself is already global
-        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part + g, s->g2 + s->n, stop);
-        THIP_RC(do_allreduce(s, s->g2 + s->n, 1));
-    } else {
-        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 1, (int)g, part + g, s->g2 + s->n, stop);
+    // ---- stage Y: y update from K rx (solver.rs:557-567), own products unless carried ---------------
+    if (!carried) {
+        THIP_RC(products(s, s->rxx, s->rxy, &gp));
+        hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g2, gp.partN, gp.nN,
+                           gp.strideN, s->h2, s->c, s->rxx, s->b, s->rxy, 0, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, ez, part, s->dst);
+        hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, s->dotc + 1, s->g2 + s->n,
+                           (float *)nullptr, (float *)nullptr, stop);
         THIP_RC(do_allreduce(s, s->g2, s->n + 1));
+        hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, 1, 0, 0, (const float *)nullptr,
+                           (const float *)nullptr, (float *)nullptr, (float *)nullptr, s->g2, s->h2, s->c, s->b, s->rxs,
+                           s->Su, s->Sv, s->u, s->v, s->xx, s->dotc + 1, s->g2 + s->n, ez, part, s->dst);
     }
-    hipLaunchKernelGGL(yupdate_k, dim3(g), dim3(BLK), 0, st, n, m, s->g2, s->h2, s->c, s->b, s->rxs, s->Su, s->Sv, s->u,
-                       s->v, s->dotc + 1, s->g2 + s->n, s->dst);
 
-    if (s->schedule != THIP_SCHED_CARRIED) {
-        THIP_RC(products(s, s->xx, s->xy, s->h3, s->g3));
-        hipLaunchKernelGGL(crit_m_k, dim3(g), dim3(BLK), 0, st, m, s->h3, s->xs, s->xy, s->b, s->par.eps_zero, part, s->dst);
-        hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 2, (int)g, part, s->g3 + s->n, stop);
-        THIP_RC(do_allreduce(s, s->g3, s->n + 2));
-    }
-    hipLaunchKernelGGL(crit_n_k, dim3(g), dim3(BLK), 0, st, n, s->g3, s->xx, s->c, s->par.eps_zero, part, s->dst);
-    hipLaunchKernelGGL(sum_partials_k, dim3(1), dim3(BLK), 0, st, 2, (int)g, part, s->dotc + 2, stop);
-    hipLaunchKernelGGL(status_k, dim3(1), dim3(1), 0, st, s->g3 + s->n, s->dotc + 2, s->par.eps_acc, s->par.eps_inf,
-                       s->par.eps_zero, (long long)s->par.max_iter, s->dst);
-    hipLaunchKernelGGL(final_scale_k, dim3(g), dim3(BLK), 0, st, n, m, s->par.eps_zero, s->xx, s->xy, s->dst, s->done_count);
+    // ---- stage C: criteria products of the new iterate (solver.rs:573-656) --------------------------
+    THIP_RC(products(s, s->xx, s->xy, &gp));
+    hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g3, gp.partN, gp.nN,
+                       gp.strideN, s->h3, carried ? s->c : (const float *)nullptr, s->rxx,
+                       carried ? s->b : (const float *)nullptr, s->rxy, 1, s->xs, s->xy, s->b, ez, part, s->dst);
+    // tail of g3: [0] ||p||^2, [1] b.x_y, [2] b.rx_y (carried) -- all sharded sums, all-reduced with g3
+    hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, carried ? s->dotc + 1 : (float *)nullptr,
+                       carried ? s->g3 + s->n + 2 : (float *)nullptr, s->g3 + s->n, s->g3 + s->n + 1, stop);
+    THIP_RC(do_allreduce(s, s->g3, s->n + 3));
+    hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, carried ? 1 : 0, 1, 1, s->g3, s->h3, s->gP, s->hP,
+                       (const float *)nullptr, (const float *)nullptr, s->c, s->b, s->rxs, s->Su, s->Sv, s->u, s->v, s->xx,
+                       s->dotc + 1, s->g3 + s->n + 2, ez, part, s->dst);
+    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part, s->g3 + s->n, s->par.eps_acc, s->par.eps_inf,
+                       ez, (long long)s->par.max_iter, s->dst);
+    hipLaunchKernelGGL(final_scale_k, dim3(g), dim3(BLK), 0, st, n, m, ez, s->xx, s->xy, s->dst, s->done_count);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -630,6 +656,7 @@ int thip_solver_create(const thip_problem *prob, const thip_param *par, int sche
             const size_t k = (size_t)((std::sqrt((double)(8 * l + 1)) - 1.0) / 2.0 + 0.5);
             if ((int64_t)(k * (k + 1) / 2) != l) { delete s; return fail(THIP_E_INVALID, "PSD segment is not triangular", __FILE__, __LINE__); }
             s->psd.push_back({off, l});
+            for (int64_t r = 0; r < l; ++r) cls[off + r] = 3;
             gb.push_back(off); ge.push_back(off + l);
             if (k > psd_kmax) psd_kmax = k;
             break; }
@@ -670,8 +697,8 @@ int thip_solver_create(const thip_problem *prob, const thip_param *par, int sche
     (void)take(pm);
     s->dotc = take(64);
 
-    THIP_TRY(hipMalloc((void **)&s->part, 4 * EG * sizeof(float)));
-    s->gemv_scr_n = dual_gemv_scratch_floats(m, n);
+    THIP_TRY(hipMalloc((void **)&s->part, 4 * PG * sizeof(float)));
+    s->gemv_scr_n = 2 * dual_gemv_scratch_floats(m, n);
     THIP_TRY(hipMalloc((void **)&s->gemv_scr, s->gemv_scr_n * sizeof(float)));
     THIP_TRY(hipMalloc((void **)&s->dst, sizeof(DevStatus)));
     THIP_TRY(hipMemsetAsync(s->dst, 0, sizeof(DevStatus), st));
