@@ -30,7 +30,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="socp", choices=["socp", "lp"])
+    ap.add_argument("--workload", default="socp", choices=["socp", "lp", "sdp"])
+    ap.add_argument("--k", type=int, default=500, help="PSD order of the sdp workload")
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--cones", type=int, default=1000)
     ap.add_argument("--schedule", default="carried", choices=["reference", "fused", "carried"])
@@ -149,6 +150,11 @@ def main():
         n = a.n or 50_000
         inst = synth.SocpInstance(n, a.cones, 99, seed=0, rank=rank, world=world, allreduce_host=allreduce_host)
         wl = "random dense SOCP n=%d, %d second-order cones of 1+99 rows (m=%d), f32" % (n, a.cones, inst.m_total)
+    elif a.workload == "sdp":
+        assert world == 1, "one PSD cone does not shard"
+        n = a.n or 2000
+        inst = synth.SdpInstance(n, a.k, seed=0)
+        wl = "dense SDP n=%d, one PSD cone of order %d (sk=%d), f32" % (n, a.k, inst.m_total)
     else:
         n = a.n or 10_000
         inst = synth.LpInstance(n, seed=0, rank=rank, world=world)
@@ -221,7 +227,7 @@ def main():
 
     out = {
         "metric": "solver iterations/sec, dense SOCP n=50k (time-to-eps with --to-eps)" if a.workload == "socp"
-                  else "solver iterations/sec, dense LP",
+                  else "solver iterations/sec, dense %s" % a.workload.upper(),
         "value": iters_per_s,
         "unit": "iter/s",
         "n_gpus": world,

@@ -35,7 +35,8 @@ def random_socp(n, cones, seed=0):
 
 
 def random_sdp(n, k, seed=0):
-    """min c^T x s.t. sum_i x_i F_i + F_n >= 0 (totsu ProbSDP form), strictly feasible and bounded"""
+    """min c^T x s.t. sum_i x_i F_i + F_n <= 0 (totsu ProbSDP form, sdp.rs:222-248; cf. test_sdp1), strictly
+    feasible and bounded"""
     rng = np.random.default_rng(seed)
 
     def sym():
@@ -43,12 +44,12 @@ def random_sdp(n, k, seed=0):
         return (b + b.T) / 2
     Fs = [sym() for _ in range(n)]
     x0 = rng.standard_normal(n)
-    # F_n makes x0 strictly feasible: sum x0_i F_i + F_n = I
-    Fn = np.eye(k) - sum(x * F for x, F in zip(x0, Fs))
-    # c from a random Y > 0 : c_i = tr(F_i Y)  (dual feasible => bounded)
+    # F_n makes x0 strictly feasible: sum x0_i F_i + F_n = -I
+    Fn = -np.eye(k) - sum(x * F for x, F in zip(x0, Fs))
+    # c from a random Y > 0 : c_i = -tr(F_i Y)  (dual feasible => bounded)
     b = rng.standard_normal((k, k))
     Y = b @ b.T / k + 0.1 * np.eye(k)
-    c = np.array([np.trace(F @ Y) for F in Fs])
+    c = np.array([-np.trace(F @ Y) for F in Fs])
 
     def pack(S):
         return np.array([S[r, cc] for cc in range(k) for r in range(cc + 1)], dtype=np.float32)

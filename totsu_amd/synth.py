@@ -127,3 +127,42 @@ class LpInstance:
     def free(self):
         for d in (self.mat_a, self.vec_b, self.vec_c):
             d.free()
+
+
+class SdpInstance:
+    """SDP of the partitioning_sdp shape (BASELINE.json configs[3]): one PSD cone of order k, n dense symmetric
+    F_i, in totsu's ProbSDP conic form (sdp.rs:250-331): A = [svec(F_0) .. svec(F_{n-1})] (sk x n), b = -svec(F_n),
+    cone = PSD(sk).  Entries of svec(F_i) ~ N(0, 1/k); F_n = -I - sum x0_i F_i (strictly feasible at x0);
+    c = -A^T svec(Y), Y = I + 0.1 R > 0 (strictly dual feasible => bounded).  Single GPU (a PSD cone does not shard)."""
+
+    def __init__(self, n, k, seed=0):
+        _lib.ensure_init()
+        self.n, self.k = n, k
+        sk = k * (k + 1) // 2
+        self.m = self.m_total = sk
+        self.mat_a = DeviceBuffer(sk * n)
+        lib.thip_gen_matrix(self.mat_a.ptr, sk, n, sk, seed, STREAM_A, 0, 0, sk, 1, 1.0 / math.sqrt(k), 0.0)
+        x0 = DeviceBuffer(n)
+        lib.thip_gen_vector(x0.ptr, n, seed, STREAM_X0, 0, 1, 1.0 / math.sqrt(n), 0.0)
+        w = DeviceBuffer(sk)
+        lib.thip_transform_ge(0, sk, n, 1.0, self.mat_a.ptr, x0.ptr, 0.0, w.ptr)
+        diag = np.array([c * (c + 1) // 2 + c for c in range(k)])
+        b = w.to_host()
+        b[diag] += 1.0                                   # b = -svec(F_n) = svec(I) + A x0
+        self.vec_b_host = b
+        self.vec_b = DeviceBuffer.from_host(b)
+        yv = 0.1 / math.sqrt(k) * _gen(sk, seed, STREAM_W, 0, 1)
+        yv[diag] += 1.0
+        yd = DeviceBuffer.from_host(yv)
+        f = DeviceBuffer(n)
+        lib.thip_transform_ge(1, sk, n, -1.0, self.mat_a.ptr, yd.ptr, 0.0, f.ptr)
+        self.vec_c_host = f.to_host()
+        self.vec_c = f
+        self.seg_type = [_lib.CONE_PSD]
+        self.seg_len = [sk]
+        for d_ in (x0, w, yd):
+            d_.free()
+
+    def free(self):
+        for d in (self.mat_a, self.vec_b, self.vec_c):
+            d.free()
