@@ -15,7 +15,7 @@
 //  (2) PSD projection without eigenvectors: P = (M + M sign(M)) / 2, sign(M) by an odd matrix polynomial
 //      iteration -- a chain of n x n x n f32 GEMMs on v_mfma_f32_32x32x2_f32.  This is where the matrix cores
 //      are a real dense contraction; a Householder/QR chain at k = 500 is O(k) dependent latency-bound
-//      steps while this is ~40 GEMMs.  Used by ConePSD::proj for n > 64.
+//      steps while this is 50 GEMMs.  Used by ConePSD::proj for n > 64.
 #include "thip_common.h"
 
 #include <cmath>
@@ -224,54 +224,80 @@ __global__ __launch_bounds__(BLK) void rebuild_k(int n, int ld, const float *__r
 // C/D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)).  K is staged through LDS in slabs of 16.
 // ---------------------------------------------------------------------------------------------------
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-constexpr int GT = 64, GK = 16;
+constexpr int GT = 32;
 
-__global__ __launch_bounds__(BLK) void gemm64_k(int ld, float alpha, const float *__restrict__ A,
-                                               const float *__restrict__ B, float beta, const float *D,
-                                               float *C, const int *__restrict__ stop)
+// f32 GEMMs of the sign-function chain on v_mfma_f32_32x32x2_f32, two shapes (ld x ld, ld % 64 == 0, zero padded):
+//   GEN = false:  C = alpha * X * Y^T + beta * D + gamma * I_n   with C symmetric by construction (X = Y, or X, Y
+//                 bitwise-symmetric polynomials of one another): the Gram matrix S S^T and the step polynomial;
+//   GEN = true :  C = alpha * Sym * Gen + beta * D + gamma * I_n  with Sym bitwise symmetric, Gen arbitrary:
+//                 the update S <- q(S S^T) S.  This LEFT-multiplied form is the Newton-Schulz polar iteration, which
+//                 damps antisymmetric round-off; S <- q(S S^T) S^T or S q(S S^T) doubles it every step.
+// Workgroup = 4 waves, one 32 x 32 output tile; the waves split K four ways and are combined through LDS, so a
+// 512^3 product runs on 256 workgroups (every CU).  The matrices are L2-resident (1 MiB each at k = 500) and the
+// operands go straight from global memory to the MFMA registers, coalesced:
+//   operand b (lane l: k = l >> 5, column index l & 31) = Mem[k * ld + j0 + (l & 31)]   (a row of a symmetric matrix)
+//   operand a: GEN = false the same from X;  GEN = true needs Gen(k, c) = GenMem[c * ld + k], contiguous in k, so each
+//   wave stages a 32 x 16 slab through LDS (float4 loads along k) and reads it back transposed.
+// acc reg r of lane l is tile element (ti = (r & 3) + 8 (r >> 2) + 4 (l >> 5), tj = l & 31); it is stored at
+// Cmem[(i0 + ti) * ld + j0 + tj] -- coalesced -- which is C(row j0 + tj, col i0 + ti): the true position for GEN
+// (a indexes columns of C there), the mirrored one for the symmetric case.
+template <bool GEN>
+__global__ __launch_bounds__(BLK) void gemm_k(int n, int ld, float alpha, const float *__restrict__ X,
+                                             const float *__restrict__ Y, float beta, const float *D, float gamma,
+                                             float *C, const int *__restrict__ stop)
 {
     if (stop != nullptr && *stop != 0) return;
-    __shared__ float As[GK][GT + 1];     // As[k][i]
-    __shared__ float Bs[GK][GT + 1];     // Bs[k][j]
+    __shared__ float red[3][16][64];
+    __shared__ float stg[GEN ? 4 : 1][16][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * GT, j0 = blockIdx.y * GT;
-    const int wi = (wave & 1) * 32, wj = (wave >> 1) * 32;
+    const int kw = ld / 4, kb = wave * kw;
+    // GEN: X is the symmetric factor (b operand), Y the general one (a operand).  !GEN: a from X, b from Y.
+    const float *pb = (GEN ? X : Y) + (size_t)(kb + (lane >> 5)) * ld + j0 + (lane & 31);
+    const float *pa = GEN ? (Y + (size_t)(i0 + (lane >> 2)) * ld + kb + (lane & 3) * 4)
+                          : (X + (size_t)(kb + (lane >> 5)) * ld + i0 + (lane & 31));
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-
-    for (int k0 = 0; k0 < ld; k0 += GK) {
-        // A tile: 64 rows x 16 k (column-major: consecutive i contiguous) ; 1024 elements, 4 per thread
+    for (int k = 0; k < kw; k += 16) {
+        float av[8], bv[8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int idx = tid + t * BLK;
-            const int i = idx & 63, k = idx >> 6;
-            As[k][i] = A[(size_t)(k0 + k) * ld + i0 + i];
-        }
-        // B tile: 16 k x 64 cols ; element (k, j) at B[(j0 + j) * ld + k0 + k]
+        for (int u = 0; u < 8; ++u) bv[u] = pb[(size_t)(k + 2 * u) * ld];
+        if constexpr (GEN) {
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(pa + k);
+            const f32x4_t q1 = *reinterpret_cast<const f32x4_t *>(pa + (size_t)16 * ld + k);
+            const int ii = lane >> 2, kq = (lane & 3) * 4;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int idx = tid + t * BLK;
-            const int k = idx & 15, j = idx >> 4;
-            Bs[k][j] = B[(size_t)(j0 + j) * ld + k0 + k];
-        }
-        __syncthreads();
+            for (int t = 0; t < 4; ++t) { stg[wave][kq + t][ii] = q0[t]; stg[wave][kq + t][ii + 16] = q1[t]; }
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 2) {
-            const float a = As[kk + (lane >> 5)][wi + (lane & 31)];
-            const float b = Bs[kk + (lane >> 5)][wj + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) av[u] = stg[wave][2 * u + (lane >> 5)][lane & 31];
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = pa[(size_t)(k + 2 * u) * ld];
         }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
     }
-    const int col = j0 + wj + (lane & 31);
+    if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const size_t o = (size_t)col * ld + row;
-        float v = alpha * acc[r];
-        if (beta != 0.0f) v = fmaf(beta, D[o], v);
-        C[o] = v;
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int tj = j0 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ti = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = alpha * ((acc[r] + red[0][r][lane]) + (red[1][r][lane] + red[2][r][lane]));
+            const size_t o = (size_t)ti * ld + tj;
+            if (beta != 0.0f) v = fmaf(beta, D[o], v);
+            if (ti == tj && ti < n) v += gamma;
+            C[o] = v;
+        }
     }
 }
 
@@ -283,20 +309,6 @@ __global__ void scale_by_fro_k(size_t tot, const float *__restrict__ M, const fl
     const float f = sc[0];
     const float inv = f > 0.0f ? 1.0f / f : 0.0f;
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) S[i] = M[i] * inv;
-}
-
-// T = a I + b Y + c Z  (quintic step polynomial in Y = S^2, Z = S^4); identity only on the leading n x n block
-__global__ void poly_k(int n, int ld, float a, float b, float c, const float *__restrict__ Y,
-                       const float *__restrict__ Z, float *__restrict__ T, const int *__restrict__ stop)
-{
-    if (stop != nullptr && *stop != 0) return;
-    const size_t tot = (size_t)ld * ld;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) {
-        const int r = (int)(i % ld), cc = (int)(i / ld);
-        float v = b * Y[i] + (Z ? c * Z[i] : 0.0f);
-        if (r == cc && r < n) v += a;
-        T[i] = v;
-    }
 }
 
 // packed(r,c) = (M + MS)(r,c) / 2 symmetrised, diag / scale
@@ -313,11 +325,13 @@ __global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const fl
     }
 }
 
-int gemm(hipStream_t st, int ld, float alpha, const float *A, const float *B, float beta, const float *D, float *C,
-         const int *stop)
+// gen == false: C = alpha X Y^T + beta D + gamma I (symmetric result); gen == true: C = alpha X Y + ... (X symmetric)
+int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, const float *Y, float beta, const float *D,
+         float gamma, float *C, const int *stop)
 {
     dim3 g(ld / GT, ld / GT);
-    hipLaunchKernelGGL(gemm64_k, g, dim3(BLK), 0, st, ld, alpha, A, B, beta, D, C, stop);
+    if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(BLK), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop);
+    else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(BLK), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -384,22 +398,23 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
     hipLaunchKernelGGL(shift_k, dim3(1), dim3(BLK), 0, st, ni, ld, (int)g, k.part, M, k.sc, 0, stop);
     hipLaunchKernelGGL(scale_by_fro_k, dim3(g), dim3(BLK), 0, st, tot, M, k.sc, S, stop);
     // phase 1: quintic with a steep slope at 0 (3.4445 x - 4.7750 x^3 + 2.0315 x^5 maps (0, 1] into ~[0.7, 1.2] and
-    // multiplies tiny singular values by 3.44 per step): 13 steps lift relative eigenvalues >= 1e-7 into the band
+    // multiplies tiny singular values by 3.44 per step): 13 steps lift relative eigenvalues >= 1e-7 into the band.
+    // Three GEMMs per step, the polynomial folded into the second one's epilogue:
+    //   Y = S S^T ;  T = c Y Y^T + b Y + a I ;  S <- T S
     for (int it = 0; it < 13; ++it) {
-        THIP_RC(gemm(st, ld, 1.0f, S, S, 0.0f, nullptr, Y, stop));
-        THIP_RC(gemm(st, ld, 1.0f, Y, Y, 0.0f, nullptr, Z, stop));
-        hipLaunchKernelGGL(poly_k, dim3(g), dim3(BLK), 0, st, ni, ld, 3.4445f, -4.7750f, 2.0315f, Y, Z, T, stop);
-        THIP_RC(gemm(st, ld, 1.0f, S, T, 0.0f, nullptr, Y, stop));       // S <- S T (into Y, then swap)
-        float *tmp = S; S = Y; Y = tmp;
+        THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop));
+        THIP_RC(gemm(st, false, ni, ld, 2.0315f, Y, Y, -4.7750f, Y, 3.4445f, T, stop));
+        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop));
+        float *tmp = S; S = Z; Z = tmp;
     }
     // phase 2: Newton-Schulz x (3 - x^2) / 2, quadratic convergence to exactly +-1 from the band
+    //   T = -0.5 S S^T + 1.5 I ;  S <- T S
     for (int it = 0; it < 5; ++it) {
-        THIP_RC(gemm(st, ld, 1.0f, S, S, 0.0f, nullptr, Y, stop));
-        hipLaunchKernelGGL(poly_k, dim3(g), dim3(BLK), 0, st, ni, ld, 1.5f, -0.5f, 0.0f, Y, (const float *)nullptr, T, stop);
-        THIP_RC(gemm(st, ld, 1.0f, S, T, 0.0f, nullptr, Y, stop));
-        float *tmp = S; S = Y; Y = tmp;
+        THIP_RC(gemm(st, false, ni, ld, -0.5f, S, S, 0.0f, nullptr, 1.5f, T, stop));
+        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop));
+        float *tmp = S; S = Z; Z = tmp;
     }
-    THIP_RC(gemm(st, ld, 1.0f, M, S, 0.0f, nullptr, Z, stop));           // M sign(M)
+    THIP_RC(gemm(st, true, ni, ld, 1.0f, M, S, 0.0f, nullptr, 0.0f, Z, stop));      // M sign(M)
     dim3 gp((unsigned)((n + BLK - 1) / BLK), (unsigned)n);
     hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop);
     THIP_LAUNCH_CHECK();
@@ -425,6 +440,14 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
 }  // namespace thip
 
 extern "C" {
+
+// test hook (not part of the ABI): C = alpha A B + beta D + gamma I_n on symmetric ld x ld operands
+int thip_dbg_gemm_sym(int n, int ld, float alpha, const float *A, const float *B, float beta, const float *D, float gamma, float *C)
+{
+    THIP_NEED_INIT();
+    // gen form: C = alpha A B + beta D + gamma I with A symmetric, B arbitrary
+    return gemm(ctx().stream, true, n, ld, alpha, A, B, beta, D, gamma, C, nullptr);
+}
 
 size_t thip_map_eig_worklen(size_t n)
 {
