@@ -360,3 +360,56 @@ def gen_vector(n, seed, stream, idx0, kind, scale=1.0, shift=0.0):
     lib().oc_gen_vector(out.ctypes.data_as(_dp), _sz(n), C.c_uint64(seed), C.c_uint64(stream), C.c_uint64(idx0),
                         C.c_int(kind), C.c_float(scale), C.c_float(shift))
     return out
+
+
+def _quadratic_dense(n, syms_p, vecs_q, scls_r, tails, eps_zero):
+    """Stacked form of ProbQP / ProbQCQP (totsu/src/problem/qp.rs:66-300, qcqp.rs:62-345): variables (x, t), c = [0; 1],
+    block i rows [0 ; q_i^T, -(i == 0) ; -P_i^{1/2}, 0] with b = [1 ; -r_i ; 0_n] in a rotated SOC of 2 + n, then the
+    tail blocks (G | A rows).  P^{1/2} by map_eig with the sqrt closure (matbuild/mod.rs:219-245).  The reference's
+    absadd_* of these operators are plain |.| sums, so the MatOp solve on the stacked matrix is the same iteration
+    (up to the summation order inside a row)."""
+    rows, bs, st, sl = [], [], [], []
+    for i, (P, q, r) in enumerate(zip(syms_p, vecs_q, scls_r)):
+        ps = map_eig(np.asarray(P, dtype=np.float64), None, eps_zero, map_kind=1)
+        full = np.zeros((n, n))
+        for c in range(n):
+            for rr in range(c + 1):
+                full[rr, c] = full[c, rr] = ps[c * (c + 1) // 2 + rr]
+        blk = np.zeros((2 + n, n + 1))
+        blk[1, :n] = q
+        blk[1, n] = -1.0 if i == 0 else 0.0
+        blk[2:, :n] = -full
+        rows.append(blk)
+        bb = np.zeros(2 + n)
+        bb[0], bb[1] = 1.0, -r
+        bs.append(bb)
+        st.append(CONE_ROTSOC)
+        sl.append(2 + n)
+    for mat, vec, typ in tails:
+        mat = np.asarray(mat, dtype=np.float64).reshape((-1, n)) if np.size(mat) else np.zeros((0, n))
+        blk = np.zeros((mat.shape[0], n + 1))
+        blk[:, :n] = mat
+        rows.append(blk)
+        bs.append(np.asarray(vec, dtype=np.float64).ravel())
+        st.append(typ)
+        sl.append(mat.shape[0])
+    a = np.vstack(rows)
+    c = np.zeros(n + 1)
+    c[n] = 1.0
+    return c, a, np.concatenate(bs), st, sl
+
+
+def solve_qp(par, sym_p, vec_q, mat_g, vec_h, mat_a, vec_b, eps_zero=1e-12, **kw):
+    """ProbQP (qp.rs:304-440); sym_p packed upper by columns"""
+    n = np.size(vec_q)
+    c, a, b, st, sl = _quadratic_dense(n, [sym_p], [np.ravel(vec_q)], [0.0],
+                                       [(mat_g, vec_h, CONE_RPOS), (mat_a, vec_b, CONE_ZERO)], eps_zero)
+    return solve_matop_cones(par, c, a, b, st, sl, **kw)
+
+
+def solve_qcqp(par, syms_p, vecs_q, scls_r, mat_a, vec_b, eps_zero=1e-12, **kw):
+    """ProbQCQP (qcqp.rs:349-505)"""
+    n = np.size(vecs_q[0])
+    c, a, b, st, sl = _quadratic_dense(n, syms_p, [np.ravel(q) for q in vecs_q], scls_r,
+                                       [(mat_a, vec_b, CONE_ZERO)], eps_zero)
+    return solve_matop_cones(par, c, a, b, st, sl, **kw)

@@ -320,3 +320,36 @@ def test_synth_sdp_converges_to_oracle_objective(T):
     assert abs(fs.status().iters - r4.iters) <= 0.05 * r4.iters + 10
     fs.destroy()
     inst.free()
+
+
+# ---- QP / QCQP ("next" rows of SURVEY.md 8f): known-answer tests on the device ---------------------------
+
+@pytest.mark.parametrize("path", ["trait", "fused", "carried"])
+def test_kat_qp_qcqp(T, path):
+    # totsu/tests/qp.rs:14-48 (== the crate doc-tests, totsu_f32cuda/src/lib.rs:31-75) and qcqp.rs:14-47
+    L = T.F32HIP
+    n = 2
+
+    def qp():
+        sym_p = _mb(T, T.MatType.SymPack(n)); sym_p[(0, 0)] = 1.0; sym_p[(1, 1)] = 1.0
+        vec_q = _mb(T, T.MatType.General(n, 1)); vec_q[(0, 0)] = 1.0; vec_q[(1, 0)] = 2.0
+        mat_g = _mb(T, T.MatType.General(1, n)); mat_g[(0, 0)] = -0.5; mat_g[(0, 1)] = -1.0 / 3.0
+        vec_h = _mb(T, T.MatType.General(1, 1)); vec_h[(0, 0)] = -1.0
+        return T.ProbQP(sym_p, vec_q, mat_g, vec_h, _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)), 1e-12)
+
+    def qcqp():
+        sp = [_mb(T, T.MatType.SymPack(n)), _mb(T, T.MatType.SymPack(n))]
+        sp[0][(0, 0)] = 1.0; sp[0][(1, 1)] = 1.0
+        vq = [_mb(T, T.MatType.General(n, 1)), _mb(T, T.MatType.General(n, 1))]
+        vq[0][(0, 0)] = -5.0; vq[0][(1, 0)] = -4.0; vq[1][(0, 0)] = -0.5; vq[1][(1, 0)] = -1.0 / 3.0
+        return T.ProbQCQP(sp, vq, [0.0, 1.0], _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)), 1e-12)
+
+    for prob, want in ((qp(), [2.0, 0.0]), (qcqp(), [5.0, 4.0])):
+        if path == "trait":
+            x, _ = _par(T.Solver(L), max_iter=100_000, eps_acc=1e-5).solve(prob.problem())
+        else:
+            p = T.SolverParam()
+            p.max_iter, p.eps_acc = 100_000, 1e-5
+            x, _ = T.FusedSolver.from_dense(prob.dense(), p, path).solve()
+        assert np.allclose(x[:2], want, atol=1e-3), (path, x)
+        prob.drop()

@@ -189,3 +189,66 @@ def test_python_loop_matches_oracle_on_random_socp_and_dense_stacking():
     r2 = O.solve_matop_cones(par, dn.vec_c, dn.mat_a, dn.vec_b, dn.seg_type, dn.seg_len, trace_cap=4000)
     assert r2.status == ro.status and r2.iters == ro.iters
     assert np.allclose(r2.x, ro.x, rtol=1e-7, atol=1e-9)
+
+
+def _qp_kat():
+    from totsu_amd.problem import ProbQP
+    n = 2
+    sym_p = _mb(MatType.SymPack(n))
+    sym_p[(0, 0)] = 1.0
+    sym_p[(1, 1)] = 1.0
+    vec_q = _mb(MatType.General(n, 1))
+    vec_q[(0, 0)] = 1.0
+    vec_q[(1, 0)] = 2.0
+    mat_g = _mb(MatType.General(1, n))
+    mat_g[(0, 0)] = -0.5
+    mat_g[(0, 1)] = -1.0 / 3.0
+    vec_h = _mb(MatType.General(1, 1))
+    vec_h[(0, 0)] = -1.0
+    return ProbQP(sym_p, vec_q, mat_g, vec_h, _mb(MatType.General(0, n)), _mb(MatType.General(0, 1)), 1e-12)
+
+
+def _qcqp_kat():
+    from totsu_amd.problem import ProbQCQP
+    n = 2
+    syms_p = [_mb(MatType.SymPack(n)), _mb(MatType.SymPack(n))]
+    syms_p[0][(0, 0)] = 1.0
+    syms_p[0][(1, 1)] = 1.0
+    vecs_q = [_mb(MatType.General(n, 1)), _mb(MatType.General(n, 1))]
+    vecs_q[0][(0, 0)] = -5.0
+    vecs_q[0][(1, 0)] = -4.0
+    vecs_q[1][(0, 0)] = -0.5
+    vecs_q[1][(1, 0)] = -1.0 / 3.0
+    return ProbQCQP(syms_p, vecs_q, [0.0, 1.0], _mb(MatType.General(0, n)), _mb(MatType.General(0, 1)), 1e-12)
+
+
+def test_qp_qcqp_kats_and_dense_stacking():
+    # totsu/tests/qp.rs:14-48 (x = [2, 0]) and qcqp.rs:14-47 (x = [5, 4]); dense() == the block operators
+    rng = np.random.default_rng(9)
+    for prob, want in ((_qp_kat(), [2.0, 0.0]), (_qcqp_kat(), [5.0, 4.0])):
+        s = Solver(La).par(lambda p: setattr(p, "max_iter", 100_000))
+        x, _ = s.solve(prob.problem())
+        assert np.allclose(x[:2], want, atol=1e-3)
+        dn = prob.dense()
+        A = dn.mat_a.reshape((dn.n, dn.m)).T
+        op_c, op_a, op_b, cone, work = prob.problem()
+        xx = rng.standard_normal(dn.n)
+        yy = np.zeros(dn.m)
+        op_a.op(1.0, La.Sl.new_ref(xx), 0.0, La.Sl.new_mut(yy))
+        assert np.allclose(A @ xx, yy, atol=1e-12)
+        yt = rng.standard_normal(dn.m)
+        xt = np.zeros(dn.n)
+        op_a.trans_op(1.0, La.Sl.new_ref(yt), 0.0, La.Sl.new_mut(xt))
+        assert np.allclose(A.T @ yt, xt, atol=1e-12)
+        bb = np.zeros(dn.m)
+        op_b.op(1.0, La.Sl.new_ref(np.ones(1)), 0.0, La.Sl.new_mut(bb))
+        assert np.allclose(dn.vec_b, bb)
+        t1, t2 = np.zeros(dn.n), np.zeros(dn.m)
+        op_a.absadd_cols(La.Sl.new_mut(t1))
+        op_a.absadd_rows(La.Sl.new_mut(t2))
+        assert np.allclose(t1, np.abs(A).sum(axis=0)) and np.allclose(t2, np.abs(A).sum(axis=1))
+        t3 = np.zeros(dn.m)
+        op_b.absadd_rows(La.Sl.new_mut(t3))
+        assert np.allclose(t3, np.abs(dn.vec_b))
+        r = O.solve_matop_cones(O.param(max_iter=100000), dn.vec_c, dn.mat_a, dn.vec_b, dn.seg_type, dn.seg_len)
+        assert r.status == O.OK and np.allclose(r.x[:2], want, atol=1e-3)

@@ -193,3 +193,20 @@ def test_rng_is_deterministic_and_sane():
     assert abs(g.mean()) < 0.06 and abs(g.std() - 1.0) < 0.05
     assert O.rng_uniform(0, 1, 17) == O.rng_uniform(0, 1, 17)
     assert O.rng_uniform(0, 1, 17) != O.rng_uniform(1, 1, 17)
+
+
+def test_qp1_kat():
+    # totsu/tests/qp.rs:14-48
+    par = O.param(max_iter=100000)
+    r = O.solve_qp(par, [1.0, 0.0, 1.0], [1.0, 2.0], np.array([[-0.5, -1.0 / 3.0]]), [-1.0], np.zeros((0, 2)), [])
+    assert r.status == O.OK
+    assert np.allclose(r.x[:2], [2.0, 0.0], atol=1e-3)
+
+
+def test_qcqp1_kat():
+    # totsu/tests/qcqp.rs:14-47
+    par = O.param(max_iter=100000)
+    r = O.solve_qcqp(par, [[1.0, 0.0, 1.0], [0.0, 0.0, 0.0]], [[-5.0, -4.0], [-0.5, -1.0 / 3.0]], [0.0, 1.0],
+                     np.zeros((0, 2)), [])
+    assert r.status == O.OK
+    assert np.allclose(r.x[:2], [5.0, 4.0], atol=1e-3)

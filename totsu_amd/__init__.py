@@ -9,9 +9,9 @@ from .solver import Solver, SolverError, SolverParam
 from .linalg import F32HIP, F32HIPSlice, splitm
 from .cone import ConeZero, ConeRPos, ConeSOC, ConeRotSOC, ConePSD
 from .matbuild import MatBuild
-from .problem import ProbLP, ProbSOCP, ProbSDP
+from .problem import ProbLP, ProbSOCP, ProbSDP, ProbQP, ProbQCQP
 from .fused import FusedSolver, DeviceBuffer
 
 __all__ = ["MatOp", "MatType", "Solver", "SolverError", "SolverParam", "F32HIP", "F32HIPSlice", "splitm",
            "ConeZero", "ConeRPos", "ConeSOC", "ConeRotSOC", "ConePSD", "MatBuild", "ProbLP", "ProbSOCP",
-           "ProbSDP", "FusedSolver", "DeviceBuffer"]
+           "ProbSDP", "ProbQP", "ProbQCQP", "FusedSolver", "DeviceBuffer"]

@@ -407,3 +407,310 @@ class ProbSDP:
         b = np.concatenate([-self.symvec_f_n.array, self.vec_b.array]).astype(F)   # sdp.rs:152: -alpha on F_n
         return _Dense(n, sk + p, a.ravel(order="F"), b, self.vec_c.array.astype(F),
                       [_lib.CONE_PSD, _lib.CONE_ZERO], [sk, p])
+
+
+# ------------------------------------------------------------------------------------------------------
+# ProbQP (totsu/src/problem/qp.rs) and ProbQCQP (qcqp.rs): variables (x, t), minimise t, the quadratic
+# objective / constraints as rotated second-order cones on (r, s, P^{1/2} x).
+# ------------------------------------------------------------------------------------------------------
+
+class _ProbQPOpC:
+    """qp.rs:9-62 (also qcqp.rs:9-58): c = [0_n ; 1]"""
+
+    def __init__(self, L, n):
+        self.L, self.n = L, n
+
+    def size(self):
+        return (self.n + 1, 1)
+
+    def op(self, alpha, x, beta, y):
+        y_n, y_t = splitm(y, self.n, 1)
+        self.L.scale(beta, y_n)
+        self.L.scale(beta, y_t)
+        self.L.add(alpha, x, y_t)
+
+    def trans_op(self, alpha, x, beta, y):
+        _, x_t = splitm(x, self.n, 1)
+        self.L.scale(beta, y)
+        self.L.add(alpha, x_t, y)
+
+    def absadd_cols(self, tau):
+        tau.set(0, tau.get(0) + 1.0)
+
+    def absadd_rows(self, sigma):
+        _, s_t = splitm(sigma, self.n, 1)
+        s_t.set(0, s_t.get(0) + 1.0)
+
+
+class _ProbQCQPOpA:
+    """qcqp.rs:62-183; ProbQPOpA (qp.rs:66-172) is the m1 == 1 case with the extra [G ; A] rows"""
+
+    def __init__(self, L, syms_p_sqrt, vecs_q, mats_tail):
+        self.L, self.ps, self.qs, self.tail = L, syms_p_sqrt, vecs_q, mats_tail    # tail: list of MatOp (rows x n)
+
+    def _dims(self):
+        n = self.qs[0].size()[0]
+        return n, len(self.ps)
+
+    def size(self):
+        n, m1 = self._dims()
+        return (m1 * (2 + n) + sum(t.size()[0] for t in self.tail), n + 1)
+
+    def op(self, alpha, x, beta, y):
+        L = self.L
+        n, m1 = self._dims()
+        x_n, x_t = splitm(x, n, 1)
+        for i, (ps, q) in enumerate(zip(self.ps, self.qs)):
+            _, y_r, y_s, y_n = splitm(y, i * (2 + n), 1, 1, n)
+            L.scale(beta, y_r)
+            q.trans_op(alpha, x_n, beta, y_s)
+            if i == 0:
+                L.add(-alpha, x_t, y_s)
+            ps.op(-alpha, x_n, beta, y_n)
+        done = m1 * (2 + n)
+        for t in self.tail:
+            r = t.size()[0]
+            _, y_p = splitm(y, done, r)
+            t.op(alpha, x_n, beta, y_p)
+            done += r
+
+    def trans_op(self, alpha, x, beta, y):
+        L = self.L
+        n, m1 = self._dims()
+        y_n, y_t = splitm(y, n, 1)
+        L.scale(beta, y_n)
+        L.scale(beta, y_t)
+        for i, (ps, q) in enumerate(zip(self.ps, self.qs)):
+            _, _, x_s, x_n = splitm(x, i * (2 + n), 1, 1, n)
+            q.op(alpha, x_s, 1.0, y_n)
+            ps.op(-alpha, x_n, 1.0, y_n)
+            if i == 0:
+                L.add(-alpha, x_s, y_t)
+        done = m1 * (2 + n)
+        for t in self.tail:
+            r = t.size()[0]
+            _, x_p = splitm(x, done, r)
+            t.trans_op(alpha, x_p, 1.0, y_n)
+            done += r
+
+    def absadd_cols(self, tau):
+        n, _ = self._dims()
+        tau_n, tau_t = splitm(tau, n, 1)
+        for q in self.qs:
+            q.absadd_rows(tau_n)
+        for ps in self.ps:
+            ps.absadd_cols(tau_n)
+        for t in self.tail:
+            t.absadd_cols(tau_n)
+        tau_t.set(0, tau_t.get(0) + 1.0)
+
+    def absadd_rows(self, sigma):
+        n, m1 = self._dims()
+        for i, (ps, q) in enumerate(zip(self.ps, self.qs)):
+            _, _, s_s, s_n = splitm(sigma, i * (2 + n), 1, 1, n)
+            q.absadd_cols(s_s)
+            if i == 0:
+                s_s.set(0, s_s.get(0) + 1.0)
+            ps.absadd_rows(s_n)
+        done = m1 * (2 + n)
+        for t in self.tail:
+            r = t.size()[0]
+            _, s_p = splitm(sigma, done, r)
+            t.absadd_rows(s_p)
+            done += r
+
+
+class _ProbQCQPOpB:
+    """qcqp.rs:187-294; ProbQPOpB (qp.rs:176-260) is scls_r == [0] with the extra [h ; b] rows"""
+
+    def __init__(self, L, n, scls_r, vecs_tail):
+        self.L, self.n, self.rs, self.tail = L, n, scls_r, vecs_tail
+
+    def size(self):
+        return (len(self.rs) * (2 + self.n) + sum(t.size()[0] for t in self.tail), 1)
+
+    def op(self, alpha, x, beta, y):
+        L, n = self.L, self.n
+        for i, r in enumerate(self.rs):
+            _, y_r, y_s, y_n = splitm(y, i * (2 + n), 1, 1, n)
+            L.scale(beta, y_r)
+            L.add(alpha, x, y_r)
+            L.scale(beta, y_s)
+            L.add(-alpha * r, x, y_s)
+            L.scale(beta, y_n)
+        done = len(self.rs) * (2 + n)
+        for t in self.tail:
+            k = t.size()[0]
+            _, y_p = splitm(y, done, k)
+            t.op(alpha, x, beta, y_p)
+            done += k
+
+    def trans_op(self, alpha, x, beta, y):
+        L, n = self.L, self.n
+        L.scale(beta, y)
+        for i, r in enumerate(self.rs):
+            _, x_r, x_s, _ = splitm(x, i * (2 + n), 1, 1, n)
+            L.add(alpha, x_r, y)
+            L.add(-alpha * r, x_s, y)
+        done = len(self.rs) * (2 + n)
+        for t in self.tail:
+            k = t.size()[0]
+            _, x_p = splitm(x, done, k)
+            t.trans_op(alpha, x_p, 1.0, y)
+            done += k
+
+    def absadd_cols(self, tau):
+        tau.set(0, tau.get(0) + len(self.rs) + sum(abs(r) for r in self.rs))
+        for t in self.tail:
+            t.absadd_cols(tau)
+
+    def absadd_rows(self, sigma):
+        n = self.n
+        for i, r in enumerate(self.rs):
+            _, s_r, s_s, _ = splitm(sigma, i * (2 + n), 1, 1, n)
+            s_r.set(0, s_r.get(0) + 1.0)
+            s_s.set(0, s_s.get(0) + abs(r))
+        done = len(self.rs) * (2 + n)
+        for t in self.tail:
+            k = t.size()[0]
+            _, s_p = splitm(sigma, done, k)
+            t.absadd_rows(s_p)
+            done += k
+
+
+class _ConeList:
+    """consecutive (cone, length) blocks: ProbQPCone (qp.rs:264-300), ProbQCQPCone (qcqp.rs:298-345)"""
+
+    def __init__(self, blocks):
+        self.blocks = blocks
+
+    def proj(self, dual_cone, x):
+        done = 0
+        for cone, ln in self.blocks:
+            _, xb = splitm(x, done, ln)
+            done += ln
+            if not cone.proj(dual_cone, xb):
+                return False
+        return True
+
+    def product_group(self, dp_tau, group):
+        done = 0
+        for cone, ln in self.blocks:
+            _, tb = splitm(dp_tau, done, ln)
+            done += ln
+            cone.product_group(tb, group)
+
+
+def _dense_quadratic(L, n, ps_sqrt, qs, rs, tails_a, tails_b, tail_types):
+    """stacked rows of ProbQP / ProbQCQP: block i = [0 ; q_i^T, -(i==0) ; -P_i^{1/2}, 0], b = [1 ; -r_i ; 0]"""
+    F = L.F
+    rows, bs, st, sl = [], [], [], []
+    for i, (ps, q, r) in enumerate(zip(ps_sqrt, qs, rs)):
+        full = np.zeros((n, n), dtype=F)
+        for c in range(n):
+            for rr in range(c + 1):
+                full[rr, c] = full[c, rr] = ps.array[c * (c + 1) // 2 + rr]
+        blk = np.zeros((2 + n, n + 1), dtype=F)
+        blk[1, :n] = q.array
+        blk[1, n] = -1.0 if i == 0 else 0.0
+        blk[2:, :n] = -full
+        rows.append(blk)
+        bb = np.zeros(2 + n, dtype=F)
+        bb[0] = 1.0
+        bb[1] = -r
+        bs.append(bb)
+        st.append(_lib.CONE_ROTSOC)
+        sl.append(2 + n)
+    for ta, tb, tt in zip(tails_a, tails_b, tail_types):
+        k = ta.size()[0]
+        blk = np.zeros((k, n + 1), dtype=F)
+        if k:
+            blk[:, :n] = ta.array.reshape((n, k)).T
+        rows.append(blk)
+        bs.append(tb.array.astype(F))
+        st.append(tt)
+        sl.append(k)
+    a = np.asfortranarray(np.vstack(rows).astype(F))
+    c = np.zeros(n + 1, dtype=F)
+    c[n] = 1.0
+    return _Dense(n + 1, a.shape[0], a.ravel(order="F"), np.concatenate(bs).astype(F), c, st, sl)
+
+
+class ProbQP:
+    """qp.rs:304-440: min (1/2) x^T P x + q^T x  s.t. G x <= h, A x = b"""
+
+    def __init__(self, sym_p, vec_q, mat_g, vec_h, mat_a, vec_b, eps_zero):
+        n, m, p = vec_q.size()[0], vec_h.size()[0], vec_b.size()[0]
+        assert sym_p.is_sympack() and sym_p.size() == (n, n) and vec_q.size() == (n, 1)
+        assert mat_g.size() == (m, n) and vec_h.size() == (m, 1) and mat_a.size() == (p, n) and vec_b.size() == (p, 1)
+        self.L = vec_q.L
+        self.sym_p_sqrt = sym_p.clone().sqrt(eps_zero)            # qp.rs:386
+        self.vec_q, self.mat_g, self.vec_h, self.mat_a, self.vec_b = vec_q, mat_g, vec_h, mat_a, vec_b
+        self.w_solver = np.zeros(0, dtype=self.L.F)
+        self._ops = []
+
+    def problem(self):                                             # qp.rs:400-439
+        L = self.L
+        n, m, p = self.vec_q.size()[0], self.vec_h.size()[0], self.vec_b.size()[0]
+        ops = [self.sym_p_sqrt.as_op(), self.vec_q.as_op(), self.mat_g.as_op(), self.mat_a.as_op(),
+               self.vec_h.as_op(), self.vec_b.as_op()]
+        self._ops = ops
+        op_c = _ProbQPOpC(L, n)
+        op_a = _ProbQCQPOpA(L, [ops[0]], [ops[1]], [ops[2], ops[3]])
+        op_b = _ProbQCQPOpB(L, n, [0.0], [ops[4], ops[5]])
+        from .cone import ConeRotSOC
+        cone = _ConeList([(ConeRotSOC(L), 2 + n), (ConeRPos(L), m), (ConeZero(L), p)])
+        self.w_solver = np.zeros(Solver.query_worklen(op_a.size()), dtype=L.F)
+        return (op_c, op_a, op_b, cone, self.w_solver)
+
+    def drop(self):
+        for o in self._ops:
+            o.drop()
+        self._ops = []
+
+    def dense(self):
+        n = self.vec_q.size()[0]
+        return _dense_quadratic(self.L, n, [self.sym_p_sqrt], [self.vec_q], [0.0], [self.mat_g, self.mat_a],
+                                [self.vec_h, self.vec_b], [_lib.CONE_RPOS, _lib.CONE_ZERO])
+
+
+class ProbQCQP:
+    """qcqp.rs:349-505: min (1/2) x^T P_0 x + q_0^T x + r_0  s.t. (1/2) x^T P_i x + q_i^T x + r_i <= 0, A x = b"""
+
+    def __init__(self, syms_p, vecs_q, scls_r, mat_a, vec_b, eps_zero):
+        p, n = mat_a.size()
+        m1 = len(syms_p)
+        assert len(vecs_q) == m1 and len(scls_r) == m1
+        for sp, q in zip(syms_p, vecs_q):
+            assert sp.is_sympack() and sp.size() == (n, n) and q.size() == (n, 1)
+        assert vec_b.size() == (p, 1)
+        self.L = mat_a.L
+        self.syms_p_sqrt = [sp.clone().sqrt(eps_zero) for sp in syms_p]      # qcqp.rs:443-448
+        self.vecs_q, self.scls_r, self.mat_a, self.vec_b = vecs_q, [float(r) for r in scls_r], mat_a, vec_b
+        self.w_solver = np.zeros(0, dtype=self.L.F)
+        self._ops = []
+
+    def problem(self):                                             # qcqp.rs:463-504
+        L = self.L
+        p, n = self.mat_a.size()
+        ps = [s.as_op() for s in self.syms_p_sqrt]
+        qs = [q.as_op() for q in self.vecs_q]
+        oa, ob = self.mat_a.as_op(), self.vec_b.as_op()
+        self._ops = ps + qs + [oa, ob]
+        op_c = _ProbQPOpC(L, n)
+        op_a = _ProbQCQPOpA(L, ps, qs, [oa])
+        op_b = _ProbQCQPOpB(L, n, self.scls_r, [ob])
+        from .cone import ConeRotSOC
+        cone = _ConeList([(ConeRotSOC(L), 2 + n) for _ in ps] + [(ConeZero(L), p)])
+        self.w_solver = np.zeros(Solver.query_worklen(op_a.size()), dtype=L.F)
+        return (op_c, op_a, op_b, cone, self.w_solver)
+
+    def drop(self):
+        for o in self._ops:
+            o.drop()
+        self._ops = []
+
+    def dense(self):
+        n = self.mat_a.size()[1]
+        return _dense_quadratic(self.L, n, self.syms_p_sqrt, self.vecs_q, self.scls_r, [self.mat_a], [self.vec_b],
+                                [_lib.CONE_ZERO])
