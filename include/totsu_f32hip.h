@@ -200,6 +200,9 @@ int thip_gen_vector(float *out, size_t n, uint64_t seed, uint64_t stream, uint64
                     int kind, float scale, float shift);
 int thip_gen_matrix(float *out, size_t n_row, size_t n_col, size_t lda, uint64_t seed, uint64_t stream,
                     uint64_t row0, uint64_t col0, uint64_t ld_index, int kind, float scale, float shift);
+/* out(r, c) = value if row0 + r == c else 0 over an n_row x n_col block (the -I rows of the benchmark_lp matrix,
+ * experimental/benchmark_lp/src/main.rs:27-40) */
+int thip_gen_identity(float *out, size_t n_row, size_t n_col, size_t lda, uint64_t row0, float value);
 
 #ifdef __cplusplus
 }

@@ -353,3 +353,25 @@ def test_kat_qp_qcqp(T, path):
             x, _ = T.FusedSolver.from_dense(prob.dense(), p, path).solve()
         assert np.allclose(x[:2], want, atol=1e-3), (path, x)
         prob.drop()
+
+
+def test_synth_lp_instance_matches_benchmark_lp_shape(T):
+    # experimental/benchmark_lp/src/main.rs:14-57: G = [-I ; U(0,1)], h = [0 ; U(0,1)], c = -U(0,1); sharded rows
+    from totsu_amd import synth
+    n = 24
+    full = synth.LpInstance(n, seed=1)
+    A = full.mat_a.to_host()[:2 * n * n].reshape((n, 2 * n)).T
+    assert np.array_equal(A[:n], -np.eye(n, dtype=np.float32))
+    assert (A[n:] >= 0).all() and (A[n:] < 1).all() and A[n:].std() > 0.2
+    assert not full.vec_b_host[:n].any() and (full.vec_c_host <= 0).all()
+    parts = [synth.LpInstance(n, seed=1, rank=r, world=3) for r in range(3)]
+    A3 = np.vstack([p.mat_a.to_host()[:p.m * n].reshape((n, p.m)).T for p in parts])
+    assert np.array_equal(A3, A)
+    assert np.array_equal(np.concatenate([p.vec_b_host for p in parts]), full.vec_b_host)
+    ro = O.solve_lp(O.param(max_iter=200000, eps_acc=1e-4), full.vec_c_host, A, full.vec_b_host, np.zeros((0, n)), [])
+    p = T.SolverParam()
+    p.eps_acc, p.max_iter = 1e-4, 200_000
+    fs = T.FusedSolver(n, full.m, full.mat_a, full.vec_b, full.vec_c, full.seg_type, full.seg_len, p, "carried")
+    x, _ = fs.solve()
+    pobj = float(full.vec_c_host.astype(np.float64) @ ro.x)
+    assert ro.status == O.OK and abs(float(full.vec_c_host.astype(np.float64) @ x) - pobj) <= 1e-3 * (1 + abs(pobj))

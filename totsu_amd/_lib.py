@@ -101,6 +101,7 @@ PROTOTYPES = {
     "thip_prof_enable": (_i, [_i]),
     "thip_prof_read": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "thip_gen_vector": (_i, [_vp, _sz, _u64, _u64, _u64, _i, _f, _f]),
+    "thip_gen_identity": (_i, [_vp, _sz, _sz, _sz, _u64, _f]),
     "thip_gen_matrix": (_i, [_vp, _sz, _sz, _sz, _u64, _u64, _u64, _u64, _u64, _i, _f, _f]),
 }
 

@@ -92,6 +92,13 @@ __global__ void gen_mat_k(float *out, size_t n_row, size_t n_col, size_t lda, ui
     }
 }
 
+__global__ void gen_ident_k(float *out, size_t n_row, size_t n_col, size_t lda, uint64_t row0, float value)
+{
+    for (size_t c = blockIdx.y; c < n_col; c += gridDim.y)
+        for (size_t r = blockIdx.x * (size_t)BLK + threadIdx.x; r < n_row; r += (size_t)gridDim.x * BLK)
+            out[c * lda + r] = (row0 + r == c) ? value : 0.0f;
+}
+
 }  // namespace
 
 namespace thip {
@@ -237,6 +244,16 @@ int thip_gen_vector(float *out, size_t n, uint64_t seed, uint64_t stream, uint64
     if (n == 0) return 0;
     hipLaunchKernelGGL(gen_vec_k, dim3(grid_for(n, BLK, MAXB)), dim3(BLK), 0, ctx().stream, out, n, seed, stream,
                        idx0, kind, scale, shift);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int thip_gen_identity(float *out, size_t n_row, size_t n_col, size_t lda, uint64_t row0, float value)
+{
+    THIP_NEED_INIT();
+    if (n_row == 0 || n_col == 0) return 0;
+    dim3 g(grid_for(n_row, BLK, 64), (unsigned)(n_col < 4096 ? n_col : 4096));
+    hipLaunchKernelGGL(gen_ident_k, g, dim3(BLK), 0, ctx().stream, out, n_row, n_col, lda, row0, value);
     THIP_LAUNCH_CHECK();
     return 0;
 }

@@ -105,15 +105,11 @@ class LpInstance:
         m = self.m = r1 - r0
         self.mat_a = DeviceBuffer(max(m * n, 1))
         lib.thip_gen_matrix(self.mat_a.ptr, m, n, m, seed, STREAM_A, r0, 0, self.m_total, 0, 1.0, 0.0)
-        # rows r < n of the full matrix are -I: overwrite that part of the shard (host round trip of the identity
-        # block only when the shard intersects it)
+        # rows r < n of the full matrix are -I: overwrite that part of the shard on the device (the first k rows of
+        # the column-major shard share its base pointer and lda)
         if r0 < n:
             k = min(n, r1) - r0
-            blk = np.zeros((k, n), dtype=np.float32)
-            blk[np.arange(k), r0 + np.arange(k)] = -1.0
-            full = self.mat_a.to_host().reshape(n, m)      # column-major (n columns of m)
-            full[:, :k] = blk.T
-            lib.thip_h2d(self.mat_a.ptr, full.ctypes.data, full.size)
+            lib.thip_gen_identity(self.mat_a.ptr, k, n, m, r0, -1.0)
         h = _gen(max(m, 1), seed, STREAM_H, r0, 0)[:m]
         h[np.arange(r0, r1) < n] = 0.0
         self.vec_b_host = h
