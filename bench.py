@@ -48,10 +48,14 @@ class _CAI:
 
 
 class TorchAllreduce:
-    """thip_allreduce_fn over torch.distributed (backend nccl == RCCL on ROCm): sums `n` floats in place."""
+    """thip_allreduce_fn over torch.distributed (backend nccl == RCCL on ROCm): sums `n` floats in place.
+    The collective is issued with the LIBRARY's launch stream as torch's current stream (ExternalStream over the
+    handle the hook receives), so RCCL is ordered after the kernels that produced the buffer and before the
+    kernels that consume it, whatever stream the library runs on."""
 
     def __init__(self, torch, dist):
         self.torch, self.dist, self.cache, self.calls = torch, dist, {}, 0
+        self.ext = {}
 
     def __call__(self, ctx, ptr, n, stream):
         try:
@@ -60,7 +64,12 @@ class TorchAllreduce:
             if t is None:
                 t = self.torch.as_tensor(_CAI(ptr, n), device="cuda")
                 self.cache[key] = t
-            self.dist.all_reduce(t)
+            ext = self.ext.get(stream)
+            if ext is None:
+                ext = self.torch.cuda.ExternalStream(stream) if stream else self.torch.cuda.default_stream()
+                self.ext[stream] = ext
+            with self.torch.cuda.stream(ext):
+                self.dist.all_reduce(t)
             self.calls += 1
             return 0
         except Exception as e:      # an exception must not unwind through the C frame
@@ -135,8 +144,7 @@ def main():
     import totsu_amd as T
     from totsu_amd import _lib, synth
     from totsu_amd._lib import lib
-    _lib.init(local_rank)
-    lib.thip_set_stream(torch.cuda.current_stream().cuda_stream)
+    _lib.init(local_rank)          # the library launches on its own non-blocking stream (thip_get_stream)
 
     def allreduce_host(v):
         if not use_dist:

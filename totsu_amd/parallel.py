@@ -48,6 +48,8 @@ class TorchComm:
                 pass
             o = _CAI()
             o.__cuda_array_interface__ = {"shape": (sl.len(),), "typestr": "<f4", "data": (sl.dev(), False), "version": 2}
+            # trait-level path: order the collective by full synchronisation on both sides (the library launches on
+            # its own stream; this path is host-driven and synchronises per scalar anyway)
             L.sync()
             t = self.torch.as_tensor(o, device="cuda")
             self.dist.all_reduce(t, group=self.group)
