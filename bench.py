@@ -249,7 +249,7 @@ def main():
         "data": "synthetic (counter-based generator on device, seed 0)",
         "config": {"workload": wl, "schedule": a.schedule, "passes_over_A_per_iter": passes,
                    "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world,
-                   "gen_seconds": round(t_gen, 3)},
+                   "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan()},
         "roofline": roofline,
     }
 

@@ -185,6 +185,9 @@ int thip_solver_destroy(thip_solver *s);
 /* physical passes over A per iteration of the schedule in use, and bytes one pass reads */
 int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_bytes_per_pass);
 
+/* the GEMV tiling chosen by the create-time autotune (rows groups per lane, grid size, its measured ms); 0 = heuristic */
+int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, float *host_ms);
+
 /* per-launch timing of the GEMV kernels of the fused loop (HIP events on the launch stream): enable, run,
  * then read the number of timed launches and their summed duration.  Used by bench.py's roofline. */
 int thip_prof_enable(int on);

@@ -38,16 +38,6 @@ def _split_rows(dense, T, cut_seg):
 
 def _run_sharded(T, parts, param, schedule, max_steps=-1):
     from totsu_amd._lib import lib
-    from totsu_amd.fused import DeviceBuffer
-    # pre-grow the library's shared scratch so that no thread reallocates it under the other one
-    big = max(p["m"] for p in parts)
-    n = parts[0]["n"]
-    a = DeviceBuffer(big * n, zero=True)
-    t = DeviceBuffer(n, zero=True)
-    lib.thip_absadd_cols(big, n, a.ptr, t.ptr)
-    lib.thip_sync()
-    a.free(); t.free()
-
     barrier = threading.Barrier(len(parts))
     bufs = [None] * len(parts)
     out = [None] * len(parts)

@@ -2,8 +2,9 @@
 # sweeps the dual-GEMV tuning knobs through bench.py (run on the GPU box); prints achieved GB/s per config
 WL=${1:-socp}
 STEPS=${2:-10}
+EXTRA=${3:-}
 for nt in 0 1; do for nj in 1 2 4; do for blocks in 1024 2048 4096 8192; do
-  out=$(THIP_GEMV_NT=$nt THIP_GEMV_NJ=$nj THIP_GEMV_BLOCKS=$blocks python bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu 2>/dev/null)
+  out=$(THIP_GEMV_NT=$nt THIP_GEMV_NJ=$nj THIP_GEMV_BLOCKS=$blocks python bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu $EXTRA 2>/dev/null)
   python - "$nt" "$nj" "$blocks" "$out" <<'PY'
 import json, sys
 nt, nj, blocks, out = sys.argv[1:5]

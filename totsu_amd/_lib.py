@@ -98,6 +98,7 @@ PROTOTYPES = {
     "thip_solver_precond": (_i, [_vp, _vp, _vp]),
     "thip_solver_destroy": (_i, [_vp]),
     "thip_solver_passes": (_i, [_vp, C.POINTER(_i), C.POINTER(_sz)]),
+    "thip_solver_gemv_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),
     "thip_prof_enable": (_i, [_i]),
     "thip_prof_read": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "thip_gen_vector": (_i, [_vp, _sz, _u64, _u64, _u64, _i, _f, _f]),

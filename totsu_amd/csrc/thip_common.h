@@ -133,10 +133,16 @@ struct GemvPartials {
     const float *partN; int nN; size_t strideN;   // outN[r] = sum_{k<nN} partN[k*strideN + r]
     const float *partT; int nT; size_t strideT;   // outT[c] = sum_{k<nT} partT[k*strideT + c]
 };
+struct GemvHint { int nj; int target_blocks; };        // tiling override: row groups per lane, grid size
+const GemvHint *gemv_candidates(int *count);           // plans worth timing on a given matrix
 int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
                        const float *xn, const float *xt, bool do_n, bool do_t, bool abs_mode,
-                       float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag);
+                       float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
+                       const GemvHint *hint = nullptr);
 size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col);
+// y[i] = alpha * sum_k part[k*stride + i] + beta * y[i]
+int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float alpha, float beta,
+                      float *y, const int *stop);
 
 int reduce_to_dev(hipStream_t st, int op, size_t n, const float *x, const float *y, size_t incx, float *dev_out);
 enum { RED_SUMSQ_SQRT = 0, RED_ABSSUM = 1, RED_DOT = 2 };

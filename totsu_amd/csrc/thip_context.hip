@@ -12,6 +12,7 @@ namespace thip {
 
 static Ctx g_ctx;
 static char g_err[512] = "";
+static std::mutex g_stage_mutex;     // the pinned staging buffer and the shared scratch are per-context resources
 
 Ctx &ctx() { return g_ctx; }
 
@@ -29,6 +30,7 @@ int need_init()
 
 int scratch(size_t n, float **out)
 {
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
     Ctx &c = ctx();
     if (n > c.scratch_n) {
         // grow geometrically; callers size the scratch before entering a hot loop
@@ -149,6 +151,7 @@ int thip_h2d(float *dst, const float *host_src, size_t n)
 {
     THIP_NEED_INIT();
     if (n == 0) return 0;
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
     Ctx &c = ctx();
     // pageable source: stage through pinned memory in chunks so the call is safe to return from
     const char *src = (const char *)host_src;

@@ -253,7 +253,7 @@ static int env_int(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
-Plan make_plan(size_t n_row, size_t n_col, bool vec_ok)
+Plan make_plan(size_t n_row, size_t n_col, bool vec_ok, const GemvHint *hint = nullptr)
 {
     static const int env_nj = env_int("THIP_GEMV_NJ", 0);
     static const int env_blocks = env_int("THIP_GEMV_BLOCKS", 0);
@@ -264,9 +264,11 @@ Plan make_plan(size_t n_row, size_t n_col, bool vec_ok)
         // measured on MI355X (gpurun_out/sweep_*.txt): 1 float4 row group per lane, 8 columns in
         // flight, is as fast as taller tiles once the grid is fine enough, and keeps partial sums small
         p.nj = 1; p.ku = 8;
-        if (env_nj == 1) { p.nj = 1; p.ku = 8; }
-        if (env_nj == 2) { p.nj = 2; p.ku = 4; }
-        if (env_nj == 4) { p.nj = 4; p.ku = 2; }
+        int nj = env_nj;
+        if (hint && hint->nj > 0) nj = hint->nj;
+        if (nj == 1) { p.nj = 1; p.ku = 8; }
+        if (nj == 2) { p.nj = 2; p.ku = 4; }
+        if (nj == 4) { p.nj = 4; p.ku = 2; }
     } else {
         if (n_row >= (size_t)BLK * 4 * 4) { p.nj = 4; p.ku = 4; }
         else { p.nj = 1; p.ku = 8; }
@@ -282,6 +284,7 @@ Plan make_plan(size_t n_row, size_t n_col, bool vec_ok)
     if (target_blocks < 2048) target_blocks = 2048;
     if (target_blocks > 8192) target_blocks = 8192;
     if (env_blocks > 0) target_blocks = env_blocks;
+    if (hint && hint->target_blocks > 0) target_blocks = hint->target_blocks;
     int chunks = target_blocks / p.tiles;
     if (chunks < 1) chunks = 1;
     int cpc = (int)((n_col + chunks - 1) / chunks);
@@ -325,17 +328,33 @@ void launch_cfg(const Plan &p, hipStream_t st, const float *A, size_t lda, int m
 
 namespace thip {
 
+const GemvHint *gemv_candidates(int *count)
+{
+    // measured on MI355X: fine grids of 1-row-group tiles win at 100k x 50k and at the 0.8 GB LP,
+    // tall tiles with ~1k workgroups win for short-and-wide row shards
+    static const GemvHint c[] = { {1, 8192}, {1, 4096}, {2, 2048}, {4, 2048}, {4, 1024}, {4, 768} };
+    *count = (int)(sizeof(c) / sizeof(c[0]));
+    return c;
+}
+
 size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col)
 {
-    const Plan a = make_plan(n_row, n_col, true), b = make_plan(n_row, n_col, false);
-    const size_t fa = (size_t)a.chunks * a.strideN + (size_t)a.tiles * a.strideT;
-    const size_t fb = (size_t)b.chunks * b.strideN + (size_t)b.tiles * b.strideT;
-    return (fa > fb ? fa : fb) + 64;
+    size_t best = 0;
+    int nc = 0;
+    const GemvHint *c = gemv_candidates(&nc);
+    for (int i = -1; i < nc; ++i)
+        for (int v = 0; v < 2; ++v) {
+            const Plan p = make_plan(n_row, n_col, v == 0, i < 0 ? nullptr : &c[i]);
+            const size_t f = (size_t)p.chunks * p.strideN + (size_t)p.tiles * p.strideT;
+            if (f > best) best = f;
+        }
+    return best + 64;
 }
 
 int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
                        const float *xn, const float *xt, bool do_n, bool do_t, bool abs_mode,
-                       float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag)
+                       float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
+                       const GemvHint *hint)
 {
     if (n_row == 0 || n_col == 0 || (!do_n && !do_t)) {
         out->partN = out->partT = nullptr; out->nN = out->nT = 0; out->strideN = out->strideT = 0;
@@ -343,7 +362,7 @@ int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const float *
     }
     if (n_row > 0x7fffffffull || n_col > 0x7fffffffull) return fail(THIP_E_INVALID, "matrix dimension > 2^31", __FILE__, __LINE__);
     const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (lda % 4 == 0);
-    const Plan p = make_plan(n_row, n_col, vec_ok);
+    const Plan p = make_plan(n_row, n_col, vec_ok, hint);
     const size_t needN = do_n ? (size_t)p.chunks * p.strideN : 0;
     const size_t needT = do_t ? (size_t)p.tiles * p.strideT : 0;
     if (needN + needT > scratch_floats) return fail(THIP_E_WORK, "gemv scratch too small", __FILE__, __LINE__);
@@ -365,6 +384,15 @@ int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const float *
     return 0;
 }
 
+int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float alpha, float beta,
+                      float *y, const int *stop)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(finalize_k, dim3(grid_for(n, BLK, 2048)), dim3(BLK), 0, st, n, part, np, stride, alpha, beta, y, stop);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
               const float *xn, float alphaN, float betaN, float *outN,
               const float *xt, float alphaT, float betaT, float *outT,
@@ -375,7 +403,7 @@ int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size
     const size_t need = dual_gemv_scratch_floats(n_row, n_col);
     THIP_RC(scratch(need, &scr));
     GemvPartials gp;
-    THIP_RC(dual_gemv_partials(st, n_row, n_col, mat, lda, xn, xt, do_n, do_t, abs_mode, scr, need, &gp, stop_flag));
+    THIP_RC(dual_gemv_partials(st, n_row, n_col, mat, lda, xn, xt, do_n, do_t, abs_mode, scr, need, &gp, stop_flag, nullptr));
     if (do_n && n_row)
         hipLaunchKernelGGL(finalize_k, dim3(grid_for(n_row, BLK, 2048)), dim3(BLK), 0, st, n_row, gp.partN, gp.nN,
                            gp.strideN, alphaN, betaN, outN, stop_flag);

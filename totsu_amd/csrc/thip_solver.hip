@@ -445,6 +445,7 @@ struct thip_solver {
     float *part = nullptr;                           // block partials (4 * EG)
     float *dotc = nullptr;                           // local scalars: [0] c.u, [1] c.rx_x, [2..3] dd,cx
     float *gemv_scr = nullptr; size_t gemv_scr_n = 0;
+    GemvHint hint{0, 0}; bool tuned = false; float tuned_ms = 0.0f;
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
     int *done_count = nullptr;
@@ -502,16 +503,16 @@ int products(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp)
         GemvPartials a, b;
         const size_t half = s->gemv_scr_n / 2;
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, nullptr, xt, false, true, false, s->gemv_scr, half, &a, stop));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, nullptr, xt, false, true, false, s->gemv_scr, half, &a, stop, s->tuned ? &s->hint : nullptr));
         prof_end(st);
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, nullptr, true, false, false, s->gemv_scr + half, half, &b, stop));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, nullptr, true, false, false, s->gemv_scr + half, half, &b, stop, s->tuned ? &s->hint : nullptr));
         prof_end(st);
         gp->partT = a.partT; gp->nT = a.nT; gp->strideT = a.strideT;
         gp->partN = b.partN; gp->nN = b.nN; gp->strideN = b.strideN;
     } else {
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, gp, stop));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, gp, stop, s->tuned ? &s->hint : nullptr));
         prof_end(st);
     }
     return 0;
@@ -591,6 +592,42 @@ int one_iteration(thip_solver *s)
                        ez, (long long)s->par.max_iter, s->dst);
     hipLaunchKernelGGL(final_scale_k, dim3(g), dim3(BLK), 0, st, n, m, ez, s->xx, s->xy, s->dst, s->done_count);
     THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Times the candidate tilings of the dual GEMV on THIS matrix (two launches each, the second one timed with HIP
+// events) and keeps the fastest: a handful of passes over A, once per solve.  THIP_GEMV_AUTOTUNE=0 disables it.
+int autotune_gemv(thip_solver *s)
+{
+    const char *env = getenv("THIP_GEMV_AUTOTUNE");
+    if ((env && atoi(env) == 0) || getenv("THIP_GEMV_NJ") || getenv("THIP_GEMV_BLOCKS")) return 0;
+    if (s->m * s->n < (size_t)1 << 22) return 0;           // tiny matrices: launch-bound anyway
+    hipStream_t st = ctx().stream;
+    hipEvent_t e0, e1;
+    THIP_TRY(hipEventCreate(&e0));
+    THIP_TRY(hipEventCreate(&e1));
+    int nc = 0;
+    const GemvHint *c = gemv_candidates(&nc);
+    float best = 1e30f;
+    GemvPartials gp;
+    for (int i = 0; i < nc; ++i) {
+        float ms = 1e30f;
+        for (int rep = 0; rep < 5; ++rep) {
+            THIP_TRY(hipEventRecord(e0, st));
+            THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, s->u, s->v, true, true, false, s->gemv_scr, s->gemv_scr_n,
+                                       &gp, nullptr, &c[i]));
+            THIP_TRY(hipEventRecord(e1, st));
+            THIP_TRY(hipEventSynchronize(e1));
+            float t = 0.0f;
+            THIP_TRY(hipEventElapsedTime(&t, e0, e1));
+            if (rep > 0 && t < ms) ms = t;
+        }
+        if (ms < best) { best = ms; s->hint = c[i]; }
+    }
+    s->tuned = true;
+    s->tuned_ms = best;
+    THIP_TRY(hipEventDestroy(e0));
+    THIP_TRY(hipEventDestroy(e1));
     return 0;
 }
 
@@ -738,7 +775,11 @@ int thip_solver_init(thip_solver *s)
     // |A| column sums (sharded partial -> all-reduce with the two scalars in the tail) and row sums
     float *colabs = s->g1, *rowabs = s->h1;
     if (n && m) {
-        THIP_RC(dual_gemv(st, m, n, s->A, m, nullptr, 1.0f, 0.0f, rowabs, nullptr, 1.0f, 0.0f, colabs, true, nullptr));
+        // solver-owned scratch (several solvers may share the context, e.g. one per thread)
+        GemvPartials gp;
+        THIP_RC(dual_gemv_partials(st, m, n, s->A, m, nullptr, nullptr, true, true, true, s->gemv_scr, s->gemv_scr_n, &gp, nullptr));
+        THIP_RC(finalize_partials(st, m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, rowabs, nullptr));
+        THIP_RC(finalize_partials(st, n, gp.partT, gp.nT, gp.strideT, 1.0f, 0.0f, colabs, nullptr));
     }
     THIP_RC(do_allreduce(s, s->g1, n + 2));
     hipLaunchKernelGGL(init_scalars_k, dim3(1), dim3(1), 0, st, sums, loc, s->par.eps_zero, s->dst);
@@ -751,6 +792,7 @@ int thip_solver_init(thip_solver *s)
     THIP_TRY(hipMemsetAsync(s->g1, 0, (n + TAIL) * sizeof(float), st));
     THIP_TRY(hipMemsetAsync(s->h1, 0, (m ? m : 1) * sizeof(float), st));
     THIP_LAUNCH_CHECK();
+    THIP_RC(autotune_gemv(s));
     s->inited = true;
     return 0;
 }
@@ -833,6 +875,15 @@ int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_byte
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
     if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : 2);
     if (host_bytes_per_pass) *host_bytes_per_pass = s->m * s->n * sizeof(float);
+    return 0;
+}
+
+int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, float *host_ms)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (host_nj) *host_nj = s->tuned ? s->hint.nj : 0;
+    if (host_blocks) *host_blocks = s->tuned ? s->hint.target_blocks : 0;
+    if (host_ms) *host_ms = s->tuned_ms;
     return 0;
 }
 

@@ -126,6 +126,11 @@ class FusedSolver:
         lib.thip_solver_precond(self.h, t.ctypes.data, s.ctypes.data)
         return t, s
 
+    def gemv_plan(self):
+        nj, bl, ms = C.c_int(), C.c_int(), C.c_float()
+        lib.thip_solver_gemv_plan(self.h, C.byref(nj), C.byref(bl), C.byref(ms))
+        return {"rows_groups_per_lane": nj.value, "target_workgroups": bl.value, "autotune_ms": ms.value}
+
     def passes(self):
         p, b = C.c_int(), C.c_size_t()
         lib.thip_solver_passes(self.h, C.byref(p), C.byref(b))
