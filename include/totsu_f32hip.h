@@ -185,6 +185,11 @@ int thip_solver_destroy(thip_solver *s);
 /* physical passes over A per iteration of the schedule in use, and bytes one pass reads */
 int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_bytes_per_pass);
 
+/* test entry point for the matrix-core GEMM of the PSD projection chain: C = alpha * A * B + beta * D + gamma * I_n
+ * with A symmetric and B arbitrary, all ld x ld column-major, ld a multiple of 64, zero padded beyond n */
+int thip_test_gemm_sym(int n, int ld, float alpha, const float *A, const float *B, float beta, const float *D,
+                       float gamma, float *C);
+
 /* the GEMV tiling chosen by the create-time autotune (rows groups per lane, grid size, its measured ms); 0 = heuristic */
 int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, float *host_ms);
 

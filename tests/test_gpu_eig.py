@@ -106,3 +106,30 @@ def test_map_eig_sqrt_and_closure(L, k):
     assert np.abs(got - wp).max() <= 1e-4 * np.abs(w).max()
     sl.drop()
     work.drop()
+
+
+@pytest.mark.parametrize("n,ld", [(64, 64), (65, 128), (200, 256), (500, 512)])
+def test_mfma_gemm_symmetric_times_general(L, n, ld):
+    # the v_mfma_f32_32x32x2_f32 GEMM of the PSD chain: transpose-detecting check (A symmetric, B NOT symmetric,
+    # D not symmetric), f32 round-off tolerance relative to sum |a||b|
+    from totsu_amd._lib import lib
+    from totsu_amd.fused import DeviceBuffer
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((ld, ld)).astype(np.float32)
+    A = (A + A.T) / 2
+    B = rng.standard_normal((ld, ld)).astype(np.float32)
+    D = rng.standard_normal((ld, ld)).astype(np.float32)
+    for M in (A, B, D):
+        M[n:, :] = 0
+        M[:, n:] = 0
+    dA, dB, dD = [DeviceBuffer.from_host(np.asfortranarray(M).ravel(order="F")) for M in (A, B, D)]
+    dC = DeviceBuffer(ld * ld)
+    lib.thip_test_gemm_sym(n, ld, 0.5, dA.ptr, dB.ptr, -2.0, dD.ptr, 3.0, dC.ptr)
+    got = dC.to_host().reshape((ld, ld)).T
+    eye = np.zeros((ld, ld))
+    eye[:n, :n] = np.eye(n)
+    ref = 0.5 * A.astype(np.float64) @ B.astype(np.float64) - 2.0 * D + 3.0 * eye
+    scale = 0.5 * np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64) + 2.0 * np.abs(D) + 3.0
+    assert np.all(np.abs(got - ref) <= 2e-6 * scale)
+    for d in (dA, dB, dD, dC):
+        d.free()

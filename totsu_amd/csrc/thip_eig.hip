@@ -441,8 +441,8 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
 
 extern "C" {
 
-// test hook (not part of the ABI): C = alpha A B + beta D + gamma I_n on symmetric ld x ld operands
-int thip_dbg_gemm_sym(int n, int ld, float alpha, const float *A, const float *B, float beta, const float *D, float gamma, float *C)
+// test entry point: C = alpha A B + beta D + gamma I_n, A symmetric, B arbitrary, ld x ld (ld % 64 == 0)
+int thip_test_gemm_sym(int n, int ld, float alpha, const float *A, const float *B, float beta, const float *D, float gamma, float *C)
 {
     THIP_NEED_INIT();
     // gen form: C = alpha A B + beta D + gamma I with A symmetric, B arbitrary
