@@ -23,6 +23,8 @@ def _mb(T, typ):
 
 
 def _par(s, **kw):
+    """trait-level Solver: the fused drop-in dispatch is switched off so that every L call is exercised"""
+    s.fused = None
     for k, v in kw.items():
         setattr(s.param, k, v)
     return s
@@ -375,3 +377,22 @@ def test_synth_lp_instance_matches_benchmark_lp_shape(T):
     x, _ = fs.solve()
     pobj = float(full.vec_c_host.astype(np.float64) @ ro.x)
     assert ro.status == O.OK and abs(float(full.vec_c_host.astype(np.float64) @ x) - pobj) <= 1e-3 * (1 + abs(pobj))
+
+
+def test_unchanged_caller_takes_the_fused_path(T):
+    # `Solver::<F32HIP>::new().par(..).solve(lp.problem())` -- the reference's calling sequence, unchanged
+    # (experimental/benchmark_lp/src/main.rs:60-69) -- runs the device-resident loop and fills `work` like solver.rs:317-320
+    c, G, h = benchmark_lp(30, seed=8)
+    lp = T.ProbLP(_mb(T, T.MatType.General(30, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(60, 30)).set_array(G),
+                  _mb(T, T.MatType.General(60, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, 30)),
+                  _mb(T, T.MatType.General(0, 1)))
+    s = T.Solver(T.F32HIP)
+    s.param.eps_acc = 1e-3
+    x, y = s.solve(lp.problem())
+    assert s.fused == "carried" and s.iters > 10
+    assert np.array_equal(lp.w_solver[:30], x) and np.array_equal(lp.w_solver[30:90], y)
+    ro = O.solve_lp(O.param(eps_acc=1e-3), c, G, h, np.zeros((0, 30)), [])
+    assert abs(s.iters - ro.iters) <= max(3, 0.02 * ro.iters)
+    pobj = float(c.astype(np.float64) @ ro.x)
+    assert abs(float(c.astype(np.float64) @ x) - pobj) <= 1e-3 * (1 + abs(pobj))
+    lp.drop()

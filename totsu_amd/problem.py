@@ -119,6 +119,7 @@ class ProbLP:
         self._ops = ops
         op_c = _OpVec(ops[0])
         op_a = _OpStack2(ops[1], ops[2])
+        op_a.dense_src = self
         op_b = _OpStack2(ops[3], ops[4])
         cone = _ConeStack2(m, p, ConeRPos(L), ConeZero(L))
         self.w_solver = np.zeros(Solver.query_worklen(op_a.size()), dtype=L.F)
@@ -314,6 +315,7 @@ class ProbSOCP:
         d_sl.drop()
         op_c = _OpVec(of)
         op_a = _ProbSOCPOpA(L, og, ocs, oa)
+        op_a.dense_src = self
         op_b = _ProbSOCPOpB(L, oh, self.scls_d, abssum_d, ob)
         cone = _ProbSOCPCone(L, [g.size()[0] for g in self.mats_g], p)
         self.w_solver = np.zeros(Solver.query_worklen(op_a.size()), dtype=L.F)
@@ -383,6 +385,7 @@ class ProbSDP:
         self._ops = ops
         op_c = _OpVec(ops[0])
         op_a = _OpStack2(ops[1], ops[2])
+        op_a.dense_src = self
         op_b = _OpStack2(ops[3], ops[4], sign_first=-1.0)
         self.w_cone_psd = np.zeros(ConePSD.query_worklen(L, sk), dtype=L.F)
         self._cone = ConePSD(L, self.w_cone_psd, self.eps_zero)
@@ -657,6 +660,7 @@ class ProbQP:
         self._ops = ops
         op_c = _ProbQPOpC(L, n)
         op_a = _ProbQCQPOpA(L, [ops[0]], [ops[1]], [ops[2], ops[3]])
+        op_a.dense_src = self
         op_b = _ProbQCQPOpB(L, n, [0.0], [ops[4], ops[5]])
         from .cone import ConeRotSOC
         cone = _ConeList([(ConeRotSOC(L), 2 + n), (ConeRPos(L), m), (ConeZero(L), p)])
@@ -699,6 +703,7 @@ class ProbQCQP:
         self._ops = ps + qs + [oa, ob]
         op_c = _ProbQPOpC(L, n)
         op_a = _ProbQCQPOpA(L, ps, qs, [oa])
+        op_a.dense_src = self
         op_b = _ProbQCQPOpB(L, n, self.scls_r, [ob])
         from .cone import ConeRotSOC
         cone = _ConeList([(ConeRotSOC(L), 2 + n) for _ in ps] + [(ConeZero(L), p)])
