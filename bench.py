@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--schedule", default="carried", choices=["reference", "fused", "carried"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--force-collective", action="store_true", help="install the all-reduce hook even at N = 1")
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
+                    help="rccl: native RCCL call on the library's stream; torch: torch.distributed.all_reduce hook")
     ap.add_argument("--to-eps", type=float, default=None, help="also solve to this eps_acc and report time-to-eps")
     ap.add_argument("--cpu-cones", type=int, default=0, help="cones in the CPU sample (0: pick from the thread count)")
     return ap.parse_args()
@@ -127,6 +129,22 @@ def cpu_baseline(n, n_cones_full, ni, seed, cones_sub, budget_s=25.0):
 
 def main():
     a = parse()
+    # RCCL prints a version banner on stdout when a communicator is created: keep fd 1 clean for the ONE JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        out, rank, cleanup = run(a)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    cleanup()
+
+
+def run(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -174,7 +192,23 @@ def main():
     p.max_iter = None
     p.eps_acc = 0.0            # never terminates inside the timed region: every step does full work
     p.eps_inf = 0.0
-    hook = TorchAllreduce(torch, dist) if use_dist else None
+    hook, coll = None, "none"
+    if use_dist:
+        if a.collective == "rccl":
+            try:
+                def bcast(payload):
+                    t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                    if rank == 0:
+                        t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+                    dist.broadcast(t, src=0)
+                    return bytes(t.cpu().numpy().tobytes())
+                from totsu_amd.fused import comm_init
+                comm_init(rank, world, bcast)
+                hook, coll = "rccl", "native RCCL all-reduce on the compute stream"
+            except Exception as e:           # keep the run alive on the tested fallback
+                sys.stderr.write("native RCCL unavailable (%r): falling back to the torch.distributed hook\n" % (e,))
+        if hook is None:
+            hook, coll = TorchAllreduce(torch, dist), "torch.distributed.all_reduce hook (nccl)"
     fs = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, a.schedule,
                        allreduce=hook)
 
@@ -248,7 +282,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic (counter-based generator on device, seed 0)",
         "config": {"workload": wl, "schedule": a.schedule, "passes_over_A_per_iter": passes,
-                   "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world,
+                   "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll,
                    "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan()},
         "roofline": roofline,
     }
@@ -281,11 +315,14 @@ def main():
 
     fs.destroy()
     inst.free()
-    if rank == 0:
-        print(json.dumps(out))
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if hook == "rccl":
+        from totsu_amd.fused import comm_destroy
+        comm_destroy()
+    def cleanup():
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+    return out, rank, cleanup
 
 
 if __name__ == "__main__":

@@ -169,6 +169,15 @@ typedef struct thip_status {
  * given stream.  NULL = single GPU. */
 typedef int (*thip_allreduce_fn)(void *ctx, float *dev_buf, size_t n, void *hip_stream);
 
+/* Native RCCL (xGMI) communicator, one per process: rank 0 creates the 128-byte id, the launcher distributes it
+ * (e.g. one torch.distributed broadcast), every rank calls thip_comm_init.  thip_solver_use_rccl installs an
+ * all-reduce that is enqueued on the library's own stream (no event hand-off to a communication stream). */
+int thip_comm_unique_id(uint8_t *host_id128);
+int thip_comm_init(int rank, int world, const uint8_t *host_id128);
+int thip_comm_allreduce(float *dev_buf, size_t n);       /* in-place float sum over the ranks, on the context stream */
+int thip_comm_destroy(void);
+int thip_solver_use_rccl(thip_solver *s);                /* before thip_solver_init */
+
 int thip_solver_create(const thip_problem *prob, const thip_param *par, int schedule, thip_solver **out);
 int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
 int thip_solver_init(thip_solver *s);                                 /* calc_norms + init_vecs + calc_precond, solver.rs:460-524 */

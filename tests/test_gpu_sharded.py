@@ -140,3 +140,33 @@ def test_sharded_lp_first_iterates(T):
     assert np.abs(x - rx).max() <= 1e-3 * max(np.abs(rx).max(), 1e-6)
     assert np.abs(y - ry).max() <= 1e-3 * max(np.abs(ry).max(), 1e-6)
     assert xa[-1] == xb[-1] and ya[-1] == yb[-1]          # tau, kappa replicated
+
+
+def test_native_rccl_single_rank(T):
+    # the native communicator at world size 1 (all a 1-GPU box can run): id -> init -> in-place sum -> solver hook
+    import ctypes as C
+    from totsu_amd._lib import lib
+    from totsu_amd.fused import comm_destroy, comm_init
+    comm_init(0, 1, lambda b: b)
+    try:
+        x = np.arange(1000, dtype=np.float32)
+        d = T.DeviceBuffer.from_host(x)
+        lib.thip_comm_allreduce(d.ptr, 1000)
+        assert np.array_equal(d.to_host(), x)
+        d.free()
+        c, G, h = benchmark_lp(20, seed=3)
+        lp = T.ProbLP(_mb(T, T.MatType.General(20, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(40, 20)).set_array(G),
+                      _mb(T, T.MatType.General(40, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, 20)),
+                      _mb(T, T.MatType.General(0, 1)))
+        dn = lp.dense()
+        p = T.SolverParam()
+        p.eps_acc, p.max_iter = 1e-4, 100_000
+        a = T.FusedSolver.from_dense(dn, p, "carried")
+        xa, _ = a.solve()
+        b = T.FusedSolver(dn.n, dn.m, dn.mat_a, dn.vec_b, dn.vec_c, dn.seg_type, dn.seg_len, p, "carried", allreduce="rccl")
+        xb, _ = b.solve()
+        assert a.status().iters == b.status().iters and np.array_equal(xa, xb)
+        a.destroy()
+        b.destroy()
+    finally:
+        comm_destroy()

@@ -88,6 +88,11 @@ PROTOTYPES = {
     "thip_proj_soc_batched": (_i, [_vp, _vp, _sz, _i, _sz]),
     "thip_proj_psd": (_i, [_sz, _vp, _f, _vp, _sz]),
     "thip_group_min_batched": (_i, [_vp, _vp, _sz, _sz]),
+    "thip_comm_unique_id": (_i, [C.POINTER(C.c_uint8)]),
+    "thip_comm_init": (_i, [_i, _i, C.POINTER(C.c_uint8)]),
+    "thip_comm_allreduce": (_i, [_vp, _sz]),
+    "thip_comm_destroy": (_i, []),
+    "thip_solver_use_rccl": (_i, [_vp]),
     "thip_solver_create": (_i, [C.POINTER(Problem), C.POINTER(Param), _i, C.POINTER(_vp)]),
     "thip_solver_set_allreduce": (_i, [_vp, ALLREDUCE_FN, _vp]),
     "thip_solver_init": (_i, [_vp]),

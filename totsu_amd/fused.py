@@ -56,7 +56,9 @@ class FusedResult:
 class FusedSolver:
     def __init__(self, n, m, mat_a, vec_b, vec_c, seg_type, seg_len, param=None, schedule="fused",
                  vec_b_rowabs=None, allreduce=None):
-        """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded)."""
+        """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded).
+        allreduce: None (single GPU), "rccl" (native communicator set up with comm_init), or a Python callable
+        (ctx, dev_ptr, count, stream) -> 0."""
         _lib.ensure_init()
         self.n, self.m = int(n), int(m)
         self._owned = []
@@ -79,7 +81,9 @@ class FusedSolver:
         self.h = h
         self.schedule = schedule
         self._cb = None
-        if allreduce is not None:
+        if allreduce == "rccl":
+            lib.thip_solver_use_rccl(self.h)            # native RCCL on the library's stream (thip_comm_init first)
+        elif allreduce is not None:
             self._cb = _lib.ALLREDUCE_FN(allreduce)
             lib.thip_solver_set_allreduce(self.h, self._cb, None)
         lib.thip_solver_init(self.h)
@@ -150,3 +154,19 @@ class FusedSolver:
         for d in self._owned:
             d.free()
         self._owned = []
+
+
+def comm_init(rank, world, broadcast_bytes):
+    """Creates the process's native RCCL communicator.  `broadcast_bytes(b: bytes | None) -> bytes` must return rank
+    0's 128 bytes on every rank (e.g. through one torch.distributed broadcast)."""
+    _lib.ensure_init()
+    buf = (C.c_uint8 * 128)()
+    if rank == 0:
+        lib.thip_comm_unique_id(buf)
+    data = broadcast_bytes(bytes(buf) if rank == 0 else None)
+    buf2 = (C.c_uint8 * 128).from_buffer_copy(data)
+    lib.thip_comm_init(rank, world, buf2)
+
+
+def comm_destroy():
+    lib.thip_comm_destroy()
