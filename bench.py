@@ -195,18 +195,37 @@ def run(a):
     hook, coll = None, "none"
     if use_dist:
         if a.collective == "rccl":
-            try:
-                def bcast(payload):
-                    t = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                    if rank == 0:
-                        t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
-                    dist.broadcast(t, src=0)
-                    return bytes(t.cpu().numpy().tobytes())
-                from totsu_amd.fused import comm_init
-                comm_init(rank, world, bcast)
+            # every rank takes part in every collective below, whatever fails locally, so that no rank is left waiting
+            import ctypes as C
+            idbuf = (C.c_uint8 * 128)()
+            ok = 1
+            if rank == 0:
+                try:
+                    lib.thip_comm_unique_id(idbuf)
+                except Exception as e:
+                    ok = 0
+                    sys.stderr.write("native RCCL unavailable (%r)\n" % (e,))
+            t = torch.zeros(129, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                t[0] = ok
+                t[1:] = torch.frombuffer(bytearray(bytes(idbuf)), dtype=torch.uint8).cuda()
+            dist.broadcast(t, src=0)
+            th = t.cpu().numpy()
+            mine = 0
+            if int(th[0]) == 1:
+                try:
+                    lib.thip_comm_init(rank, world, (C.c_uint8 * 128).from_buffer_copy(th[1:].tobytes()))
+                    mine = 1
+                except Exception as e:
+                    sys.stderr.write("thip_comm_init failed on rank %d (%r)\n" % (rank, e))
+            flag = torch.tensor([mine], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
                 hook, coll = "rccl", "native RCCL all-reduce on the compute stream"
-            except Exception as e:           # keep the run alive on the tested fallback
-                sys.stderr.write("native RCCL unavailable (%r): falling back to the torch.distributed hook\n" % (e,))
+            else:
+                if mine:
+                    lib.thip_comm_destroy()
+                sys.stderr.write("falling back to the torch.distributed all-reduce hook\n")
         if hook is None:
             hook, coll = TorchAllreduce(torch, dist), "torch.distributed.all_reduce hook (nccl)"
     fs = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, a.schedule,

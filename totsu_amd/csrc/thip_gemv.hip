@@ -73,7 +73,10 @@ template <> struct Log2<2> { static constexpr int v = 1; };
 template <> struct Log2<4> { static constexpr int v = 2; };
 template <> struct Log2<8> { static constexpr int v = 3; };
 
-template <int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS, bool NT>
+// FULL: every row of the block's tile is < m (uniform per block): loads are unconditional, so the KU * NJ loads of a
+// step are issued back to back (with the per-lane row guard each load sits in its own branch followed by a
+// vmcnt(0) wait, i.e. one load in flight per wave -- seen in the ISA, worth +1..+9 % depending on the shape)
+template <int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS, bool NT, bool FULL>
 __device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, int m, int r_first, int c, int cc,
                                      const float *__restrict__ xn, const float (&xtv)[NJ][VW],
                                      float (&accN)[NJ][VW], float *ldsT_wave, int lane)
@@ -86,7 +89,7 @@ __device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, in
         for (int j = 0; j < NJ; ++j) {
             const int r = r_first + j * (BLK * VW);
             if constexpr (VW == 4) {
-                if (r + 4 <= m) {
+                if (FULL || r + 4 <= m) {
                     typedef float f32x4_t __attribute__((ext_vector_type(4)));
                     const f32x4_t *src = reinterpret_cast<const f32x4_t *>(col + r);
                     const f32x4_t q = NT ? __builtin_nontemporal_load(src) : *src;
@@ -96,7 +99,7 @@ __device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, in
                     for (int k = 0; k < 4; ++k) av[u][j][k] = (r + k < m) ? col[r + k] : 0.0f;
                 }
             } else {
-                av[u][j][0] = (r < m) ? col[r] : 0.0f;
+                av[u][j][0] = (FULL || r < m) ? col[r] : 0.0f;
             }
         }
     }
@@ -165,10 +168,17 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const float *__restrict__ A, 
 
     float *ldsT_wave = ldsT + wave * (DO_T ? MAXCW : 1);
     int c = c0;
-    for (; c + KU <= c1; c += KU)
-        step<VW, NJ, KU, DO_N, DO_T, ABS, NT>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
-    for (; c < c1; ++c)
-        step<VW, NJ, 1, DO_N, DO_T, ABS, NT>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+    if ((tile + 1) * TILE <= m) {
+        for (; c + KU <= c1; c += KU)
+            step<VW, NJ, KU, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+        for (; c < c1; ++c)
+            step<VW, NJ, 1, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+    } else {
+        for (; c + KU <= c1; c += KU)
+            step<VW, NJ, KU, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+        for (; c < c1; ++c)
+            step<VW, NJ, 1, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+    }
 
     if constexpr (DO_N) {
         float *dst = partN + (size_t)chunk * strideN;
@@ -332,7 +342,7 @@ const GemvHint *gemv_candidates(int *count)
 {
     // measured on MI355X: fine grids of 1-row-group tiles win at 100k x 50k and at the 0.8 GB LP,
     // tall tiles with ~1k workgroups win for short-and-wide row shards
-    static const GemvHint c[] = { {1, 8192}, {1, 4096}, {2, 2048}, {4, 2048}, {4, 1024}, {4, 768} };
+    static const GemvHint c[] = { {1, 8192}, {1, 4096}, {2, 2048}, {4, 4096}, {4, 2048}, {4, 1024}, {4, 768} };
     *count = (int)(sizeof(c) / sizeof(c[0]));
     return c;
 }
