@@ -54,3 +54,35 @@ def random_sdp(n, k, seed=0):
     def pack(S):
         return np.array([S[r, cc] for cc in range(k) for r in range(cc + 1)], dtype=np.float32)
     return c.astype(np.float32), [pack(F) for F in Fs] + [pack(Fn)]
+
+
+def l1reg_lp(l=20, seed=0, lam=0.2):
+    """BASELINE.json configs[0]: the construction of examples/l1reg_lp/src/main.rs:50-116 (L1-regularised L1-error
+    kernel regression as an LP; gaussian kernel sigma^2 = 1/8, lambda = 0.2; n = 3l + 1, m = 4l, p = 0).  The
+    reference draws the sample points from Xoshiro256StarStar::seed_from_u64(0), whose stream is not reproducible
+    here (crate not vendored): the points come from numpy's generator instead -- same construction, other data."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 1, (2, l))
+    y = np.cos(5.0 * x[0]) * np.cos(7.0 * x[1])
+    n, m = 3 * l + 1, 4 * l
+    c = np.zeros(n)
+    c[:l] = 1.0
+    c[2 * l:3 * l] = lam
+    G = np.zeros((m, n))
+    for i in range(l):
+        G[i, i] = -1.0
+        G[l + i, i] = -1.0
+        G[2 * l + i, l + i] = 1.0
+        G[3 * l + i, l + i] = -1.0
+        G[2 * l + i, 2 * l + i] = -1.0
+        G[3 * l + i, 2 * l + i] = -1.0
+        G[i, 3 * l] = 1.0
+        G[l + i, 3 * l] = -1.0
+    d2 = ((x[:, :, None] - x[:, None, :]) ** 2).sum(axis=0)
+    K = np.exp(-d2 / (1.0 / 8.0))
+    G[:l, l:2 * l] = K
+    G[l:2 * l, l:2 * l] = -K
+    h = np.zeros(m)
+    h[:l] = y
+    h[l:2 * l] = -y
+    return c, G, h

@@ -396,3 +396,23 @@ def test_unchanged_caller_takes_the_fused_path(T):
     pobj = float(c.astype(np.float64) @ ro.x)
     assert abs(float(c.astype(np.float64) @ x) - pobj) <= 1e-3 * (1 + abs(pobj))
     lp.drop()
+
+
+def test_config0_l1reg_lp_gpu_vs_oracle(T):
+    # BASELINE.json configs[0] (examples/l1reg_lp) through the unchanged-caller path on F32HIP vs the f64 oracle
+    from problems import l1reg_lp
+    c, G, h = l1reg_lp(20, seed=0)
+    n, m = c.size, h.size
+    ro = O.solve_lp(O.param(eps_acc=1e-3), c, G, h, np.zeros((0, n)), [])
+    lp = T.ProbLP(_mb(T, T.MatType.General(n, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(m, n)).set_array(G),
+                  _mb(T, T.MatType.General(m, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, n)),
+                  _mb(T, T.MatType.General(0, 1)))
+    for fused in ("carried", None):
+        s = T.Solver(T.F32HIP)
+        s.fused = fused
+        s.param.eps_acc = 1e-3
+        x, y = s.solve(lp.problem())
+        assert abs(s.iters - ro.iters) <= max(3, 0.03 * ro.iters), (fused, s.iters, ro.iters)
+        pobj = float(c @ ro.x)
+        assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj))
+    lp.drop()

@@ -252,3 +252,24 @@ def test_qp_qcqp_kats_and_dense_stacking():
         assert np.allclose(t3, np.abs(dn.vec_b))
         r = O.solve_matop_cones(O.param(max_iter=100000), dn.vec_c, dn.mat_a, dn.vec_b, dn.seg_type, dn.seg_len)
         assert r.status == O.OK and np.allclose(r.x[:2], want, atol=1e-3)
+
+
+def test_config0_l1reg_lp_on_cpu_backend():
+    # BASELINE.json configs[0]: l1reg_lp on the f64 CPU backend (plumbing, no GPU): ProbLP through the generic
+    # Python loop == the oracle, iteration for iteration; eps_acc 1e-3 as in examples/l1reg_lp/src/main.rs:111-114
+    from problems import l1reg_lp
+    c, G, h = l1reg_lp(20, seed=0)
+    n, m = c.size, h.size
+    assert (n, m) == (61, 80)
+    ro = O.solve_lp(O.param(eps_acc=1e-3), c, G, h, np.zeros((0, n)), [], trace_cap=20000)
+    assert ro.status == O.OK
+    lp = ProbLP(_mb(MatType.General(n, 1)).set_array(c.reshape(-1, 1)), _mb(MatType.General(m, n)).set_array(G),
+                _mb(MatType.General(m, 1)).set_array(h.reshape(-1, 1)), _mb(MatType.General(0, n)),
+                _mb(MatType.General(0, 1)))
+    s = Solver(La).par(lambda p: setattr(p, "eps_acc", 1e-3))
+    s.trace = []
+    x, y = s.solve(lp.problem())
+    assert s.trace[-1][0] == ro.iters
+    assert np.allclose(x, ro.x, rtol=1e-8, atol=1e-10) and np.allclose(y, ro.y, rtol=1e-8, atol=1e-10)
+    # the regression fits: L1 error + regulariser is the objective, and it is small compared with sum |y|
+    assert 0 < c @ x < np.abs(h[:20]).sum()
