@@ -416,3 +416,16 @@ def test_config0_l1reg_lp_gpu_vs_oracle(T):
         pobj = float(c @ ro.x)
         assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj))
     lp.drop()
+
+
+def test_plain_c_host_over_the_abi():
+    # examples/c_api_demo.c: a C program linked against libtotsu_f32hip.so solves the nostd_cortex-m LP (no Python)
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "c_api_demo")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "x = [2.0000" in r.stdout or "x = [1.9999" in r.stdout
