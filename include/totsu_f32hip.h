@@ -91,6 +91,12 @@ int thip_eig_decompose(size_t n, float *mat, int has_scale, float scale_diag, fl
 int thip_eig_rebuild(size_t n, float *mat, int has_scale, float scale_diag,
                      float *work, size_t worklen, const float *host_e, const uint8_t *host_keep);
 
+/* Sparse operators: y = alpha * A x + beta * y, A in CSR (int64 row pointers, int32 column indices,
+ * all on the device); abs_mode != 0 uses |A| and x = 1 (MatOp::absadd_*, matop.rs:98-117).  The transposed product
+ * is the same call on the CSR of A^T.  Backs a user-level `Operator` (operator.rs:11-156) on the trait-level path. */
+int thip_spmv_csr(size_t n_row, size_t n_col, size_t nnz, const int64_t *dev_rowptr, const int32_t *dev_colidx,
+                  const float *vals, float alpha, const float *x, float beta, float *y, int abs_mode);
+
 /* ---------------------------------------------------------------------------------------------
  * Device-resident variants used by the fused path (no host round trip).  They replace host loops
  * in totsu_core that a generic backend cannot intercept ("hard parts").

@@ -1,0 +1,83 @@
+"""GPU: sparse (CSR) Operator on the trait-level path.  The operator contract is the
+reference's: trans_op is the adjoint of op and absadd_* are the |.| column / row sums (operator.rs:40-154; the
+adjointness-test pattern of examples/imgnr_udef/src/prob_op_a.rs:137-203); the solve must agree with the dense
+oracle on the same matrix."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle as O
+from problems import l1reg_lp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import totsu_amd
+    from totsu_amd import _lib
+    _lib.init()
+    return totsu_amd
+
+
+def _sl(L, a):
+    return L.Sl.new_mut(np.ascontiguousarray(a, dtype=np.float32))
+
+
+@pytest.mark.parametrize("shape,density", [((1, 1), 1.0), ((50, 30), 0.1), ((300, 1000), 0.01), ((5000, 4000), 0.002),
+                                           ((64, 64), 0.9), ((7, 2000), 0.5), ((2000, 3), 0.4)])
+def test_sparse_operator_contract(T, shape, density):
+    from totsu_amd.sparse import SparseMatOp
+    L = T.F32HIP
+    rng = np.random.default_rng(shape[0] + shape[1])
+    a = sp.random(shape[0], shape[1], density=density, format="csr", random_state=rng, dtype=np.float64)
+    a.data = rng.standard_normal(a.nnz)
+    op = SparseMatOp(L, a)
+    d = a.toarray()
+    x = rng.standard_normal(shape[1]).astype(np.float32)
+    y0 = rng.standard_normal(shape[0]).astype(np.float32)
+    sx, sy = _sl(L, x), _sl(L, y0.copy())
+    op.op(0.7, sx, -0.3, sy)
+    ref = 0.7 * d @ x - 0.3 * y0
+    scale = 0.7 * np.abs(d) @ np.abs(x) + 0.3 * np.abs(y0) + 1e-6
+    assert np.all(np.abs(sy.get_ref() - ref) <= 1e-5 * scale)
+    sy2, sx2 = _sl(L, y0), _sl(L, x.copy())
+    op.trans_op(-1.5, sy2, 0.5, sx2)
+    ref = -1.5 * d.T @ y0 + 0.5 * x
+    scale = 1.5 * np.abs(d.T) @ np.abs(y0) + 0.5 * np.abs(x) + 1e-6
+    assert np.all(np.abs(sx2.get_ref() - ref) <= 1e-5 * scale)
+    # adjointness <A x, y> == <x, A^T y>
+    ax, aty = _sl(L, np.zeros(shape[0])), _sl(L, np.zeros(shape[1]))
+    op.op(1.0, sx, 0.0, ax)
+    op.trans_op(1.0, sy2, 0.0, aty)
+    lhs = float(ax.get_ref().astype(np.float64) @ y0)
+    rhs = float(x.astype(np.float64) @ aty.get_ref().astype(np.float64))
+    assert abs(lhs - rhs) <= 1e-5 * (np.abs(d) @ np.abs(x)) @ np.abs(y0) + 1e-6
+    t0 = rng.uniform(0, 1, shape[1]).astype(np.float32)
+    s0 = rng.uniform(0, 1, shape[0]).astype(np.float32)
+    st, ss = _sl(L, t0.copy()), _sl(L, s0.copy())
+    op.absadd_cols(st)
+    op.absadd_rows(ss)
+    assert np.allclose(st.get_ref(), t0 + np.abs(d).sum(axis=0), rtol=1e-5, atol=1e-6)
+    assert np.allclose(ss.get_ref(), s0 + np.abs(d).sum(axis=1), rtol=1e-5, atol=1e-6)
+    op.drop()
+
+
+def test_sparse_l1reg_lp_solve_matches_dense_oracle(T):
+    # the l1reg_lp matrix (examples/l1reg_lp) is ~80 % zeros: solve it with the sparse operator on the trait-level path
+    from totsu_amd.sparse import SparseMatOp
+    L = T.F32HIP
+    c, G, h = l1reg_lp(20, seed=0)
+    n, m = c.size, h.size
+    op_c = T.MatOp(L, T.MatType.General(n, 1), c.astype(np.float32))
+    op_a = SparseMatOp(L, sp.csr_matrix(G))
+    op_b = T.MatOp(L, T.MatType.General(m, 1), h.astype(np.float32))
+    s = T.Solver(L)
+    s.param.eps_acc = 1e-3
+    work = np.zeros(T.Solver.query_worklen((m, n)), dtype=np.float32)
+    x, y = s.solve((op_c, op_a, op_b, T.ConeRPos(L), work))
+    ro = O.solve_lp(O.param(eps_acc=1e-3), c, G, h, np.zeros((0, n)), [])
+    assert abs(s.iters - ro.iters) <= max(3, 0.03 * ro.iters)
+    pobj = float(c @ ro.x)
+    assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj))
+    op_a.drop()

@@ -11,7 +11,10 @@ from .cone import ConeZero, ConeRPos, ConeSOC, ConeRotSOC, ConePSD
 from .matbuild import MatBuild
 from .problem import ProbLP, ProbSOCP, ProbSDP, ProbQP, ProbQCQP
 from .fused import FusedSolver, DeviceBuffer
+from .parallel import ShardedSolver, TorchComm, shard_segments
+from .sparse import SparseMatOp
 
 __all__ = ["MatOp", "MatType", "Solver", "SolverError", "SolverParam", "F32HIP", "F32HIPSlice", "splitm",
            "ConeZero", "ConeRPos", "ConeSOC", "ConeRotSOC", "ConePSD", "MatBuild", "ProbLP", "ProbSOCP",
-           "ProbSDP", "ProbQP", "ProbQCQP", "FusedSolver", "DeviceBuffer"]
+           "ProbSDP", "ProbQP", "ProbQCQP", "FusedSolver", "DeviceBuffer", "ShardedSolver", "TorchComm",
+           "shard_segments", "SparseMatOp"]

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "thip_transform_di": (_i, [_sz, _f, _vp, _vp, _f, _vp]),
     "thip_transform_ge": (_i, [_i, _sz, _sz, _f, _vp, _vp, _f, _vp]),
     "thip_transform_sp": (_i, [_sz, _f, _vp, _vp, _f, _vp]),
+    "thip_spmv_csr": (_i, [_sz, _sz, _sz, _vp, _vp, _vp, _f, _vp, _f, _vp, _i]),
     "thip_map_eig_worklen": (_sz, [_sz]),
     "thip_map_eig": (_i, [_sz, _vp, _i, _f, _f, _vp, _sz, _i]),
     "thip_eig_decompose": (_i, [_sz, _vp, _i, _f, _f, _vp, _sz, fp]),
