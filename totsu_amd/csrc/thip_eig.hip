@@ -232,55 +232,85 @@ constexpr int GT = 32;
 //   GEN = true :  C = alpha * Sym * Gen + beta * D + gamma * I_n  with Sym bitwise symmetric, Gen arbitrary:
 //                 the update S <- q(S S^T) S.  This LEFT-multiplied form is the Newton-Schulz polar iteration, which
 //                 damps antisymmetric round-off; S <- q(S S^T) S^T or S q(S S^T) doubles it every step.
-// Workgroup = 4 waves, one 32 x 32 output tile; the waves split K four ways and are combined through LDS, so a
-// 512^3 product runs on 256 workgroups (every CU).  The matrices are L2-resident (1 MiB each at k = 500) and the
+// Workgroup = 8 waves, one 32 x 32 output tile; the waves split K eight ways and are combined through LDS, so a
+// 512^3 product runs on 256 workgroups (every CU) with 8 short dependent load->MFMA chains each.  The matrices are L2-resident (1 MiB each at k = 500) and the
 // operands go straight from global memory to the MFMA registers, coalesced:
 //   operand b (lane l: k = l >> 5, column index l & 31) = Mem[k * ld + j0 + (l & 31)]   (a row of a symmetric matrix)
 //   operand a: GEN = false the same from X;  GEN = true needs Gen(k, c) = GenMem[c * ld + k], contiguous in k, so each
-//   wave stages a 32 x 16 slab through LDS (float4 loads along k) and reads it back transposed.
+//   wave stages a 32 x 8 slab through LDS (one float4 load along k per lane) and reads it back transposed.
 // acc reg r of lane l is tile element (ti = (r & 3) + 8 (r >> 2) + 4 (l >> 5), tj = l & 31); it is stored at
 // Cmem[(i0 + ti) * ld + j0 + tj] -- coalesced -- which is C(row j0 + tj, col i0 + ti): the true position for GEN
 // (a indexes columns of C there), the mirrored one for the symmetric case.
+// NW waves per workgroup split K NW ways (NW = 8: 512 threads; each wave walks ld / 8 of K in slabs of 8 = 4 MFMAs,
+// the next slab's loads are issued before the current slab's MFMAs).
+constexpr int GNW = 8;
+constexpr int GSL = 8;              // K slab per wave per step
+
 template <bool GEN>
-__global__ __launch_bounds__(BLK) void gemm_k(int n, int ld, float alpha, const float *__restrict__ X,
-                                             const float *__restrict__ Y, float beta, const float *D, float gamma,
-                                             float *C, const int *__restrict__ stop)
+__global__ __launch_bounds__(GNW * 64) void gemm_k(int n, int ld, float alpha, const float *__restrict__ X,
+                                                   const float *__restrict__ Y, float beta, const float *D, float gamma,
+                                                   float *C, const int *__restrict__ stop)
 {
     if (stop != nullptr && *stop != 0) return;
-    __shared__ float red[3][16][64];
-    __shared__ float stg[GEN ? 4 : 1][16][33];
+    __shared__ float red[GNW - 1][16][64];
+    __shared__ float stg[GEN ? GNW : 1][GSL][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * GT, j0 = blockIdx.y * GT;
-    const int kw = ld / 4, kb = wave * kw;
+    const int kw = ld / GNW, kb = wave * kw;
     // GEN: X is the symmetric factor (b operand), Y the general one (a operand).  !GEN: a from X, b from Y.
     const float *pb = (GEN ? X : Y) + (size_t)(kb + (lane >> 5)) * ld + j0 + (lane & 31);
-    const float *pa = GEN ? (Y + (size_t)(i0 + (lane >> 2)) * ld + kb + (lane & 3) * 4)
+    // GEN staging: lane -> (column i' = lane >> 1, 4 consecutive k starting at (lane & 1) * 4): one float4 per slab
+    const float *pa = GEN ? (Y + (size_t)(i0 + (lane >> 1)) * ld + kb + (lane & 1) * 4)
                           : (X + (size_t)(kb + (lane >> 5)) * ld + i0 + (lane & 31));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int k = 0; k < kw; k += 16) {
-        float av[8], bv[8];
+
+    float bv[GSL / 2], av[GSL / 2];
+    f32x4_t q;
+    // prologue: slab 0
 #pragma unroll
-        for (int u = 0; u < 8; ++u) bv[u] = pb[(size_t)(k + 2 * u) * ld];
+    for (int u = 0; u < GSL / 2; ++u) bv[u] = pb[(size_t)(2 * u) * ld];
+    if constexpr (GEN) q = *reinterpret_cast<const f32x4_t *>(pa);
+    else {
+#pragma unroll
+        for (int u = 0; u < GSL / 2; ++u) av[u] = pa[(size_t)(2 * u) * ld];
+    }
+    for (int k = 0; k < kw; k += GSL) {
+        float bn[GSL / 2], an[GSL / 2];
+        f32x4_t qn;
+        const bool more = k + GSL < kw;
+        if (more) {                                       // next slab's loads in flight during this slab's MFMAs
+#pragma unroll
+            for (int u = 0; u < GSL / 2; ++u) bn[u] = pb[(size_t)(k + GSL + 2 * u) * ld];
+            if constexpr (GEN) qn = *reinterpret_cast<const f32x4_t *>(pa + k + GSL);
+            else {
+#pragma unroll
+                for (int u = 0; u < GSL / 2; ++u) an[u] = pa[(size_t)(k + GSL + 2 * u) * ld];
+            }
+        }
         if constexpr (GEN) {
-            typedef float f32x4_t __attribute__((ext_vector_type(4)));
-            const f32x4_t q0 = *reinterpret_cast<const f32x4_t *>(pa + k);
-            const f32x4_t q1 = *reinterpret_cast<const f32x4_t *>(pa + (size_t)16 * ld + k);
-            const int ii = lane >> 2, kq = (lane & 3) * 4;
+            const int ii = lane >> 1, kq = (lane & 1) * 4;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { stg[wave][kq + t][ii] = q0[t]; stg[wave][kq + t][ii + 16] = q1[t]; }
+            for (int t = 0; t < 4; ++t) stg[wave][kq + t][ii] = q[t];
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's LDS writes have landed
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = stg[wave][2 * u + (lane >> 5)][lane & 31];
+            for (int u = 0; u < GSL / 2; ++u) av[u] = stg[wave][2 * u + (lane >> 5)][lane & 31];
             __builtin_amdgcn_wave_barrier();
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = pa[(size_t)(k + 2 * u) * ld];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < GSL / 2; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < GSL / 2; ++u) bv[u] = bn[u];
+            if constexpr (GEN) q = qn;
+            else {
+#pragma unroll
+                for (int u = 0; u < GSL / 2; ++u) av[u] = an[u];
+            }
+        }
     }
     if (wave > 0) {
 #pragma unroll
@@ -292,7 +322,10 @@ __global__ __launch_bounds__(BLK) void gemm_k(int n, int ld, float alpha, const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ti = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float v = alpha * ((acc[r] + red[0][r][lane]) + (red[1][r][lane] + red[2][r][lane]));
+            float v = acc[r];
+#pragma unroll
+            for (int w = 0; w < GNW - 1; ++w) v += red[w][r][lane];
+            v *= alpha;
             const size_t o = (size_t)ti * ld + tj;
             if (beta != 0.0f) v = fmaf(beta, D[o], v);
             if (ti == tj && ti < n) v += gamma;
@@ -330,8 +363,8 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
          float gamma, float *C, const int *stop)
 {
     dim3 g(ld / GT, ld / GT);
-    if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(BLK), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop);
-    else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(BLK), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop);
+    if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop);
+    else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop);
     THIP_LAUNCH_CHECK();
     return 0;
 }
