@@ -185,6 +185,12 @@ int thip_comm_destroy(void);
 int thip_solver_use_rccl(thip_solver *s);                /* before thip_solver_init */
 
 int thip_solver_create(const thip_problem *prob, const thip_param *par, int schedule, thip_solver **out);
+/* Sparse A for the fused loop (before thip_solver_init; prob->mat_a may then be NULL): CSR of A (m x n) and CSR of
+ * A^T (n x m), int64 row pointers / int32 column indices / f32 values, all on the device.  Each stage then costs one
+ * gather over A and one over A^T instead of a pass over a dense matrix. */
+int thip_solver_set_csr(thip_solver *s, size_t nnz,
+                        const int64_t *dev_rowptr, const int32_t *dev_colidx, const float *dev_vals,
+                        const int64_t *dev_t_rowptr, const int32_t *dev_t_colidx, const float *dev_t_vals);
 int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
 int thip_solver_init(thip_solver *s);                                 /* calc_norms + init_vecs + calc_precond, solver.rs:460-524 */
 /* enqueue up to max_steps iterations (the device stops by itself on termination), poll every

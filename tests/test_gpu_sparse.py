@@ -81,3 +81,55 @@ def test_sparse_l1reg_lp_solve_matches_dense_oracle(T):
     pobj = float(c @ ro.x)
     assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj))
     op_a.drop()
+
+
+@pytest.mark.parametrize("schedule", ["reference", "fused", "carried"])
+def test_fused_loop_on_csr_matches_dense(T, schedule):
+    # the device-resident loop with A given as scipy.sparse: same iterates as with the dense matrix
+    c, G, h = l1reg_lp(20, seed=1)
+    n, m = c.size, h.size
+    p = T.SolverParam()
+    p.eps_acc = 1e-3
+    dense = T.FusedSolver(n, m, np.asfortranarray(G).ravel(order="F").astype(np.float32), h, c, [1], [m], p, schedule)
+    xd, yd = dense.solve()
+    sparse = T.FusedSolver(n, m, sp.csr_matrix(G.astype(np.float32)), h, c, [1], [m], p, schedule)
+    xs, ys = sparse.solve()
+    assert abs(dense.status().iters - sparse.status().iters) <= max(3, 0.02 * dense.status().iters)
+    ro = O.solve_lp(O.param(eps_acc=1e-3), c, G, h, np.zeros((0, n)), [])
+    pobj = float(c @ ro.x)
+    for x in (xd, xs):
+        assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj))
+    td, sd = dense.precond()
+    ts, ss = sparse.precond()
+    assert np.allclose(td, ts, rtol=1e-5) and np.allclose(sd, ss, rtol=1e-5)
+    dense.destroy()
+    sparse.destroy()
+
+
+def test_fused_loop_sparse_socp_iterates_vs_oracle(T):
+    # sparse SOCP blocks (90 % zeros): iterates of the CSR fused loop against the dense f64 oracle
+    from problems import random_socp
+    n, cones = 40, [6, 25, 0, 11]
+    f, Gs, hs, cs, d = random_socp(n, cones, seed=7)
+    rng = np.random.default_rng(0)
+    Gs = [g * (rng.uniform(0, 1, g.shape) < 0.15) for g in Gs]
+    rows = [np.vstack([-c_.reshape(1, n), -g]) for g, c_ in zip(Gs, cs)]
+    A = np.vstack(rows).astype(np.float32)
+    b = np.concatenate([np.concatenate([[dd], h_]) for dd, h_ in zip(d, hs)]).astype(np.float32)
+    seg_t, seg_l = [2] * len(cones), [1 + k for k in cones]
+    m = A.shape[0]
+    ro = O.solve_matop_cones(O.param(max_iter=60, eps_acc=1e-300), f, np.asfortranarray(A).ravel(order="F"), b, seg_t, seg_l,
+                             snap_iters=[0, 9, 49], trace_cap=64)
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    fs = T.FusedSolver(n, m, sp.csr_matrix(A), b, f, seg_t, seg_l, p, "carried")
+    N = n + 2 * m + 1
+    done = 0
+    for q, (it, tol) in enumerate(zip([0, 9, 49], [3e-5, 2e-4, 2e-3])):
+        fs.run(it + 1 - done, poll_every=64)
+        done = it + 1
+        x, y = fs.iterate()
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        assert np.abs(x - rx).max() <= tol * max(np.abs(rx).max(), 1e-6)
+        assert np.abs(y - ry).max() <= tol * max(np.abs(ry).max(), 1e-6)
+    fs.destroy()

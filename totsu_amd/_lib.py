@@ -95,6 +95,7 @@ PROTOTYPES = {
     "thip_comm_destroy": (_i, []),
     "thip_solver_use_rccl": (_i, [_vp]),
     "thip_solver_create": (_i, [C.POINTER(Problem), C.POINTER(Param), _i, C.POINTER(_vp)]),
+    "thip_solver_set_csr": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thip_solver_set_allreduce": (_i, [_vp, ALLREDUCE_FN, _vp]),
     "thip_solver_init": (_i, [_vp]),
     "thip_solver_run": (_i, [_vp, C.c_int64, C.c_int64, C.POINTER(Status)]),

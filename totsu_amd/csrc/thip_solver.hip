@@ -89,8 +89,8 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
         if (kq > 0) comb[kq - 1][e] = s;
         __syncthreads();
         if (kq == 0 && i < (size_t)n) {
-            s = (s + comb[0][e]) + (comb[1][e] + comb[2][e]);
-            g[i] = s;
+            if (nT >= 0) { s = (s + comb[0][e]) + (comb[1][e] + comb[2][e]); g[i] = s; }
+            else s = g[i];                    // nT < 0: g already holds the finished product (sparse path)
             if (dn_a) q0 = fmaf(dn_a[i], dn_b[i], q0);
         }
         __syncthreads();
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
         if (kq > 0) comb[kq - 1][e] = s;
         __syncthreads();
         if (kq == 0 && i < (size_t)m) {
-            s = (s + comb[0][e]) + (comb[1][e] + comb[2][e]);
-            h[i] = s;
+            if (nN >= 0) { s = (s + comb[0][e]) + (comb[1][e] + comb[2][e]); h[i] = s; }
+            else s = h[i];
             if (dm_a) q1 = fmaf(dm_a[i], dm_b[i], q1);
             if (crit) {
                 const float bi = b[i];
@@ -428,6 +428,12 @@ struct thip_solver {
     thip_allreduce_fn allreduce = nullptr;
     void *allreduce_ctx = nullptr;
 
+    // optional sparse A (CSR of A and of A^T)
+    bool sparse = false; size_t nnz = 0;
+    const int64_t *rp = nullptr, *trp = nullptr;
+    const int32_t *ci = nullptr, *tci = nullptr;
+    const float *sv = nullptr, *tsv = nullptr;
+
     // cone structure
     std::vector<int32_t> seg_type;
     std::vector<int64_t> seg_len;
@@ -493,12 +499,23 @@ unsigned egrid(size_t n) { return grid_for(n, BLK, EG); }
 
 // one stage's products as partial sums: N partials of A xn (m), T partials of A^T xt (n).  The fused and carried
 // schedules read A once (dual launch); the reference schedule issues the reference's two single GEMVs.
-int products(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp)
+int products(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp, float *hN, float *gT)
 {
     hipStream_t st = ctx().stream;
     const int *stop = &s->dst->stop;
     gp->partN = gp->partT = nullptr; gp->nN = gp->nT = 0; gp->strideN = gp->strideT = 0;
     if (s->m == 0 || s->n == 0) return 0;     // zero-sized operator: products are 0 (matop.rs:83-85)
+    if (s->sparse) {
+        // hN = A xn and gT = A^T xt as finished vectors (gathers over the CSR of A and of A^T); nN = nT = -1 tells
+        // post_k to take them as they are.  The stop flag is honoured by the consumers (a stray product is harmless).
+        (void)stop;
+        prof_begin(st);
+        THIP_RC(thip_spmv_csr(s->m, s->n, s->nnz, s->rp, s->ci, s->sv, 1.0f, xn, 0.0f, hN, 0));
+        THIP_RC(thip_spmv_csr(s->n, s->m, s->nnz, s->trp, s->tci, s->tsv, 1.0f, xt, 0.0f, gT, 0));
+        prof_end(st);
+        gp->nN = gp->nT = -1;
+        return 0;
+    }
     if (s->schedule == THIP_SCHED_REFERENCE) {
         GemvPartials a, b;
         const size_t half = s->gemv_scr_n / 2;
@@ -551,7 +568,7 @@ int one_iteration(thip_solver *s)
     const unsigned gq = grid_for(s->n > s->m ? s->n : s->m, 64, PG);
 
     // ---- stage X: x update (solver.rs:538-555) ----------------------------------------------------
-    THIP_RC(products(s, s->u, s->v, &gp));
+    THIP_RC(products(s, s->u, s->v, &gp, s->h1, s->g1));
     hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g1, gp.partN, gp.nN,
                        gp.strideN, s->h1, s->c, s->u, s->b, s->v, 0, (const float *)nullptr, (const float *)nullptr,
                        (const float *)nullptr, ez, part, s->dst);
@@ -564,7 +581,7 @@ int one_iteration(thip_solver *s)
 
     // ---- stage Y: y update from K rx (solver.rs:557-567), own products unless carried ---------------
     if (!carried) {
-        THIP_RC(products(s, s->rxx, s->rxy, &gp));
+        THIP_RC(products(s, s->rxx, s->rxy, &gp, s->h2, s->g2));
         hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g2, gp.partN, gp.nN,
                            gp.strideN, s->h2, s->c, s->rxx, s->b, s->rxy, 0, (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, ez, part, s->dst);
@@ -577,7 +594,7 @@ int one_iteration(thip_solver *s)
     }
 
     // ---- stage C: criteria products of the new iterate (solver.rs:573-656) --------------------------
-    THIP_RC(products(s, s->xx, s->xy, &gp));
+    THIP_RC(products(s, s->xx, s->xy, &gp, s->h3, s->g3));
     hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g3, gp.partN, gp.nN,
                        gp.strideN, s->h3, carried ? s->c : (const float *)nullptr, s->rxx,
                        carried ? s->b : (const float *)nullptr, s->rxy, 1, s->xs, s->xy, s->b, ez, part, s->dst);
@@ -601,7 +618,7 @@ int autotune_gemv(thip_solver *s)
 {
     const char *env = getenv("THIP_GEMV_AUTOTUNE");
     if ((env && atoi(env) == 0) || getenv("THIP_GEMV_NJ") || getenv("THIP_GEMV_BLOCKS")) return 0;
-    if (s->m * s->n < (size_t)1 << 22) return 0;           // tiny matrices: launch-bound anyway
+    if (s->sparse || s->m * s->n < (size_t)1 << 22) return 0;   // sparse, or tiny: nothing to tune
     hipStream_t st = ctx().stream;
     hipEvent_t e0, e1;
     THIP_TRY(hipEventCreate(&e0));
@@ -746,6 +763,18 @@ int thip_solver_create(const thip_problem *prob, const thip_param *par, int sche
     return 0;
 }
 
+int thip_solver_set_csr(thip_solver *s, size_t nnz, const int64_t *dev_rowptr, const int32_t *dev_colidx,
+                        const float *dev_vals, const int64_t *dev_t_rowptr, const int32_t *dev_t_colidx,
+                        const float *dev_t_vals)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (!dev_rowptr || !dev_t_rowptr) return fail(THIP_E_INVALID, "null CSR arrays", __FILE__, __LINE__);
+    s->sparse = true; s->nnz = nnz;
+    s->rp = dev_rowptr; s->ci = dev_colidx; s->sv = dev_vals;
+    s->trp = dev_t_rowptr; s->tci = dev_t_colidx; s->tsv = dev_t_vals;
+    return 0;
+}
+
 int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *c)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
@@ -774,7 +803,10 @@ int thip_solver_init(thip_solver *s)
 
     // |A| column sums (sharded partial -> all-reduce with the two scalars in the tail) and row sums
     float *colabs = s->g1, *rowabs = s->h1;
-    if (n && m) {
+    if (n && m && s->sparse) {
+        THIP_RC(thip_spmv_csr(m, n, s->nnz, s->rp, s->ci, s->sv, 1.0f, s->sv, 0.0f, rowabs, 1));
+        THIP_RC(thip_spmv_csr(n, m, s->nnz, s->trp, s->tci, s->tsv, 1.0f, s->tsv, 0.0f, colabs, 1));
+    } else if (n && m) {
         // solver-owned scratch (several solvers may share the context, e.g. one per thread)
         GemvPartials gp;
         THIP_RC(dual_gemv_partials(st, m, n, s->A, m, nullptr, nullptr, true, true, true, s->gemv_scr, s->gemv_scr_n, &gp, nullptr));
@@ -874,7 +906,8 @@ int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_byte
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
     if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : 2);
-    if (host_bytes_per_pass) *host_bytes_per_pass = s->m * s->n * sizeof(float);
+    if (host_bytes_per_pass) *host_bytes_per_pass = s->sparse ? 2 * s->nnz * (sizeof(float) + sizeof(int32_t))
+                                                              : s->m * s->n * sizeof(float);
     return 0;
 }
 

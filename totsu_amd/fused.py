@@ -62,7 +62,14 @@ class FusedSolver:
         _lib.ensure_init()
         self.n, self.m = int(n), int(m)
         self._owned = []
-        self.mat_a = self._dev(mat_a, self.n * self.m)
+        self._csr = None
+        if hasattr(mat_a, "tocsr"):                       # scipy.sparse matrix: the fused loop runs on CSR gathers
+            from .sparse import _Csr
+            assert mat_a.shape == (self.m, self.n)
+            self._csr = (_Csr(mat_a), _Csr(mat_a.T))
+            mat_a = DeviceBuffer(1)
+            self._owned.append(mat_a)
+        self.mat_a = self._dev(mat_a, 1 if self._csr else self.n * self.m)
         self.vec_b = self._dev(vec_b, self.m)
         self.vec_c = self._dev(vec_c, self.n)
         self.vec_b_rowabs = None if vec_b_rowabs is None else self._dev(vec_b_rowabs, self.m)
@@ -80,6 +87,10 @@ class FusedSolver:
         lib.thip_solver_create(C.byref(prob), C.byref(par), SCHEDULES[schedule], C.byref(h))
         self.h = h
         self.schedule = schedule
+        if self._csr:
+            a, at = self._csr
+            lib.thip_solver_set_csr(self.h, a.nnz, a.rowptr.ptr, a.colidx.ptr, a.vals.ptr, at.rowptr.ptr, at.colidx.ptr,
+                                    at.vals.ptr)
         self._cb = None
         if allreduce == "rccl":
             lib.thip_solver_use_rccl(self.h)            # native RCCL on the library's stream (thip_comm_init first)
@@ -154,6 +165,10 @@ class FusedSolver:
         for d in self._owned:
             d.free()
         self._owned = []
+        if self._csr:
+            for c in self._csr:
+                c.free()
+            self._csr = None
 
 
 def comm_init(rank, world, broadcast_bytes):
