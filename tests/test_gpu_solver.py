@@ -429,3 +429,31 @@ def test_plain_c_host_over_the_abi():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "x = [2.0000" in r.stdout or "x = [1.9999" in r.stdout
+
+
+@pytest.mark.parametrize("path", ["trait", "reference", "fused", "carried"])
+def test_lp_with_equality_rows_zero_cone(T, path):
+    # ProbLP with p > 0: the ConeZero block (cone_zero.rs:38-44: primal -> 0, dual -> identity) next to ConeRPos
+    rng = np.random.default_rng(21)
+    n, m, p_ = 12, 20, 4
+    x0 = rng.uniform(0.1, 1.0, n)
+    G = np.vstack([-np.eye(n), rng.uniform(0, 1, (m - n, n))])
+    h = np.concatenate([np.zeros(n), G[n:] @ x0 + rng.uniform(0.1, 1, m - n)])
+    A = rng.standard_normal((p_, n))
+    b = A @ x0
+    c = rng.uniform(0.1, 1, n)                      # c > 0, x >= 0: bounded
+    ro = O.solve_lp(O.param(max_iter=400000, eps_acc=1e-5), c, G, h, A, b)
+    assert ro.status == O.OK
+    pobj = float(c @ ro.x)
+    lp = T.ProbLP(_mb(T, T.MatType.General(n, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(m, n)).set_array(G),
+                  _mb(T, T.MatType.General(m, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(p_, n)).set_array(A),
+                  _mb(T, T.MatType.General(p_, 1)).set_array(b.reshape(-1, 1)))
+    if path == "trait":
+        x, y = _par(T.Solver(T.F32HIP), max_iter=400_000, eps_acc=1e-4).solve(lp.problem())
+    else:
+        pr = T.SolverParam()
+        pr.max_iter, pr.eps_acc = 400_000, 1e-4
+        x, y = T.FusedSolver.from_dense(lp.dense(), pr, path).solve()
+    assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj)), (path, float(c @ x), pobj)
+    assert np.abs(A @ x.astype(np.float64) - b).max() <= 5e-3 * (1 + np.abs(b).max())
+    lp.drop()
