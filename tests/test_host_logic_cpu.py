@@ -273,3 +273,26 @@ def test_config0_l1reg_lp_on_cpu_backend():
     assert np.allclose(x, ro.x, rtol=1e-8, atol=1e-10) and np.allclose(y, ro.y, rtol=1e-8, atol=1e-10)
     # the regression fits: L1 error + regulariser is the objective, and it is small compared with sum |y|
     assert 0 < c @ x < np.abs(h[:20]).sum()
+
+
+def test_debug_log_reproduces_the_golden_log_lines(caplog):
+    # the reference's log facade (solver.rs:342-446): with log_period = 10 the generic loop emits exactly the
+    # [DEBUG] / [INFO] lines of examples/nostd_cortex-m/log_qemu.txt
+    import logging
+    g = json.load(open(os.path.join(HERE, "golden", "log_qemu.json")))
+    pb = g["problem"]
+    op_c = MatOp(La, MatType.General(2, 1), np.array(pb["vec_c"]))
+    op_a = MatOp(La, MatType.General(3, 2), np.array(pb["mat_a_colmajor"]))
+    op_b = MatOp(La, MatType.General(3, 1), np.array(pb["vec_b"]))
+    s = Solver(La).par(lambda p: (setattr(p, "max_iter", 100_000), setattr(p, "log_period", 10)))
+    with caplog.at_level(logging.DEBUG, logger="totsu_amd"):
+        s.solve((op_c, op_a, op_b, ConeRPos(La), np.zeros(48)))
+    msgs = [r.getMessage() for r in caplog.records]
+    assert msgs[0] == "----- Initializing" and msgs[1] == "----- Started" and msgs[-1] == "----- Converged"
+    dbg = [m for m in msgs if "pri_dual_gap" in m]
+    assert len(dbg) == len(g["trace"])
+    for m, rec in zip(dbg, g["trace"]):
+        it, _, a, b, c = m.replace(":", "").split()
+        assert int(it) == rec["iter"]
+        for got, want in zip((a, b, c), rec["text"]):
+            assert abs(float(got) - float(want)) <= 0.006 * max(abs(float(want)), 1e-300)

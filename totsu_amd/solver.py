@@ -3,9 +3,12 @@
 meaning, same error behaviour); every arithmetic step is a call on `L`, so with `L = F32HIP` each one is a
 gfx950 kernel.  The fused device-resident loop for dense operators is `totsu_amd.fused.FusedSolver`.
 """
+import logging
 import math
 
 import numpy as np
+
+log = logging.getLogger("totsu_amd")     # the reference logs through the `log` crate facade (solver.rs:342-446)
 
 from .linalg import splitm
 
@@ -141,12 +144,25 @@ class Solver:
         src = getattr(op_a, "dense_src", None)
         if self.fused and src is not None and getattr(L, "name", "") == "F32HIP" and self.trace is None:
             from .fused import FusedSolver
+            log.info("----- Initializing")
             fs = FusedSolver.from_dense(src.dense(), self.param, self.fused)
+            log.info("----- Started")
             try:
-                r = fs.run(-1, 64)
+                period = int(self.param.log_period)
+                if period > 0 and log.isEnabledFor(logging.DEBUG):
+                    # solver.rs:371-395: the residual triple every log_period iterations
+                    while True:
+                        r = fs.run(period, min(64, period))
+                        _log_status(r)
+                        if r.state != -1:
+                            break
+                else:
+                    r = fs.run(-1, 64)
+                    _log_status(r)
                 x, y = fs.solution()
             finally:
                 fs.destroy()
+            _log_end(r.state)
             self.iters = r.iters
             work[:n] = x                  # solver.rs:317-320: the answers are the head of the caller's work slice
             work[n:n + m] = y
@@ -165,6 +181,20 @@ class Solver:
         return work[:n], work[n:n + m]
 
 
+def _log_status(r):
+    if r.kind == 0:
+        log.debug("%d: pri_dual_gap %.2e %.2e %.2e", r.iters, r.cri[0], r.cri[1], r.cri[2])
+    else:
+        log.debug("%d: unbdd_infeas %.2e %.2e", r.iters, r.cri[0], r.cri[1])
+
+
+def _log_end(state):
+    if state == 0:
+        log.info("----- Converged")
+    else:
+        log.warning("----- %s", {1: "Unbounded", 2: "Infeasible", 3: "ExcessIter"}.get(state, "Error %d" % state))
+
+
 class _SolverCore:
     """solver.rs:326-657"""
 
@@ -175,14 +205,17 @@ class _SolverCore:
     def solve(self, work):                                          # solver.rs:340-458
         L, par = self.L, self.par
         m, n = self.op_k.a.size()
+        log.info("----- Initializing")
         norm_b, norm_c = self.calc_norms(work)
         N, M = n + m + m + 1, n + m + 1
         x, y, dp_tau, dp_sigma, tmpw = splitm(work, N, M, N, M, 2 * N)
         self.init_vecs(x, y)
         self.calc_precond(dp_tau, dp_sigma)
+        log.info("----- Started")
         i = 0
         while True:
             excess_iter = (i + 1 >= par.max_iter) if par.max_iter is not None else False
+            log_trig = (i % par.log_period == 0) if par.log_period > 0 else False
             val_tau = self.update_vecs(x, y, dp_tau, dp_sigma, tmpw)
             if val_tau is None:
                 return SolverError.ConeFailure
@@ -192,10 +225,13 @@ class _SolverCore:
                 if self.trace is not None:
                     self.trace.append((i, 0, cri_pri, cri_dual, cri_gap))
                 term_conv = cri_pri <= par.eps_acc and cri_dual <= par.eps_acc and cri_gap <= par.eps_acc
+                if log_trig or excess_iter or term_conv:
+                    log.debug("%d: pri_dual_gap %.2e %.2e %.2e", i, cri_pri, cri_dual, cri_gap)
                 if excess_iter or term_conv:
                     x_x_ast, x_y_ast = splitm(x, n, m)
                     L.scale(1.0 / val_tau, x_x_ast)
                     L.scale(1.0 / val_tau, x_y_ast)
+                    _log_end(0 if term_conv else 3)
                     return None if term_conv else SolverError.ExcessIter
             else:
                 cri_unbdd, cri_infeas = self.criteria_inf(x, norm_c, norm_b, tmpw)
@@ -203,7 +239,10 @@ class _SolverCore:
                     self.trace.append((i, 1, cri_unbdd, cri_infeas, 0.0))
                 term_unbdd = cri_unbdd <= par.eps_inf
                 term_infeas = cri_infeas <= par.eps_inf
+                if log_trig or excess_iter or term_unbdd or term_infeas:
+                    log.debug("%d: unbdd_infeas %.2e %.2e", i, cri_unbdd, cri_infeas)
                 if excess_iter or term_unbdd or term_infeas:
+                    _log_end(1 if term_unbdd else (2 if term_infeas else 3))
                     if term_unbdd:
                         return SolverError.Unbounded
                     if term_infeas:
