@@ -457,3 +457,19 @@ def test_lp_with_equality_rows_zero_cone(T, path):
     assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj)), (path, float(c @ x), pobj)
     assert np.abs(A @ x.astype(np.float64) - b).max() <= 5e-3 * (1 + np.abs(b).max())
     lp.drop()
+
+
+def test_box_lp_vertex(T):
+    # the known-answer LP of rust/totsu_f32hip/tests/kat_box_lp.rs, here through the Python mirror on the GPU
+    rows = np.array([[-1., 0.], [0., -1.], [1., 0.], [0., 1.], [1., 1.]])
+    rhs = np.array([0., 0., 3., 1.5, 4.])
+    lp = T.ProbLP(_mb(T, T.MatType.General(2, 1)).iter_colmaj([-1., -2.]), _mb(T, T.MatType.General(5, 2)).set_array(rows),
+                  _mb(T, T.MatType.General(5, 1)).iter_colmaj(rhs), _mb(T, T.MatType.General(0, 2)),
+                  _mb(T, T.MatType.General(0, 1)))
+    for fused in ("carried", None):
+        s = T.Solver(T.F32HIP)
+        s.fused = fused
+        s.param.eps_acc, s.param.max_iter = 1e-4, 200_000
+        x, _ = s.solve(lp.problem())
+        assert np.allclose(x, [2.5, 1.5], atol=2e-3), (fused, x)
+    lp.drop()
