@@ -15,7 +15,7 @@
 //  (2) PSD projection without eigenvectors: P = (M + M sign(M)) / 2, sign(M) by an odd matrix polynomial
 //      iteration -- a chain of n x n x n f32 GEMMs on v_mfma_f32_32x32x2_f32.  This is where the matrix cores
 //      are a real dense contraction; a Householder/QR chain at k = 500 is O(k) dependent latency-bound
-//      steps while this is 50 GEMMs.  Used by ConePSD::proj for n > 64.
+//      steps while this is 50 GEMMs.  Used by ConePSD::proj for n > 20 (measured cross-over with (1)).
 #include "thip_common.h"
 
 #include <cmath>
@@ -25,7 +25,8 @@ using namespace thip;
 namespace {
 
 constexpr int BLK = 256;
-constexpr int SMALL_N = 64;
+constexpr int SMALL_N = 64;          // largest order the single-workgroup Jacobi kernel holds in LDS
+constexpr int POLAR_MIN_N = 20;      // from here on the MFMA polar chain (~0.3 ms flat) beats it for PSD projections
 constexpr int MAX_SWEEPS = 18;
 
 __host__ __device__ inline size_t np_of(size_t n) { return (n + 63) / 64 * 64; }
@@ -400,10 +401,18 @@ int decompose(hipStream_t st, size_t n, const float *packed, int has_scale, floa
         hipLaunchKernelGGL(zero_counters_k, dim3(1), dim3(64), 0, st, k.counters, MAX_SWEEPS + 2);
         const int n_even = (ni + 1) & ~1;
         const unsigned blocks = (unsigned)((n_even / 2 + 3) / 4);
-        for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep)
+        for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
             for (int step = 0; step < n_even - 1; ++step)
                 hipLaunchKernelGGL(jacobi_step_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, k.G, k.V, step, k.counters,
                                    sweep, stop);
+            if (stop == nullptr) {
+                // host-facing call (thip_map_eig / thip_eig_decompose): stop enqueuing once a sweep rotated nothing
+                int rotated = 1;
+                THIP_TRY(hipMemcpyAsync(&rotated, k.counters + sweep, sizeof(int), hipMemcpyDeviceToHost, st));
+                THIP_TRY(hipStreamSynchronize(st));
+                if (rotated == 0) break;
+            }
+        }
     }
     hipLaunchKernelGGL(eigvals_k, dim3((unsigned)((n + 3) / 4)), dim3(BLK), 0, st, ni, ld, k.G, k.V, k.sc, map_kind, k.w,
                        k.e, stop);
@@ -465,7 +474,7 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
     if (n == 0) return 0;
     if (worklen < thip_map_eig_worklen(n)) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
     const Work k = carve(work, n);
-    if (map_kind == 0 && n > SMALL_N) return polar_project(st, n, packed, has_scale, scale_diag, k, stop);
+    if (map_kind == 0 && n > POLAR_MIN_N) return polar_project(st, n, packed, has_scale, scale_diag, k, stop);
     THIP_RC(decompose(st, n, packed, has_scale, scale_diag, k, map_kind, stop));
     return rebuild(st, n, packed, has_scale, scale_diag, k, stop);
 }
