@@ -1,0 +1,50 @@
+// cpp_trait_demo.cpp -- a compiled host over include/totsu_f32hip.hpp (which is layered only on the C ABI):
+// the reference's trait-level calling sequence `Solver::solve((op_c, op_a, op_b, cone, work))` in C++, on three
+// known-answer problems: the nostd_cortex-m LP (x = [2, 2]), a second-order-cone problem (x = [-1, -1], the data of
+// totsu/tests/socp.rs test_socp1 in stacked form) and the 2x2 PSD problem of totsu_core/tests/solver.rs (x = -2).
+#include <cstdio>
+#include "totsu_f32hip.hpp"
+
+using namespace totsu;
+
+static int run(const char *name, size_t n, size_t m, const std::vector<float> &c, const std::vector<float> &a,
+               const std::vector<float> &b, Cone &cone, const std::vector<float> &want, float tol)
+{
+    DeviceVec dc(c), da(a), db(b);
+    MatOp op_c(n, 1, dc.slice()), op_a(m, n, da.slice()), op_b(m, 1, db.slice());
+    DeviceVec work(Solver::query_worklen(m, n));
+    Solver s;
+    s.par.max_iter = 100000;
+    s.par.eps_acc = 1e-5f;
+    const SolverError e = s.solve(op_c, op_a, op_b, cone, work.slice());
+    const std::vector<float> w = work.to_host();
+    bool ok = e == SolverError::Ok;
+    printf("%-10s status %d after %lld iterations: x = [", name, (int)e, (long long)s.iters);
+    for (size_t i = 0; i < n; ++i) { printf("%s%.5f", i ? ", " : "", w[i]); ok = ok && std::fabs(w[i] - want[i]) <= tol; }
+    printf("]  %s\n", ok ? "OK" : "MISMATCH");
+    return ok ? 0 : 1;
+}
+
+int main()
+{
+    int ndev = 0;
+    thip_device_count(&ndev);
+    if (ndev == 0) { fprintf(stderr, "no GPU: no CPU fallback\n"); return 3; }
+    chk(thip_init(0));
+    int bad = 0;
+    {
+        ConeRPos cone;
+        bad += run("lp", 2, 3, { -1, 0 }, { 4, -1, -1, -1, 4, -1 }, { 6, 6, 1 }, cone, { 2, 2 }, 1e-3f);
+    }
+    {   // min x0 + x1  s.t.  ||x|| <= sqrt 2 : rows [-c^T ; -G] = [0 0 ; -1 0 ; 0 -1], b = [sqrt 2 ; 0 ; 0]
+        ConeSOC cone;
+        bad += run("socp", 2, 3, { 1, 1 }, { 0, -1, 0, 0, 0, -1 }, { 1.41421356f, 0, 0 }, cone, { -1, -1 }, 1e-3f);
+    }
+    {
+        DeviceVec w(ConePSD::query_worklen(3));
+        ConePSD cone(w.slice(), 1e-12f);
+        bad += run("psd", 1, 3, { 1 }, { 0, -1.41421356f, -3 }, { 1, 0, 10 }, cone, { -2 }, 1e-3f);
+    }
+    chk(thip_shutdown());
+    return bad;
+}

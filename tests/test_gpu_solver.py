@@ -473,3 +473,16 @@ def test_box_lp_vertex(T):
         x, _ = s.solve(lp.problem())
         assert np.allclose(x, [2.5, 1.5], atol=2e-3), (fused, x)
     lp.drop()
+
+
+def test_cpp_trait_mirror_host():
+    # examples/cpp_trait_demo.cpp over include/totsu_f32hip.hpp: the trait-level loop in C++ on three KATs
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "cpp_trait_demo")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("OK") == 3
