@@ -32,13 +32,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="socp", choices=["socp", "lp", "sdp"])
     ap.add_argument("--k", type=int, default=500, help="PSD order of the sdp workload")
-    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--n", "--size", dest="n", type=int, default=None, help="number of variables (use --size under torchrun: --n is an ambiguous prefix there)")
     ap.add_argument("--cones", type=int, default=1000)
     ap.add_argument("--schedule", default="carried", choices=["reference", "fused", "carried"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--force-collective", action="store_true", help="install the all-reduce hook even at N = 1")
-    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch"],
-                    help="rccl: native RCCL call on the library's stream; torch: torch.distributed.all_reduce hook")
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch", "gloo"],
+                    help="rccl: native RCCL call on the library's stream; torch: torch.distributed.all_reduce hook; "
+                         "gloo: all-reduce staged through the host (lets several ranks share ONE GPU: plumbing tests)")
     ap.add_argument("--to-eps", type=float, default=None, help="also solve to this eps_acc and report time-to-eps")
     ap.add_argument("--cpu-cones", type=int, default=0, help="cones in the CPU sample (0: pick from the thread count)")
     return ap.parse_args()
@@ -47,6 +48,27 @@ def parse():
 class _CAI:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class GlooAllreduce:
+    """all-reduce through host memory over the gloo backend: slow, but lets N processes share one GPU, which RCCL
+    refuses -- used to test the multi-process plumbing (sharding, hook placement, rank-0 output) on a 1-GPU box"""
+
+    def __init__(self, torch, dist, lib):
+        self.torch, self.dist, self.lib, self.calls = torch, dist, lib, 0
+
+    def __call__(self, ctx, ptr, n, stream):
+        try:
+            h = np.empty(n, dtype=np.float32)
+            self.lib.thip_d2h(h.ctypes.data, ptr, n)          # synchronises the library's stream
+            t = self.torch.from_numpy(h)
+            self.dist.all_reduce(t)
+            self.lib.thip_h2d(ptr, h.ctypes.data, n)
+            self.calls += 1
+            return 0
+        except Exception as e:
+            sys.stderr.write("gloo all-reduce hook failed: %r\n" % (e,))
+            return 1
 
 
 class TorchAllreduce:
@@ -152,12 +174,17 @@ def run(a):
 
     import torch
     import torch.distributed as dist
+    if a.collective == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)      # ranks may share a GPU
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_collective
     if use_dist and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.collective == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import totsu_amd as T
     from totsu_amd import _lib, synth
@@ -167,7 +194,9 @@ def run(a):
     def allreduce_host(v):
         if not use_dist:
             return v
-        t = torch.from_numpy(np.ascontiguousarray(v)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(v).copy())
+        if a.collective != "gloo":
+            t = t.cuda()
         dist.all_reduce(t)
         return t.cpu().numpy()
 
@@ -193,7 +222,9 @@ def run(a):
     p.eps_acc = 0.0            # never terminates inside the timed region: every step does full work
     p.eps_inf = 0.0
     hook, coll = None, "none"
-    if use_dist:
+    if use_dist and a.collective == "gloo":
+        hook, coll = GlooAllreduce(torch, dist, lib), "gloo through host memory (plumbing test mode)"
+    elif use_dist:
         if a.collective == "rccl":
             # every rank takes part in every collective below, whatever fails locally, so that no rank is left waiting
             import ctypes as C
@@ -248,7 +279,7 @@ def run(a):
     lib.thip_prof_read(C.byref(nl), C.byref(tot_ms))
     lib.thip_prof_enable(0)
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if a.collective == "gloo" else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert r.state == _lib.ST_RUNNING and r.iters == a.warmup + a.steps, (r.state, r.iters)

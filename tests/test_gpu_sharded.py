@@ -170,3 +170,34 @@ def test_native_rccl_single_rank(T):
         b.destroy()
     finally:
         comm_destroy()
+
+
+def test_bench_two_processes_share_one_gpu_and_reproduce_single_process():
+    # bench.py under torch.distributed.run with 2 ranks on ONE GPU (all-reduce staged through gloo, since RCCL refuses
+    # two ranks per device): the row-sharded run must reproduce the single-process run -- same iteration count to
+    # eps (+-1 %), same primal / dual objective -- and print exactly one JSON line from rank 0.
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--size", "1500", "--cones", "30", "--steps", "5", "--warmup", "1", "--no-cpu", "--to-eps", "1e-3"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
+                        timeout=900, env=env, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(root, "bench.py"),
+                         "--gpus", "2", "--collective", "gloo"] + common, capture_output=True, text=True, timeout=900,
+                        env=env, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    lines1 = [l for l in r1.stdout.splitlines() if l.strip()]
+    lines2 = [l for l in r2.stdout.splitlines() if l.strip()]
+    assert len(lines1) == 1 and len(lines2) == 1, (lines1, lines2)
+    d1, d2 = json.loads(lines1[0]), json.loads(lines2[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["rows_per_gpu"] == 1500
+    t1, t2 = d1["time_to_eps"], d2["time_to_eps"]
+    assert t1["state"] == t2["state"] == 0
+    assert abs(t1["iterations"] - t2["iterations"]) <= max(3, 0.01 * t1["iterations"]), (t1, t2)
+    assert abs(t1["primal_obj"] - t2["primal_obj"]) <= 1e-4 * (1 + abs(t1["primal_obj"]))
+    assert abs(t1["dual_obj"] - t2["dual_obj"]) <= 1e-4 * (1 + abs(t1["dual_obj"]))
