@@ -86,3 +86,35 @@ def l1reg_lp(l=20, seed=0, lam=0.2):
     h[:l] = y
     h[l:2 * l] = -y
     return c, G, h
+
+
+def partitioning_sdp(x_num, y_num, seed=0):
+    """BASELINE.json configs[3] template: the construction of examples/partitioning_sdp/src/main.rs:21-79 (max-cut style
+    SDP relaxation on an x_num x y_num grid graph): minimise sum W_ij X_ij over packed X (n = l(l+1)/2 variables),
+    X >= 0 (F_k = -E_ij, F_n = 0), diag(X) = 1 (A picks the diagonal entries, b = 1).  Edge weights ~ N(0,1) from
+    numpy's generator (the reference's Xoshiro stream is not reproducible here)."""
+    rng = np.random.default_rng(seed)
+    l = x_num * y_num
+    n = l * (l + 1) // 2
+
+    def pidx(r, c):
+        return c * (c + 1) // 2 + r
+    w = np.zeros(n)
+    for i in range(l):
+        x, y = divmod(i, y_num)
+        if x < x_num - 1:
+            w[pidx(i, i + y_num)] = rng.standard_normal()
+        if y < y_num - 1:
+            w[pidx(i, i + 1)] = rng.standard_normal()
+    syms_f = [np.zeros(n) for _ in range(n + 1)]
+    kk = 0
+    for j in range(l):
+        for i in range(j + 1):
+            syms_f[kk][pidx(i, j)] = -1.0
+            kk += 1
+    mat_a = np.zeros((l, n))
+    j = 0
+    for i in range(l):
+        mat_a[i, j] = 1.0
+        j += i + 2
+    return w, syms_f, mat_a, np.ones(l)

@@ -486,3 +486,28 @@ def test_cpp_trait_mirror_host():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("OK") == 3
+
+
+@pytest.mark.parametrize("grid", [(2, 3), (3, 4)])
+def test_partitioning_sdp_gpu_vs_oracle(T, grid):
+    # BASELINE.json configs[3] template (examples/partitioning_sdp): PSD cone + equality rows through ProbSDP
+    from problems import partitioning_sdp
+    w, syms_f, mat_a, vec_b = partitioning_sdp(*grid, seed=1)
+    l = grid[0] * grid[1]
+    n = w.size
+    ro = O.solve_sdp(O.param(max_iter=400000, eps_acc=1e-5), w, syms_f, mat_a, vec_b, 1e-12, use_ql=True)
+    assert ro.status == O.OK
+    pobj = float(w @ ro.x)
+    sdp = T.ProbSDP(_mb(T, T.MatType.General(n, 1)).set_array(w.reshape(-1, 1)),
+                    [_mb(T, T.MatType.SymPack(l)).set_array(s) for s in syms_f],
+                    _mb(T, T.MatType.General(l, n)).set_array(mat_a), _mb(T, T.MatType.General(l, 1)).set_array(vec_b.reshape(-1, 1)),
+                    1e-12)
+    for fused in (("carried", None) if l <= 6 else ("carried",)):
+        s = T.Solver(T.F32HIP)
+        s.fused = fused
+        s.param.eps_acc, s.param.max_iter = 1e-4, 400_000
+        x, _ = s.solve(sdp.problem())
+        assert abs(float(w @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj)), (fused, float(w @ x), pobj)
+        diag = [x[c * (c + 1) // 2 + c] for c in range(l)]
+        assert np.allclose(diag, 1.0, atol=5e-3)
+    sdp.drop()

@@ -210,3 +210,32 @@ def test_qcqp1_kat():
                      np.zeros((0, 2)), [])
     assert r.status == O.OK
     assert np.allclose(r.x[:2], [5.0, 4.0], atol=1e-3)
+
+
+def test_partitioning_sdp_construction_on_oracle():
+    # examples/partitioning_sdp/src/main.rs:45-79 at 2 x 3 nodes: the relaxation's optimum has unit diagonal, is PSD,
+    # and its value is a lower bound of every cut sampled from it (main.rs:82-140)
+    from problems import partitioning_sdp
+    w, syms_f, mat_a, vec_b = partitioning_sdp(2, 3, seed=1)
+    par = O.param(max_iter=200000, eps_acc=1e-6)
+    for use_ql in (False, True):
+        r = O.solve_sdp(par, w, syms_f, mat_a, vec_b, 1e-12, use_ql=use_ql)
+        assert r.status == O.OK
+        l = 6
+        X = np.zeros((l, l))
+        kk = 0
+        for j in range(l):
+            for i in range(j + 1):
+                X[i, j] = X[j, i] = r.x[kk]
+                kk += 1
+        assert np.allclose(np.diag(X), 1.0, atol=1e-4)
+        assert np.linalg.eigvalsh(X).min() >= -1e-4
+        Wm = np.zeros((l, l))
+        kk = 0
+        for j in range(l):
+            for i in range(j + 1):
+                Wm[i, j] = Wm[j, i] = w[kk] / (1.0 if i == j else 2.0)   # sum_k w_k X_k counts each edge once
+                kk += 1
+        relax = float(w @ r.x)
+        best = min(float(s @ Wm @ s) for s in (np.array([1 if (b >> t) & 1 else -1 for t in range(l)]) for b in range(64)))
+        assert relax <= best + 1e-3
