@@ -12,6 +12,9 @@
  *     The reference backends assert on library status (f32cuda.rs:38 etc.): a binding should
  *     `assert_eq!(rc, 0)`;
  *   - zero-length vectors and zero-sized matrices are legal everywhere (matop.rs:83-85);
+ *   - one context per process (one process per GPU); like the reference's backends (thread_local state, !Send types)
+ *     the API is meant to be driven from one host thread -- uploads and the shared scratch are mutex-protected, and
+ *     separate thip_solver objects may be driven from separate threads (they own their scratch);
  *   - citations are relative to /root/reference/solver_rust_conic/.
  */
 #ifndef TOTSU_F32HIP_H

@@ -42,6 +42,12 @@ class DeviceBuffer:
             lib.thip_free(self.ptr)
             self.ptr = None
 
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
 
 class FusedResult:
     def __init__(self, st):
@@ -158,14 +164,20 @@ class FusedSolver:
             raise SolverError(r.state)
         return self.solution()
 
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
     def destroy(self):
-        if self.h is not None:
+        if getattr(self, "h", None) is not None:
             lib.thip_solver_destroy(self.h)
             self.h = None
-        for d in self._owned:
+        for d in getattr(self, "_owned", []):
             d.free()
         self._owned = []
-        if self._csr:
+        if getattr(self, "_csr", None):
             for c in self._csr:
                 c.free()
             self._csr = None
