@@ -511,3 +511,23 @@ def test_partitioning_sdp_gpu_vs_oracle(T, grid):
         diag = [x[c * (c + 1) // 2 + c] for c in range(l)]
         assert np.allclose(diag, 1.0, atol=5e-3)
     sdp.drop()
+
+
+def test_abi_rejects_bad_arguments(T):
+    # the boundary fails loudly: bad cone segments, bad schedule, PSD segment that is not triangular, short work
+    from totsu_amd._lib import ThipError, E_INVALID, E_WORK, lib
+    a = np.zeros(6, np.float32)
+    with pytest.raises(ThipError) as e:
+        T.FusedSolver(2, 3, a, np.zeros(3, np.float32), np.zeros(2, np.float32), [1], [2])        # segments cover 2 of 3 rows
+    assert e.value.code == E_INVALID
+    with pytest.raises(ThipError) as e:
+        T.FusedSolver(2, 4, np.zeros(8, np.float32), np.zeros(4, np.float32), np.zeros(2, np.float32), [4], [4])   # 4 is not k(k+1)/2
+    assert e.value.code == E_INVALID
+    with pytest.raises(KeyError):
+        T.FusedSolver(2, 3, a, np.zeros(3, np.float32), np.zeros(2, np.float32), [1], [3], schedule="nope")
+    x = T.DeviceBuffer(6)
+    w = T.DeviceBuffer(4)
+    with pytest.raises(ThipError) as e:
+        lib.thip_proj_psd(6, x.ptr, 1e-12, w.ptr, 4)
+    assert e.value.code == E_WORK
+    x.free(); w.free()

@@ -296,3 +296,20 @@ def test_debug_log_reproduces_the_golden_log_lines(caplog):
         assert int(it) == rec["iter"]
         for got, want in zip((a, b, c), rec["text"]):
             assert abs(float(got) - float(want)) <= 0.006 * max(abs(float(want)), 1e-300)
+
+
+def test_invalid_op_and_work_shortage():
+    # solver.rs:292-300: size mismatch -> InvalidOp, short work slice -> WorkShortage (checked before anything runs)
+    op_c = MatOp(La, MatType.General(2, 1), np.array([-1.0, 0.0]))
+    op_a = MatOp(La, MatType.General(3, 2), np.array([4.0, -1.0, -1.0, -1.0, 4.0, -1.0]))
+    op_b = MatOp(La, MatType.General(3, 1), np.array([6.0, 6.0, 1.0]))
+    bad_c = MatOp(La, MatType.General(3, 1), np.zeros(3))
+    bad_b = MatOp(La, MatType.General(2, 1), np.zeros(2))
+    for oc, ob in ((bad_c, op_b), (op_c, bad_b)):
+        with pytest.raises(SolverError) as e:
+            Solver(La).solve((oc, op_a, ob, ConeRPos(La), np.zeros(48)))
+        assert e.value.kind == SolverError.InvalidOp
+    with pytest.raises(SolverError) as e:
+        Solver(La).solve((op_c, op_a, op_b, ConeRPos(La), np.zeros(47)))
+    assert e.value.kind == SolverError.WorkShortage
+    assert O.lib().oc_query_worklen(3, 2) == Solver.query_worklen((3, 2)) == 48
