@@ -531,3 +531,27 @@ def test_abi_rejects_bad_arguments(T):
         lib.thip_proj_psd(6, x.ptr, 1e-12, w.ptr, 4)
     assert e.value.code == E_WORK
     x.free(); w.free()
+
+
+def test_gemv_bandwidth_floor_at_lp_size(T):
+    # regression guard, deliberately loose: at BASELINE.json's LP size (800 MB of A) the dual-GEMV kernel has measured
+    # 5.8-6.1 TB/s on MI355X; anything below 4 TB/s means a tiling / codegen regression (e.g. serialised loads)
+    import ctypes as C
+    from totsu_amd import synth
+    from totsu_amd._lib import lib
+    inst = synth.LpInstance(10_000, seed=0)
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried")
+    fs.run(10, poll_every=10)
+    lib.thip_prof_enable(1)
+    fs.run(50, poll_every=50)
+    nl, ms = C.c_int64(), C.c_double()
+    lib.thip_prof_read(C.byref(nl), C.byref(ms))
+    lib.thip_prof_enable(0)
+    passes, nbytes = fs.passes()
+    assert nl.value == 50 * passes
+    gbps = nbytes / (ms.value / nl.value * 1e-3) / 1e9
+    assert gbps >= 4000.0, gbps
+    fs.destroy()
+    inst.free()
