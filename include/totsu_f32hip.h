@@ -77,6 +77,14 @@ int thip_transform_ge(int transpose, size_t n_row, size_t n_col, float alpha, co
                       const float *x, float beta, float *y);
 /* y = alpha * S x + beta * y, S symmetric, packed upper by columns.  linalg_ex.rs:37 (cublasSspmv, f32cuda.rs:174-187) */
 int thip_transform_sp(size_t n, float alpha, const float *mat, const float *x, float beta, float *y);
+/* Reduced-precision STORAGE of a dense operator (not part of the reference's trait surface):
+ * bf16 elements (round to nearest even), f32 accumulation.  mat16 is column-major with leading dimension ld16 >= n_row
+ * (a multiple of 8 and a 16-byte aligned base give the 16-byte-load kernel); rows n_row..ld16 are written as zeros.
+ * thip_transform_ge_bf16 has the semantics of thip_transform_ge on the rounded matrix. */
+enum { THIP_A_F32 = 0, THIP_A_BF16 = 1 };
+int thip_to_bf16(size_t n_row, size_t n_col, const float *mat, uint16_t *mat16, size_t ld16);
+int thip_transform_ge_bf16(int transpose, size_t n_row, size_t n_col, float alpha, const uint16_t *mat16, size_t ld16,
+                           const float *x, float beta, float *y);
 /* linalg_ex.rs:44 (f32cuda.rs:243-251) */
 size_t thip_map_eig_worklen(size_t n);
 /* linalg_ex.rs:64-65 with the two closures that exist in the reference, evaluated on the device:
@@ -195,11 +203,24 @@ int thip_solver_set_csr(thip_solver *s, size_t nnz,
                         const int64_t *dev_rowptr, const int32_t *dev_colidx, const float *dev_vals,
                         const int64_t *dev_t_rowptr, const int32_t *dev_t_colidx, const float *dev_t_vals);
 int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
+/* Storage of the dense A the iteration streams: THIP_A_F32 (default: prob->mat_a as given) or THIP_A_BF16 (a
+ * library-owned bf16 copy, made on the first request: half the bytes per pass, the problem solved is the one with
+ * the ROUNDED matrix).  Before thip_solver_init the preconditioners are computed from the stored form; between
+ * thip_solver_run calls it switches the operator of the running iteration (e.g. bf16 passes first, f32 passes to
+ * finish on the exact matrix) -- the iteration is a fixed-point method, so the iterate carries over.
+ * prob->mat_a must stay valid while THIP_A_F32 may still be selected. */
+int thip_solver_set_a_storage(thip_solver *s, int a_kind);
 int thip_solver_init(thip_solver *s);                                 /* calc_norms + init_vecs + calc_precond, solver.rs:460-524 */
 /* enqueue up to max_steps iterations (the device stops by itself on termination), poll every
  * `poll_every` iterations; returns when terminated or after max_steps.  SYNC. */
 int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_status *host_status);
 int thip_solver_status(thip_solver *s, thip_status *host_status);     /* SYNC */
+/* Continue a solve that ended THIP_ST_OK / THIP_ST_EXCESS_ITER (criteria kind 0): undoes the final 1/tau scaling of
+ * solver.rs:397-400 and clears the termination, so that thip_solver_run goes on from the same iterate -- after
+ * thip_solver_set_a_storage (finish on the exact matrix) or thip_solver_set_param (a tighter eps_acc, a larger
+ * max_iter).  A no-op on a running solve. */
+int thip_solver_resume(thip_solver *s);
+int thip_solver_set_param(thip_solver *s, const thip_param *par);
 /* solver.rs:317-320: x = work[0..n], y = work[n..n+m] */
 int thip_solver_solution(thip_solver *s, float *host_x, float *host_y);
 /* raw iterate (x: n+2m+1, y: n+m+1, reference layout solver.rs:349-355), for parity tests */

@@ -70,6 +70,8 @@ PROTOTYPES = {
     "thip_transform_di": (_i, [_sz, _f, _vp, _vp, _f, _vp]),
     "thip_transform_ge": (_i, [_i, _sz, _sz, _f, _vp, _vp, _f, _vp]),
     "thip_transform_sp": (_i, [_sz, _f, _vp, _vp, _f, _vp]),
+    "thip_to_bf16": (_i, [_sz, _sz, _vp, _vp, _sz]),
+    "thip_transform_ge_bf16": (_i, [_i, _sz, _sz, _f, _vp, _sz, _vp, _f, _vp]),
     "thip_spmv_csr": (_i, [_sz, _sz, _sz, _vp, _vp, _vp, _f, _vp, _f, _vp, _i]),
     "thip_map_eig_worklen": (_sz, [_sz]),
     "thip_map_eig": (_i, [_sz, _vp, _i, _f, _f, _vp, _sz, _i]),
@@ -97,6 +99,9 @@ PROTOTYPES = {
     "thip_solver_create": (_i, [C.POINTER(Problem), C.POINTER(Param), _i, C.POINTER(_vp)]),
     "thip_solver_set_csr": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thip_solver_set_allreduce": (_i, [_vp, ALLREDUCE_FN, _vp]),
+    "thip_solver_set_a_storage": (_i, [_vp, _i]),
+    "thip_solver_resume": (_i, [_vp]),
+    "thip_solver_set_param": (_i, [_vp, _vp]),
     "thip_solver_init": (_i, [_vp]),
     "thip_solver_run": (_i, [_vp, C.c_int64, C.c_int64, C.POINTER(Status)]),
     "thip_solver_status": (_i, [_vp, C.POINTER(Status)]),

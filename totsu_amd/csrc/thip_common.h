@@ -123,10 +123,12 @@ static inline unsigned grid_for(size_t n, unsigned block, unsigned max_blocks)
 //   outN[r] = alphaN * (A xn)[r] + betaN * outN[r]      (betaN == 0: outN not read)
 //   outT[c] = alphaT * (A^T xt)[c] + betaT * outT[c]
 // abs_mode: use |A| (for absadd_*), x vectors ignored (taken as all-ones).
-int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
+// a_kind: THIP_A_F32 (mat = const float *) or THIP_A_BF16 (mat = const uint16_t *, lda in elements)
+int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
               const float *xn, float alphaN, float betaN, float *outN,
               const float *xt, float alphaT, float betaT, float *outT,
-              bool abs_mode, const int *stop_flag);
+              bool abs_mode, const int *stop_flag, int a_kind = 0);
+int to_bf16(hipStream_t st, size_t n_row, size_t n_col, const float *src, uint16_t *dst, size_t ld16);
 // raw form: leaves per-chunk / per-tile partial sums in scratch and reports their geometry so that a
 // consumer kernel can fold the second reduction stage into its own pass
 struct GemvPartials {
@@ -135,10 +137,10 @@ struct GemvPartials {
 };
 struct GemvHint { int nj; int target_blocks; };        // tiling override: row groups per lane, grid size
 const GemvHint *gemv_candidates(int *count);           // plans worth timing on a given matrix
-int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
+int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
                        const float *xn, const float *xt, bool do_n, bool do_t, bool abs_mode,
                        float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
-                       const GemvHint *hint = nullptr);
+                       const GemvHint *hint = nullptr, int a_kind = 0);
 size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col);
 // y[i] = alpha * sum_k part[k*stride + i] + beta * y[i]
 int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float alpha, float beta,

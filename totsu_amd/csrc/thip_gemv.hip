@@ -76,15 +76,106 @@ template <> struct Log2<8> { static constexpr int v = 3; };
 // FULL: every row of the block's tile is < m (uniform per block): loads are unconditional, so the KU * NJ loads of a
 // step are issued back to back (with the per-lane row guard each load sits in its own branch followed by a
 // vmcnt(0) wait, i.e. one load in flight per wave -- seen in the ISA, worth +1..+9 % depending on the shape)
-template <int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS, bool NT, bool FULL>
-__device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, int m, int r_first, int c, int cc,
+// element types of the stored matrix: float, or bf16 as raw 16-bit patterns (the upper half of the f32 encoding)
+typedef unsigned short bf16raw;
+__device__ __forceinline__ float elt_f32(float v) { return v; }
+__device__ __forceinline__ float elt_f32(bf16raw v) { return __uint_as_float((unsigned)v << 16); }
+
+template <typename E, int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS, bool NT, bool FULL>
+__device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m, int r_first, int c, int cc,
                                      const float *__restrict__ xn, const float (&xtv)[NJ][VW],
                                      float (&accN)[NJ][VW], float *ldsT_wave, int lane)
 {
+    if constexpr (VW == 8) {
+        // bf16 storage: 8 rows per 16-byte load.  The raw dwords stay in registers and are widened (one shift or
+        // mask per element) right where they are consumed, so the live set is the loads themselves
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t raw[K][NJ];
+        float xsv[K];
+#pragma unroll
+        for (int u = 0; u < K; ++u) xsv[u] = (ABS || !DO_N) ? 1.0f : xn[c + u];
+        if constexpr (FULL) {
+            // All K * NJ loads are issued back to back and each column is consumed as soon as ITS loads have landed
+            // (explicit vmcnt waits).  Left to itself the compiler either keeps every widened value alive (115+ VGPRs)
+            // or, once the updates are pinned per column, splits the loads into two groups of four.
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                const E *col = A + (size_t)(c + u) * lda + r_first;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const E *src = col + j * (BLK * VW);
+                    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(raw[u][j]) : "v"(src));
+                    else              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[u][j]) : "v"(src));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < K; ++u) {
+                const E *col = A + (size_t)(c + u) * lda;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int r = r_first + j * (BLK * VW);
+                    if (r + 8 <= m) {
+                        raw[u][j] = *reinterpret_cast<const u32x4_t *>(col + r);
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const unsigned lo = (r + 2 * d < m) ? (unsigned)col[r + 2 * d] : 0u;
+                            const unsigned hi = (r + 2 * d + 1 < m) ? (unsigned)col[r + 2 * d + 1] : 0u;
+                            raw[u][j][d] = lo | (hi << 16);
+                        }
+                    }
+                }
+            }
+        }
+        float p[K];
+        constexpr unsigned HI = ABS ? 0x7fff0000u : 0xffff0000u;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const float xs = xsv[u];
+            float s0 = 0.0f, s1 = 0.0f;
+            if constexpr (FULL) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[u][j]) : "n"((K - 1 - u) * NJ));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned q = raw[u][j][d];
+                    const float lo = __uint_as_float((q << 16) & HI), hi = __uint_as_float(q & HI);
+                    if constexpr (DO_N) {
+                        accN[j][2 * d] = fmaf(lo, xs, accN[j][2 * d]);
+                        accN[j][2 * d + 1] = fmaf(hi, xs, accN[j][2 * d + 1]);
+                    }
+                    if constexpr (DO_T) {
+                        s0 = fmaf(lo, xtv[j][2 * d], s0);
+                        s1 = fmaf(hi, xtv[j][2 * d + 1], s1);
+                    }
+                }
+            p[u] = s0 + s1;
+            // pin column u's updates here: the scheduler otherwise defers every N update behind the T phase and
+            // keeps 8 * K * NJ widened values alive (115+ VGPRs, half the waves per SIMD)
+            if constexpr (DO_N) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(accN[j][k]));
+            }
+            asm volatile("" : "+v"(p[u]));
+        }
+        if constexpr (DO_T) {
+            const float r = multi_reduce<K>(p, lane);
+            constexpr int SH = 6 - Log2<K>::v;
+            if ((lane & ((64 >> Log2<K>::v) - 1)) == 0) ldsT_wave[cc + (lane >> SH)] = r;
+        }
+        return;
+    }
     float av[K][NJ][VW];
 #pragma unroll
     for (int u = 0; u < K; ++u) {
-        const float *col = A + (size_t)(c + u) * lda;
+        const E *col = A + (size_t)(c + u) * lda;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int r = r_first + j * (BLK * VW);
@@ -96,10 +187,10 @@ __device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, in
                     av[u][j][0] = q[0]; av[u][j][1] = q[1]; av[u][j][2] = q[2]; av[u][j][3] = q[3];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) av[u][j][k] = (r + k < m) ? col[r + k] : 0.0f;
+                    for (int k = 0; k < 4; ++k) av[u][j][k] = (r + k < m) ? elt_f32(col[r + k]) : 0.0f;
                 }
             } else {
-                av[u][j][0] = (FULL || r < m) ? col[r] : 0.0f;
+                av[u][j][0] = (FULL || r < m) ? elt_f32(col[r]) : 0.0f;
             }
         }
     }
@@ -138,8 +229,8 @@ __device__ __forceinline__ void step(const float *__restrict__ A, size_t lda, in
     }
 }
 
-template <int VW, int NJ, int KU, bool DO_N, bool DO_T, bool ABS, bool NT>
-__global__ __launch_bounds__(BLK) void dual_gemv_k(const float *__restrict__ A, size_t lda, int m, int n,
+template <typename E, int VW, int NJ, int KU, bool DO_N, bool DO_T, bool ABS, bool NT>
+__global__ __launch_bounds__(BLK) void dual_gemv_k(const E *__restrict__ A, size_t lda, int m, int n,
                                                    const float *__restrict__ xn, const float *__restrict__ xt,
                                                    float *__restrict__ partN, size_t strideN,
                                                    float *__restrict__ partT, size_t strideT,
@@ -166,18 +257,27 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const float *__restrict__ A, 
             xtv[j][k] = (DO_T && r < m) ? (ABS ? 1.0f : xt[r]) : 0.0f;
         }
 
+    if constexpr (VW == 8 && DO_T) {
+        // the bf16 step issues its loads from inline asm with its own vmcnt waits: make the compiler wait for the
+        // x_T loads HERE (a use), or it places a vmcnt(0) for them at their first use inside the column loop
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int k = 0; k < VW; ++k) asm volatile("" : "+v"(xtv[j][k]));
+    }
+
     float *ldsT_wave = ldsT + wave * (DO_T ? MAXCW : 1);
     int c = c0;
     if ((tile + 1) * TILE <= m) {
         for (; c + KU <= c1; c += KU)
-            step<VW, NJ, KU, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
         for (; c < c1; ++c)
-            step<VW, NJ, 1, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
     } else {
         for (; c + KU <= c1; c += KU)
-            step<VW, NJ, KU, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
         for (; c < c1; ++c)
-            step<VW, NJ, 1, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
     }
 
     if constexpr (DO_N) {
@@ -185,12 +285,15 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const float *__restrict__ A, 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int r = r_first + j * (BLK * VW);
-            if constexpr (VW == 4) {
-                if (r + 4 <= m) {
-                    *reinterpret_cast<float4 *>(dst + r) = make_float4(accN[j][0], accN[j][1], accN[j][2], accN[j][3]);
+            if constexpr (VW >= 4) {
+                if (r + VW <= m) {
+#pragma unroll
+                    for (int q = 0; q < VW; q += 4)
+                        *reinterpret_cast<float4 *>(dst + r + q) =
+                            make_float4(accN[j][q], accN[j][q + 1], accN[j][q + 2], accN[j][q + 3]);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (r + k < m) dst[r + k] = accN[j][k];
+                    for (int k = 0; k < VW; ++k) if (r + k < m) dst[r + k] = accN[j][k];
                 }
             } else {
                 if (r < m) dst[r] = accN[j][0];
@@ -263,13 +366,15 @@ static int env_int(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
-Plan make_plan(size_t n_row, size_t n_col, bool vec_ok, const GemvHint *hint = nullptr)
+// vw: rows per lane and load -- 4 (f32, 16-byte loads), 8 (bf16, 16-byte loads) or 1 (unaligned fallback)
+Plan make_plan(size_t n_row, size_t n_col, int vw, const GemvHint *hint = nullptr)
 {
+    const bool vec_ok = vw > 1;
     static const int env_nj = env_int("THIP_GEMV_NJ", 0);
     static const int env_blocks = env_int("THIP_GEMV_BLOCKS", 0);
     static const int env_nt = env_int("THIP_GEMV_NT", -1);
     Plan p;
-    p.vw = vec_ok ? 4 : 1;
+    p.vw = vw;
     if (vec_ok) {
         // measured on MI355X (gpurun_out/sweep_*.txt): 1 float4 row group per lane, 8 columns in
         // flight, is as fast as taller tiles once the grid is fine enough, and keeps partial sums small
@@ -290,7 +395,7 @@ Plan make_plan(size_t n_row, size_t n_col, bool vec_ok, const GemvHint *hint = n
     // 8 to 32 workgroups per CU (0.2 MB of A each at the low end): a fine grid shortens the ramp and the tail of
     // the last round of workgroups (MI355X sweep: 8192 beat 2048 by 2-4 % at 20 GB, 4096 beat 1024 by 30 % at
     // 0.8 GB); the partial-sum traffic (chunks x m + tiles x n floats) stays at 1-2 % of A
-    int target_blocks = (int)((double)n_row * (double)n_col * 4.0 / 2.0e5);
+    int target_blocks = (int)((double)n_row * (double)n_col * (vw == 8 ? 2.0 : 4.0) / 2.0e5);
     if (target_blocks < 2048) target_blocks = 2048;
     if (target_blocks > 8192) target_blocks = 8192;
     if (env_blocks > 0) target_blocks = env_blocks;
@@ -309,29 +414,61 @@ Plan make_plan(size_t n_row, size_t n_col, bool vec_ok, const GemvHint *hint = n
     return p;
 }
 
-template <bool DO_N, bool DO_T, bool ABS>
-void launch_cfg(const Plan &p, hipStream_t st, const float *A, size_t lda, int m, int n, const float *xn,
+template <typename E, bool DO_N, bool DO_T, bool ABS>
+void launch_cfg(const Plan &p, hipStream_t st, const E *A, size_t lda, int m, int n, const float *xn,
                 const float *xt, float *partN, float *partT, const int *stop)
 {
     dim3 g(p.tiles, p.chunks), b(BLK);
+    constexpr int VV = sizeof(E) == 2 ? 8 : 4;      // rows per 16-byte load
 #define THIP_GEMV_LAUNCH(VW, NJ, KU)                                                                          \
     do {                                                                                                      \
         if (p.nt)                                                                                             \
-            hipLaunchKernelGGL((dual_gemv_k<VW, NJ, KU, DO_N, DO_T, ABS, true>), g, b, 0, st, A, lda, m, n, xn, xt, \
+            hipLaunchKernelGGL((dual_gemv_k<E, VW, NJ, KU, DO_N, DO_T, ABS, true>), g, b, 0, st, A, lda, m, n, xn, xt, \
                                partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop);                   \
         else                                                                                                  \
-            hipLaunchKernelGGL((dual_gemv_k<VW, NJ, KU, DO_N, DO_T, ABS, false>), g, b, 0, st, A, lda, m, n, xn, xt, \
+            hipLaunchKernelGGL((dual_gemv_k<E, VW, NJ, KU, DO_N, DO_T, ABS, false>), g, b, 0, st, A, lda, m, n, xn, xt, \
                                partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop);                   \
     } while (0)
-    if (p.vw == 4) {
-        if (p.nj == 4) THIP_GEMV_LAUNCH(4, 4, 2);
-        else if (p.nj == 2) THIP_GEMV_LAUNCH(4, 2, 4);
-        else THIP_GEMV_LAUNCH(4, 1, 8);
+    if (p.vw == VV) {
+        if (p.nj == 4) THIP_GEMV_LAUNCH(VV, 4, 2);
+        else if (p.nj == 2) THIP_GEMV_LAUNCH(VV, 2, 4);
+        else THIP_GEMV_LAUNCH(VV, 1, 8);
     } else {
         if (p.nj == 4) THIP_GEMV_LAUNCH(1, 4, 4);
         else THIP_GEMV_LAUNCH(1, 1, 8);
     }
 #undef THIP_GEMV_LAUNCH
+}
+
+template <typename E>
+void launch_any(const Plan &p, hipStream_t st, const E *mat, size_t lda, int m, int n, const float *xn, const float *xt,
+                bool do_n, bool do_t, bool abs_mode, float *partN, float *partT, const int *stop_flag)
+{
+    if (abs_mode) {
+        if (do_n && do_t) launch_cfg<E, true, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        else if (do_n)    launch_cfg<E, true, false, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        else              launch_cfg<E, false, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+    } else {
+        if (do_n && do_t) launch_cfg<E, true, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        else if (do_n)    launch_cfg<E, true, false, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        else              launch_cfg<E, false, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+    }
+}
+
+// f32 (ld = n_row) -> bf16 round-to-nearest-even (ld16 >= n_row, the padding rows are written as zeros)
+__global__ void to_bf16_k(size_t n_row, size_t n_col, const float *__restrict__ src, bf16raw *__restrict__ dst, size_t ld16)
+{
+    const size_t total = ld16 * n_col;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < total; i += (size_t)gridDim.x * BLK) {
+        const size_t c = i / ld16, r = i - c * ld16;
+        unsigned out = 0;
+        if (r < n_row) {
+            const unsigned b = __float_as_uint(src[c * n_row + r]);
+            if ((b & 0x7f800000u) == 0x7f800000u) out = (b >> 16) | ((b & 0xffffu) ? 0x40u : 0u);   // inf / nan
+            else out = (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+        }
+        dst[i] = (bf16raw)out;
+    }
 }
 
 }  // namespace
@@ -342,7 +479,7 @@ const GemvHint *gemv_candidates(int *count)
 {
     // measured on MI355X: fine grids of 1-row-group tiles win at 100k x 50k and at the 0.8 GB LP,
     // tall tiles with ~1k workgroups win for short-and-wide row shards
-    static const GemvHint c[] = { {1, 8192}, {1, 4096}, {2, 2048}, {4, 4096}, {4, 2048}, {4, 1024}, {4, 768} };
+    static const GemvHint c[] = { {1, 8192}, {1, 4096}, {2, 8192}, {2, 2048}, {4, 8192}, {4, 4096}, {4, 2048}, {4, 1024}, {4, 768} };
     *count = (int)(sizeof(c) / sizeof(c[0]));
     return c;
 }
@@ -352,42 +489,37 @@ size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col)
     size_t best = 0;
     int nc = 0;
     const GemvHint *c = gemv_candidates(&nc);
+    static const int vws[3] = { 4, 1, 8 };
     for (int i = -1; i < nc; ++i)
-        for (int v = 0; v < 2; ++v) {
-            const Plan p = make_plan(n_row, n_col, v == 0, i < 0 ? nullptr : &c[i]);
+        for (int v = 0; v < 3; ++v) {
+            const Plan p = make_plan(n_row, n_col, vws[v], i < 0 ? nullptr : &c[i]);
             const size_t f = (size_t)p.chunks * p.strideN + (size_t)p.tiles * p.strideT;
             if (f > best) best = f;
         }
     return best + 64;
 }
 
-int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
+int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
                        const float *xn, const float *xt, bool do_n, bool do_t, bool abs_mode,
                        float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
-                       const GemvHint *hint)
+                       const GemvHint *hint, int a_kind)
 {
     if (n_row == 0 || n_col == 0 || (!do_n && !do_t)) {
         out->partN = out->partT = nullptr; out->nN = out->nT = 0; out->strideN = out->strideT = 0;
         return 0;
     }
     if (n_row > 0x7fffffffull || n_col > 0x7fffffffull) return fail(THIP_E_INVALID, "matrix dimension > 2^31", __FILE__, __LINE__);
-    const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (lda % 4 == 0);
-    const Plan p = make_plan(n_row, n_col, vec_ok, hint);
+    const bool bf16 = a_kind == THIP_A_BF16;
+    const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (lda % (bf16 ? 8 : 4) == 0);
+    const Plan p = make_plan(n_row, n_col, vec_ok ? (bf16 ? 8 : 4) : 1, hint);
     const size_t needN = do_n ? (size_t)p.chunks * p.strideN : 0;
     const size_t needT = do_t ? (size_t)p.tiles * p.strideT : 0;
     if (needN + needT > scratch_floats) return fail(THIP_E_WORK, "gemv scratch too small", __FILE__, __LINE__);
     float *partN = scratch_base;
     float *partT = scratch_base + needN;
     const int m = (int)n_row, n = (int)n_col;
-    if (abs_mode) {
-        if (do_n && do_t) launch_cfg<true, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-        else if (do_n)    launch_cfg<true, false, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-        else              launch_cfg<false, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-    } else {
-        if (do_n && do_t) launch_cfg<true, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-        else if (do_n)    launch_cfg<true, false, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-        else              launch_cfg<false, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-    }
+    if (bf16) launch_any(p, st, (const bf16raw *)mat, lda, m, n, xn, xt, do_n, do_t, abs_mode, partN, partT, stop_flag);
+    else      launch_any(p, st, (const float *)mat, lda, m, n, xn, xt, do_n, do_t, abs_mode, partN, partT, stop_flag);
     THIP_LAUNCH_CHECK();
     out->partN = do_n ? partN : nullptr; out->nN = do_n ? p.chunks : 0; out->strideN = p.strideN;
     out->partT = do_t ? partT : nullptr; out->nT = do_t ? p.tiles : 0;  out->strideT = p.strideT;
@@ -403,17 +535,26 @@ int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_
     return 0;
 }
 
-int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const float *mat, size_t lda,
+int to_bf16(hipStream_t st, size_t n_row, size_t n_col, const float *src, uint16_t *dst, size_t ld16)
+{
+    if (ld16 < n_row) return fail(THIP_E_INVALID, "ld16 < n_row", __FILE__, __LINE__);
+    if (ld16 * n_col == 0) return 0;
+    hipLaunchKernelGGL(to_bf16_k, dim3(grid_for(ld16 * n_col, BLK, 16384)), dim3(BLK), 0, st, n_row, n_col, src, dst, ld16);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
               const float *xn, float alphaN, float betaN, float *outN,
               const float *xt, float alphaT, float betaT, float *outT,
-              bool abs_mode, const int *stop_flag)
+              bool abs_mode, const int *stop_flag, int a_kind)
 {
     const bool do_n = outN != nullptr, do_t = outT != nullptr;
     float *scr = nullptr;
     const size_t need = dual_gemv_scratch_floats(n_row, n_col);
     THIP_RC(scratch(need, &scr));
     GemvPartials gp;
-    THIP_RC(dual_gemv_partials(st, n_row, n_col, mat, lda, xn, xt, do_n, do_t, abs_mode, scr, need, &gp, stop_flag, nullptr));
+    THIP_RC(dual_gemv_partials(st, n_row, n_col, mat, lda, xn, xt, do_n, do_t, abs_mode, scr, need, &gp, stop_flag, nullptr, a_kind));
     if (do_n && n_row)
         hipLaunchKernelGGL(finalize_k, dim3(grid_for(n_row, BLK, 2048)), dim3(BLK), 0, st, n_row, gp.partN, gp.nN,
                            gp.strideN, alphaN, betaN, outN, stop_flag);
@@ -439,6 +580,25 @@ int thip_transform_ge(int transpose, size_t n_row, size_t n_col, float alpha, co
     if (transpose)
         return dual_gemv(ctx().stream, n_row, n_col, mat, n_row, nullptr, 0.f, 0.f, nullptr, x, alpha, beta, y, false, nullptr);
     return dual_gemv(ctx().stream, n_row, n_col, mat, n_row, x, alpha, beta, y, nullptr, 0.f, 0.f, nullptr, false, nullptr);
+}
+
+int thip_to_bf16(size_t n_row, size_t n_col, const float *mat, uint16_t *mat16, size_t ld16)
+{
+    THIP_NEED_INIT();
+    return to_bf16(ctx().stream, n_row, n_col, mat, mat16, ld16);
+}
+
+int thip_transform_ge_bf16(int transpose, size_t n_row, size_t n_col, float alpha, const uint16_t *mat16, size_t ld16,
+                           const float *x, float beta, float *y)
+{
+    THIP_NEED_INIT();
+    const size_t ylen = transpose ? n_col : n_row;
+    if (ylen == 0) return 0;
+    if (n_row == 0 || n_col == 0) return thip_scale(ylen, beta, y);
+    if (ld16 < n_row) return fail(THIP_E_INVALID, "ld16 < n_row", __FILE__, __LINE__);
+    if (transpose)
+        return dual_gemv(ctx().stream, n_row, n_col, mat16, ld16, nullptr, 0.f, 0.f, nullptr, x, alpha, beta, y, false, nullptr, THIP_A_BF16);
+    return dual_gemv(ctx().stream, n_row, n_col, mat16, ld16, x, alpha, beta, y, nullptr, 0.f, 0.f, nullptr, false, nullptr, THIP_A_BF16);
 }
 
 int thip_absadd_cols(size_t n_row, size_t n_col, const float *mat, float *tau)

@@ -338,6 +338,21 @@ __global__ void final_scale_k(int n, int m, float eps_zero, float *__restrict__ 
     }
 }
 
+// thip_solver_resume: undo final_scale_k (x_x, x_y back to the homogeneous iterate) and clear the termination
+__global__ void resume_k(int n, int m, float *__restrict__ xx, float *__restrict__ xy, const DevStatus *st)
+{
+    const float tau = st->tau;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) xx[i] = tau * xx[i];
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) xy[i] = tau * xy[i];
+}
+__global__ void resume_flags_k(DevStatus *st)
+{
+    st->state = THIP_ST_RUNNING;
+    st->iter = st->iter + 1;
+    st->stop = 0;
+}
+
 // sum of `np` block partials of `nq` quantities (part[q*np + k]) -> out[q]; one block (init only)
 __global__ void sum_partials_k(int nq, int np, const float *__restrict__ part, float *__restrict__ out,
                                const int *__restrict__ stop)
@@ -452,6 +467,12 @@ struct thip_solver {
     float *dotc = nullptr;                           // local scalars: [0] c.u, [1] c.rx_x, [2..3] dd,cx
     float *gemv_scr = nullptr; size_t gemv_scr_n = 0;
     GemvHint hint{0, 0}; bool tuned = false; float tuned_ms = 0.0f;
+    // storage of A streamed by the iteration: the caller's f32 matrix, or an owned bf16 copy (ld16 = m rounded to 8)
+    int a_kind = THIP_A_F32; uint16_t *A16 = nullptr; size_t ld16 = 0;
+    GemvHint hint16{0, 0}; bool tuned16 = false; float tuned16_ms = 0.0f;
+    const void *amat() const { return a_kind == THIP_A_BF16 ? (const void *)A16 : (const void *)A; }
+    size_t alda() const { return a_kind == THIP_A_BF16 ? ld16 : m; }
+    const GemvHint *ahint() const { return a_kind == THIP_A_BF16 ? (tuned16 ? &hint16 : nullptr) : (tuned ? &hint : nullptr); }
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
     int *done_count = nullptr;
@@ -520,16 +541,16 @@ int products(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp,
         GemvPartials a, b;
         const size_t half = s->gemv_scr_n / 2;
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, nullptr, xt, false, true, false, s->gemv_scr, half, &a, stop, s->tuned ? &s->hint : nullptr));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), nullptr, xt, false, true, false, s->gemv_scr, half, &a, stop, s->ahint(), s->a_kind));
         prof_end(st);
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, nullptr, true, false, false, s->gemv_scr + half, half, &b, stop, s->tuned ? &s->hint : nullptr));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, nullptr, true, false, false, s->gemv_scr + half, half, &b, stop, s->ahint(), s->a_kind));
         prof_end(st);
         gp->partT = a.partT; gp->nT = a.nT; gp->strideT = a.strideT;
         gp->partN = b.partN; gp->nN = b.nN; gp->strideN = b.strideN;
     } else {
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, gp, stop, s->tuned ? &s->hint : nullptr));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, gp, stop, s->ahint(), s->a_kind));
         prof_end(st);
     }
     return 0;
@@ -619,6 +640,8 @@ int autotune_gemv(thip_solver *s)
     const char *env = getenv("THIP_GEMV_AUTOTUNE");
     if ((env && atoi(env) == 0) || getenv("THIP_GEMV_NJ") || getenv("THIP_GEMV_BLOCKS")) return 0;
     if (s->sparse || s->m * s->n < (size_t)1 << 22) return 0;   // sparse, or tiny: nothing to tune
+    const bool b16 = s->a_kind == THIP_A_BF16;
+    if (b16 ? s->tuned16 : s->tuned) return 0;
     hipStream_t st = ctx().stream;
     hipEvent_t e0, e1;
     THIP_TRY(hipEventCreate(&e0));
@@ -627,22 +650,27 @@ int autotune_gemv(thip_solver *s)
     const GemvHint *c = gemv_candidates(&nc);
     float best = 1e30f;
     GemvPartials gp;
+    GemvHint pick{0, 0};
+    for (int w = 0; w < 3; ++w)         // clocks and caches settle before anything is timed
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
+                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind));
+    // inputs: the iterate if the loop is already running (storage switch), else zeros -- timing does not depend on them
     for (int i = 0; i < nc; ++i) {
         float ms = 1e30f;
         for (int rep = 0; rep < 5; ++rep) {
             THIP_TRY(hipEventRecord(e0, st));
-            THIP_RC(dual_gemv_partials(st, s->m, s->n, s->A, s->m, s->u, s->v, true, true, false, s->gemv_scr, s->gemv_scr_n,
-                                       &gp, nullptr, &c[i]));
+            THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
+                                       s->gemv_scr_n, &gp, nullptr, &c[i], s->a_kind));
             THIP_TRY(hipEventRecord(e1, st));
             THIP_TRY(hipEventSynchronize(e1));
             float t = 0.0f;
             THIP_TRY(hipEventElapsedTime(&t, e0, e1));
             if (rep > 0 && t < ms) ms = t;
         }
-        if (ms < best) { best = ms; s->hint = c[i]; }
+        if (ms < best) { best = ms; pick = c[i]; }
     }
-    s->tuned = true;
-    s->tuned_ms = best;
+    if (b16) { s->hint16 = pick; s->tuned16 = true; s->tuned16_ms = best; }
+    else     { s->hint = pick; s->tuned = true; s->tuned_ms = best; }
     THIP_TRY(hipEventDestroy(e0));
     THIP_TRY(hipEventDestroy(e1));
     return 0;
@@ -809,7 +837,8 @@ int thip_solver_init(thip_solver *s)
     } else if (n && m) {
         // solver-owned scratch (several solvers may share the context, e.g. one per thread)
         GemvPartials gp;
-        THIP_RC(dual_gemv_partials(st, m, n, s->A, m, nullptr, nullptr, true, true, true, s->gemv_scr, s->gemv_scr_n, &gp, nullptr));
+        THIP_RC(dual_gemv_partials(st, m, n, s->amat(), s->alda(), nullptr, nullptr, true, true, true, s->gemv_scr,
+                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind));
         THIP_RC(finalize_partials(st, m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, rowabs, nullptr));
         THIP_RC(finalize_partials(st, n, gp.partT, gp.nT, gp.strideT, 1.0f, 0.0f, colabs, nullptr));
     }
@@ -902,21 +931,65 @@ int thip_solver_precond(thip_solver *s, float *host_dp_tau, float *host_dp_sigma
     return 0;
 }
 
+int thip_solver_set_a_storage(thip_solver *s, int a_kind)
+{
+    THIP_NEED_INIT();
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (a_kind != THIP_A_F32 && a_kind != THIP_A_BF16) return fail(THIP_E_INVALID, "bad storage kind", __FILE__, __LINE__);
+    if (s->sparse) return fail(THIP_E_INVALID, "storage kinds apply to a dense A", __FILE__, __LINE__);
+    if (a_kind == THIP_A_F32 && !s->A && s->m && s->n) return fail(THIP_E_INVALID, "no f32 matrix was given", __FILE__, __LINE__);
+    if (a_kind == THIP_A_BF16 && !s->A16 && s->m && s->n) {
+        if (!s->A) return fail(THIP_E_INVALID, "no f32 matrix to convert", __FILE__, __LINE__);
+        s->ld16 = (s->m + 7) / 8 * 8;
+        THIP_TRY(hipMalloc((void **)&s->A16, s->ld16 * s->n * sizeof(uint16_t)));
+        THIP_RC(to_bf16(ctx().stream, s->m, s->n, s->A, s->A16, s->ld16));
+    }
+    s->a_kind = a_kind;
+    if (s->inited) THIP_RC(autotune_gemv(s));      // a switch inside a running solve: tune the other kernel once
+    return 0;
+}
+
+int thip_solver_set_param(thip_solver *s, const thip_param *par)
+{
+    if (!s || !par) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    s->par = *par;
+    return 0;
+}
+
+int thip_solver_resume(thip_solver *s)
+{
+    THIP_NEED_INIT();
+    if (!s || !s->inited) return fail(THIP_E_INVALID, "solver not initialised", __FILE__, __LINE__);
+    THIP_RC(poll(s, nullptr));
+    const int state = s->hst->state;
+    if (state == THIP_ST_RUNNING) return 0;
+    if (!(s->hst->kind == 0 && (state == THIP_ST_OK || state == THIP_ST_EXCESS_ITER)))
+        return fail(THIP_E_INVALID, "only a solve that ended Converged / ExcessIter (tau > eps_zero) can be resumed",
+                    __FILE__, __LINE__);
+    hipStream_t st = ctx().stream;
+    const unsigned g = egrid(s->n > s->m ? s->n : s->m);
+    hipLaunchKernelGGL(resume_k, dim3(g), dim3(BLK), 0, st, (int)s->n, (int)s->m, s->xx, s->xy, s->dst);
+    hipLaunchKernelGGL(resume_flags_k, dim3(1), dim3(1), 0, st, s->dst);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_bytes_per_pass)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
     if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : 2);
     if (host_bytes_per_pass) *host_bytes_per_pass = s->sparse ? 2 * s->nnz * (sizeof(float) + sizeof(int32_t))
-                                                              : s->m * s->n * sizeof(float);
+                                                              : s->m * s->n * (s->a_kind == THIP_A_BF16 ? 2 : sizeof(float));
     return 0;
 }
 
 int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, float *host_ms)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
-    if (host_nj) *host_nj = s->tuned ? s->hint.nj : 0;
-    if (host_blocks) *host_blocks = s->tuned ? s->hint.target_blocks : 0;
-    if (host_ms) *host_ms = s->tuned_ms;
+    const GemvHint *h = s->ahint();
+    if (host_nj) *host_nj = h ? h->nj : 0;
+    if (host_blocks) *host_blocks = h ? h->target_blocks : 0;
+    if (host_ms) *host_ms = s->a_kind == THIP_A_BF16 ? s->tuned16_ms : s->tuned_ms;
     return 0;
 }
 
@@ -950,7 +1023,7 @@ int thip_solver_destroy(thip_solver *s)
     if (ctx().inited) hipStreamSynchronize(ctx().stream);
     hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
-    hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->done_count);
+    hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->done_count); hipFree(s->A16);
     if (s->hst) hipHostFree(s->hst);
     delete s;
     return 0;

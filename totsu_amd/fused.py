@@ -49,6 +49,9 @@ class DeviceBuffer:
             pass
 
 
+A_STORAGE = {"f32": 0, "bf16": 1}
+
+
 class FusedResult:
     def __init__(self, st):
         self.state = st.state
@@ -61,8 +64,10 @@ class FusedResult:
 
 class FusedSolver:
     def __init__(self, n, m, mat_a, vec_b, vec_c, seg_type, seg_len, param=None, schedule="fused",
-                 vec_b_rowabs=None, allreduce=None):
+                 vec_b_rowabs=None, allreduce=None, a_storage="f32"):
         """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded).
+        a_storage: "f32" (the matrix as given) or "bf16" (a rounded copy streamed at half the bytes; see
+        set_a_storage / include/totsu_f32hip.h).
         allreduce: None (single GPU), "rccl" (native communicator set up with comm_init), or a Python callable
         (ctx, dev_ptr, count, stream) -> 0."""
         _lib.ensure_init()
@@ -103,12 +108,29 @@ class FusedSolver:
         elif allreduce is not None:
             self._cb = _lib.ALLREDUCE_FN(allreduce)
             lib.thip_solver_set_allreduce(self.h, self._cb, None)
+        self.a_storage = "f32"
+        if a_storage != "f32":
+            self.set_a_storage(a_storage)
         lib.thip_solver_init(self.h)
 
+    def resume(self, param=None):
+        """continue a solve that ended Converged / ExcessIter, optionally with new parameters"""
+        if param is not None:
+            self.param = param
+            par = _lib.Param(-1 if param.max_iter is None else int(param.max_iter), param.eps_acc, param.eps_inf,
+                             param.eps_zero, int(param.log_period))
+            lib.thip_solver_set_param(self.h, C.byref(par))
+        lib.thip_solver_resume(self.h)
+
+    def set_a_storage(self, kind):
+        """Switch the stored form of the dense A ("f32" | "bf16"); allowed between run() calls."""
+        lib.thip_solver_set_a_storage(self.h, A_STORAGE[kind])
+        self.a_storage = kind
+
     @staticmethod
-    def from_dense(d, param=None, schedule="fused"):
+    def from_dense(d, param=None, schedule="fused", a_storage="f32"):
         return FusedSolver(d.n, d.m, d.mat_a, d.vec_b, d.vec_c, d.seg_type, d.seg_len, param, schedule,
-                           d.vec_b_rowabs)
+                           d.vec_b_rowabs, a_storage=a_storage)
 
     def _dev(self, a, n):
         if isinstance(a, DeviceBuffer):
