@@ -208,9 +208,10 @@ def test_iterates_socp(T, schedule):
     _check_iterates(T, socp.dense(), schedule, [0, 1, 9, 99], [2e-5, 2e-5, 1e-4, 2e-3])
 
 
+@pytest.mark.parametrize("k", [9, 24])     # 9: Jacobi engine; 24: matrix-core polar chain, x_y and x_s batched per launch
 @pytest.mark.parametrize("schedule", ["fused", "carried"])
-def test_iterates_sdp(T, schedule):
-    n, k = 6, 9
+def test_iterates_sdp(T, schedule, k):
+    n = 6
     c, syms = random_sdp(n, k, seed=3)
     sdp = T.ProbSDP(_mb(T, T.MatType.General(n, 1)).set_array(c.reshape(-1, 1)),
                     [_mb(T, T.MatType.SymPack(k)).set_array(s) for s in syms],
@@ -306,9 +307,10 @@ def test_synth_socp_converges_to_oracle_objective(T, schedule):
     inst.free()
 
 
-def test_synth_sdp_converges_to_oracle_objective(T):
+@pytest.mark.parametrize("nk", [(12, 20), (10, 33)])
+def test_synth_sdp_converges_to_oracle_objective(T, nk):
     from totsu_amd import synth
-    inst = synth.SdpInstance(12, 20, seed=4)
+    inst = synth.SdpInstance(nk[0], nk[1], seed=4)
     a, b, c = _synth_dense_to_host(inst)
     ro = O.solve_matop_cones(O.param(max_iter=200000, eps_acc=1e-5), c, a, b, [O.CONE_PSD], [inst.m], use_ql=True)
     assert ro.status == O.OK
@@ -317,9 +319,11 @@ def test_synth_sdp_converges_to_oracle_objective(T):
     p.eps_acc, p.max_iter = 1e-4, 200_000
     fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried")
     x, y = fs.solve(poll_every=64)
-    assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-4 * (1 + abs(pobj))
+    gobj = float(c @ x.astype(np.float64))
+    assert abs(gobj - pobj) <= 3e-4 * (1 + abs(pobj))            # eps 1e-4 stop vs the eps 1e-5 answer
     r4 = O.solve_matop_cones(O.param(max_iter=200000, eps_acc=1e-4), c, a, b, [O.CONE_PSD], [inst.m], use_ql=True)
     assert abs(fs.status().iters - r4.iters) <= 0.05 * r4.iters + 10
+    assert abs(gobj - float(c @ r4.x)) <= 1e-5 * (1 + abs(pobj))  # like for like: the oracle stopped at the same eps
     fs.destroy()
     inst.free()
 

@@ -156,8 +156,9 @@ int soc_batched2(hipStream_t st, float *x0, float *x1, float *rx0, float *rx1, c
 int group_min_batched(hipStream_t st, float *t, const int64_t *dev_begs, const int64_t *dev_ends, size_t n_groups,
                       size_t max_len);
 
+// nbatch matrices per call: packed + z * pstride each, work holds nbatch * thip_map_eig_worklen(n) floats
 int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale_diag, float eps_zero,
-                    float *work, size_t worklen, int map_kind, const int *stop);
+                    float *work, size_t worklen, int map_kind, const int *stop, int nbatch = 1, ptrdiff_t pstride = 0);
 
 // counter-based generator, identical integer function to oracle/totsu_oracle.c:oc_rng_hash
 __host__ __device__ __forceinline__ uint64_t rng_hash(uint64_t seed, uint64_t stream, uint64_t idx)

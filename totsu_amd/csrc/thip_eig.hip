@@ -71,11 +71,14 @@ __device__ __forceinline__ int rotate_pair(float *G, float *V, int ld, int n, in
 
 // packed upper (by columns) -> full symmetric G (ld x ld, zero padded), diag * scale ; V = I ; block partials of
 // the squared Frobenius norm
+// Batched launches (blockIdx.z = item): item z works on packed + z * ps and on work pointers + z * ws.
 __global__ void unpack_k(int n, int ld, const float *__restrict__ packed, int has_scale, float scale,
                          float *__restrict__ G, float *__restrict__ V, float *__restrict__ part,
-                         const int *__restrict__ stop)
+                         const int *__restrict__ stop, size_t ws = 0, ptrdiff_t ps = 0)
 {
     if (stop != nullptr && *stop != 0) return;
+    packed += (ptrdiff_t)blockIdx.z * ps; G += blockIdx.z * ws; part += blockIdx.z * ws;
+    if (V) V += blockIdx.z * ws;
     __shared__ float sh[16];
     float acc = 0.0f;
     const size_t tot = (size_t)ld * ld;
@@ -97,9 +100,10 @@ __global__ void unpack_k(int n, int ld, const float *__restrict__ packed, int ha
 
 // sc[0] = ||M||_F, sc[1] = sigma = 1.01 ||M||_F + tiny ; G += sigma I (when shift != 0)
 __global__ void shift_k(int n, int ld, int np, const float *__restrict__ part, float *__restrict__ G,
-                        float *__restrict__ sc, int shift, const int *__restrict__ stop)
+                        float *__restrict__ sc, int shift, const int *__restrict__ stop, size_t ws = 0)
 {
     if (stop != nullptr && *stop != 0) return;
+    part += blockIdx.z * ws; G += blockIdx.z * ws; sc += blockIdx.z * ws;
     __shared__ double shd[16];
     double acc = 0.0;
     for (int k = threadIdx.x; k < np; k += blockDim.x) acc += (double)part[k];
@@ -250,9 +254,11 @@ constexpr int GSL = 8;              // K slab per wave per step
 template <bool GEN>
 __global__ __launch_bounds__(GNW * 64) void gemm_k(int n, int ld, float alpha, const float *__restrict__ X,
                                                    const float *__restrict__ Y, float beta, const float *D, float gamma,
-                                                   float *C, const int *__restrict__ stop)
+                                                   float *C, const int *__restrict__ stop, size_t ws)
 {
     if (stop != nullptr && *stop != 0) return;
+    X += blockIdx.z * ws; Y += blockIdx.z * ws; C += blockIdx.z * ws;
+    if (D) D += blockIdx.z * ws;
     __shared__ float red[GNW - 1][16][64];
     __shared__ float stg[GEN ? GNW : 1][GSL][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -337,9 +343,10 @@ __global__ __launch_bounds__(GNW * 64) void gemm_k(int n, int ld, float alpha, c
 
 // S = M / ||M||_F  (sc[0] = ||M||_F); exact zero matrix stays zero
 __global__ void scale_by_fro_k(size_t tot, const float *__restrict__ M, const float *__restrict__ sc,
-                               float *__restrict__ S, const int *__restrict__ stop)
+                               float *__restrict__ S, const int *__restrict__ stop, size_t ws)
 {
     if (stop != nullptr && *stop != 0) return;
+    M += blockIdx.z * ws; sc += blockIdx.z * ws; S += blockIdx.z * ws;
     const float f = sc[0];
     const float inv = f > 0.0f ? 1.0f / f : 0.0f;
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) S[i] = M[i] * inv;
@@ -347,9 +354,10 @@ __global__ void scale_by_fro_k(size_t tot, const float *__restrict__ M, const fl
 
 // packed(r,c) = (M + MS)(r,c) / 2 symmetrised, diag / scale
 __global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const float *__restrict__ MS, int has_scale,
-                            float scale, float *__restrict__ packed, const int *__restrict__ stop)
+                            float scale, float *__restrict__ packed, const int *__restrict__ stop, size_t ws, ptrdiff_t ps)
 {
     if (stop != nullptr && *stop != 0) return;
+    M += blockIdx.z * ws; MS += blockIdx.z * ws; packed += (ptrdiff_t)blockIdx.z * ps;
     const int c = blockIdx.y;
     for (int r = blockIdx.x * BLK + threadIdx.x; r <= c; r += gridDim.x * BLK) {
         const size_t o1 = (size_t)c * ld + r, o2 = (size_t)r * ld + c;
@@ -361,11 +369,11 @@ __global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const fl
 
 // gen == false: C = alpha X Y^T + beta D + gamma I (symmetric result); gen == true: C = alpha X Y + ... (X symmetric)
 int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, const float *Y, float beta, const float *D,
-         float gamma, float *C, const int *stop)
+         float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0)
 {
-    dim3 g(ld / GT, ld / GT);
-    if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop);
-    else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop);
+    dim3 g(ld / GT, ld / GT, nb);
+    if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
+    else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -429,36 +437,40 @@ int rebuild(hipStream_t st, size_t n, float *packed, int has_scale, float scale,
     return 0;
 }
 
-// P = (M + M sign(M)) / 2 through the matrix cores
-int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop)
+// P = (M + M sign(M)) / 2 through the matrix cores; nb items per launch (work regions ws floats apart, packed
+// vectors ps floats apart): the chain is launch-bound (8.7 us per 512^3 GEMM on 256 workgroups), so the x_y and x_s
+// projections of one iteration share its 50+ launches
+int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop,
+                  int nb, size_t ws, ptrdiff_t ps)
 {
     const int ni = (int)n, ld = (int)np_of(n);
     const size_t tot = (size_t)ld * ld;
     const unsigned g = grid_for(tot, BLK, 512);
     float *M = k.G, *S = k.S, *Y = k.Y, *Z = k.Z, *T = k.V;
-    hipLaunchKernelGGL(unpack_k, dim3(g), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, M, (float *)nullptr, k.part, stop);
-    hipLaunchKernelGGL(shift_k, dim3(1), dim3(BLK), 0, st, ni, ld, (int)g, k.part, M, k.sc, 0, stop);
-    hipLaunchKernelGGL(scale_by_fro_k, dim3(g), dim3(BLK), 0, st, tot, M, k.sc, S, stop);
+    hipLaunchKernelGGL(unpack_k, dim3(g, 1, nb), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, M, (float *)nullptr,
+                       k.part, stop, ws, ps);
+    hipLaunchKernelGGL(shift_k, dim3(1, 1, nb), dim3(BLK), 0, st, ni, ld, (int)g, k.part, M, k.sc, 0, stop, ws);
+    hipLaunchKernelGGL(scale_by_fro_k, dim3(g, 1, nb), dim3(BLK), 0, st, tot, M, k.sc, S, stop, ws);
     // phase 1: quintic with a steep slope at 0 (3.4445 x - 4.7750 x^3 + 2.0315 x^5 maps (0, 1] into ~[0.7, 1.2] and
     // multiplies tiny singular values by 3.44 per step): 13 steps lift relative eigenvalues >= 1e-7 into the band.
     // Three GEMMs per step, the polynomial folded into the second one's epilogue:
     //   Y = S S^T ;  T = c Y Y^T + b Y + a I ;  S <- T S
     for (int it = 0; it < 13; ++it) {
-        THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop));
-        THIP_RC(gemm(st, false, ni, ld, 2.0315f, Y, Y, -4.7750f, Y, 3.4445f, T, stop));
-        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop));
+        THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop, nb, ws));
+        THIP_RC(gemm(st, false, ni, ld, 2.0315f, Y, Y, -4.7750f, Y, 3.4445f, T, stop, nb, ws));
+        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));
         float *tmp = S; S = Z; Z = tmp;
     }
     // phase 2: Newton-Schulz x (3 - x^2) / 2, quadratic convergence to exactly +-1 from the band
     //   T = -0.5 S S^T + 1.5 I ;  S <- T S
     for (int it = 0; it < 5; ++it) {
-        THIP_RC(gemm(st, false, ni, ld, -0.5f, S, S, 0.0f, nullptr, 1.5f, T, stop));
-        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop));
+        THIP_RC(gemm(st, false, ni, ld, -0.5f, S, S, 0.0f, nullptr, 1.5f, T, stop, nb, ws));
+        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));
         float *tmp = S; S = Z; Z = tmp;
     }
-    THIP_RC(gemm(st, true, ni, ld, 1.0f, M, S, 0.0f, nullptr, 0.0f, Z, stop));      // M sign(M)
-    dim3 gp((unsigned)((n + BLK - 1) / BLK), (unsigned)n);
-    hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop);
+    THIP_RC(gemm(st, true, ni, ld, 1.0f, M, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));      // M sign(M)
+    dim3 gp((unsigned)((n + BLK - 1) / BLK), (unsigned)n, nb);
+    hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop, ws, ps);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -468,15 +480,20 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
 namespace thip {
 
 int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale_diag, float eps_zero,
-                    float *work, size_t worklen, int map_kind, const int *stop)
+                    float *work, size_t worklen, int map_kind, const int *stop, int nbatch, ptrdiff_t pstride)
 {
     (void)eps_zero;   // F32CUDA ignores eps_zero as well (f32cuda.rs:196); f32 round-off is the floor
-    if (n == 0) return 0;
-    if (worklen < thip_map_eig_worklen(n)) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
+    if (n == 0 || nbatch <= 0) return 0;
+    const size_t ws = thip_map_eig_worklen(n);
+    if (worklen < ws * (size_t)nbatch) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
     const Work k = carve(work, n);
-    if (map_kind == 0 && n > POLAR_MIN_N) return polar_project(st, n, packed, has_scale, scale_diag, k, stop);
-    THIP_RC(decompose(st, n, packed, has_scale, scale_diag, k, map_kind, stop));
-    return rebuild(st, n, packed, has_scale, scale_diag, k, stop);
+    if (map_kind == 0 && n > POLAR_MIN_N)
+        return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride);
+    for (int z = 0; z < nbatch; ++z) {          // the Jacobi engine works on one matrix at a time
+        THIP_RC(decompose(st, n, packed + z * pstride, has_scale, scale_diag, k, map_kind, stop));
+        THIP_RC(rebuild(st, n, packed + z * pstride, has_scale, scale_diag, k, stop));
+    }
+    return 0;
 }
 
 }  // namespace thip

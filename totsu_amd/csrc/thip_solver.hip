@@ -564,13 +564,13 @@ int project_blocks(thip_solver *s)
     THIP_RC(soc_batched2(st, s->xy, s->xs, s->rxy, s->rxs, s->soc_beg, s->soc_end, s->n_soc, 0, s->soc_max, stop));
     THIP_RC(soc_batched2(st, s->xy, s->xs, s->rxy, s->rxs, s->rot_beg, s->rot_end, s->n_rot, 1, s->rot_max, stop));
     if (!s->psd.empty()) {
-        for (float *x : { s->xy, s->xs })
-            for (auto &pr : s->psd) {
-                const size_t sn = (size_t)pr.second;
-                const size_t k = (size_t)((std::sqrt((double)(8 * sn + 1)) - 1.0) / 2.0 + 0.5);
-                THIP_RC(eig_psd_project(st, k, x + pr.first, 1, std::sqrt(2.0f), s->par.eps_zero, s->psd_work,
-                                        s->psd_worklen, 0, stop));
-            }
+        // the x_y and x_s blocks of a cone go through the projection chain together (2 items per launch)
+        for (auto &pr : s->psd) {
+            const size_t sn = (size_t)pr.second;
+            const size_t k = (size_t)((std::sqrt((double)(8 * sn + 1)) - 1.0) / 2.0 + 0.5);
+            THIP_RC(eig_psd_project(st, k, s->xy + pr.first, 1, std::sqrt(2.0f), s->par.eps_zero, s->psd_work,
+                                    s->psd_worklen, 0, stop, 2, s->xs - s->xy));
+        }
         hipLaunchKernelGGL(rx_psd_k, dim3(egrid(s->m)), dim3(BLK), 0, st, (int)s->m, s->cls, s->xy, s->xs, s->rxy, s->rxs, s->dst);
     }
     return 0;
@@ -760,7 +760,7 @@ int thip_solver_create(const thip_problem *prob, const thip_param *par, int sche
     THIP_TRY(hipMalloc((void **)&s->cls, cls.size()));
     THIP_TRY(hipMemcpy(s->cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
     if (psd_kmax) {
-        s->psd_worklen = thip_map_eig_worklen(psd_kmax);
+        s->psd_worklen = 2 * thip_map_eig_worklen(psd_kmax);
         THIP_TRY(hipMalloc((void **)&s->psd_work, s->psd_worklen * sizeof(float)));
     }
 
