@@ -73,7 +73,59 @@ extern "C" {
     pub fn thip_solver_run(s: *mut thip_solver, max_steps: i64, poll_every: i64, host_status: *mut thip_status) -> c_int;
     pub fn thip_solver_solution(s: *mut thip_solver, host_x: *mut f32, host_y: *mut f32) -> c_int;
     pub fn thip_solver_destroy(s: *mut thip_solver) -> c_int;
+
+    // ---- the rest of include/totsu_f32hip.h: context, device-scalar reductions, batched cones, sparse and
+    // ---- reduced-precision operators, solver controls, RCCL communicator, generators, profiling ----
+    pub fn thip_version() -> *const c_char;
+    pub fn thip_device_count(host_count: *mut c_int) -> c_int;
+    pub fn thip_set_stream(hip_stream: *mut c_void) -> c_int;
+    pub fn thip_get_stream() -> *mut c_void;
+    pub fn thip_alloc_zeroed(n: usize, out: *mut *mut f32) -> c_int;
+
+    pub fn thip_norm_dev(n: usize, x: *const f32, dev_out: *mut f32) -> c_int;
+    pub fn thip_dot_dev(n: usize, x: *const f32, y: *const f32, dev_out: *mut f32) -> c_int;
+    pub fn thip_abssum_dev(len: usize, x: *const f32, incx: usize, dev_out: *mut f32) -> c_int;
+    pub fn thip_absadd_sympack(n: usize, mat: *const f32, y: *mut f32) -> c_int;
+    pub fn thip_spmv_csr(n_row: usize, n_col: usize, nnz: usize, dev_rowptr: *const i64, dev_colidx: *const i32,
+                         vals: *const f32, alpha: f32, x: *const f32, beta: f32, y: *mut f32, abs_mode: c_int) -> c_int;
+    pub fn thip_to_bf16(n_row: usize, n_col: usize, mat: *const f32, mat16: *mut u16, ld16: usize) -> c_int;
+    pub fn thip_transform_ge_bf16(transpose: c_int, n_row: usize, n_col: usize, alpha: f32, mat16: *const u16,
+                                  ld16: usize, x: *const f32, beta: f32, y: *mut f32) -> c_int;
+
+    pub fn thip_proj_soc_batched(x: *mut f32, dev_offs: *const i64, n_cones: usize, rotated: c_int, max_len: usize) -> c_int;
+    pub fn thip_group_min_batched(dp_tau: *mut f32, dev_offs: *const i64, n_groups: usize, max_len: usize) -> c_int;
+
+    pub fn thip_solver_set_csr(s: *mut thip_solver, nnz: usize, dev_rowptr: *const i64, dev_colidx: *const i32,
+                               dev_vals: *const f32, dev_t_rowptr: *const i64, dev_t_colidx: *const i32,
+                               dev_t_vals: *const f32) -> c_int;
+    pub fn thip_solver_set_a_storage(s: *mut thip_solver, a_kind: c_int) -> c_int;
+    pub fn thip_solver_set_param(s: *mut thip_solver, par: *const thip_param) -> c_int;
+    pub fn thip_solver_resume(s: *mut thip_solver) -> c_int;
+    pub fn thip_solver_status(s: *mut thip_solver, host_status: *mut thip_status) -> c_int;
+    pub fn thip_solver_iterate(s: *mut thip_solver, host_x: *mut f32, host_y: *mut f32) -> c_int;
+    pub fn thip_solver_precond(s: *mut thip_solver, host_dp_tau: *mut f32, host_dp_sigma: *mut f32) -> c_int;
+    pub fn thip_solver_passes(s: *const thip_solver, host_passes: *mut c_int, host_bytes_per_pass: *mut usize) -> c_int;
+    pub fn thip_solver_gemv_plan(s: *const thip_solver, host_nj: *mut c_int, host_blocks: *mut c_int, host_ms: *mut f32) -> c_int;
+
+    pub fn thip_comm_unique_id(host_id128: *mut u8) -> c_int;
+    pub fn thip_comm_init(rank: c_int, world: c_int, host_id128: *const u8) -> c_int;
+    pub fn thip_comm_allreduce(dev_buf: *mut f32, n: usize) -> c_int;
+    pub fn thip_comm_destroy() -> c_int;
+    pub fn thip_solver_use_rccl(s: *mut thip_solver) -> c_int;
+
+    pub fn thip_gen_vector(out: *mut f32, n: usize, seed: u64, stream: u64, idx0: u64, kind: c_int, scale: f32, shift: f32) -> c_int;
+    pub fn thip_gen_matrix(out: *mut f32, n_row: usize, n_col: usize, lda: usize, seed: u64, stream: u64, row0: u64,
+                           col0: u64, ld_index: u64, kind: c_int, scale: f32, shift: f32) -> c_int;
+    pub fn thip_gen_identity(out: *mut f32, n_row: usize, n_col: usize, lda: usize, row0: u64, value: f32) -> c_int;
+
+    pub fn thip_prof_enable(on: c_int) -> c_int;
+    pub fn thip_prof_read(host_launches: *mut i64, host_total_ms: *mut f64) -> c_int;
+    pub fn thip_test_gemm_sym(n: c_int, ld: c_int, alpha: f32, a: *const f32, b: *const f32, beta: f32, d: *const f32,
+                              gamma: f32, c: *mut f32) -> c_int;
 }
+
+pub const THIP_A_F32: c_int = 0;
+pub const THIP_A_BF16: c_int = 1;
 
 /// The reference backends assert on library status (totsu_f32cuda/src/f32cuda.rs:38): so does this one.
 pub fn chk(rc: c_int) {

@@ -50,3 +50,10 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "libtotsu_oracle" not in src, f
+
+
+def test_authored_rust_binding_declares_every_symbol():
+    # rust/totsu_f32hip cannot be compiled here (no cargo); at least its extern block stays one-to-one with the header
+    src = open(os.path.join(ROOT, "rust", "totsu_f32hip", "src", "ffi.rs")).read()
+    rust = set(re.findall(r"pub fn (thip_[a-z0-9_]+)\s*\(", src))
+    assert rust == set(_declared()), rust ^ set(_declared())
