@@ -694,7 +694,7 @@ int poll(thip_solver *s, thip_status *out)
 
 extern "C" {
 
-int thip_solver_create(const thip_problem *prob, const thip_param *par, int schedule, thip_solver **out)
+static int solver_create_impl(const thip_problem *prob, const thip_param *par, int schedule, thip_solver **out)
 {
     THIP_NEED_INIT();
     if (!prob || !par || !out) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
@@ -708,6 +708,7 @@ int thip_solver_create(const thip_problem *prob, const thip_param *par, int sche
     if ((size_t)tot != prob->m) return fail(THIP_E_INVALID, "cone segments do not cover m rows", __FILE__, __LINE__);
 
     thip_solver *s = new thip_solver();
+    *out = s;                      // the caller releases it if anything below fails
     s->n = prob->n; s->m = prob->m;
     s->A = prob->mat_a; s->b = prob->vec_b; s->c = prob->vec_c; s->b_rowabs = prob->vec_b_rowabs;
     s->par = *par; s->schedule = schedule;
@@ -736,7 +737,7 @@ int thip_solver_create(const thip_problem *prob, const thip_param *par, int sche
             break;
         case THIP_CONE_PSD: {
             const size_t k = (size_t)((std::sqrt((double)(8 * l + 1)) - 1.0) / 2.0 + 0.5);
-            if ((int64_t)(k * (k + 1) / 2) != l) { delete s; return fail(THIP_E_INVALID, "PSD segment is not triangular", __FILE__, __LINE__); }
+            if ((int64_t)(k * (k + 1) / 2) != l) { return fail(THIP_E_INVALID, "PSD segment is not triangular", __FILE__, __LINE__); }
             s->psd.push_back({off, l});
             for (int64_t r = 0; r < l; ++r) cls[off + r] = 3;
             gb.push_back(off); ge.push_back(off + l);
@@ -787,6 +788,19 @@ int thip_solver_create(const thip_problem *prob, const thip_param *par, int sche
     THIP_TRY(hipHostMalloc((void **)&s->hst, sizeof(DevStatus), hipHostMallocDefault));
     THIP_TRY(hipMalloc((void **)&s->done_count, sizeof(int)));
     THIP_TRY(hipMemsetAsync(s->done_count, 0, sizeof(int), st));
+    return 0;
+}
+
+int thip_solver_create(const thip_problem *prob, const thip_param *par, int schedule, thip_solver **out)
+{
+    if (!out) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    *out = nullptr;
+    thip_solver *s = nullptr;
+    const int rc = solver_create_impl(prob, par, schedule, &s);
+    if (rc != 0) {
+        if (s) thip_solver_destroy(s);      // partial device allocations (e.g. out of memory half-way)
+        return rc;
+    }
     *out = s;
     return 0;
 }
