@@ -1,0 +1,58 @@
+"""One-off measurement for SURVEY.md 8d ("final objective within 1e-4 relative of the f64 CPU result on the same
+instance") at a size the CPU oracle still finishes: the synthetic SOCP of bench.py at n = 5000, 100 cones, solved to
+the same eps_acc by the GPU (f32, carried schedule; optionally bf16 -> f32) and by the C oracle (f64, OpenMP) on the
+host.  Prints one JSON line.  Usage: python tests/measure_objective_gap.py [n] [cones] [eps]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle as O                     # noqa: E402  (lives under tests/: the oracle is the checker here)
+import totsu_amd as T                  # noqa: E402
+from totsu_amd import _lib, synth      # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    cones = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    eps = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-3
+    _lib.init()
+    inst = synth.SocpInstance(n, cones, 99, seed=0)
+    a = inst.mat_a.to_host()[:inst.m * inst.n].astype(np.float64)
+    b, c = inst.vec_b_host.astype(np.float64), inst.vec_c_host.astype(np.float64)
+    out = {"instance": "synthetic SOCP n=%d, %d cones of 1+99 rows (m=%d), seed 0" % (n, cones, inst.m), "eps_acc": eps}
+    p = T.SolverParam()
+    p.eps_acc, p.max_iter = eps, None
+    for mode in ("f32", "mixed"):
+        fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried",
+                           a_storage="f32" if mode == "f32" else "bf16")
+        t0 = time.perf_counter()
+        r = fs.run(-1, poll_every=64)
+        if mode == "mixed":
+            fs.set_a_storage("f32")
+            fs.resume()
+            r = fs.run(-1, poll_every=64)
+        dt = time.perf_counter() - t0
+        x, y = fs.solution()
+        out["gpu_" + mode] = {"state": r.state, "iterations": r.iters + 1, "seconds": dt, "cri": list(r.cri),
+                              "primal_obj": float(c @ x.astype(np.float64)), "dual_obj": -float(b @ y.astype(np.float64))}
+        fs.destroy()
+        sys.stderr.write(json.dumps(out) + "\n")       # the CPU leg below can take very long: keep what is known
+        sys.stderr.flush()
+    t0 = time.perf_counter()
+    ro = O.solve_matop_cones(O.param(max_iter=10_000_000, eps_acc=eps), c, a, b, [O.CONE_SOC] * cones, [100] * cones)
+    out["cpu_oracle_f64"] = {"status": ro.status, "iterations": ro.iters + 1, "seconds": time.perf_counter() - t0,
+                             "threads": O.num_threads(), "primal_obj": float(c @ ro.x), "dual_obj": -float(b @ ro.y)}
+    ref = out["cpu_oracle_f64"]["primal_obj"]
+    for mode in ("f32", "mixed"):
+        g = out["gpu_" + mode]
+        g["rel_gap_to_cpu_primal"] = abs(g["primal_obj"] - ref) / abs(ref)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -132,8 +132,10 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
         constexpr unsigned HI = ABS ? 0x7fff0000u : 0xffff0000u;
 #pragma unroll
         for (int u = 0; u < K; ++u) {
-            const float xs = xsv[u];
-            float s0 = 0.0f, s1 = 0.0f;
+            // packed f32 math (v_pk_fma_f32): the (low, high) halves of a dword are one 2-vector for both products
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t xs2 = { xsv[u], xsv[u] };
+            f32x2_t s2 = { 0.0f, 0.0f };
             if constexpr (FULL) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
@@ -144,17 +146,18 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const unsigned q = raw[u][j][d];
-                    const float lo = __uint_as_float((q << 16) & HI), hi = __uint_as_float(q & HI);
+                    const f32x2_t a2 = { __uint_as_float((q << 16) & HI), __uint_as_float(q & HI) };
                     if constexpr (DO_N) {
-                        accN[j][2 * d] = fmaf(lo, xs, accN[j][2 * d]);
-                        accN[j][2 * d + 1] = fmaf(hi, xs, accN[j][2 * d + 1]);
+                        f32x2_t acc2 = { accN[j][2 * d], accN[j][2 * d + 1] };
+                        acc2 = __builtin_elementwise_fma(a2, xs2, acc2);
+                        accN[j][2 * d] = acc2[0]; accN[j][2 * d + 1] = acc2[1];
                     }
                     if constexpr (DO_T) {
-                        s0 = fmaf(lo, xtv[j][2 * d], s0);
-                        s1 = fmaf(hi, xtv[j][2 * d + 1], s1);
+                        const f32x2_t t2 = { xtv[j][2 * d], xtv[j][2 * d + 1] };
+                        s2 = __builtin_elementwise_fma(a2, t2, s2);
                     }
                 }
-            p[u] = s0 + s1;
+            p[u] = s2[0] + s2[1];
             // pin column u's updates here: the scheduler otherwise defers every N update behind the T phase and
             // keeps 8 * K * NJ widened values alive (115+ VGPRs, half the waves per SIMD)
             if constexpr (DO_N) {
