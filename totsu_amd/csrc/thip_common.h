@@ -18,8 +18,9 @@ struct Ctx {
     size_t       scratch_n = 0;
     float       *dev_scalar = nullptr;   // 64 floats of device scalars for SYNC calls
     float       *pinned = nullptr;       // 64 floats, host-pinned
-    void        *stage = nullptr;        // pinned staging for pageable h2d
+    void        *stage = nullptr;        // pinned staging for pageable h2d: two halves of stage_bytes each
     size_t       stage_bytes = 0;
+    hipEvent_t   stage_ev[2] = { nullptr, nullptr };   // "the DMA out of half k has finished"
     int          num_cu = 256;
 };
 

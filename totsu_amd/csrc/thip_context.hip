@@ -81,7 +81,8 @@ int thip_init(int device)
     THIP_TRY(hipMalloc((void **)&c.dev_scalar, 64 * sizeof(float)));
     THIP_TRY(hipHostMalloc((void **)&c.pinned, 64 * sizeof(float), hipHostMallocDefault));
     c.stage_bytes = 8u << 20;
-    THIP_TRY(hipHostMalloc(&c.stage, c.stage_bytes, hipHostMallocDefault));
+    THIP_TRY(hipHostMalloc(&c.stage, 2 * c.stage_bytes, hipHostMallocDefault));
+    for (int k = 0; k < 2; ++k) THIP_TRY(hipEventCreateWithFlags(&c.stage_ev[k], hipEventDisableTiming));
     hipDeviceProp_t prop;
     THIP_TRY(hipGetDeviceProperties(&prop, device));
     c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -99,6 +100,7 @@ int thip_shutdown(void)
     if (c.dev_scalar) hipFree(c.dev_scalar);
     if (c.pinned) hipHostFree(c.pinned);
     if (c.stage) hipHostFree(c.stage);
+    for (int k = 0; k < 2; ++k) if (c.stage_ev[k]) hipEventDestroy(c.stage_ev[k]);
     if (c.own_stream) hipStreamDestroy(c.own_stream);
     c = Ctx();
     return 0;
@@ -153,15 +155,19 @@ int thip_h2d(float *dst, const float *host_src, size_t n)
     if (n == 0) return 0;
     std::lock_guard<std::mutex> lock(g_stage_mutex);
     Ctx &c = ctx();
-    // pageable source: stage through pinned memory in chunks so the call is safe to return from
+    // pageable source: staged through two pinned halves, so the host copy of chunk i + 1 overlaps the DMA of chunk i;
+    // the call returns only when everything has landed (the caller may reuse host_src)
     const char *src = (const char *)host_src;
     char *d = (char *)dst;
     size_t bytes = n * sizeof(float);
-    while (bytes) {
+    for (size_t i = 0; bytes; ++i) {
         const size_t b = bytes < c.stage_bytes ? bytes : c.stage_bytes;
-        THIP_TRY(hipStreamSynchronize(c.stream));   // staging buffer reuse
-        memcpy(c.stage, src, b);
-        THIP_TRY(hipMemcpyAsync(d, c.stage, b, hipMemcpyHostToDevice, c.stream));
+        const int k = (int)(i & 1);
+        char *half = (char *)c.stage + (size_t)k * c.stage_bytes;
+        if (i >= 2) THIP_TRY(hipEventSynchronize(c.stage_ev[k]));     // the DMA that last read this half is done
+        memcpy(half, src, b);
+        THIP_TRY(hipMemcpyAsync(d, half, b, hipMemcpyHostToDevice, c.stream));
+        THIP_TRY(hipEventRecord(c.stage_ev[k], c.stream));
         src += b; d += b; bytes -= b;
     }
     THIP_TRY(hipStreamSynchronize(c.stream));
