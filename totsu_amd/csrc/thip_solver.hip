@@ -50,8 +50,9 @@ struct DevStatus {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// kernels.  One iteration of the carried schedule is 11 launches:
+// kernels.  One iteration of the carried schedule is 11 launches when the rows are sharded over GPUs:
 //   gemv, post, sumfin, [all-reduce], xupdate, soc | gemv, post, sumfin, [all-reduce], ycrit, status, final_scale
+// and 9 on a single GPU, where the consumers sum post's block partials themselves and sumfin is dropped.
 // ---------------------------------------------------------------------------------------------------
 
 // After a dual GEMV: second reduction stage of both products + the stage's sharded / replicated reductions.
@@ -125,6 +126,17 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
     }
 }
 
+// sum of the np block partials of quantity q (part[q * np + k]) by one whole block, in sumfin_k's order (so the value
+// is the one sumfin_k would have stored); the result is valid in every thread.  shd: 16 doubles of LDS.
+__device__ __forceinline__ float block_sum_of_partials(const float *part, int q, int np, double *shd)
+{
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < np; k += BLK) acc += (double)part[(size_t)q * np + k];
+    acc = block_sum_d(acc, shd);
+    __syncthreads();
+    return (float)acc;
+}
+
 // sums of the block partials of up to 4 quantities -> their destinations (null = skip); one block
 __global__ __launch_bounds__(BLK) void sumfin_k(int np, const float *__restrict__ part, float *d0, float *d1, float *d2,
                                                float *d3, const int *__restrict__ stop)
@@ -161,9 +173,19 @@ __global__ __launch_bounds__(BLK) void xupdate_k(int n, int m, const float *__re
                                                 float *__restrict__ xx, float *__restrict__ xy, float *__restrict__ xs,
                                                 float *__restrict__ rxx, float *__restrict__ rxy, float *__restrict__ rxs,
                                                 const float *__restrict__ dot_c, const float *__restrict__ dot_b,
-                                                DevStatus *st)
+                                                DevStatus *st, const float *psum, int npsum)
 {
     if (st->stop != 0) return;
+    // single GPU (no all-reduce between post_k and this kernel): block 0 sums post_k's block partials of c.u and b.v
+    // itself instead of a sumfin_k launch in between
+    float dc = 0.0f, db = 0.0f;
+    if (blockIdx.x == 0) {
+        if (psum != nullptr) {
+            __shared__ double shd[16];
+            dc = block_sum_of_partials(psum, 0, npsum, shd);
+            db = block_sum_of_partials(psum, 1, npsum, shd);
+        } else { dc = dot_c[0]; db = dot_b[0]; }
+    }
     const float kappa = st->kappa;
     const size_t gstride = (size_t)gridDim.x * BLK;
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(BLK) void xupdate_k(int n, int m, const float *__re
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // every other thread only reads st->kappa / st->stop; tau is written by this thread alone
         const float old = st->tau;
-        float t = old + st->t_tau * (-(dot_c[0]) - dot_b[0]);
+        float t = old + st->t_tau * (-dc - db);
         t = fmaxf(t, 0.0f);
         st->tau = t;
         st->r_tau = old - 2.0f * t;
@@ -221,10 +243,18 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
                                               const float *__restrict__ Sv, float *__restrict__ u, float *__restrict__ v,
                                               const float *__restrict__ xx, const float *__restrict__ dot_c,
                                               const float *__restrict__ dot_b, float eps_zero, float *__restrict__ part,
-                                              DevStatus *st)
+                                              DevStatus *st, const float *psum, int npsum)
 {
     if (st->stop != 0) return;
     __shared__ float sh[16];
+    float dc = 0.0f, db = 0.0f;      // c.rx_x and b.rx_y: from sumfin_k (sharded run) or summed here by block 0
+    if (doy && blockIdx.x == 0) {
+        if (psum != nullptr) {
+            __shared__ double shd[16];
+            dc = block_sum_of_partials(psum, 0, npsum, shd);
+            db = block_sum_of_partials(psum, 1, npsum, shd);
+        } else { dc = dot_c[0]; db = dot_b[0]; }
+    }
     const float rtau = st->r_tau;
     const float tau = st->tau;
     const bool conv = tau > eps_zero;
@@ -253,7 +283,7 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
             v[i] = v[i] + Sv[i] * (h2 + rxs[i] - b[i] * rtau);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            const float k = st->kappa + st->s_kappa * (dot_c[0] + dot_b[0]);
+            const float k = st->kappa + st->s_kappa * (dc + db);
             st->kappa = fminf(k, 0.0f);       // solver.rs:566-567
         }
     }
@@ -269,10 +299,16 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
 // pp_by[0] = ||p||^2, pp_by[1] = b.x_y (already all-reduced).
 __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict__ part, const float *__restrict__ pp_by,
                                                float eps_acc, float eps_inf, float eps_zero, long long max_iter,
-                                               DevStatus *st)
+                                               DevStatus *st, const float *psum, int npsum)
 {
     if (st->stop != 0) return;
     __shared__ double shd[16];
+    // ||p||^2 and b.x_y: all-reduced tail scalars (sharded run), or summed here from post_k's partials (q2, q3)
+    float pp, by;
+    if (psum != nullptr) {
+        pp = block_sum_of_partials(psum, 2, npsum, shd);
+        by = block_sum_of_partials(psum, 3, npsum, shd);
+    } else { pp = pp_by[0]; by = pp_by[1]; }
     double a0 = 0.0, a1 = 0.0;
     for (int k = threadIdx.x; k < np; k += BLK) { a0 += (double)part[k]; a1 += (double)part[np + k]; }
     a0 = block_sum_d(a0, shd);
@@ -282,12 +318,12 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
     const long long i = st->iter;
     const bool excess_iter = (max_iter >= 0) ? (i + 1 >= max_iter) : false;
     const float tau = st->tau;
-    const float norm_p = sqrtf(pp_by[0]), norm_d = sqrtf(dd);
+    const float norm_p = sqrtf(pp), norm_d = sqrtf(dd);
     int state = THIP_ST_RUNNING;
     if (tau > eps_zero) {
         const float rt = 1.0f / tau;
         const float g_x = rt * cx;
-        const float g_y = rt * pp_by[1];
+        const float g_y = rt * by;
         const float g = g_x + g_y;
         const float cri_pri = norm_p / (1.0f + st->norm_b);
         const float cri_dual = norm_d / (1.0f + st->norm_c);
@@ -298,7 +334,7 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
         else if (excess_iter) state = THIP_ST_EXCESS_ITER;
     } else {
         const float m_cx = -cx;
-        const float m_by = -pp_by[1];
+        const float m_by = -by;
         const float cri_unbdd = (m_cx > eps_zero) ? norm_p * st->norm_c / m_cx : __builtin_inff();
         const float cri_infeas = (m_by > eps_zero) ? norm_d * st->norm_b / m_by : __builtin_inff();
         st->kind = 1; st->cri[0] = cri_unbdd; st->cri[1] = cri_infeas; st->cri[2] = 0.0f;
@@ -587,17 +623,24 @@ int one_iteration(thip_solver *s)
     const float ez = s->par.eps_zero;
     GemvPartials gp;
     const unsigned gq = grid_for(s->n > s->m ? s->n : s->m, 64, PG);
+    // Without an all-reduce between post_k and its consumers (single GPU) the consumers sum post_k's block partials
+    // themselves (block 0 / the status block) and the three sumfin_k launches are dropped; a sharded run needs the
+    // local sums in the tail of the all-reduced vector, so it keeps them.
+    const bool local = s->allreduce == nullptr;
+    const float *psum = local ? part : (const float *)nullptr;
+    float *const part_y = s->part + 4 * PG;          // ycrit_k's own partials (read by status_k)
 
     // ---- stage X: x update (solver.rs:538-555) ----------------------------------------------------
     THIP_RC(products(s, s->u, s->v, &gp, s->h1, s->g1));
     hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g1, gp.partN, gp.nN,
                        gp.strideN, s->h1, s->c, s->u, s->b, s->v, 0, (const float *)nullptr, (const float *)nullptr,
                        (const float *)nullptr, ez, part, s->dst);
-    hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, s->dotc + 0, s->g1 + s->n, (float *)nullptr,
-                       (float *)nullptr, stop);
+    if (!local)
+        hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, s->dotc + 0, s->g1 + s->n, (float *)nullptr,
+                           (float *)nullptr, stop);
     THIP_RC(do_allreduce(s, s->g1, s->n + 1));
     hipLaunchKernelGGL(xupdate_k, dim3(g), dim3(BLK), 0, st, n, m, s->g1, s->h1, s->c, s->b, s->v, s->Tx, s->Ty, s->Ts,
-                       s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dotc + 0, s->g1 + s->n, s->dst);
+                       s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dotc + 0, s->g1 + s->n, s->dst, psum, (int)gq);
     THIP_RC(project_blocks(s));
 
     // ---- stage Y: y update from K rx (solver.rs:557-567), own products unless carried ---------------
@@ -606,12 +649,13 @@ int one_iteration(thip_solver *s)
         hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g2, gp.partN, gp.nN,
                            gp.strideN, s->h2, s->c, s->rxx, s->b, s->rxy, 0, (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, ez, part, s->dst);
-        hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, s->dotc + 1, s->g2 + s->n,
-                           (float *)nullptr, (float *)nullptr, stop);
+        if (!local)
+            hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, s->dotc + 1, s->g2 + s->n,
+                               (float *)nullptr, (float *)nullptr, stop);
         THIP_RC(do_allreduce(s, s->g2, s->n + 1));
         hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, 1, 0, 0, (const float *)nullptr,
                            (const float *)nullptr, (float *)nullptr, (float *)nullptr, s->g2, s->h2, s->c, s->b, s->rxs,
-                           s->Su, s->Sv, s->u, s->v, s->xx, s->dotc + 1, s->g2 + s->n, ez, part, s->dst);
+                           s->Su, s->Sv, s->u, s->v, s->xx, s->dotc + 1, s->g2 + s->n, ez, part_y, s->dst, psum, (int)gq);
     }
 
     // ---- stage C: criteria products of the new iterate (solver.rs:573-656) --------------------------
@@ -620,14 +664,15 @@ int one_iteration(thip_solver *s)
                        gp.strideN, s->h3, carried ? s->c : (const float *)nullptr, s->rxx,
                        carried ? s->b : (const float *)nullptr, s->rxy, 1, s->xs, s->xy, s->b, ez, part, s->dst);
     // tail of g3: [0] ||p||^2, [1] b.x_y, [2] b.rx_y (carried) -- all sharded sums, all-reduced with g3
-    hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, carried ? s->dotc + 1 : (float *)nullptr,
-                       carried ? s->g3 + s->n + 2 : (float *)nullptr, s->g3 + s->n, s->g3 + s->n + 1, stop);
+    if (!local)
+        hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, carried ? s->dotc + 1 : (float *)nullptr,
+                           carried ? s->g3 + s->n + 2 : (float *)nullptr, s->g3 + s->n, s->g3 + s->n + 1, stop);
     THIP_RC(do_allreduce(s, s->g3, s->n + 3));
     hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, carried ? 1 : 0, 1, 1, s->g3, s->h3, s->gP, s->hP,
                        (const float *)nullptr, (const float *)nullptr, s->c, s->b, s->rxs, s->Su, s->Sv, s->u, s->v, s->xx,
-                       s->dotc + 1, s->g3 + s->n + 2, ez, part, s->dst);
-    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part, s->g3 + s->n, s->par.eps_acc, s->par.eps_inf,
-                       ez, (long long)s->par.max_iter, s->dst);
+                       s->dotc + 1, s->g3 + s->n + 2, ez, part_y, s->dst, carried ? psum : (const float *)nullptr, (int)gq);
+    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part_y, s->g3 + s->n, s->par.eps_acc, s->par.eps_inf,
+                       ez, (long long)s->par.max_iter, s->dst, psum, (int)gq);
     hipLaunchKernelGGL(final_scale_k, dim3(g), dim3(BLK), 0, st, n, m, ez, s->xx, s->xy, s->dst, s->done_count);
     THIP_LAUNCH_CHECK();
     return 0;
@@ -780,7 +825,7 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
     (void)take(pm);
     s->dotc = take(64);
 
-    THIP_TRY(hipMalloc((void **)&s->part, 4 * PG * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&s->part, (4 * PG + 2 * EG) * sizeof(float)));
     s->gemv_scr_n = 2 * dual_gemv_scratch_floats(m, n);
     THIP_TRY(hipMalloc((void **)&s->gemv_scr, s->gemv_scr_n * sizeof(float)));
     THIP_TRY(hipMalloc((void **)&s->dst, sizeof(DevStatus)));
