@@ -50,9 +50,10 @@ struct DevStatus {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// kernels.  One iteration of the carried schedule is 11 launches when the rows are sharded over GPUs:
-//   gemv, post, sumfin, [all-reduce], xupdate, soc | gemv, post, sumfin, [all-reduce], ycrit, status, final_scale
-// and 9 on a single GPU, where the consumers sum post's block partials themselves and sumfin is dropped.
+// kernels.  One iteration of the carried schedule is 10 launches when the rows are sharded over GPUs:
+//   gemv, post, sumfin, [all-reduce], xupdate, soc | gemv, post, sumfin, [all-reduce], ycrit, status
+// and 7 on a single GPU, where the consumers sum post's block partials themselves and sumfin is dropped.  The final
+// 1/tau scaling is not a per-iteration launch: the host applies it once when it sees the terminated state.
 // ---------------------------------------------------------------------------------------------------
 
 // After a dual GEMV: second reduction stage of both products + the stage's sharded / replicated reductions.
@@ -344,37 +345,23 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
         else if (excess_iter) state = THIP_ST_EXCESS_ITER;
     }
     if (state == THIP_ST_RUNNING) st->iter = i + 1;
-    else st->state = state;      // stop is raised by final_scale_k, which still has to run for this iteration
+    else { st->state = state; st->stop = 1; }     // one block, last kernel of the iteration: later launches are no-ops
 }
 
-// solver.rs:397-400: on Converged / ExcessIter in the tau > eps_zero branch, x_x and x_y are scaled by 1/tau.
-// Runs after status_k in every iteration; a no-op unless status_k has just decided to terminate.
-__global__ void final_scale_k(int n, int m, float eps_zero, float *__restrict__ xx, float *__restrict__ xy,
-                              DevStatus *st, int *done_count)
+// solver.rs:397-400: on Converged / ExcessIter in the tau > eps_zero branch, x_x and x_y are scaled by 1/tau.  Launched
+// once, by the host, when it first sees the terminated state (poll()): status_k itself raises the stop flag, so
+// nothing else touches the iterate in between and no per-iteration launch is spent on a no-op.
+__global__ void finalize_k(int n, int m, float *__restrict__ xx, float *__restrict__ xy, const DevStatus *st)
 {
-    if (st->stop != 0) return;
-    if (st->state == THIP_ST_RUNNING) return;
     const bool scale = (st->kind == 0) && (st->state == THIP_ST_OK || st->state == THIP_ST_EXCESS_ITER);
-    if (scale) {
-        const float rt = 1.0f / st->tau;
-        const size_t gstride = (size_t)gridDim.x * BLK;
-        for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) xx[i] = rt * xx[i];
-        for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) xy[i] = rt * xy[i];
-    }
-    // the last block to finish raises the stop flag (every block must have read state/stop before that)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const int prev = atomicAdd(done_count, 1);
-        if (prev == (int)gridDim.x - 1) {
-            *done_count = 0;
-            __threadfence();
-            atomicExch(&st->stop, 1);
-        }
-    }
+    if (!scale) return;
+    const float rt = 1.0f / st->tau;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) xx[i] = rt * xx[i];
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) xy[i] = rt * xy[i];
 }
 
-// thip_solver_resume: undo final_scale_k (x_x, x_y back to the homogeneous iterate) and clear the termination
+// thip_solver_resume: undo finalize_k (x_x, x_y back to the homogeneous iterate) and clear the termination
 __global__ void resume_k(int n, int m, float *__restrict__ xx, float *__restrict__ xy, const DevStatus *st)
 {
     const float tau = st->tau;
@@ -511,8 +498,8 @@ struct thip_solver {
     const GemvHint *ahint() const { return a_kind == THIP_A_BF16 ? (tuned16 ? &hint16 : nullptr) : (tuned ? &hint : nullptr); }
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
-    int *done_count = nullptr;
     bool inited = false;
+    bool finalized = false;      // finalize_k has been applied to the terminated iterate
 };
 
 namespace {
@@ -673,7 +660,6 @@ int one_iteration(thip_solver *s)
                        s->dotc + 1, s->g3 + s->n + 2, ez, part_y, s->dst, carried ? psum : (const float *)nullptr, (int)gq);
     hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part_y, s->g3 + s->n, s->par.eps_acc, s->par.eps_inf,
                        ez, (long long)s->par.max_iter, s->dst, psum, (int)gq);
-    hipLaunchKernelGGL(final_scale_k, dim3(g), dim3(BLK), 0, st, n, m, ez, s->xx, s->xy, s->dst, s->done_count);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -726,6 +712,13 @@ int poll(thip_solver *s, thip_status *out)
     hipStream_t st = ctx().stream;
     THIP_TRY(hipMemcpyAsync(s->hst, s->dst, sizeof(DevStatus), hipMemcpyDeviceToHost, st));
     THIP_TRY(hipStreamSynchronize(st));
+    if (s->hst->state != THIP_ST_RUNNING && !s->finalized) {
+        // the device has stopped by itself: apply the final 1/tau scaling once (solver.rs:397-400)
+        hipLaunchKernelGGL(finalize_k, dim3(egrid(s->n > s->m ? s->n : s->m)), dim3(BLK), 0, st, (int)s->n, (int)s->m,
+                           s->xx, s->xy, s->dst);
+        THIP_LAUNCH_CHECK();
+        s->finalized = true;
+    }
     if (out) {
         out->state = s->hst->state; out->iter = s->hst->iter; out->kind = s->hst->kind;
         out->cri[0] = s->hst->cri[0]; out->cri[1] = s->hst->cri[1]; out->cri[2] = s->hst->cri[2];
@@ -831,8 +824,6 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
     THIP_TRY(hipMalloc((void **)&s->dst, sizeof(DevStatus)));
     THIP_TRY(hipMemsetAsync(s->dst, 0, sizeof(DevStatus), st));
     THIP_TRY(hipHostMalloc((void **)&s->hst, sizeof(DevStatus), hipHostMallocDefault));
-    THIP_TRY(hipMalloc((void **)&s->done_count, sizeof(int)));
-    THIP_TRY(hipMemsetAsync(s->done_count, 0, sizeof(int), st));
     return 0;
 }
 
@@ -945,6 +936,7 @@ int thip_solver_solution(thip_solver *s, float *host_x, float *host_y)
 {
     THIP_NEED_INIT();
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    THIP_RC(poll(s, nullptr));           // a terminated iterate gets its final scaling before it is read
     if (host_x) THIP_RC(thip_d2h(host_x, s->xx, s->n));
     if (host_y) THIP_RC(thip_d2h(host_y, s->xy, s->m));
     return 0;
@@ -1027,7 +1019,8 @@ int thip_solver_resume(thip_solver *s)
                     __FILE__, __LINE__);
     hipStream_t st = ctx().stream;
     const unsigned g = egrid(s->n > s->m ? s->n : s->m);
-    hipLaunchKernelGGL(resume_k, dim3(g), dim3(BLK), 0, st, (int)s->n, (int)s->m, s->xx, s->xy, s->dst);
+    if (s->finalized) hipLaunchKernelGGL(resume_k, dim3(g), dim3(BLK), 0, st, (int)s->n, (int)s->m, s->xx, s->xy, s->dst);
+    s->finalized = false;
     hipLaunchKernelGGL(resume_flags_k, dim3(1), dim3(1), 0, st, s->dst);
     THIP_LAUNCH_CHECK();
     return 0;
@@ -1082,7 +1075,7 @@ int thip_solver_destroy(thip_solver *s)
     if (ctx().inited) hipStreamSynchronize(ctx().stream);
     hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
-    hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->done_count); hipFree(s->A16);
+    hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->A16);
     if (s->hst) hipHostFree(s->hst);
     delete s;
     return 0;
