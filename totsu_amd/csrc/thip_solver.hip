@@ -692,6 +692,10 @@ int autotune_gemv(thip_solver *s)
             THIP_TRY(hipEventRecord(e0, st));
             THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
                                        s->gemv_scr_n, &gp, nullptr, &c[i], s->a_kind));
+            // the second reduction stage is part of the price of a plan (finer grids leave more partials to post_k):
+            // time it too, into g2 / h2, which every schedule rewrites before reading
+            THIP_RC(finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, s->h2, nullptr));
+            THIP_RC(finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, 1.0f, 0.0f, s->g2, nullptr));
             THIP_TRY(hipEventRecord(e1, st));
             THIP_TRY(hipEventSynchronize(e1));
             float t = 0.0f;
