@@ -559,3 +559,27 @@ def test_gemv_bandwidth_floor_at_lp_size(T):
     assert gbps >= 4000.0, gbps
     fs.destroy()
     inst.free()
+
+
+@pytest.mark.parametrize("schedule", ["reference", "fused", "carried"])
+def test_two_solves_of_the_same_problem_are_bitwise_identical(T, schedule):
+    # every reduction is two-stage with a fixed order (no float atomics): same input, same bits -- iterates, criteria
+    # and iteration count -- which is also what keeps the replicated vectors of a sharded solve in lockstep
+    from totsu_amd import synth
+    inst = synth.SocpInstance(700, 12, 99, seed=11)
+    p = T.SolverParam()
+    p.eps_acc, p.max_iter = 1e-4, 50_000
+    out = []
+    for rep in range(2):
+        fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule)
+        fs.run(37, poll_every=37)
+        mid = fs.iterate()
+        r = fs.run(-1, poll_every=64)
+        x, y = fs.solution()
+        out.append((mid[0].copy(), mid[1].copy(), r.iters, r.cri, x.copy(), y.copy()))
+        fs.destroy()
+    a, b = out
+    assert a[2] == b[2] and a[3] == b[3]
+    for u, v in ((a[0], b[0]), (a[1], b[1]), (a[4], b[4]), (a[5], b[5])):
+        assert np.array_equal(u, v)
+    inst.free()
