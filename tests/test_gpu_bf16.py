@@ -212,3 +212,25 @@ def test_resume_with_tighter_eps_continues_the_same_solve(T):
     # stopping and resuming costs one 1/tau scaling round trip (1 ulp per element): same iteration count +-1, same answer
     assert abs(r3.iters - r2.iters) <= 2, (r2.iters, r3.iters)
     assert np.allclose(x2, x3, rtol=1e-4, atol=1e-5 * np.abs(x3).max())
+
+
+def test_resume_after_excess_iter_reaches_the_same_answer(T):
+    dense = _socp(T, 30, [5, 1, 0, 17, 99, 3], 2).dense()
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 100, 1e-4
+    fs = T.FusedSolver.from_dense(dense, p, "carried")
+    r1 = fs.run(-1, poll_every=16)
+    assert r1.state == 3 and r1.iters == 99              # SolverError::ExcessIter at i + 1 >= max_iter (solver.rs:424-432)
+    p2 = T.SolverParam()
+    p2.max_iter, p2.eps_acc = 1_000_000, 1e-4
+    fs.resume(p2)
+    r2 = fs.run(-1, poll_every=16)
+    assert r2.state == 0
+    x2, _ = fs.solution()
+    fs.destroy()
+    fs = T.FusedSolver.from_dense(dense, p2, "carried")
+    r3 = fs.run(-1, poll_every=16)
+    x3, _ = fs.solution()
+    fs.destroy()
+    assert abs(r3.iters - r2.iters) <= 2, (r2.iters, r3.iters)
+    assert np.allclose(x2, x3, rtol=1e-4, atol=1e-5 * np.abs(x3).max())
