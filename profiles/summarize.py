@@ -2,6 +2,7 @@
 
   python profiles/summarize.py stats gpurun_out/prof_r01/bench_results.db > profiles/r01_socp_carried_kernel_stats.txt
   python profiles/summarize.py pmc gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db KEY
+  python profiles/summarize.py counters gpurun_out/pmc_a/x_results.db [more.db ...]
 
 `pmc` prints per-kernel averages of FETCH_SIZE / WRITE_SIZE (KiB as rocprofv3 reports them) and updates
 profiles/hbm_traffic.json[KEY] with the corrected HBM bytes per launch of the dominant kernel: on gfx950
@@ -24,6 +25,20 @@ def stats(db):
         short = name.replace("(anonymous namespace)::", "").replace("void ", "")
         short = short.split("(")[0]
         print("%-8d %-14.1f %-12.2f %-8.3f  %s" % (calls, tot, avg, pct, short))
+
+
+def counters(*dbs):
+    """per (counter, kernel): launches, average counter value, average kernel duration"""
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        q = ("select counter_name, kernel_name, count(*), avg(value), avg(duration) from counters_collection "
+             "group by counter_name, kernel_name order by counter_name, sum(duration) desc")
+        print("# source: %s" % db)
+        for cname, name, calls, val, dur in cur.execute(q):
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            if calls < 20:
+                continue
+            print("%-30s %-44s launches %-6d avg %-12.5g avg_us %.2f" % (cname, short, calls, val, dur / 1e3))
 
 
 def pmc(fetch_db, write_db, key):
@@ -55,5 +70,7 @@ def pmc(fetch_db, write_db, key):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "counters":
+        counters(*sys.argv[2:])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
