@@ -192,6 +192,13 @@ def main():
         out, rank, cleanup = run(a)
     finally:
         sys.stdout.flush()
+        try:
+            # RCCL's banner goes through C stdio: it sits in libc's buffer (stdout is a pipe, so fully buffered)
+            # until exit -- flush it to stderr NOW, while fd 1 still points there
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     if rank == 0:

@@ -201,3 +201,22 @@ def test_bench_two_processes_share_one_gpu_and_reproduce_single_process():
     assert abs(t1["iterations"] - t2["iterations"]) <= max(3, 0.01 * t1["iterations"]), (t1, t2)
     assert abs(t1["primal_obj"] - t2["primal_obj"]) <= 1e-4 * (1 + abs(t1["primal_obj"]))
     assert abs(t1["dual_obj"] - t2["dual_obj"]) <= 1e-4 * (1 + abs(t1["dual_obj"]))
+
+
+def test_bench_prints_one_json_line_with_native_rccl_in_the_loop():
+    # RCCL writes a version banner through C stdio when a communicator is created; it must not land on stdout next
+    # to the ONE JSON line of the bench contract (it used to: flushed from libc's buffer at exit)
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "1500", "--cones", "30", "--steps", "5",
+                        "--warmup", "1", "--no-cpu", "--force-collective"], capture_output=True, text=True, timeout=900,
+                       env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert "RCCL" in d["config"]["collective"] and d["n_gpus"] == 1
