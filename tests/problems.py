@@ -118,3 +118,57 @@ def partitioning_sdp(x_num, y_num, seed=0):
         mat_a[i, j] = 1.0
         j += i + 2
     return w, syms_f, mat_a, np.ones(l)
+
+
+def sym_pack(S):
+    """full symmetric matrix -> packed upper triangle by columns (MatType::SymPack storage, matbuild/mod.rs:254-279)"""
+    S = np.asarray(S)
+    return np.concatenate([S[:c + 1, c] for c in range(S.shape[0])])
+
+
+def svm_qp(l=50, seed=0):
+    """The QP of examples/svm_qp/src/main.rs:47-106 (dual of a hard-margin SVM with a Gaussian kernel, sigma^2 = 1/8, on
+    l random points of the unit square labelled +1 inside a ring 0.25 < r < 0.4 around the centre): minimise
+    0.5 a^T P a - 1^T a  s.t. a >= 0, y^T a = 0, P_ij = y_i y_j k(x_i, x_j).  Sample points from numpy's generator (the
+    reference's Xoshiro stream is not reproducible here)."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 1, (2, l))
+    r = np.hypot(x[0] - 0.5, x[1] - 0.5)
+    y = np.where((r > 0.25) & (r < 0.4), 1.0, -1.0)
+    d2 = ((x[:, :, None] - x[:, None, :]) ** 2).sum(axis=0)
+    P = np.outer(y, y) * np.exp(-d2 * 8.0)
+    return dict(sym_p=P, vec_q=-np.ones(l), mat_g=-np.eye(l), vec_h=np.zeros(l), mat_a=y.reshape(1, l), vec_b=np.zeros(1))
+
+
+def trajplan_qcqp(t_cap=30, a_cap=90.0):
+    """The QCQP of examples/trajplan_qcqp/src/main.rs:19-151: a 2-D trajectory on t_cap time grids minimising the total
+    squared velocity, every acceleration bounded by a_cap, start / end positions with zero velocity and two way
+    points.  Unknowns: x-coordinates then y-coordinates (n = 2 t_cap); m = t_cap - 2 quadratic constraints; p = 12."""
+    n, m, dt = 2 * t_cap, t_cap - 2, 1.0 / t_cap
+    D = np.zeros((n, n))
+    for i in range(t_cap - 1):
+        for off in (0, t_cap):
+            D[off + i, off + i], D[off + i, off + i + 1] = -1.0 / dt, 1.0 / dt
+    syms_p, scls_r = [D.T @ D], [0.0]
+    for i in range(m):
+        D2 = np.zeros((n, n))
+        for off in (0, t_cap):
+            D2[off + i, off + i:off + i + 3] = np.array([1.0, -2.0, 1.0]) / (dt * dt)
+        syms_p.append(D2.T @ D2)
+        scls_r.append(-0.5 * a_cap * a_cap)
+    A, b = np.zeros((12, n)), np.zeros(12)
+    x_s, x_m1, x_m2, x_t = (0.0, 0.0), (0.5, -1.5), (0.25, 1.5), (1.0, 1.0)
+    A[0, 0], b[0] = 1.0, x_s[0]
+    A[1, t_cap], b[1] = 1.0, x_s[0]                       # the reference uses x_s.0 for both coordinates (main.rs:101-106)
+    A[2, 0], A[2, 1] = -1.0, 1.0
+    A[3, t_cap], A[3, t_cap + 1] = -1.0, 1.0
+    A[4, t_cap - 1], b[4] = 1.0, x_t[0]
+    A[5, 2 * t_cap - 1], b[5] = 1.0, x_t[1]
+    A[6, t_cap - 2], A[6, t_cap - 1] = -1.0, 1.0
+    A[7, 2 * t_cap - 2], A[7, 2 * t_cap - 1] = -1.0, 1.0
+    t1, t2 = t_cap // 3, t_cap * 2 // 3
+    A[8, t1], b[8] = 1.0, x_m1[0]
+    A[9, t_cap + t1], b[9] = 1.0, x_m1[1]
+    A[10, t2], b[10] = 1.0, x_m2[0]
+    A[11, t_cap + t2], b[11] = 1.0, x_m2[1]
+    return dict(syms_p=syms_p, vecs_q=[np.zeros(n) for _ in range(m + 1)], scls_r=scls_r, mat_a=A, vec_b=b)

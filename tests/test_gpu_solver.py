@@ -583,3 +583,65 @@ def test_two_solves_of_the_same_problem_are_bitwise_identical(T, schedule):
     for u, v in ((a[0], b[0]), (a[1], b[1]), (a[4], b[4]), (a[5], b[5])):
         assert np.array_equal(u, v)
     inst.free()
+
+
+# ---- the reference's QP / QCQP examples as parity cases (constructions in tests/problems.py) ------------------
+
+def test_svm_qp_example_gpu_vs_oracle(T):
+    # examples/svm_qp/src/main.rs:47-106 through ProbQP (sqrt of the kernel matrix on the device eigen engine,
+    # rotated cone + nonneg + zero cone) and the fused loop, eps_acc 1e-3 like the example (main.rs:98-101)
+    from problems import svm_qp, sym_pack
+    l = 30                                  # the example uses 50 samples; 30 keeps the GPU suite short
+    q = svm_qp(l, seed=0)
+    ro = O.solve_qp(O.param(max_iter=2_000_000, eps_acc=1e-3), sym_pack(q["sym_p"]), q["vec_q"], q["mat_g"], q["vec_h"],
+                    q["mat_a"], q["vec_b"])
+    assert ro.status == O.OK
+    sym_p = _mb(T, T.MatType.SymPack(l)).set_by_fn(lambda r, c: q["sym_p"][r, c])
+    qp = T.ProbQP(sym_p, _mb(T, T.MatType.General(l, 1)).set_array(q["vec_q"].reshape(-1, 1)),
+                  _mb(T, T.MatType.General(l, l)).set_array(q["mat_g"]),
+                  _mb(T, T.MatType.General(l, 1)).set_array(q["vec_h"].reshape(-1, 1)),
+                  _mb(T, T.MatType.General(1, l)).set_array(q["mat_a"]),
+                  _mb(T, T.MatType.General(1, 1)).set_array(q["vec_b"].reshape(-1, 1)), 1e-12)
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 2_000_000, 1e-3
+    fs = T.FusedSolver.from_dense(qp.dense(), p, "carried")
+    x, _ = fs.solve(poll_every=256)
+    st = fs.status()
+    fs.destroy()
+    assert st.state == 0 and abs(st.iters - ro.iters) <= 0.1 * ro.iters, (st.iters, ro.iters)
+    a, ar = x[:l].astype(np.float64), ro.x[:l]
+    obj = lambda v: 0.5 * v @ q["sym_p"] @ v - v.sum()
+    assert abs(obj(a) - obj(ar)) <= 2e-3 * (1 + abs(obj(ar))), (obj(a), obj(ar))
+    assert np.abs(a - ar).max() <= 2e-2 * np.abs(ar).max()
+    qp.drop()
+
+
+def test_trajplan_qcqp_example_gpu_vs_oracle(T):
+    # examples/trajplan_qcqp/src/main.rs:19-151 through ProbQCQP: 29 matrix square roots, 29 rotated cones, 12
+    # equality rows; eps_acc 1e-3 like the example
+    from problems import sym_pack, trajplan_qcqp
+    t_cap, a_cap = 15, 70.0                 # the example: 30 grids, a_cap 90; this size keeps the bound active too
+    n = 2 * t_cap
+    c = trajplan_qcqp(t_cap, a_cap)
+    ro = O.solve_qcqp(O.param(max_iter=2_000_000, eps_acc=1e-3), [sym_pack(s) for s in c["syms_p"]], c["vecs_q"],
+                      c["scls_r"], c["mat_a"], c["vec_b"])
+    assert ro.status == O.OK
+    syms = [_mb(T, T.MatType.SymPack(n)).set_by_fn(lambda r, cc, S=S: S[r, cc]) for S in c["syms_p"]]
+    vqs = [_mb(T, T.MatType.General(n, 1)).set_array(v.reshape(-1, 1)) for v in c["vecs_q"]]
+    prob = T.ProbQCQP(syms, vqs, list(c["scls_r"]), _mb(T, T.MatType.General(12, n)).set_array(c["mat_a"]),
+                      _mb(T, T.MatType.General(12, 1)).set_array(c["vec_b"].reshape(-1, 1)), 1e-12)
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 2_000_000, 1e-3
+    fs = T.FusedSolver.from_dense(prob.dense(), p, "carried")
+    x, _ = fs.solve(poll_every=256)
+    st = fs.status()
+    fs.destroy()
+    assert st.state == 0 and abs(st.iters - ro.iters) <= 0.3 * ro.iters, (st.iters, ro.iters)   # f32 square roots of 1/dt^4-scaled matrices
+    xg, xr = x[:n].astype(np.float64), ro.x[:n]
+    obj = lambda v: 0.5 * v @ c["syms_p"][0] @ v
+    assert abs(obj(xg) - obj(xr)) <= 3e-3 * (1 + abs(obj(xr))), (obj(xg), obj(xr))
+    # the primal criterion is relative to 1 + ||b|| (solver.rs:605), and b carries the 0.5 a_cap^2 = 2450 of every
+    # constraint (||b|| ~ 9000): eps_acc 1e-3 leaves the equality rows satisfied to ~0.1 in absolute terms
+    assert np.abs(c["mat_a"] @ xg - c["vec_b"]).max() < 0.15
+    assert np.abs(xg - xr).max() <= 0.1 * np.abs(xr).max()
+    prob.drop()

@@ -239,3 +239,36 @@ def test_partitioning_sdp_construction_on_oracle():
         relax = float(w @ r.x)
         best = min(float(s @ Wm @ s) for s in (np.array([1 if (b >> t) & 1 else -1 for t in range(l)]) for b in range(64)))
         assert relax <= best + 1e-3
+
+
+def test_svm_qp_construction_on_oracle():
+    # examples/svm_qp/src/main.rs:47-106 (ProbQP with a SymPack kernel matrix, one equality row): KKT-level checks
+    from problems import svm_qp, sym_pack
+    q = svm_qp(50, seed=0)
+    r = O.solve_qp(O.param(max_iter=2_000_000, eps_acc=1e-4), sym_pack(q["sym_p"]), q["vec_q"], q["mat_g"], q["vec_h"],
+                   q["mat_a"], q["vec_b"])
+    assert r.status == O.OK
+    a = r.x[:50]
+    assert a.min() > -1e-3 * a.max() and abs(float(q["mat_a"][0] @ a)) < 1e-3 * np.abs(a).sum()
+    # the support vectors (a_i > 0) sit on the margin: y_i (w.x_i + bias) = 1 for a common bias (main.rs:112-121)
+    y = q["mat_a"][0]
+    f = (q["sym_p"] * y[None, :] * y[:, None]) @ (a * y)         # sum_j a_j y_j k(x_i, x_j)
+    sv = a > 1e-2 * a.max()
+    bias = (y[sv] - f[sv]).mean()
+    assert np.abs(y[sv] * (f[sv] + bias) - 1.0).max() < 5e-2
+
+
+def test_trajplan_qcqp_construction_on_oracle():
+    # examples/trajplan_qcqp/src/main.rs:19-151 (ProbQCQP: 28 rotated-cone constraints + 12 equality rows)
+    from problems import sym_pack, trajplan_qcqp
+    t_cap, a_cap = 30, 90.0
+    c = trajplan_qcqp(t_cap, a_cap)
+    r = O.solve_qcqp(O.param(max_iter=2_000_000, eps_acc=1e-3), [sym_pack(s) for s in c["syms_p"]], c["vecs_q"],
+                     c["scls_r"], c["mat_a"], c["vec_b"])
+    assert r.status == O.OK
+    x = r.x[:2 * t_cap]
+    assert np.abs(c["mat_a"] @ x - c["vec_b"]).max() < 2e-3
+    px, py = x[:t_cap], x[t_cap:]
+    acc = np.hypot(np.diff(px, 2), np.diff(py, 2)) * t_cap * t_cap
+    assert acc.max() <= a_cap * 1.01
+    assert acc.max() >= a_cap * 0.9                       # the bound is active somewhere at a_cap = 90 (the example's point)
