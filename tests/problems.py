@@ -172,3 +172,61 @@ def trajplan_qcqp(t_cap=30, a_cap=90.0):
     A[10, t2], b[10] = 1.0, x_m2[0]
     A[11, t_cap + t2], b[11] = 1.0, x_m2[1]
     return dict(syms_p=syms_p, vecs_q=[np.zeros(n) for _ in range(m + 1)], scls_r=scls_r, mat_a=A, vec_b=b)
+
+
+def toruscompl_socp(x_num=9, y_num=7, vol_ratio=0.2):
+    """The SOCP of examples/toruscompl_socp/src/main.rs:43-268: compliance minimisation of a planar truss on an
+    x_num x y_num grid of nodes (left column clamped, unit downward load on the middle node of the right column).
+    Members: right and up neighbours of every node, plus the four diagonals and (1,-1)/(-1,-1) from nodes with odd x
+    and even y.  Unknowns [x (cross sections), q (member forces), w (energies)], n = 3 l.  3 l + 1 cones: l of
+    1 + 2 rows (w_i x_i >= v_i q_i^2 / 2 as a second-order cone), then 2 l + 1 cones WITHOUT rows (0 <= x_i <= 1 and the
+    volume bound, i.e. one-dimensional cones c^T x + d >= 0), and one equality row per free degree of freedom."""
+    nodes = [(x, y) for x in range(x_num) for y in range(y_num)]
+    idx = {xy: k for k, xy in enumerate(nodes)}
+    members = []
+    for (hx, hy) in nodes:
+        steps = [(1, 0), (0, 1), (1, 1), (-1, 1), (1, -1), (-1, -1)] if (hx % 2 == 1 and hy % 2 == 0) else [(1, 0), (0, 1)]
+        for dx, dy in steps:
+            if (hx + dx, hy + dy) in idx:
+                members.append((idx[(hx, hy)], idx[(hx + dx, hy + dy)]))
+    load = {k: (0.0, 0.0) for k in range(len(nodes))}
+    for y in range(y_num):
+        load[idx[(0, y)]] = None                                   # clamped: no degrees of freedom
+    load[idx[(x_num - 1, y_num // 2)]] = (0.0, -1.0)
+    dof_of, dof = {}, 0
+    for k in range(len(nodes)):
+        dof_of[k] = dof
+        if load[k] is not None:
+            dof += 2
+    l = len(members)
+    n = 3 * l
+    length = np.array([np.hypot(nodes[h][0] - nodes[t][0], nodes[h][1] - nodes[t][1]) for h, t in members])
+    f = np.concatenate([np.zeros(2 * l), np.ones(l)])
+    mats_g, vecs_h, vecs_c, d = [], [], [], []
+    for i in range(l):
+        G = np.zeros((2, n))
+        G[0, i], G[0, 2 * l + i], G[1, l + i] = -1.0, 1.0, np.sqrt(2.0 * length[i])
+        c = np.zeros(n)
+        c[i], c[2 * l + i] = 1.0, 1.0
+        mats_g.append(G); vecs_h.append(np.zeros(2)); vecs_c.append(c); d.append(0.0)
+    for sign, off in ((1.0, 0.0), (-1.0, 1.0)):
+        for i in range(l):
+            c = np.zeros(n)
+            c[i] = sign
+            mats_g.append(np.zeros((0, n))); vecs_h.append(np.zeros(0)); vecs_c.append(c); d.append(off)
+    c = np.zeros(n)
+    c[:l] = -length
+    mats_g.append(np.zeros((0, n))); vecs_h.append(np.zeros(0)); vecs_c.append(c); d.append(vol_ratio * length.sum())
+    A, b = np.zeros((dof, n)), np.zeros(dof)
+    for i, (h, t) in enumerate(members):
+        beta = np.array([nodes[t][0] - nodes[h][0], nodes[t][1] - nodes[h][1]], float)
+        beta /= np.hypot(*beta)
+        if load[h] is not None:
+            A[dof_of[h], l + i] -= beta[0]; A[dof_of[h] + 1, l + i] -= beta[1]
+        if load[t] is not None:
+            A[dof_of[t], l + i] += beta[0]; A[dof_of[t] + 1, l + i] += beta[1]
+    for k in range(len(nodes)):
+        if load[k] is not None:
+            b[dof_of[k]], b[dof_of[k] + 1] = load[k]
+    return dict(vec_f=f, mats_g=mats_g, vecs_h=vecs_h, vecs_c=vecs_c, scls_d=d, mat_a=A, vec_b=b, members=members,
+                length=length)

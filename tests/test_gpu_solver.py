@@ -645,3 +645,32 @@ def test_trajplan_qcqp_example_gpu_vs_oracle(T):
     assert np.abs(c["mat_a"] @ xg - c["vec_b"]).max() < 0.15
     assert np.abs(xg - xr).max() <= 0.1 * np.abs(xr).max()
     prob.drop()
+
+
+def test_toruscompl_socp_example_gpu_vs_oracle(T):
+    # examples/toruscompl_socp/src/main.rs:43-268 at the example's size through ProbSOCP and the fused loop: 158 cones
+    # of 1 + 2 rows and 317 cones of 1 + 0 rows in one batched launch, 112 zero-cone rows; eps_acc 1e-3 like the example
+    from problems import toruscompl_socp
+    q = toruscompl_socp(9, 7, 0.2)
+    n = q["vec_f"].size
+    ro = O.solve_socp(O.param(max_iter=1_000_000, eps_acc=1e-3), q["vec_f"], q["mats_g"], q["vecs_h"], q["vecs_c"],
+                      q["scls_d"], q["mat_a"], q["vec_b"])
+    assert ro.status == O.OK
+    col = lambda v: np.asarray(v, np.float32).reshape(-1, 1)
+    socp = T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(col(q["vec_f"])),
+                      [_mb(T, T.MatType.General(G.shape[0], n)).set_array(G) for G in q["mats_g"]],
+                      [_mb(T, T.MatType.General(len(h_), 1)).set_array(col(h_)) for h_ in q["vecs_h"]],
+                      [_mb(T, T.MatType.General(n, 1)).set_array(col(c_)) for c_ in q["vecs_c"]], list(q["scls_d"]),
+                      _mb(T, T.MatType.General(q["vec_b"].size, n)).set_array(q["mat_a"]),
+                      _mb(T, T.MatType.General(q["vec_b"].size, 1)).set_array(col(q["vec_b"])))
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 1_000_000, 1e-3
+    for sched in ("reference", "carried"):
+        fs = T.FusedSolver.from_dense(socp.dense(), p, sched)
+        x, _ = fs.solve(poll_every=64)
+        st = fs.status()
+        fs.destroy()
+        assert st.state == 0 and abs(st.iters - ro.iters) <= 0.05 * ro.iters + 5, (sched, st.iters, ro.iters)
+        obj, obj_r = float(q["vec_f"] @ x.astype(np.float64)), float(q["vec_f"] @ ro.x)
+        assert abs(obj - obj_r) <= 1e-3 * (1 + abs(obj_r)), (sched, obj, obj_r)
+        assert np.abs(x - ro.x).max() <= 1e-2 * np.abs(ro.x).max(), sched

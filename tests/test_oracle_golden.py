@@ -272,3 +272,20 @@ def test_trajplan_qcqp_construction_on_oracle():
     acc = np.hypot(np.diff(px, 2), np.diff(py, 2)) * t_cap * t_cap
     assert acc.max() <= a_cap * 1.01
     assert acc.max() >= a_cap * 0.9                       # the bound is active somewhere at a_cap = 90 (the example's point)
+
+
+def test_toruscompl_socp_construction_on_oracle():
+    # examples/toruscompl_socp/src/main.rs:43-268 at the example's size (9 x 7 nodes): 158 three-row cones, 317 cones
+    # WITHOUT rows (bounds and the volume constraint as one-dimensional cones), 112 equality rows
+    from problems import toruscompl_socp
+    q = toruscompl_socp(9, 7, 0.2)
+    l = len(q["members"])
+    assert (l, q["vec_b"].size) == (158, 112)
+    r = O.solve_socp(O.param(max_iter=1_000_000, eps_acc=1e-3), q["vec_f"], q["mats_g"], q["vecs_h"], q["vecs_c"],
+                     q["scls_d"], q["mat_a"], q["vec_b"])
+    assert r.status == O.OK
+    x, qf, w = r.x[:l], r.x[l:2 * l], r.x[2 * l:3 * l]
+    assert x.min() > -1e-3 and x.max() < 1 + 1e-3
+    assert abs(float(q["length"] @ x) / (0.2 * q["length"].sum()) - 1.0) < 5e-3          # the volume bound is active
+    assert np.abs(q["mat_a"] @ r.x - q["vec_b"]).max() < 1e-2                               # force balance at every free node
+    assert np.all(2.0 * w * x + 1e-2 >= q["length"] * qf * qf)                               # w_i x_i >= v_i q_i^2 / 2
