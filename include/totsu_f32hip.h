@@ -210,6 +210,11 @@ int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
  * finish on the exact matrix) -- the iteration is a fixed-point method, so the iterate carries over.
  * prob->mat_a must stay valid while THIP_A_F32 may still be selected. */
 int thip_solver_set_a_storage(thip_solver *s, int a_kind);
+/* A caller-built bf16 matrix (thip_to_bf16 on column blocks, or any producer of bf16 bit patterns), column-major with
+ * leading dimension ld16 >= m; before thip_solver_init; prob->mat_a may then be NULL (and THIP_A_F32 cannot be
+ * selected).  The f32 matrix never has to exist as a whole: a 16-bit A is half the HBM footprint, e.g. BASELINE.json's
+ * 320 GB LP (configs[4]) is 160 GB and fits one 288 GB MI355X.  The matrix stays caller-owned. */
+int thip_solver_set_a_bf16(thip_solver *s, const uint16_t *mat16, size_t ld16);
 int thip_solver_init(thip_solver *s);                                 /* calc_norms + init_vecs + calc_precond, solver.rs:460-524 */
 /* enqueue up to max_steps iterations (the device stops by itself on termination), poll every
  * `poll_every` iterations; returns when terminated or after max_steps.  SYNC. */

@@ -99,6 +99,7 @@ extern "C" {
                                dev_vals: *const f32, dev_t_rowptr: *const i64, dev_t_colidx: *const i32,
                                dev_t_vals: *const f32) -> c_int;
     pub fn thip_solver_set_a_storage(s: *mut thip_solver, a_kind: c_int) -> c_int;
+    pub fn thip_solver_set_a_bf16(s: *mut thip_solver, mat16: *const u16, ld16: usize) -> c_int;
     pub fn thip_solver_set_param(s: *mut thip_solver, par: *const thip_param) -> c_int;
     pub fn thip_solver_resume(s: *mut thip_solver) -> c_int;
     pub fn thip_solver_status(s: *mut thip_solver, host_status: *mut thip_status) -> c_int;

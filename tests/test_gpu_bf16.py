@@ -234,3 +234,37 @@ def test_resume_after_excess_iter_reaches_the_same_answer(T):
     fs.destroy()
     assert abs(r3.iters - r2.iters) <= 2, (r2.iters, r3.iters)
     assert np.allclose(x2, x3, rtol=1e-4, atol=1e-5 * np.abs(x3).max())
+
+
+def test_caller_built_bf16_matrix_needs_no_f32_copy(T):
+    # thip_solver_set_a_bf16: the matrix arrives as bf16 column blocks; same bits as the library's own conversion, so the
+    # two solves are identical -- and the block-wise generator of synth.LpInstance produces exactly those bits
+    from totsu_amd import synth
+    n = 48
+    inst = synth.LpInstance(n, seed=5)
+    direct = synth.LpInstance(n, seed=5, bf16_direct=True, block_cols=7)
+    conv = T.Bf16Matrix.from_f32(inst.mat_a, inst.m, n)
+    a = direct.mat_a._buf.to_host().view(np.uint16)[:conv.ld16 * n]
+    b = conv._buf.to_host().view(np.uint16)[:conv.ld16 * n]
+    assert np.array_equal(a, b)
+    assert np.array_equal(b.reshape(n, conv.ld16)[:, :inst.m], bf16_bits(inst.mat_a.to_host()[:inst.m * n]).reshape(n, inst.m))
+    p = T.SolverParam()
+    p.eps_acc, p.max_iter = 1e-4, 200_000
+    res = []
+    for mat, kw in ((inst.mat_a, dict(a_storage="bf16")), (direct.mat_a, {})):
+        fs = T.FusedSolver(n, inst.m, mat, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried", **kw)
+        assert fs.a_storage == "bf16" and fs.passes()[1] == 2 * n * inst.m
+        r = fs.run(-1, poll_every=64)
+        x, y = fs.solution()
+        res.append((r.iters, x.copy(), y.copy()))
+        if not kw:
+            with pytest.raises(_lib_error(T)):
+                fs.set_a_storage("f32")                    # there is no f32 matrix to go back to
+        fs.destroy()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    conv.free(); direct.free(); inst.free()
+
+
+def _lib_error(T):
+    from totsu_amd._lib import ThipError
+    return ThipError

@@ -10,11 +10,11 @@ from .linalg import F32HIP, F32HIPSlice, splitm
 from .cone import ConeZero, ConeRPos, ConeSOC, ConeRotSOC, ConePSD
 from .matbuild import MatBuild
 from .problem import ProbLP, ProbSOCP, ProbSDP, ProbQP, ProbQCQP
-from .fused import FusedSolver, DeviceBuffer
+from .fused import FusedSolver, DeviceBuffer, Bf16Matrix
 from .parallel import ShardedSolver, TorchComm, shard_segments
 from .sparse import SparseMatOp
 
 __all__ = ["MatOp", "MatType", "Solver", "SolverError", "SolverParam", "F32HIP", "F32HIPSlice", "splitm",
            "ConeZero", "ConeRPos", "ConeSOC", "ConeRotSOC", "ConePSD", "MatBuild", "ProbLP", "ProbSOCP",
-           "ProbSDP", "ProbQP", "ProbQCQP", "FusedSolver", "DeviceBuffer", "ShardedSolver", "TorchComm",
+           "ProbSDP", "ProbQP", "ProbQCQP", "FusedSolver", "DeviceBuffer", "Bf16Matrix", "ShardedSolver", "TorchComm",
            "shard_segments", "SparseMatOp"]

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "thip_solver_set_csr": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thip_solver_set_allreduce": (_i, [_vp, ALLREDUCE_FN, _vp]),
     "thip_solver_set_a_storage": (_i, [_vp, _i]),
+    "thip_solver_set_a_bf16": (_i, [_vp, _vp, _sz]),
     "thip_solver_resume": (_i, [_vp]),
     "thip_solver_set_param": (_i, [_vp, _vp]),
     "thip_solver_init": (_i, [_vp]),

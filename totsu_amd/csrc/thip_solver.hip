@@ -491,7 +491,7 @@ struct thip_solver {
     float *gemv_scr = nullptr; size_t gemv_scr_n = 0;
     GemvHint hint{0, 0}; bool tuned = false; float tuned_ms = 0.0f;
     // storage of A streamed by the iteration: the caller's f32 matrix, or an owned bf16 copy (ld16 = m rounded to 8)
-    int a_kind = THIP_A_F32; uint16_t *A16 = nullptr; size_t ld16 = 0;
+    int a_kind = THIP_A_F32; uint16_t *A16 = nullptr; size_t ld16 = 0; bool A16_owned = false;
     GemvHint hint16{0, 0}; bool tuned16 = false; float tuned16_ms = 0.0f;
     const void *amat() const { return a_kind == THIP_A_BF16 ? (const void *)A16 : (const void *)A; }
     size_t alda() const { return a_kind == THIP_A_BF16 ? ld16 : m; }
@@ -986,6 +986,20 @@ int thip_solver_precond(thip_solver *s, float *host_dp_tau, float *host_dp_sigma
     return 0;
 }
 
+int thip_solver_set_a_bf16(thip_solver *s, const uint16_t *mat16, size_t ld16)
+{
+    THIP_NEED_INIT();
+    if (!s || !mat16) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    if (s->inited) return fail(THIP_E_INVALID, "thip_solver_set_a_bf16 must precede thip_solver_init", __FILE__, __LINE__);
+    if (s->sparse) return fail(THIP_E_INVALID, "storage kinds apply to a dense A", __FILE__, __LINE__);
+    if (ld16 < s->m) return fail(THIP_E_INVALID, "ld16 < m", __FILE__, __LINE__);
+    if (s->A16_owned) { THIP_TRY(hipFree(s->A16)); s->A16_owned = false; }
+    s->A16 = const_cast<uint16_t *>(mat16);      // caller-owned, only ever read
+    s->ld16 = ld16;
+    s->a_kind = THIP_A_BF16;
+    return 0;
+}
+
 int thip_solver_set_a_storage(thip_solver *s, int a_kind)
 {
     THIP_NEED_INIT();
@@ -997,6 +1011,7 @@ int thip_solver_set_a_storage(thip_solver *s, int a_kind)
         if (!s->A) return fail(THIP_E_INVALID, "no f32 matrix to convert", __FILE__, __LINE__);
         s->ld16 = (s->m + 7) / 8 * 8;
         THIP_TRY(hipMalloc((void **)&s->A16, s->ld16 * s->n * sizeof(uint16_t)));
+        s->A16_owned = true;
         THIP_RC(to_bf16(ctx().stream, s->m, s->n, s->A, s->A16, s->ld16));
     }
     s->a_kind = a_kind;
@@ -1079,7 +1094,7 @@ int thip_solver_destroy(thip_solver *s)
     if (ctx().inited) hipStreamSynchronize(ctx().stream);
     hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
-    hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->A16);
+    hipFree(s->gemv_scr); hipFree(s->dst); if (s->A16_owned) hipFree(s->A16);
     if (s->hst) hipHostFree(s->hst);
     delete s;
     return 0;

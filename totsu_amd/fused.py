@@ -52,6 +52,38 @@ class DeviceBuffer:
 A_STORAGE = {"f32": 0, "bf16": 1}
 
 
+class Bf16Matrix:
+    """A dense m x n matrix held on the device as bf16 bit patterns only (column-major, leading dimension ld16 = m
+    rounded up to 8): built from f32 column blocks that are converted in place of being kept (thip_to_bf16), so the f32
+    matrix never exists as a whole.  Accepted by FusedSolver as `mat_a` (thip_solver_set_a_bf16)."""
+
+    def __init__(self, m, n):
+        _lib.ensure_init()
+        self.m, self.n = int(m), int(n)
+        self.ld16 = (self.m + 7) // 8 * 8
+        self._buf = DeviceBuffer((self.ld16 * self.n + 1) // 2 + 4)      # 2 elements per float slot
+        self.ptr = self._buf.ptr
+
+    def set_columns(self, c0, block, ncols):
+        """columns c0 .. c0 + ncols of the matrix <- the f32 block (DeviceBuffer, m x ncols, lda = m)"""
+        assert 0 <= c0 and c0 + ncols <= self.n and block.n >= self.m * ncols
+        lib.thip_to_bf16(self.m, ncols, block.ptr, self.ptr + 2 * self.ld16 * c0, self.ld16)
+
+    @staticmethod
+    def from_f32(mat, m, n):
+        """mat: DeviceBuffer or host array, column-major m x n"""
+        d = mat if isinstance(mat, DeviceBuffer) else DeviceBuffer.from_host(mat)
+        out = Bf16Matrix(m, n)
+        out.set_columns(0, d, n)
+        if d is not mat:
+            d.free()
+        return out
+
+    def free(self):
+        self._buf.free()
+        self.ptr = None
+
+
 class FusedResult:
     def __init__(self, st):
         self.state = st.state
@@ -80,14 +112,19 @@ class FusedSolver:
             self._csr = (_Csr(mat_a), _Csr(mat_a.T))
             mat_a = DeviceBuffer(1)
             self._owned.append(mat_a)
-        self.mat_a = self._dev(mat_a, 1 if self._csr else self.n * self.m)
+        self._a16 = mat_a if isinstance(mat_a, Bf16Matrix) else None
+        if self._a16 is not None:
+            assert (mat_a.m, mat_a.n) == (self.m, self.n)
+            mat_a = DeviceBuffer(1)                       # no f32 matrix: thip_problem.mat_a is not read
+            self._owned.append(mat_a)
+        self.mat_a = self._dev(mat_a, 1 if (self._csr or self._a16 is not None) else self.n * self.m)
         self.vec_b = self._dev(vec_b, self.m)
         self.vec_c = self._dev(vec_c, self.n)
         self.vec_b_rowabs = None if vec_b_rowabs is None else self._dev(vec_b_rowabs, self.m)
         self.param = param or SolverParam()
         self._st = np.ascontiguousarray(seg_type, dtype=np.int32)
         self._sl = np.ascontiguousarray(seg_len, dtype=np.int64)
-        prob = _lib.Problem(self.n, self.m, self.mat_a.ptr, self.vec_b.ptr, self.vec_c.ptr,
+        prob = _lib.Problem(self.n, self.m, None if self._a16 is not None else self.mat_a.ptr, self.vec_b.ptr, self.vec_c.ptr,
                             None if self.vec_b_rowabs is None else self.vec_b_rowabs.ptr, len(self._st),
                             self._st.ctypes.data_as(C.POINTER(C.c_int32)),
                             self._sl.ctypes.data_as(C.POINTER(C.c_int64)))
@@ -109,7 +146,10 @@ class FusedSolver:
             self._cb = _lib.ALLREDUCE_FN(allreduce)
             lib.thip_solver_set_allreduce(self.h, self._cb, None)
         self.a_storage = "f32"
-        if a_storage != "f32":
+        if self._a16 is not None:
+            lib.thip_solver_set_a_bf16(self.h, self._a16.ptr, self._a16.ld16)
+            self.a_storage = "bf16"
+        elif a_storage != "f32":
             self.set_a_storage(a_storage)
         lib.thip_solver_init(self.h)
 

@@ -94,7 +94,9 @@ class SocpInstance:
 class LpInstance:
     """device-resident row shard of the benchmark_lp construction (rows split evenly; nonneg cone is separable)"""
 
-    def __init__(self, n, seed=0, rank=0, world=1):
+    def __init__(self, n, seed=0, rank=0, world=1, bf16_direct=False, block_cols=2048):
+        """bf16_direct: build the shard as a Bf16Matrix from f32 column blocks of block_cols columns (identical
+        entries, rounded); the f32 shard is never allocated -- for shards that only fit HBM at 16 bits per entry."""
         _lib.ensure_init()
         self.n = n
         self.m_total = 2 * n
@@ -103,13 +105,26 @@ class LpInstance:
         r1 = r0 + base + (1 if rank < rem else 0)
         self.r0, self.r1 = r0, r1
         m = self.m = r1 - r0
-        self.mat_a = DeviceBuffer(max(m * n, 1))
-        lib.thip_gen_matrix(self.mat_a.ptr, m, n, m, seed, STREAM_A, r0, 0, self.m_total, 0, 1.0, 0.0)
-        # rows r < n of the full matrix are -I: overwrite that part of the shard on the device (the first k rows of
-        # the column-major shard share its base pointer and lda)
-        if r0 < n:
-            k = min(n, r1) - r0
-            lib.thip_gen_identity(self.mat_a.ptr, k, n, m, r0, -1.0)
+        if bf16_direct:
+            from .fused import Bf16Matrix
+            self.mat_a = Bf16Matrix(m, n)
+            blk = DeviceBuffer(max(m * min(block_cols, n), 1))
+            for c0 in range(0, n, block_cols):
+                nc = min(block_cols, n - c0)
+                lib.thip_gen_matrix(blk.ptr, m, nc, m, seed, STREAM_A, r0, c0, self.m_total, 0, 1.0, 0.0)
+                if r0 < n:      # -I rows: (r0 + r == c0 + c) in the block's own column index
+                    lib.thip_gen_identity(blk.ptr, min(n, r1) - r0, nc, m, (r0 - c0) & 0xFFFFFFFFFFFFFFFF, -1.0)
+                self.mat_a.set_columns(c0, blk, nc)
+            lib.thip_sync()
+            blk.free()
+        else:
+            self.mat_a = DeviceBuffer(max(m * n, 1))
+            lib.thip_gen_matrix(self.mat_a.ptr, m, n, m, seed, STREAM_A, r0, 0, self.m_total, 0, 1.0, 0.0)
+            # rows r < n of the full matrix are -I: overwrite that part of the shard on the device (the first k rows
+            # of the column-major shard share its base pointer and lda)
+            if r0 < n:
+                k = min(n, r1) - r0
+                lib.thip_gen_identity(self.mat_a.ptr, k, n, m, r0, -1.0)
         h = _gen(max(m, 1), seed, STREAM_H, r0, 0)[:m]
         h[np.arange(r0, r1) < n] = 0.0
         self.vec_b_host = h
