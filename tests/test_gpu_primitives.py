@@ -216,3 +216,34 @@ def test_rng_matches_oracle_bitwise(L):
     mm = m.to_host().reshape((5, 12)).T
     assert mm[3, 2] == np.float32(0.5) * np.float32(O.rng_normal(1, 2, (10 + 2) * 1000 + 100 + 3))
     d.free(); m.free()
+
+
+@pytest.mark.parametrize("rot", [0, 1])
+def test_soc_batched_moreau_decomposition_at_configs2_layout(L, rot):
+    # BASELINE.json configs[2]: 1000 cones of 1 + 99 rows in one launch.  Size-independent properties of a projection
+    # onto a self-dual cone K (cone_soc.rs:38-65, cone_rotsoc.rs:38-65): P(P(x)) = P(x);  x = P(x) - P(-x);  <P(x), P(-x)> = 0
+    from totsu_amd._lib import lib
+    from totsu_amd.fused import DeviceBuffer
+    rng = np.random.default_rng(3 + rot)
+    ncone, ln = 1000, 100
+    offs = (np.arange(ncone + 1) * ln).astype(np.int64)
+    x = rng.standard_normal(ncone * ln).astype(np.float32)
+    x[::ln] *= rng.choice([0.1, 1.0, 10.0], ncone).astype(np.float32) * 5.0       # inside / boundary region / outside mix
+    od = DeviceBuffer(2 * len(offs))
+    lib.thip_h2d(od.ptr, offs.ctypes.data, 2 * len(offs))
+
+    def proj(v):
+        d = DeviceBuffer.from_host(v)
+        lib.thip_proj_soc_batched(d.ptr, od.ptr, ncone, rot, ln)
+        out = d.to_host()
+        d.free()
+        return out
+
+    p, q = proj(x), proj(-x)
+    scale = np.abs(x).reshape(ncone, ln).max(axis=1).repeat(ln)
+    assert np.all(np.abs(proj(p) - p) <= 2e-6 * scale)
+    assert np.all(np.abs(p - q - x) <= 4e-6 * scale)
+    dots = (p.astype(np.float64) * q).reshape(ncone, ln).sum(axis=1)
+    norms = np.linalg.norm(p.reshape(ncone, ln), axis=1) * np.linalg.norm(q.reshape(ncone, ln), axis=1)
+    assert np.all(np.abs(dots) <= 1e-5 * (norms + 1e-30) + 1e-30)
+    od.free()
