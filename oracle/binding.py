@@ -346,6 +346,11 @@ def num_threads():
     return int(lib().oc_num_threads())
 
 
+def set_num_threads(k):
+    """OpenMP threads of the oracle from now on (small problems: a handful beats every core of a big host)"""
+    lib().oc_set_num_threads(int(k))
+
+
 def gen_matrix(n_row, n_col, seed, stream, row0, col0, ld_index, kind, scale, shift=0.0):
     """column-major (n_row x n_col) block of the synthetic matrix, f64 holding the exact f32 entries"""
     out = np.empty(n_row * n_col, dtype=np.float64)

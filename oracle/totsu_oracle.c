@@ -16,6 +16,17 @@
 #include <omp.h>
 #endif
 
+/* test / bench convenience (no counterpart in the reference): small problems run faster on a few threads than on
+ * every core of a large host, where each parallel region costs more than the loop it splits */
+void oc_set_num_threads(int k)
+{
+#ifdef _OPENMP
+    if (k > 0) omp_set_num_threads(k);
+#else
+    (void)k;
+#endif
+}
+
 int oc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -158,6 +158,7 @@ void oc_gen_matrix(double *out, size_t n_row, size_t n_col, size_t lda, uint64_t
 void oc_gen_vector(double *out, size_t n, uint64_t seed, uint64_t stream, uint64_t idx0, int kind, float scale, float shift);
 
 int oc_num_threads(void);
+void oc_set_num_threads(int k);
 
 #ifdef __cplusplus
 }

@@ -283,12 +283,29 @@ def _synth_dense_to_host(inst):
     return a, inst.vec_b_host.astype(np.float64), inst.vec_c_host.astype(np.float64)
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle_few_threads(key, fn):
+    """the oracle's answer for a small instance, computed once per module and on 8 OpenMP threads: on the GPU box's
+    256-CPU host every parallel region costs more than the 1000 x 500 loop it splits (2 x 110 s of the suite before)"""
+    if key not in _ORACLE_CACHE:
+        k = O.num_threads()
+        O.set_num_threads(min(k, 8))
+        try:
+            _ORACLE_CACHE[key] = fn()
+        finally:
+            O.set_num_threads(k)
+    return _ORACLE_CACHE[key]
+
+
 @pytest.mark.parametrize("schedule", ["fused", "carried"])
 def test_synth_socp_converges_to_oracle_objective(T, schedule):
     from totsu_amd import synth
     inst = synth.SocpInstance(500, 10, 99, seed=3)
     a, b, c = _synth_dense_to_host(inst)
-    ro = O.solve_matop_cones(O.param(max_iter=400000, eps_acc=1e-5), c, a, b, [O.CONE_SOC] * 10, [100] * 10)
+    ro = _oracle_few_threads("synth_socp_500_10", lambda: O.solve_matop_cones(
+        O.param(max_iter=400000, eps_acc=1e-5), c, a, b, [O.CONE_SOC] * 10, [100] * 10))
     assert ro.status == O.OK
     pobj, dobj = float(c @ ro.x), -float(b @ ro.y)
     assert abs(pobj - dobj) <= 1e-4 * (1 + abs(pobj))
