@@ -69,7 +69,9 @@ def test_level1(L, n, off):
 
 
 SHAPES = [(1, 1), (3, 2), (4, 4), (99, 50), (100, 64), (256, 33), (1024, 17), (1028, 300), (4096, 129),
-          (5000, 1030), (20000, 37), (8, 5000), (33000, 70)]
+          (5000, 1030), (20000, 37), (8, 5000), (33000, 70),
+          # the n x 1 / 1 x n operators of c, b (solver.rs:129-130, 599-603) and other extreme aspect ratios
+          (100_000, 1), (1, 100_000), (2, 70_001), (300_001, 3)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
