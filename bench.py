@@ -353,10 +353,10 @@ def run(a):
         "algorithmic_frac": b_iter * iters_per_s / 1e9 / world / HBM_PEAK_GBPS,
     }
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(prof) and a.a_storage == "f32":
+    if os.path.exists(prof) and a.a_storage in ("f32", "bf16"):
         try:
             tr = json.load(open(prof))
-            key = "%s_n%d_m%d_%s" % (a.workload, n, inst.m, a.schedule)
+            key = "%s_n%d_m%d_%s%s" % (a.workload, n, inst.m, a.schedule, "" if a.a_storage == "f32" else "_bf16")
             if key in tr:
                 roofline["traffic"] = tr[key]["hbm_bytes_per_launch"]
         except Exception:

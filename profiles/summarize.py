@@ -52,7 +52,8 @@ def pmc(fetch_db, write_db, key):
         for name, calls, val, dur in cur.execute(q, (label,)):
             short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             print("%-6d %-16.1f %-12.1f %s" % (calls, val, dur / 1e3, short))
-            if short.startswith("dual_gemv_k<") and ", true, true, false" in short:     # DO_N, DO_T, !ABS
+            if short.startswith("dual_gemv_k<") and ", true, true, false" in short \
+                    and ("unsigned short" in short) == key.endswith("_bf16"):                # DO_N, DO_T, !ABS; storage type
                 out.setdefault(label, val)      # rows are ordered by total traffic: keep the dominant plan
         print()
     if "FETCH_SIZE" in out:
