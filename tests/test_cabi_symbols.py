@@ -57,3 +57,18 @@ def test_authored_rust_binding_declares_every_symbol():
     src = open(os.path.join(ROOT, "rust", "totsu_f32hip", "src", "ffi.rs")).read()
     rust = set(re.findall(r"pub fn (thip_[a-z0-9_]+)\s*\(", src))
     assert rust == set(_declared()), rust ^ set(_declared())
+
+
+def test_authored_rust_binding_has_the_header_arities():
+    # second line of defence for the uncompiled crate: every extern declaration takes as many arguments as the header says
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "totsu_f32hip.h")).read(), flags=re.S)
+    arity = {}
+    for m in re.finditer(r"\b(thip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        arity[m.group(1)] = 0 if args in ("void", "") else args.count(",") + 1
+    for path in (os.path.join(ROOT, "rust", "totsu_f32hip", "src", "ffi.rs"), os.path.join(ROOT, "INTEGRATION.md")):
+        src = open(path).read()
+        for m in re.finditer(r"pub fn (thip_[a-z0-9_]+)\(([^;]*?)\)\s*(->[^;]*)?;", src, flags=re.S):
+            if m.group(1) in arity:
+                n = 0 if not m.group(2).strip() else m.group(2).count(":")
+                assert n == arity[m.group(1)], (path, m.group(1), n, arity[m.group(1)])
