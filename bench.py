@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--n", "--size", dest="n", type=int, default=None, help="number of variables (use --size under torchrun: --n is an ambiguous prefix there)")
     ap.add_argument("--cones", type=int, default=1000)
     ap.add_argument("--schedule", default="carried", choices=["reference", "fused", "carried"])
-    ap.add_argument("--a-storage", default="f32", choices=["f32", "bf16", "mixed"],
+    ap.add_argument("--a-storage", default="f32", choices=["f32", "bf16", "f16", "mixed"],
                     help="stored form of A streamed by the iteration (default f32 = the reference's data). bf16: a rounded copy, "
                          "half the bytes per pass, f32 accumulation -- solves the ROUNDED problem, not the headline metric. "
                          "mixed (with --to-eps): bf16 passes to eps, then f32 passes to eps on the exact matrix")
@@ -305,7 +305,7 @@ def run(a):
         if hook is None:
             hook, coll = TorchAllreduce(torch, dist), "torch.distributed.all_reduce hook (nccl)"
     fs = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, a.schedule,
-                       allreduce=hook, a_storage="f32" if a.a_storage == "f32" else "bf16")
+                       allreduce=hook, a_storage={"f32": "f32", "f16": "f16"}.get(a.a_storage, "bf16"))
 
     def barrier():
         if use_dist:
@@ -353,10 +353,10 @@ def run(a):
         "algorithmic_frac": b_iter * iters_per_s / 1e9 / world / HBM_PEAK_GBPS,
     }
     prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(prof) and a.a_storage in ("f32", "bf16"):
+    if os.path.exists(prof) and a.a_storage in ("f32", "bf16", "f16"):
         try:
             tr = json.load(open(prof))
-            key = "%s_n%d_m%d_%s%s" % (a.workload, n, inst.m, a.schedule, "" if a.a_storage == "f32" else "_bf16")
+            key = "%s_n%d_m%d_%s%s" % (a.workload, n, inst.m, a.schedule, "" if a.a_storage == "f32" else "_" + a.a_storage)
             if key in tr:
                 roofline["traffic"] = tr[key]["hbm_bytes_per_launch"]
         except Exception:
@@ -375,7 +375,7 @@ def run(a):
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32" if a.a_storage == "f32" else "f32 arithmetic on a bf16-STORED A (rounded problem; not the headline)",
+        "dtype": "f32" if a.a_storage == "f32" else "f32 arithmetic on a 16-bit-STORED A (%s; rounded problem; not the headline)" % a.a_storage,
         "data": "synthetic (counter-based generator on device, seed 0)",
         "config": {"workload": wl, "schedule": a.schedule, "passes_over_A_per_iter": passes,
                    "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll,
@@ -387,7 +387,7 @@ def run(a):
         p2 = T.SolverParam()
         p2.eps_acc = a.to_eps
         fs2 = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
-                            a.schedule, allreduce=hook, a_storage="f32" if a.a_storage == "f32" else "bf16")
+                            a.schedule, allreduce=hook, a_storage={"f32": "f32", "f16": "f16"}.get(a.a_storage, "bf16"))
         barrier()
         t0 = time.perf_counter()
         r2 = fs2.run(-1, poll_every=64)

@@ -81,10 +81,17 @@ int thip_transform_sp(size_t n, float alpha, const float *mat, const float *x, f
  * bf16 elements (round to nearest even), f32 accumulation.  mat16 is column-major with leading dimension ld16 >= n_row
  * (a multiple of 8 and a 16-byte aligned base give the 16-byte-load kernel); rows n_row..ld16 are written as zeros.
  * thip_transform_ge_bf16 has the semantics of thip_transform_ge on the rounded matrix. */
-enum { THIP_A_F32 = 0, THIP_A_BF16 = 1 };
+enum { THIP_A_F32 = 0, THIP_A_BF16 = 1, THIP_A_F16 = 2 };
 int thip_to_bf16(size_t n_row, size_t n_col, const float *mat, uint16_t *mat16, size_t ld16);
 int thip_transform_ge_bf16(int transpose, size_t n_row, size_t n_col, float alpha, const uint16_t *mat16, size_t ld16,
                            const float *x, float beta, float *y);
+/* The same with IEEE f16 elements and one power-of-two scale per column (8x finer rounding than bf16 at the same
+ * bytes; the scale keeps any f32 column inside f16's range): stored(r, c) = f16(a(r, c) * s_c), s_c the power of two
+ * that brings the column's largest magnitude into [2^13, 2^14); inv_scale[c] = 1 / s_c (n_col floats, written by
+ * thip_to_f16, read by the products). */
+int thip_to_f16(size_t n_row, size_t n_col, const float *mat, uint16_t *mat16, size_t ld16, float *inv_scale);
+int thip_transform_ge_f16(int transpose, size_t n_row, size_t n_col, float alpha, const uint16_t *mat16, size_t ld16,
+                          const float *inv_scale, const float *x, float beta, float *y);
 /* linalg_ex.rs:44 (f32cuda.rs:243-251) */
 size_t thip_map_eig_worklen(size_t n);
 /* linalg_ex.rs:64-65 with the two closures that exist in the reference, evaluated on the device:
@@ -203,9 +210,9 @@ int thip_solver_set_csr(thip_solver *s, size_t nnz,
                         const int64_t *dev_rowptr, const int32_t *dev_colidx, const float *dev_vals,
                         const int64_t *dev_t_rowptr, const int32_t *dev_t_colidx, const float *dev_t_vals);
 int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
-/* Storage of the dense A the iteration streams: THIP_A_F32 (default: prob->mat_a as given) or THIP_A_BF16 (a
- * library-owned bf16 copy, made on the first request: half the bytes per pass, the problem solved is the one with
- * the ROUNDED matrix).  Before thip_solver_init the preconditioners are computed from the stored form; between
+/* Storage of the dense A the iteration streams: THIP_A_F32 (default: prob->mat_a as given), or THIP_A_BF16 /
+ * THIP_A_F16 (a library-owned 16-bit copy, made on the first request; f16 is column-scaled and rounds 8x finer than
+ * bf16: half the bytes per pass, the problem solved is the one with the ROUNDED matrix).  Before thip_solver_init the preconditioners are computed from the stored form; between
  * thip_solver_run calls it switches the operator of the running iteration (e.g. bf16 passes first, f32 passes to
  * finish on the exact matrix) -- the iteration is a fixed-point method, so the iterate carries over.
  * prob->mat_a must stay valid while THIP_A_F32 may still be selected. */
@@ -215,6 +222,8 @@ int thip_solver_set_a_storage(thip_solver *s, int a_kind);
  * selected).  The f32 matrix never has to exist as a whole: a 16-bit A is half the HBM footprint, e.g. BASELINE.json's
  * 320 GB LP (configs[4]) is 160 GB and fits one 288 GB MI355X.  The matrix stays caller-owned. */
 int thip_solver_set_a_bf16(thip_solver *s, const uint16_t *mat16, size_t ld16);
+/* the same for a caller-built f16 matrix with its per-column inverse scales (thip_to_f16) */
+int thip_solver_set_a_f16(thip_solver *s, const uint16_t *mat16, size_t ld16, const float *inv_scale);
 int thip_solver_init(thip_solver *s);                                 /* calc_norms + init_vecs + calc_precond, solver.rs:460-524 */
 /* enqueue up to max_steps iterations (the device stops by itself on termination), poll every
  * `poll_every` iterations; returns when terminated or after max_steps.  SYNC. */

@@ -100,6 +100,10 @@ extern "C" {
                                dev_t_vals: *const f32) -> c_int;
     pub fn thip_solver_set_a_storage(s: *mut thip_solver, a_kind: c_int) -> c_int;
     pub fn thip_solver_set_a_bf16(s: *mut thip_solver, mat16: *const u16, ld16: usize) -> c_int;
+    pub fn thip_solver_set_a_f16(s: *mut thip_solver, mat16: *const u16, ld16: usize, inv_scale: *const f32) -> c_int;
+    pub fn thip_to_f16(n_row: usize, n_col: usize, mat: *const f32, mat16: *mut u16, ld16: usize, inv_scale: *mut f32) -> c_int;
+    pub fn thip_transform_ge_f16(transpose: c_int, n_row: usize, n_col: usize, alpha: f32, mat16: *const u16, ld16: usize,
+                                 inv_scale: *const f32, x: *const f32, beta: f32, y: *mut f32) -> c_int;
     pub fn thip_solver_set_param(s: *mut thip_solver, par: *const thip_param) -> c_int;
     pub fn thip_solver_resume(s: *mut thip_solver) -> c_int;
     pub fn thip_solver_status(s: *mut thip_solver, host_status: *mut thip_status) -> c_int;
@@ -127,6 +131,7 @@ extern "C" {
 
 pub const THIP_A_F32: c_int = 0;
 pub const THIP_A_BF16: c_int = 1;
+pub const THIP_A_F16: c_int = 2;
 
 /// The reference backends assert on library status (totsu_f32cuda/src/f32cuda.rs:38): so does this one.
 pub fn chk(rc: c_int) {

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "thip_transform_ge": (_i, [_i, _sz, _sz, _f, _vp, _vp, _f, _vp]),
     "thip_transform_sp": (_i, [_sz, _f, _vp, _vp, _f, _vp]),
     "thip_to_bf16": (_i, [_sz, _sz, _vp, _vp, _sz]),
+    "thip_to_f16": (_i, [_sz, _sz, _vp, _vp, _sz, _vp]),
+    "thip_transform_ge_f16": (_i, [_i, _sz, _sz, _f, _vp, _sz, _vp, _vp, _f, _vp]),
     "thip_transform_ge_bf16": (_i, [_i, _sz, _sz, _f, _vp, _sz, _vp, _f, _vp]),
     "thip_spmv_csr": (_i, [_sz, _sz, _sz, _vp, _vp, _vp, _f, _vp, _f, _vp, _i]),
     "thip_map_eig_worklen": (_sz, [_sz]),
@@ -101,6 +103,7 @@ PROTOTYPES = {
     "thip_solver_set_allreduce": (_i, [_vp, ALLREDUCE_FN, _vp]),
     "thip_solver_set_a_storage": (_i, [_vp, _i]),
     "thip_solver_set_a_bf16": (_i, [_vp, _vp, _sz]),
+    "thip_solver_set_a_f16": (_i, [_vp, _vp, _sz, _vp]),
     "thip_solver_resume": (_i, [_vp]),
     "thip_solver_set_param": (_i, [_vp, _vp]),
     "thip_solver_init": (_i, [_vp]),

@@ -124,12 +124,15 @@ static inline unsigned grid_for(size_t n, unsigned block, unsigned max_blocks)
 //   outN[r] = alphaN * (A xn)[r] + betaN * outN[r]      (betaN == 0: outN not read)
 //   outT[c] = alphaT * (A^T xt)[c] + betaT * outT[c]
 // abs_mode: use |A| (for absadd_*), x vectors ignored (taken as all-ones).
-// a_kind: THIP_A_F32 (mat = const float *) or THIP_A_BF16 (mat = const uint16_t *, lda in elements)
+// a_kind: THIP_A_F32 (mat = const float *), THIP_A_BF16 or THIP_A_F16 (mat = const uint16_t *, lda in elements;
+// F16 also needs inv_s, the per-column 1 / scale)
 int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
               const float *xn, float alphaN, float betaN, float *outN,
               const float *xt, float alphaT, float betaT, float *outT,
-              bool abs_mode, const int *stop_flag, int a_kind = 0);
+              bool abs_mode, const int *stop_flag, int a_kind = 0, const float *inv_s = nullptr);
 int to_bf16(hipStream_t st, size_t n_row, size_t n_col, const float *src, uint16_t *dst, size_t ld16);
+// f16 with one power-of-two scale per column: inv_s[c] = 1 / s_c is written (n_col floats)
+int to_f16(hipStream_t st, size_t n_row, size_t n_col, const float *src, uint16_t *dst, size_t ld16, float *inv_s);
 // raw form: leaves per-chunk / per-tile partial sums in scratch and reports their geometry so that a
 // consumer kernel can fold the second reduction stage into its own pass
 struct GemvPartials {
@@ -141,7 +144,7 @@ const GemvHint *gemv_candidates(int *count);           // plans worth timing on 
 int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
                        const float *xn, const float *xt, bool do_n, bool do_t, bool abs_mode,
                        float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
-                       const GemvHint *hint = nullptr, int a_kind = 0);
+                       const GemvHint *hint = nullptr, int a_kind = 0, const float *inv_s = nullptr);
 size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col);
 // y[i] = alpha * sum_k part[k*stride + i] + beta * y[i]
 int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float alpha, float beta,

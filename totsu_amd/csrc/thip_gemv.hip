@@ -77,23 +77,35 @@ template <> struct Log2<8> { static constexpr int v = 3; };
 // step are issued back to back (with the per-lane row guard each load sits in its own branch followed by a
 // vmcnt(0) wait, i.e. one load in flight per wave -- seen in the ISA, worth +1..+9 % depending on the shape)
 // element types of the stored matrix: float, or bf16 as raw 16-bit patterns (the upper half of the f32 encoding)
+// or IEEE f16 with one power-of-two scale per column (stored = f16(a * s_c); the kernel multiplies x_N[c] and the
+// column's A^T product by 1 / s_c, so the result is that of the matrix stored / s_c)
 typedef unsigned short bf16raw;
+typedef _Float16 f16elt;
+template <typename E> struct IsF16 { static constexpr bool v = false; };
+template <> struct IsF16<f16elt> { static constexpr bool v = true; };
 __device__ __forceinline__ float elt_f32(float v) { return v; }
 __device__ __forceinline__ float elt_f32(bf16raw v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ float elt_f32(f16elt v) { return (float)v; }
+__device__ __forceinline__ unsigned raw16(bf16raw v) { return v; }
+__device__ __forceinline__ unsigned raw16(f16elt v) { return (unsigned)__builtin_bit_cast(unsigned short, v); }
 
 template <typename E, int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS, bool NT, bool FULL>
 __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m, int r_first, int c, int cc,
                                      const float *__restrict__ xn, const float (&xtv)[NJ][VW],
-                                     float (&accN)[NJ][VW], float *ldsT_wave, int lane)
+                                     float (&accN)[NJ][VW], float *ldsT_wave, int lane, const float *__restrict__ inv_s)
 {
+    constexpr bool F16 = IsF16<E>::v;
     if constexpr (VW == 8) {
         // bf16 storage: 8 rows per 16-byte load.  The raw dwords stay in registers and are widened (one shift or
         // mask per element) right where they are consumed, so the live set is the loads themselves
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         u32x4_t raw[K][NJ];
-        float xsv[K];
+        float xsv[K], isv[K];
 #pragma unroll
-        for (int u = 0; u < K; ++u) xsv[u] = (ABS || !DO_N) ? 1.0f : xn[c + u];
+        for (int u = 0; u < K; ++u) {
+            isv[u] = F16 ? inv_s[c + u] : 1.0f;
+            xsv[u] = ((ABS || !DO_N) ? 1.0f : xn[c + u]) * isv[u];
+        }
         if constexpr (FULL) {
             // All K * NJ loads are issued back to back and each column is consumed as soon as ITS loads have landed
             // (explicit vmcnt waits).  Left to itself the compiler either keeps every widened value alive (115+ VGPRs)
@@ -120,8 +132,8 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
                     } else {
 #pragma unroll
                         for (int d = 0; d < 4; ++d) {
-                            const unsigned lo = (r + 2 * d < m) ? (unsigned)col[r + 2 * d] : 0u;
-                            const unsigned hi = (r + 2 * d + 1 < m) ? (unsigned)col[r + 2 * d + 1] : 0u;
+                            const unsigned lo = (r + 2 * d < m) ? raw16(col[r + 2 * d]) : 0u;
+                            const unsigned hi = (r + 2 * d + 1 < m) ? raw16(col[r + 2 * d + 1]) : 0u;
                             raw[u][j][d] = lo | (hi << 16);
                         }
                     }
@@ -146,7 +158,15 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const unsigned q = raw[u][j][d];
-                    const f32x2_t a2 = { __uint_as_float((q << 16) & HI), __uint_as_float(q & HI) };
+                    f32x2_t a2;
+                    if constexpr (F16) {
+                        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                        const f16x2_t hv = __builtin_bit_cast(f16x2_t, q);
+                        a2 = f32x2_t{ (float)hv[0], (float)hv[1] };
+                        if constexpr (ABS) a2 = f32x2_t{ fabsf(a2[0]), fabsf(a2[1]) };
+                    } else {
+                        a2 = f32x2_t{ __uint_as_float((q << 16) & HI), __uint_as_float(q & HI) };
+                    }
                     if constexpr (DO_N) {
                         f32x2_t acc2 = { accN[j][2 * d], accN[j][2 * d + 1] };
                         acc2 = __builtin_elementwise_fma(a2, xs2, acc2);
@@ -157,7 +177,7 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
                         s2 = __builtin_elementwise_fma(a2, t2, s2);
                     }
                 }
-            p[u] = s2[0] + s2[1];
+            p[u] = (s2[0] + s2[1]) * isv[u];
             // pin column u's updates here: the scheduler otherwise defers every N update behind the T phase and
             // keeps 8 * K * NJ widened values alive (115+ VGPRs, half the waves per SIMD)
             if constexpr (DO_N) {
@@ -208,7 +228,7 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
     if constexpr (DO_N) {
 #pragma unroll
         for (int u = 0; u < K; ++u) {
-            const float xs = ABS ? 1.0f : xn[c + u];
+            const float xs = (ABS ? 1.0f : xn[c + u]) * (F16 ? inv_s[c + u] : 1.0f);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -224,7 +244,7 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int k = 0; k < VW; ++k) s = fmaf(av[u][j][k], xtv[j][k], s);
-            p[u] = s;
+            p[u] = F16 ? s * inv_s[c + u] : s;
         }
         const float r = multi_reduce<K>(p, lane);
         constexpr int SH = 6 - Log2<K>::v;
@@ -237,7 +257,8 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const E *__restrict__ A, size
                                                    const float *__restrict__ xn, const float *__restrict__ xt,
                                                    float *__restrict__ partN, size_t strideN,
                                                    float *__restrict__ partT, size_t strideT,
-                                                   int cols_per_chunk, const int *__restrict__ stop)
+                                                   int cols_per_chunk, const int *__restrict__ stop,
+                                                   const float *__restrict__ inv_s)
 {
     if (stop != nullptr && *stop != 0) return;
     __shared__ float ldsT[DO_T ? 4 * MAXCW : 4];
@@ -273,14 +294,14 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const E *__restrict__ A, size
     int c = c0;
     if ((tile + 1) * TILE <= m) {
         for (; c + KU <= c1; c += KU)
-            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s);
         for (; c < c1; ++c)
-            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s);
     } else {
         for (; c + KU <= c1; c += KU)
-            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s);
         for (; c < c1; ++c)
-            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane);
+            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s);
     }
 
     if constexpr (DO_N) {
@@ -423,7 +444,7 @@ Plan make_plan(size_t n_row, size_t n_col, int vw, const GemvHint *hint = nullpt
 
 template <typename E, bool DO_N, bool DO_T, bool ABS>
 void launch_cfg(const Plan &p, hipStream_t st, const E *A, size_t lda, int m, int n, const float *xn,
-                const float *xt, float *partN, float *partT, const int *stop)
+                const float *xt, float *partN, float *partT, const int *stop, const float *inv_s)
 {
     dim3 g(p.tiles, p.chunks), b(BLK);
     constexpr int VV = sizeof(E) == 2 ? 8 : 4;      // rows per 16-byte load
@@ -431,10 +452,10 @@ void launch_cfg(const Plan &p, hipStream_t st, const E *A, size_t lda, int m, in
     do {                                                                                                      \
         if (p.nt)                                                                                             \
             hipLaunchKernelGGL((dual_gemv_k<E, VW, NJ, KU, DO_N, DO_T, ABS, true>), g, b, 0, st, A, lda, m, n, xn, xt, \
-                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop);                   \
+                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop, inv_s);            \
         else                                                                                                  \
             hipLaunchKernelGGL((dual_gemv_k<E, VW, NJ, KU, DO_N, DO_T, ABS, false>), g, b, 0, st, A, lda, m, n, xn, xt, \
-                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop);                   \
+                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop, inv_s);            \
     } while (0)
     if (p.vw == VV) {
         if (p.nj == 4) THIP_GEMV_LAUNCH(VV, 4, 2);
@@ -449,16 +470,17 @@ void launch_cfg(const Plan &p, hipStream_t st, const E *A, size_t lda, int m, in
 
 template <typename E>
 void launch_any(const Plan &p, hipStream_t st, const E *mat, size_t lda, int m, int n, const float *xn, const float *xt,
-                bool do_n, bool do_t, bool abs_mode, float *partN, float *partT, const int *stop_flag)
+                bool do_n, bool do_t, bool abs_mode, float *partN, float *partT, const int *stop_flag,
+                const float *inv_s = nullptr)
 {
     if (abs_mode) {
-        if (do_n && do_t) launch_cfg<E, true, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-        else if (do_n)    launch_cfg<E, true, false, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-        else              launch_cfg<E, false, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        if (do_n && do_t) launch_cfg<E, true, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag, inv_s);
+        else if (do_n)    launch_cfg<E, true, false, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag, inv_s);
+        else              launch_cfg<E, false, true, true>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag, inv_s);
     } else {
-        if (do_n && do_t) launch_cfg<E, true, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-        else if (do_n)    launch_cfg<E, true, false, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
-        else              launch_cfg<E, false, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag);
+        if (do_n && do_t) launch_cfg<E, true, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag, inv_s);
+        else if (do_n)    launch_cfg<E, true, false, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag, inv_s);
+        else              launch_cfg<E, false, true, false>(p, st, mat, lda, m, n, xn, xt, partN, partT, stop_flag, inv_s);
     }
 }
 
@@ -475,6 +497,40 @@ __global__ void to_bf16_k(size_t n_row, size_t n_col, const float *__restrict__ 
             else out = (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
         }
         dst[i] = (bf16raw)out;
+    }
+}
+
+// per column: inv_s[c] = 1 / s_c with s_c the power of two that brings max_r |a(r, c)| into [2^13, 2^14) (f16 overflows
+// at 65504 = 2^16; an all-zero column keeps s_c = 1).  One block per column.
+__global__ __launch_bounds__(BLK) void f16_scale_k(size_t n_row, const float *__restrict__ src, float *__restrict__ inv_s)
+{
+    __shared__ float sh[16];
+    const float *col = src + (size_t)blockIdx.x * n_row;
+    float mx = 0.0f;
+    for (size_t r = threadIdx.x; r < n_row; r += BLK) {
+        const float v = fabsf(col[r]);
+        if (v > mx && v <= 3.4028235e38f) mx = v;          // inf / nan do not set the scale
+    }
+    mx = -block_min(-mx, sh);
+    if (threadIdx.x == 0) {
+        float inv = 1.0f;
+        if (mx > 0.0f) {
+            int e;
+            (void)frexpf(mx, &e);                          // mx = f * 2^e, f in [0.5, 1)  =>  mx * 2^(14 - e) in [2^13, 2^14)
+            inv = ldexpf(1.0f, e - 14);
+        }
+        inv_s[blockIdx.x] = inv;
+    }
+}
+
+// stored(r, c) = f16(a(r, c) / inv_s[c]) (round to nearest even), ld16 >= n_row, padding rows zero
+__global__ void to_f16_k(size_t n_row, size_t n_col, const float *__restrict__ src, const float *__restrict__ inv_s,
+                         f16elt *__restrict__ dst, size_t ld16)
+{
+    const size_t total = ld16 * n_col;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < total; i += (size_t)gridDim.x * BLK) {
+        const size_t c = i / ld16, r = i - c * ld16;
+        dst[i] = (r < n_row) ? (f16elt)(src[c * n_row + r] / inv_s[c]) : (f16elt)0.0f;
     }
 }
 
@@ -509,16 +565,17 @@ size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col)
 int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
                        const float *xn, const float *xt, bool do_n, bool do_t, bool abs_mode,
                        float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
-                       const GemvHint *hint, int a_kind)
+                       const GemvHint *hint, int a_kind, const float *inv_s)
 {
     if (n_row == 0 || n_col == 0 || (!do_n && !do_t)) {
         out->partN = out->partT = nullptr; out->nN = out->nT = 0; out->strideN = out->strideT = 0;
         return 0;
     }
     if (n_row > 0x7fffffffull || n_col > 0x7fffffffull) return fail(THIP_E_INVALID, "matrix dimension > 2^31", __FILE__, __LINE__);
-    const bool bf16 = a_kind == THIP_A_BF16;
-    const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (lda % (bf16 ? 8 : 4) == 0);
-    const Plan p = make_plan(n_row, n_col, vec_ok ? (bf16 ? 8 : 4) : 1, hint);
+    const bool bf16 = a_kind == THIP_A_BF16, f16 = a_kind == THIP_A_F16;
+    if (f16 && inv_s == nullptr) return fail(THIP_E_INVALID, "f16 storage needs the per-column scales", __FILE__, __LINE__);
+    const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (lda % ((bf16 || f16) ? 8 : 4) == 0);
+    const Plan p = make_plan(n_row, n_col, vec_ok ? ((bf16 || f16) ? 8 : 4) : 1, hint);
     const size_t needN = do_n ? (size_t)p.chunks * p.strideN : 0;
     const size_t needT = do_t ? (size_t)p.tiles * p.strideT : 0;
     if (needN + needT > scratch_floats) return fail(THIP_E_WORK, "gemv scratch too small", __FILE__, __LINE__);
@@ -526,6 +583,7 @@ int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *m
     float *partT = scratch_base + needN;
     const int m = (int)n_row, n = (int)n_col;
     if (bf16) launch_any(p, st, (const bf16raw *)mat, lda, m, n, xn, xt, do_n, do_t, abs_mode, partN, partT, stop_flag);
+    else if (f16) launch_any(p, st, (const f16elt *)mat, lda, m, n, xn, xt, do_n, do_t, abs_mode, partN, partT, stop_flag, inv_s);
     else      launch_any(p, st, (const float *)mat, lda, m, n, xn, xt, do_n, do_t, abs_mode, partN, partT, stop_flag);
     THIP_LAUNCH_CHECK();
     out->partN = do_n ? partN : nullptr; out->nN = do_n ? p.chunks : 0; out->strideN = p.strideN;
@@ -551,17 +609,28 @@ int to_bf16(hipStream_t st, size_t n_row, size_t n_col, const float *src, uint16
     return 0;
 }
 
+int to_f16(hipStream_t st, size_t n_row, size_t n_col, const float *src, uint16_t *dst, size_t ld16, float *inv_s)
+{
+    if (ld16 < n_row) return fail(THIP_E_INVALID, "ld16 < n_row", __FILE__, __LINE__);
+    if (n_col == 0) return 0;
+    hipLaunchKernelGGL(f16_scale_k, dim3((unsigned)n_col), dim3(BLK), 0, st, n_row, src, inv_s);
+    hipLaunchKernelGGL(to_f16_k, dim3(grid_for(ld16 * n_col, BLK, 16384)), dim3(BLK), 0, st, n_row, n_col, src, inv_s,
+                       reinterpret_cast<f16elt *>(dst), ld16);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int dual_gemv(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
               const float *xn, float alphaN, float betaN, float *outN,
               const float *xt, float alphaT, float betaT, float *outT,
-              bool abs_mode, const int *stop_flag, int a_kind)
+              bool abs_mode, const int *stop_flag, int a_kind, const float *inv_s)
 {
     const bool do_n = outN != nullptr, do_t = outT != nullptr;
     float *scr = nullptr;
     const size_t need = dual_gemv_scratch_floats(n_row, n_col);
     THIP_RC(scratch(need, &scr));
     GemvPartials gp;
-    THIP_RC(dual_gemv_partials(st, n_row, n_col, mat, lda, xn, xt, do_n, do_t, abs_mode, scr, need, &gp, stop_flag, nullptr, a_kind));
+    THIP_RC(dual_gemv_partials(st, n_row, n_col, mat, lda, xn, xt, do_n, do_t, abs_mode, scr, need, &gp, stop_flag, nullptr, a_kind, inv_s));
     if (do_n && n_row)
         hipLaunchKernelGGL(finalize_k, dim3(grid_for(n_row, BLK, 2048)), dim3(BLK), 0, st, n_row, gp.partN, gp.nN,
                            gp.strideN, alphaN, betaN, outN, stop_flag);
@@ -606,6 +675,26 @@ int thip_transform_ge_bf16(int transpose, size_t n_row, size_t n_col, float alph
     if (transpose)
         return dual_gemv(ctx().stream, n_row, n_col, mat16, ld16, nullptr, 0.f, 0.f, nullptr, x, alpha, beta, y, false, nullptr, THIP_A_BF16);
     return dual_gemv(ctx().stream, n_row, n_col, mat16, ld16, x, alpha, beta, y, nullptr, 0.f, 0.f, nullptr, false, nullptr, THIP_A_BF16);
+}
+
+int thip_to_f16(size_t n_row, size_t n_col, const float *mat, uint16_t *mat16, size_t ld16, float *inv_scale)
+{
+    THIP_NEED_INIT();
+    if (!inv_scale) return fail(THIP_E_INVALID, "inv_scale == NULL", __FILE__, __LINE__);
+    return to_f16(ctx().stream, n_row, n_col, mat, mat16, ld16, inv_scale);
+}
+
+int thip_transform_ge_f16(int transpose, size_t n_row, size_t n_col, float alpha, const uint16_t *mat16, size_t ld16,
+                          const float *inv_scale, const float *x, float beta, float *y)
+{
+    THIP_NEED_INIT();
+    const size_t ylen = transpose ? n_col : n_row;
+    if (ylen == 0) return 0;
+    if (n_row == 0 || n_col == 0) return thip_scale(ylen, beta, y);
+    if (ld16 < n_row) return fail(THIP_E_INVALID, "ld16 < n_row", __FILE__, __LINE__);
+    if (transpose)
+        return dual_gemv(ctx().stream, n_row, n_col, mat16, ld16, nullptr, 0.f, 0.f, nullptr, x, alpha, beta, y, false, nullptr, THIP_A_F16, inv_scale);
+    return dual_gemv(ctx().stream, n_row, n_col, mat16, ld16, x, alpha, beta, y, nullptr, 0.f, 0.f, nullptr, false, nullptr, THIP_A_F16, inv_scale);
 }
 
 int thip_absadd_cols(size_t n_row, size_t n_col, const float *mat, float *tau)

@@ -491,11 +491,15 @@ struct thip_solver {
     float *gemv_scr = nullptr; size_t gemv_scr_n = 0;
     GemvHint hint{0, 0}; bool tuned = false; float tuned_ms = 0.0f;
     // storage of A streamed by the iteration: the caller's f32 matrix, or an owned bf16 copy (ld16 = m rounded to 8)
-    int a_kind = THIP_A_F32; uint16_t *A16 = nullptr; size_t ld16 = 0; bool A16_owned = false;
+    // (one 16-bit copy at a time: a16_kind says whether A16 holds bf16 or scaled f16; inv_s = the f16 column scales)
+    int a_kind = THIP_A_F32; uint16_t *A16 = nullptr; size_t ld16 = 0; bool A16_owned = false; int a16_kind = 0;
+    float *inv_s = nullptr; bool inv_s_owned = false;
     GemvHint hint16{0, 0}; bool tuned16 = false; float tuned16_ms = 0.0f;
-    const void *amat() const { return a_kind == THIP_A_BF16 ? (const void *)A16 : (const void *)A; }
-    size_t alda() const { return a_kind == THIP_A_BF16 ? ld16 : m; }
-    const GemvHint *ahint() const { return a_kind == THIP_A_BF16 ? (tuned16 ? &hint16 : nullptr) : (tuned ? &hint : nullptr); }
+    bool is16() const { return a_kind != THIP_A_F32; }
+    const void *amat() const { return is16() ? (const void *)A16 : (const void *)A; }
+    size_t alda() const { return is16() ? ld16 : m; }
+    const float *ainv() const { return a_kind == THIP_A_F16 ? inv_s : nullptr; }
+    const GemvHint *ahint() const { return is16() ? (tuned16 ? &hint16 : nullptr) : (tuned ? &hint : nullptr); }
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
     bool inited = false;
@@ -564,16 +568,16 @@ int products(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp,
         GemvPartials a, b;
         const size_t half = s->gemv_scr_n / 2;
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), nullptr, xt, false, true, false, s->gemv_scr, half, &a, stop, s->ahint(), s->a_kind));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), nullptr, xt, false, true, false, s->gemv_scr, half, &a, stop, s->ahint(), s->a_kind, s->ainv()));
         prof_end(st);
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, nullptr, true, false, false, s->gemv_scr + half, half, &b, stop, s->ahint(), s->a_kind));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, nullptr, true, false, false, s->gemv_scr + half, half, &b, stop, s->ahint(), s->a_kind, s->ainv()));
         prof_end(st);
         gp->partT = a.partT; gp->nT = a.nT; gp->strideT = a.strideT;
         gp->partN = b.partN; gp->nN = b.nN; gp->strideN = b.strideN;
     } else {
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, gp, stop, s->ahint(), s->a_kind));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, gp, stop, s->ahint(), s->a_kind, s->ainv()));
         prof_end(st);
     }
     return 0;
@@ -671,7 +675,7 @@ int autotune_gemv(thip_solver *s)
     const char *env = getenv("THIP_GEMV_AUTOTUNE");
     if ((env && atoi(env) == 0) || getenv("THIP_GEMV_NJ") || getenv("THIP_GEMV_BLOCKS")) return 0;
     if (s->sparse || s->m * s->n < (size_t)1 << 22) return 0;   // sparse, or tiny: nothing to tune
-    const bool b16 = s->a_kind == THIP_A_BF16;
+    const bool b16 = s->is16();
     if (b16 ? s->tuned16 : s->tuned) return 0;
     hipStream_t st = ctx().stream;
     hipEvent_t e0, e1;
@@ -684,14 +688,14 @@ int autotune_gemv(thip_solver *s)
     GemvHint pick{0, 0};
     for (int w = 0; w < 3; ++w)         // clocks and caches settle before anything is timed
         THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
-                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind));
+                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind, s->ainv()));
     // inputs: the iterate if the loop is already running (storage switch), else zeros -- timing does not depend on them
     for (int i = 0; i < nc; ++i) {
         float ms = 1e30f;
         for (int rep = 0; rep < 5; ++rep) {
             THIP_TRY(hipEventRecord(e0, st));
             THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
-                                       s->gemv_scr_n, &gp, nullptr, &c[i], s->a_kind));
+                                       s->gemv_scr_n, &gp, nullptr, &c[i], s->a_kind, s->ainv()));
             // the second reduction stage is part of the price of a plan (finer grids leave more partials to post_k):
             // time it too, into g2 / h2, which every schedule rewrites before reading
             THIP_RC(finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, s->h2, nullptr));
@@ -892,7 +896,7 @@ int thip_solver_init(thip_solver *s)
         // solver-owned scratch (several solvers may share the context, e.g. one per thread)
         GemvPartials gp;
         THIP_RC(dual_gemv_partials(st, m, n, s->amat(), s->alda(), nullptr, nullptr, true, true, true, s->gemv_scr,
-                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind));
+                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind, s->ainv()));
         THIP_RC(finalize_partials(st, m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, rowabs, nullptr));
         THIP_RC(finalize_partials(st, n, gp.partT, gp.nT, gp.strideT, 1.0f, 0.0f, colabs, nullptr));
     }
@@ -986,33 +990,59 @@ int thip_solver_precond(thip_solver *s, float *host_dp_tau, float *host_dp_sigma
     return 0;
 }
 
-int thip_solver_set_a_bf16(thip_solver *s, const uint16_t *mat16, size_t ld16)
+static int set_a16_external(thip_solver *s, const uint16_t *mat16, size_t ld16, int kind, const float *inv_scale)
 {
     THIP_NEED_INIT();
     if (!s || !mat16) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
-    if (s->inited) return fail(THIP_E_INVALID, "thip_solver_set_a_bf16 must precede thip_solver_init", __FILE__, __LINE__);
+    if (s->inited) return fail(THIP_E_INVALID, "a caller-built 16-bit matrix must precede thip_solver_init", __FILE__, __LINE__);
     if (s->sparse) return fail(THIP_E_INVALID, "storage kinds apply to a dense A", __FILE__, __LINE__);
     if (ld16 < s->m) return fail(THIP_E_INVALID, "ld16 < m", __FILE__, __LINE__);
+    if (kind == THIP_A_F16 && !inv_scale) return fail(THIP_E_INVALID, "f16 storage needs the per-column scales", __FILE__, __LINE__);
     if (s->A16_owned) { THIP_TRY(hipFree(s->A16)); s->A16_owned = false; }
+    if (s->inv_s_owned) { THIP_TRY(hipFree(s->inv_s)); s->inv_s_owned = false; }
     s->A16 = const_cast<uint16_t *>(mat16);      // caller-owned, only ever read
+    s->inv_s = const_cast<float *>(inv_scale);
     s->ld16 = ld16;
-    s->a_kind = THIP_A_BF16;
+    s->a_kind = s->a16_kind = kind;
     return 0;
+}
+
+int thip_solver_set_a_bf16(thip_solver *s, const uint16_t *mat16, size_t ld16)
+{
+    return set_a16_external(s, mat16, ld16, THIP_A_BF16, nullptr);
+}
+
+int thip_solver_set_a_f16(thip_solver *s, const uint16_t *mat16, size_t ld16, const float *inv_scale)
+{
+    return set_a16_external(s, mat16, ld16, THIP_A_F16, inv_scale);
 }
 
 int thip_solver_set_a_storage(thip_solver *s, int a_kind)
 {
     THIP_NEED_INIT();
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
-    if (a_kind != THIP_A_F32 && a_kind != THIP_A_BF16) return fail(THIP_E_INVALID, "bad storage kind", __FILE__, __LINE__);
+    if (a_kind != THIP_A_F32 && a_kind != THIP_A_BF16 && a_kind != THIP_A_F16)
+        return fail(THIP_E_INVALID, "bad storage kind", __FILE__, __LINE__);
     if (s->sparse) return fail(THIP_E_INVALID, "storage kinds apply to a dense A", __FILE__, __LINE__);
     if (a_kind == THIP_A_F32 && !s->A && s->m && s->n) return fail(THIP_E_INVALID, "no f32 matrix was given", __FILE__, __LINE__);
-    if (a_kind == THIP_A_BF16 && !s->A16 && s->m && s->n) {
+    if (a_kind != THIP_A_F32 && s->a16_kind != a_kind && s->m && s->n) {
+        // (re)build the library-owned 16-bit copy in the requested format
         if (!s->A) return fail(THIP_E_INVALID, "no f32 matrix to convert", __FILE__, __LINE__);
-        s->ld16 = (s->m + 7) / 8 * 8;
-        THIP_TRY(hipMalloc((void **)&s->A16, s->ld16 * s->n * sizeof(uint16_t)));
-        s->A16_owned = true;
-        THIP_RC(to_bf16(ctx().stream, s->m, s->n, s->A, s->A16, s->ld16));
+        if (s->A16 && !s->A16_owned) return fail(THIP_E_INVALID, "the 16-bit matrix is caller-built", __FILE__, __LINE__);
+        hipStream_t st = ctx().stream;
+        if (!s->A16) {
+            s->ld16 = (s->m + 7) / 8 * 8;
+            THIP_TRY(hipMalloc((void **)&s->A16, s->ld16 * s->n * sizeof(uint16_t)));
+            s->A16_owned = true;
+        }
+        if (a_kind == THIP_A_F16) {
+            if (!s->inv_s) { THIP_TRY(hipMalloc((void **)&s->inv_s, s->n * sizeof(float))); s->inv_s_owned = true; }
+            THIP_RC(to_f16(st, s->m, s->n, s->A, s->A16, s->ld16, s->inv_s));
+        } else {
+            THIP_RC(to_bf16(st, s->m, s->n, s->A, s->A16, s->ld16));
+        }
+        s->a16_kind = a_kind;
+        s->tuned16 = false;
     }
     s->a_kind = a_kind;
     if (s->inited) THIP_RC(autotune_gemv(s));      // a switch inside a running solve: tune the other kernel once
@@ -1050,7 +1080,7 @@ int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_byte
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
     if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : 2);
     if (host_bytes_per_pass) *host_bytes_per_pass = s->sparse ? 2 * s->nnz * (sizeof(float) + sizeof(int32_t))
-                                                              : s->m * s->n * (s->a_kind == THIP_A_BF16 ? 2 : sizeof(float));
+                                                              : s->m * s->n * (s->is16() ? 2 : sizeof(float));
     return 0;
 }
 
@@ -1060,7 +1090,7 @@ int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, 
     const GemvHint *h = s->ahint();
     if (host_nj) *host_nj = h ? h->nj : 0;
     if (host_blocks) *host_blocks = h ? h->target_blocks : 0;
-    if (host_ms) *host_ms = s->a_kind == THIP_A_BF16 ? s->tuned16_ms : s->tuned_ms;
+    if (host_ms) *host_ms = s->is16() ? s->tuned16_ms : s->tuned_ms;
     return 0;
 }
 
@@ -1094,7 +1124,7 @@ int thip_solver_destroy(thip_solver *s)
     if (ctx().inited) hipStreamSynchronize(ctx().stream);
     hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
-    hipFree(s->gemv_scr); hipFree(s->dst); if (s->A16_owned) hipFree(s->A16);
+    hipFree(s->gemv_scr); hipFree(s->dst); if (s->A16_owned) hipFree(s->A16); if (s->inv_s_owned) hipFree(s->inv_s);
     if (s->hst) hipHostFree(s->hst);
     delete s;
     return 0;

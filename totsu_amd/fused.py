@@ -49,7 +49,7 @@ class DeviceBuffer:
             pass
 
 
-A_STORAGE = {"f32": 0, "bf16": 1}
+A_STORAGE = {"f32": 0, "bf16": 1, "f16": 2}
 
 
 class Bf16Matrix:
@@ -98,8 +98,8 @@ class FusedSolver:
     def __init__(self, n, m, mat_a, vec_b, vec_c, seg_type, seg_len, param=None, schedule="fused",
                  vec_b_rowabs=None, allreduce=None, a_storage="f32"):
         """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded).
-        a_storage: "f32" (the matrix as given) or "bf16" (a rounded copy streamed at half the bytes; see
-        set_a_storage / include/totsu_f32hip.h).
+        a_storage: "f32" (the matrix as given), "bf16" or "f16" (a rounded 16-bit copy streamed at half the bytes; f16
+        is column-scaled and rounds 8x finer; see set_a_storage / include/totsu_f32hip.h).
         allreduce: None (single GPU), "rccl" (native communicator set up with comm_init), or a Python callable
         (ctx, dev_ptr, count, stream) -> 0."""
         _lib.ensure_init()
@@ -163,7 +163,7 @@ class FusedSolver:
         lib.thip_solver_resume(self.h)
 
     def set_a_storage(self, kind):
-        """Switch the stored form of the dense A ("f32" | "bf16"); allowed between run() calls."""
+        """Switch the stored form of the dense A ("f32" | "bf16" | "f16"); allowed between run() calls."""
         lib.thip_solver_set_a_storage(self.h, A_STORAGE[kind])
         self.a_storage = kind
 
