@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--bf16-direct", action="store_true",
                     help="lp workload: build A as bf16 from f32 column blocks, never holding the f32 matrix (a 16-bit A is half "
                          "the HBM: configs[4], n = 200000, fits ONE GPU this way); implies --a-storage bf16")
+    ap.add_argument("--f16-direct", action="store_true", help="like --bf16-direct with column-scaled f16 entries")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--force-collective", action="store_true", help="install the all-reduce hook even at N = 1")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch", "gloo"],
@@ -255,9 +256,10 @@ def run(a):
         wl = "dense SDP n=%d, one PSD cone of order %d (sk=%d), f32" % (n, a.k, inst.m_total)
     else:
         n = a.n or 10_000
-        if a.bf16_direct:
-            a.a_storage = "bf16"
-        inst = synth.LpInstance(n, seed=0, rank=rank, world=world, bf16_direct=a.bf16_direct)
+        if a.bf16_direct or a.f16_direct:
+            a.a_storage = "f16" if a.f16_direct else "bf16"
+        inst = synth.LpInstance(n, seed=0, rank=rank, world=world,
+                                bf16_direct="f16" if a.f16_direct else a.bf16_direct)
         wl = "benchmark_lp dense LP n=%d m=%d, f32" % (n, inst.m_total)
     lib.thip_sync()
     t_gen = time.perf_counter() - t_gen0

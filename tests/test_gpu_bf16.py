@@ -377,3 +377,26 @@ def test_f16_storage_alone_is_inside_the_objective_gate(T, n, cones, seed):
     r2 = fs.run(-1, poll_every=64)
     assert r2.state == 0 and fs.a_storage == "bf16"
     fs.destroy()
+
+
+def test_caller_built_f16_matrix_equals_the_library_conversion(T):
+    from totsu_amd import synth
+    n = 48
+    inst = synth.LpInstance(n, seed=5)
+    direct = synth.LpInstance(n, seed=5, bf16_direct="f16", block_cols=7)
+    conv = T.Bf16Matrix.from_f32(inst.mat_a, inst.m, n, "f16")
+    assert np.array_equal(direct.mat_a._buf.to_host().view(np.uint16)[:conv.ld16 * n],
+                          conv._buf.to_host().view(np.uint16)[:conv.ld16 * n])
+    assert np.array_equal(direct.mat_a._inv.to_host(), conv._inv.to_host())
+    p = T.SolverParam()
+    p.eps_acc, p.max_iter = 1e-4, 200_000
+    res = []
+    for mat, kw in ((inst.mat_a, dict(a_storage="f16")), (direct.mat_a, {})):
+        fs = T.FusedSolver(n, inst.m, mat, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried", **kw)
+        assert fs.a_storage == "f16" and fs.passes()[1] == 2 * n * inst.m
+        r = fs.run(-1, poll_every=64)
+        x, y = fs.solution()
+        res.append((r.iters, x.copy(), y.copy()))
+        fs.destroy()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    conv.free(); direct.free(); inst.free()

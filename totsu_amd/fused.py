@@ -53,27 +53,38 @@ A_STORAGE = {"f32": 0, "bf16": 1, "f16": 2}
 
 
 class Bf16Matrix:
-    """A dense m x n matrix held on the device as bf16 bit patterns only (column-major, leading dimension ld16 = m
-    rounded up to 8): built from f32 column blocks that are converted in place of being kept (thip_to_bf16), so the f32
-    matrix never exists as a whole.  Accepted by FusedSolver as `mat_a` (thip_solver_set_a_bf16)."""
+    """A dense m x n matrix held on the device in 16 bits per entry only (column-major, leading dimension ld16 = m
+    rounded up to 8): built from f32 column blocks that are converted in place of being kept (thip_to_bf16 /
+    thip_to_f16), so the f32 matrix never exists as a whole.  kind = "bf16", or "f16" (one power-of-two scale per
+    column, 8x finer rounding).  Accepted by FusedSolver as `mat_a` (thip_solver_set_a_bf16 / _f16)."""
 
-    def __init__(self, m, n):
+    def __init__(self, m, n, kind="bf16"):
         _lib.ensure_init()
-        self.m, self.n = int(m), int(n)
+        assert kind in ("bf16", "f16")
+        self.m, self.n, self.kind = int(m), int(n), kind
         self.ld16 = (self.m + 7) // 8 * 8
         self._buf = DeviceBuffer((self.ld16 * self.n + 1) // 2 + 4)      # 2 elements per float slot
         self.ptr = self._buf.ptr
+        self._inv = DeviceBuffer(max(self.n, 1)) if kind == "f16" else None
+
+    @property
+    def inv_ptr(self):
+        return None if self._inv is None else self._inv.ptr
 
     def set_columns(self, c0, block, ncols):
         """columns c0 .. c0 + ncols of the matrix <- the f32 block (DeviceBuffer, m x ncols, lda = m)"""
         assert 0 <= c0 and c0 + ncols <= self.n and block.n >= self.m * ncols
-        lib.thip_to_bf16(self.m, ncols, block.ptr, self.ptr + 2 * self.ld16 * c0, self.ld16)
+        dst = self.ptr + 2 * self.ld16 * c0
+        if self.kind == "f16":
+            lib.thip_to_f16(self.m, ncols, block.ptr, dst, self.ld16, self._inv.ptr + 4 * c0)
+        else:
+            lib.thip_to_bf16(self.m, ncols, block.ptr, dst, self.ld16)
 
     @staticmethod
-    def from_f32(mat, m, n):
+    def from_f32(mat, m, n, kind="bf16"):
         """mat: DeviceBuffer or host array, column-major m x n"""
         d = mat if isinstance(mat, DeviceBuffer) else DeviceBuffer.from_host(mat)
-        out = Bf16Matrix(m, n)
+        out = Bf16Matrix(m, n, kind)
         out.set_columns(0, d, n)
         if d is not mat:
             d.free()
@@ -81,6 +92,8 @@ class Bf16Matrix:
 
     def free(self):
         self._buf.free()
+        if self._inv is not None:
+            self._inv.free()
         self.ptr = None
 
 
@@ -147,8 +160,11 @@ class FusedSolver:
             lib.thip_solver_set_allreduce(self.h, self._cb, None)
         self.a_storage = "f32"
         if self._a16 is not None:
-            lib.thip_solver_set_a_bf16(self.h, self._a16.ptr, self._a16.ld16)
-            self.a_storage = "bf16"
+            if self._a16.kind == "f16":
+                lib.thip_solver_set_a_f16(self.h, self._a16.ptr, self._a16.ld16, self._a16.inv_ptr)
+            else:
+                lib.thip_solver_set_a_bf16(self.h, self._a16.ptr, self._a16.ld16)
+            self.a_storage = self._a16.kind
         elif a_storage != "f32":
             self.set_a_storage(a_storage)
         lib.thip_solver_init(self.h)

@@ -95,8 +95,9 @@ class LpInstance:
     """device-resident row shard of the benchmark_lp construction (rows split evenly; nonneg cone is separable)"""
 
     def __init__(self, n, seed=0, rank=0, world=1, bf16_direct=False, block_cols=2048):
-        """bf16_direct: build the shard as a Bf16Matrix from f32 column blocks of block_cols columns (identical
-        entries, rounded); the f32 shard is never allocated -- for shards that only fit HBM at 16 bits per entry."""
+        """bf16_direct (True / "bf16" / "f16"): build the shard as a 16-bit Bf16Matrix from f32 column blocks of
+        block_cols columns (identical entries, rounded); the f32 shard is never allocated -- for shards that only fit
+        HBM at 16 bits per entry."""
         _lib.ensure_init()
         self.n = n
         self.m_total = 2 * n
@@ -107,7 +108,7 @@ class LpInstance:
         m = self.m = r1 - r0
         if bf16_direct:
             from .fused import Bf16Matrix
-            self.mat_a = Bf16Matrix(m, n)
+            self.mat_a = Bf16Matrix(m, n, "f16" if bf16_direct == "f16" else "bf16")
             blk = DeviceBuffer(max(m * min(block_cols, n), 1))
             for c0 in range(0, n, block_cols):
                 nc = min(block_cols, n - c0)
