@@ -1,7 +1,8 @@
 // cpp_trait_demo.cpp -- a compiled host over include/totsu_f32hip.hpp (which is layered only on the C ABI):
 // the reference's trait-level calling sequence `Solver::solve((op_c, op_a, op_b, cone, work))` in C++, on three
 // known-answer problems: the nostd_cortex-m LP (x = [2, 2]), a second-order-cone problem (x = [-1, -1], the data of
-// totsu/tests/socp.rs test_socp1 in stacked form) and the 2x2 PSD problem of totsu_core/tests/solver.rs (x = -2).
+// totsu/tests/socp.rs test_socp1 in stacked form) and the 2x2 PSD problem of totsu_core/tests/solver.rs (x = -2); then
+// the LP once more through FusedSolver (the device-resident loop) with f16 storage of A and an f32 finish.
 #include <cstdio>
 #include "totsu_f32hip.hpp"
 
@@ -44,6 +45,26 @@ int main()
         DeviceVec w(ConePSD::query_worklen(3));
         ConePSD cone(w.slice(), 1e-12f);
         bad += run("psd", 1, 3, { 1 }, { 0, -1.41421356f, -3 }, { 1, 0, 10 }, cone, { -2 }, 1e-3f);
+    }
+    {   // the same LP through the device-resident loop, with the 16-bit storage of A and a resumed finish on f32:
+        // f16 passes to eps 1e-4, then thip_solver_set_a_storage(F32) + resume with eps 1e-5 from the same iterate
+        DeviceVec dc(std::vector<float>{ -1, 0 }), da(std::vector<float>{ 4, -1, -1, -1, 4, -1 }), db(std::vector<float>{ 6, 6, 1 });
+        SolverParam par;
+        par.max_iter = 100000; par.eps_acc = 1e-4f;
+        FusedSolver fs(2, 3, da.slice(), db.slice(), dc.slice(), { THIP_CONE_RPOS }, { 3 }, par);
+        fs.set_a_storage(THIP_A_F16);
+        SolverError e = fs.run();
+        const long long it16 = (long long)fs.iters();
+        par.eps_acc = 1e-5f;
+        fs.set_a_storage(THIP_A_F32);
+        fs.resume(&par);
+        e = fs.run();
+        std::vector<float> x, y;
+        fs.solution(x, y);
+        const bool ok = e == SolverError::Ok && std::fabs(x[0] - 2.f) <= 1e-3f && std::fabs(x[1] - 2.f) <= 1e-3f && fs.iters() >= it16;
+        printf("%-10s status %d after %lld (+%lld on f32) iterations: x = [%.5f, %.5f]  %s\n", "fused-lp", (int)e, it16,
+               (long long)fs.iters() - it16, x[0], x[1], ok ? "OK" : "MISMATCH");
+        bad += ok ? 0 : 1;
     }
     chk(thip_shutdown());
     return bad;

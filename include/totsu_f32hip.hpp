@@ -270,4 +270,63 @@ private:
     }
 };
 
+// ---- FusedSolver: RAII over the device-resident loop (thip_solver_*), the drop-in for Solver::solve when A is a dense
+// MatOp and the cone a product of Zero / RPos / SOC / RotSOC / PSD segments over consecutive rows ----------------------
+class FusedSolver {
+public:
+    // a, b, c: device slices (A column-major m x n); seg_type: THIP_CONE_*, seg_len: rows of each segment
+    FusedSolver(size_t n, size_t m, Slice a, Slice b, Slice c, const std::vector<int32_t> &seg_type,
+                const std::vector<int64_t> &seg_len, const SolverParam &par, int schedule = THIP_SCHED_CARRIED)
+        : n_(n), m_(m), seg_type_(seg_type), seg_len_(seg_len)
+    {
+        thip_problem prob{};
+        prob.n = n; prob.m = m; prob.mat_a = a.p; prob.vec_b = b.p; prob.vec_c = c.p; prob.vec_b_rowabs = nullptr;
+        prob.n_seg = seg_type_.size(); prob.host_seg_type = seg_type_.data(); prob.host_seg_len = seg_len_.data();
+        const thip_param p = to_c(par);
+        chk(thip_solver_create(&prob, &p, schedule, &h_));
+    }
+    FusedSolver(const FusedSolver &) = delete;
+    FusedSolver &operator=(const FusedSolver &) = delete;
+    ~FusedSolver() { thip_solver_destroy(h_); }
+
+    // THIP_A_F32 / THIP_A_BF16 / THIP_A_F16; before init(), or between run() calls (then resume() if it had finished)
+    void set_a_storage(int kind) { chk(thip_solver_set_a_storage(h_, kind)); }
+    void init() { chk(thip_solver_init(h_)); inited_ = true; }
+    // runs until termination (max_steps < 0) or for max_steps iterations; returns the reference's SolverError
+    SolverError run(int64_t max_steps = -1, int64_t poll_every = 64)
+    {
+        if (!inited_) init();
+        chk(thip_solver_run(h_, max_steps, poll_every, &st_));
+        return st_.state <= 0 ? SolverError::Ok : (SolverError)st_.state;     // THIP_ST_RUNNING (-1) reads as "not failed yet"
+    }
+    bool running() const { return st_.state == THIP_ST_RUNNING; }
+    void resume(const SolverParam *par = nullptr)
+    {
+        if (par) { const thip_param p = to_c(*par); chk(thip_solver_set_param(h_, &p)); }
+        chk(thip_solver_resume(h_));
+    }
+    int64_t iters() const { return st_.iter; }
+    const thip_status &status() const { return st_; }
+    void solution(std::vector<float> &x, std::vector<float> &y)               // solver.rs:317-320
+    {
+        x.resize(n_); y.resize(m_);
+        chk(thip_solver_solution(h_, x.data(), y.data()));
+    }
+
+private:
+    static thip_param to_c(const SolverParam &par)
+    {
+        thip_param p{};
+        p.max_iter = par.max_iter; p.eps_acc = par.eps_acc; p.eps_inf = par.eps_inf; p.eps_zero = par.eps_zero;
+        p.log_period = 0;
+        return p;
+    }
+    size_t n_, m_;
+    std::vector<int32_t> seg_type_;
+    std::vector<int64_t> seg_len_;
+    thip_solver *h_ = nullptr;
+    thip_status st_{};
+    bool inited_ = false;
+};
+
 }  // namespace totsu

@@ -497,7 +497,8 @@ def test_box_lp_vertex(T):
 
 
 def test_cpp_trait_mirror_host():
-    # examples/cpp_trait_demo.cpp over include/totsu_f32hip.hpp: the trait-level loop in C++ on three KATs
+    # examples/cpp_trait_demo.cpp over include/totsu_f32hip.hpp: the trait-level loop in C++ on three KATs, then the LP
+    # through the C++ FusedSolver wrapper (f16 storage of A, switched to f32 and resumed with a tighter eps)
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "cpp_trait_demo")
@@ -506,7 +507,7 @@ def test_cpp_trait_mirror_host():
         g.build()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("OK") == 3
+    assert r.stdout.count("OK") == 4 and "fused-lp" in r.stdout
 
 
 @pytest.mark.parametrize("grid", [(2, 3), (3, 4)])
