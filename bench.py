@@ -388,11 +388,22 @@ def run(a):
     if a.to_eps is not None:
         p2 = T.SolverParam()
         p2.eps_acc = a.to_eps
+        def run_to_end(fs):
+            # in chunks, with a progress line on stderr: a run that hits an outer time limit still leaves its trail
+            while True:
+                r = fs.run(20000, poll_every=64)
+                if rank == 0:
+                    sys.stderr.write("to-eps: iter %d state %d cri %.3e %.3e %.3e t %.1f s\n"
+                                     % (r.iters + 1, r.state, r.cri[0], r.cri[1], r.cri[2], time.perf_counter() - t0))
+                    sys.stderr.flush()
+                if r.state != _lib.ST_RUNNING:
+                    return r
+
         fs2 = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
                             a.schedule, allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"))
         barrier()
         t0 = time.perf_counter()
-        r2 = fs2.run(-1, poll_every=64)
+        r2 = run_to_end(fs2)
         barrier()
         phase1 = None
         if a.a_storage in ("mixed", "mixed-bf16") and r2.state == _lib.ST_OK:
@@ -407,7 +418,7 @@ def run(a):
             t0 += time.perf_counter() - t_skip
             fs2.set_a_storage("f32")
             fs2.resume()
-            r2 = fs2.run(-1, poll_every=64)
+            r2 = run_to_end(fs2)
             barrier()
         out["time_to_eps"] = {"eps_acc": a.to_eps, "seconds": time.perf_counter() - t0, "iterations": r2.iters + 1,
                               "state": r2.state, "cri": list(r2.cri)}
