@@ -338,8 +338,9 @@ __global__ void finalize_k(size_t n, const float *__restrict__ part, int np, siz
 {
     if (stop != nullptr && *stop != 0) return;
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
-        float s = 0.0f;
-        for (int k = 0; k < np; ++k) s += part[(size_t)k * stride + i];
+        double sd = 0.0;                       // the second stage accumulates in f64 (free; keeps the f32 floor down)
+        for (int k = 0; k < np; ++k) sd += (double)part[(size_t)k * stride + i];
+        const float s = (float)sd;
         y[i] = (beta == 0.0f) ? alpha * s : alpha * s + beta * y[i];
     }
 }

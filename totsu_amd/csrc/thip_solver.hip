@@ -75,7 +75,7 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
     // 256 threads = 64 elements x 4 partial-index lanes: the sum over the ~100 partials of one element is split
     // four ways (4x the loads in flight), combined through LDS, and lane 0 of each element does the epilogue
     __shared__ float sh[16];
-    __shared__ float comb[3][64];
+    __shared__ double comb[3][64];       // the second reduction stage accumulates in f64 (free here; see DESIGN.md 5, f32 floor)
     const int e = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const size_t gstride = (size_t)gridDim.x * 64;
     float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
@@ -85,13 +85,14 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
 
     for (size_t i0 = blockIdx.x * (size_t)64; i0 < (size_t)n; i0 += gstride) {
         const size_t i = i0 + e;
-        float s = 0.0f;
+        double sd = 0.0;
         if (i < (size_t)n)
-            for (int k = kq; k < nT; k += 4) s += partT[(size_t)k * strideT + i];
-        if (kq > 0) comb[kq - 1][e] = s;
+            for (int k = kq; k < nT; k += 4) sd += (double)partT[(size_t)k * strideT + i];
+        if (kq > 0) comb[kq - 1][e] = sd;
         __syncthreads();
         if (kq == 0 && i < (size_t)n) {
-            if (nT >= 0) { s = (s + comb[0][e]) + (comb[1][e] + comb[2][e]); g[i] = s; }
+            float s;
+            if (nT >= 0) { s = (float)((sd + comb[0][e]) + (comb[1][e] + comb[2][e])); g[i] = s; }
             else s = g[i];                    // nT < 0: g already holds the finished product (sparse path)
             if (dn_a) q0 = fmaf(dn_a[i], dn_b[i], q0);
         }
@@ -99,13 +100,14 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
     }
     for (size_t i0 = blockIdx.x * (size_t)64; i0 < (size_t)m; i0 += gstride) {
         const size_t i = i0 + e;
-        float s = 0.0f;
+        double sd = 0.0;
         if (i < (size_t)m)
-            for (int k = kq; k < nN; k += 4) s += partN[(size_t)k * strideN + i];
-        if (kq > 0) comb[kq - 1][e] = s;
+            for (int k = kq; k < nN; k += 4) sd += (double)partN[(size_t)k * strideN + i];
+        if (kq > 0) comb[kq - 1][e] = sd;
         __syncthreads();
         if (kq == 0 && i < (size_t)m) {
-            if (nN >= 0) { s = (s + comb[0][e]) + (comb[1][e] + comb[2][e]); h[i] = s; }
+            float s;
+            if (nN >= 0) { s = (float)((sd + comb[0][e]) + (comb[1][e] + comb[2][e])); h[i] = s; }
             else s = h[i];
             if (dm_a) q1 = fmaf(dm_a[i], dm_b[i], q1);
             if (crit) {
