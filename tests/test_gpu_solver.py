@@ -714,3 +714,30 @@ def test_schedules_agree_at_the_full_socp_size(T):
     assert np.abs(xr - xc).max() <= 2e-4 * np.abs(xr).max() and np.abs(yr - yc).max() <= 2e-4 * np.abs(yr).max()
     assert np.allclose(rr.cri, rc.cri, rtol=2e-3, atol=1e-6)
     inst.free()
+
+
+def test_compensated_state_lowers_the_f32_floor(T, monkeypatch):
+    # In plain f32 the iterate stops moving once an update is below half an ulp of the entry it is added to: the dual
+    # criterion of this n = 200 SOCP freezes at 6.3e-6 (the same number in a numpy f32 emulation of the reference's
+    # loop, 1.2e-14 in f64).  THIP_COMPENSATED_STATE=1 (Kahan terms for x_x, x_y, x_s, u, v; experimental, default
+    # off) takes it to ~1e-7 with the same f32 storage and arithmetic.
+    f, Gs, hs, cs, d = random_socp(200, [99] * 6, seed=1)
+    n = 200
+    socp = T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(f.reshape(-1, 1)),
+                      [_mb(T, T.MatType.General(G.shape[0], n)).set_array(G) for G in Gs],
+                      [_mb(T, T.MatType.General(len(h_), 1)).set_array(h_.reshape(-1, 1)) for h_ in hs],
+                      [_mb(T, T.MatType.General(n, 1)).set_array(c_.reshape(-1, 1)) for c_ in cs], d,
+                      _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+    dense = socp.dense()
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    floors = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("THIP_COMPENSATED_STATE", flag)        # read by thip_solver_create
+        fs = T.FusedSolver.from_dense(dense, p, "carried")
+        r = fs.run(15000, poll_every=64)
+        floors[flag] = r.cri[1]
+        assert r.cri[0] < 1e-6 and r.cri[2] < 1e-6
+        fs.destroy()
+    assert 2e-6 < floors["0"] < 2e-5, floors
+    assert floors["1"] < 5e-7, floors

@@ -158,6 +158,18 @@ __global__ __launch_bounds__(BLK) void sumfin_k(int np, const float *__restrict_
     }
 }
 
+// x + inc, optionally compensated: k[i] carries the rounding error of the previous additions into this entry (Kahan).
+// The f32 iterate otherwise stops moving once an update is below half an ulp of the entry while the dual residual
+// is still ~1e-5..1e-4 (a floor the reference's f32 arithmetic has too; numpy emulation: 6.3e-6 -> 1e-7 at n = 200).
+__device__ __forceinline__ float comp_add(float x, float inc, float *__restrict__ k, size_t i)
+{
+    if (k == nullptr) return x + inc;
+    const float y = inc - k[i];
+    const float t = x + y;
+    k[i] = (t - x) - y;
+    return t;
+}
+
 // x-update, solver.rs:538-555 (everything except the block cones):
 //   x += T o tx with tx = -K^T y (SelfDualEmbed::trans_op, solver.rs:133-157):
 //     x_x += Tx o ( gT + c kappa)        gT = A^T v   (after the all-reduce)
@@ -176,9 +188,11 @@ __global__ __launch_bounds__(BLK) void xupdate_k(int n, int m, const float *__re
                                                 float *__restrict__ xx, float *__restrict__ xy, float *__restrict__ xs,
                                                 float *__restrict__ rxx, float *__restrict__ rxy, float *__restrict__ rxs,
                                                 const float *__restrict__ dot_c, const float *__restrict__ dot_b,
-                                                DevStatus *st, const float *psum, int npsum)
+                                                DevStatus *st, const float *psum, int npsum,
+                                                float *__restrict__ kx, float *__restrict__ ky, float *__restrict__ ks)
 {
     if (st->stop != 0) return;
+    // kx / ky / ks != NULL: compensated (Kahan) accumulation of the iterate -- see comp_add
     // single GPU (no all-reduce between post_k and this kernel): block 0 sums post_k's block partials of c.u and b.v
     // itself instead of a sumfin_k launch in between
     float dc = 0.0f, db = 0.0f;
@@ -193,15 +207,15 @@ __global__ __launch_bounds__(BLK) void xupdate_k(int n, int m, const float *__re
     const size_t gstride = (size_t)gridDim.x * BLK;
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
         const float old = xx[i];
-        const float nw = old + Tx[i] * (gT[i] + c[i] * kappa);
+        const float nw = comp_add(old, Tx[i] * (gT[i] + c[i] * kappa), kx, i);
         xx[i] = nw;
         rxx[i] = old - 2.0f * nw;
     }
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
         const unsigned char k = cls[i];
         const float oy = xy[i], os = xs[i];
-        float ny = oy + Ty[i] * (b[i] * kappa - hN[i]);
-        float ns = os + Ts[i] * v[i];
+        float ny = comp_add(oy, Ty[i] * (b[i] * kappa - hN[i]), ky, i);
+        float ns = comp_add(os, Ts[i] * v[i], ks, i);
         if (k == 1) { ny = fmaxf(ny, 0.0f); ns = fmaxf(ns, 0.0f); }
         else if (k == 0) { ns = 0.0f; }
         xy[i] = ny;
@@ -246,7 +260,8 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
                                               const float *__restrict__ Sv, float *__restrict__ u, float *__restrict__ v,
                                               const float *__restrict__ xx, const float *__restrict__ dot_c,
                                               const float *__restrict__ dot_b, float eps_zero, float *__restrict__ part,
-                                              DevStatus *st, const float *psum, int npsum)
+                                              DevStatus *st, const float *psum, int npsum,
+                                              float *__restrict__ ku, float *__restrict__ kv)
 {
     if (st->stop != 0) return;
     __shared__ float sh[16];
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
             float g2;
             if (carried) { const float nw = g3[i]; g2 = gP[i] - 2.0f * nw; gP[i] = nw; }
             else g2 = g2in[i];
-            u[i] = u[i] + Su[i] * (-g2 - ci * rtau);
+            u[i] = comp_add(u[i], Su[i] * (-g2 - ci * rtau), ku, i);
         }
         if (docrit) {
             const float d = conv ? fmaf(rt, g3[i], ci) : g3[i];
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
             float h2;
             if (carried) { const float nw = h3[i]; h2 = hP[i] - 2.0f * nw; hP[i] = nw; }
             else h2 = h2in[i];
-            v[i] = v[i] + Sv[i] * (h2 + rxs[i] - b[i] * rtau);
+            v[i] = comp_add(v[i], Sv[i] * (h2 + rxs[i] - b[i] * rtau), kv, i);
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             const float k = st->kappa + st->s_kappa * (dc + db);
@@ -487,7 +502,8 @@ struct thip_solver {
     // device vectors (one arena)
     float *arena = nullptr; size_t arena_n = 0;
     float *xx, *xy, *xs, *u, *v, *Tx, *Ty, *Ts, *Su, *Sv, *rxx, *rxy, *rxs;
-    float *g1, *h1, *g2, *h2, *g3, *h3, *gP, *hP;   // n-vectors carry TAIL extra floats
+    float *g1, *h1, *g2, *h2, *g3, *h3, *gP, *hP;
+    float *kx = nullptr, *ky = nullptr, *ks = nullptr, *ku = nullptr, *kv = nullptr;   // Kahan terms of the iterate (optional)   // n-vectors carry TAIL extra floats
     float *part = nullptr;                           // block partials (4 * EG)
     float *dotc = nullptr;                           // local scalars: [0] c.u, [1] c.rx_x, [2..3] dd,cx
     float *gemv_scr = nullptr; size_t gemv_scr_n = 0;
@@ -633,7 +649,8 @@ int one_iteration(thip_solver *s)
                            (float *)nullptr, stop);
     THIP_RC(do_allreduce(s, s->g1, s->n + 1));
     hipLaunchKernelGGL(xupdate_k, dim3(g), dim3(BLK), 0, st, n, m, s->g1, s->h1, s->c, s->b, s->v, s->Tx, s->Ty, s->Ts,
-                       s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dotc + 0, s->g1 + s->n, s->dst, psum, (int)gq);
+                       s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dotc + 0, s->g1 + s->n, s->dst, psum, (int)gq,
+                       s->kx, s->ky, s->ks);
     THIP_RC(project_blocks(s));
 
     // ---- stage Y: y update from K rx (solver.rs:557-567), own products unless carried ---------------
@@ -648,7 +665,8 @@ int one_iteration(thip_solver *s)
         THIP_RC(do_allreduce(s, s->g2, s->n + 1));
         hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, 1, 0, 0, (const float *)nullptr,
                            (const float *)nullptr, (float *)nullptr, (float *)nullptr, s->g2, s->h2, s->c, s->b, s->rxs,
-                           s->Su, s->Sv, s->u, s->v, s->xx, s->dotc + 1, s->g2 + s->n, ez, part_y, s->dst, psum, (int)gq);
+                           s->Su, s->Sv, s->u, s->v, s->xx, s->dotc + 1, s->g2 + s->n, ez, part_y, s->dst, psum, (int)gq,
+                           s->ku, s->kv);
     }
 
     // ---- stage C: criteria products of the new iterate (solver.rs:573-656) --------------------------
@@ -663,7 +681,8 @@ int one_iteration(thip_solver *s)
     THIP_RC(do_allreduce(s, s->g3, s->n + 3));
     hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, carried ? 1 : 0, 1, 1, s->g3, s->h3, s->gP, s->hP,
                        (const float *)nullptr, (const float *)nullptr, s->c, s->b, s->rxs, s->Su, s->Sv, s->u, s->v, s->xx,
-                       s->dotc + 1, s->g3 + s->n + 2, ez, part_y, s->dst, carried ? psum : (const float *)nullptr, (int)gq);
+                       s->dotc + 1, s->g3 + s->n + 2, ez, part_y, s->dst, carried ? psum : (const float *)nullptr, (int)gq,
+                       s->ku, s->kv);
     hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part_y, s->g3 + s->n, s->par.eps_acc, s->par.eps_inf,
                        ez, (long long)s->par.max_iter, s->dst, psum, (int)gq);
     THIP_LAUNCH_CHECK();
@@ -815,7 +834,10 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
 
     // ---- vectors ----
     const size_t pn = pad64(n + TAIL), pm = pad64(m + 1);
-    const size_t total = 7 * pn /*xx u Tx Su rxx + g1 g2 g3 gP = 9*/ + 2 * pn + 13 * pm + 64;
+    // THIP_COMPENSATED_STATE=1 (experimental, default off): compensated accumulation of the iterate vectors
+    const char *env_comp = getenv("THIP_COMPENSATED_STATE");
+    const bool compensated = env_comp && atoi(env_comp) != 0;
+    const size_t total = 7 * pn /*xx u Tx Su rxx + g1 g2 g3 gP = 9*/ + 2 * pn + 13 * pm + 64 + (compensated ? 2 * pn + 3 * pm : 0);
     THIP_TRY(hipMalloc((void **)&s->arena, total * sizeof(float)));
     THIP_TRY(hipMemsetAsync(s->arena, 0, total * sizeof(float), st));
     s->arena_n = total;
@@ -827,6 +849,7 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
     s->rxy = take(pm); s->rxs = take(pm); s->h1 = take(pm); s->h2 = take(pm); s->h3 = take(pm); s->hP = take(pm);
     (void)take(pm);
     s->dotc = take(64);
+    if (compensated) { s->kx = take(pn); s->ku = take(pn); s->ky = take(pm); s->ks = take(pm); s->kv = take(pm); }
 
     THIP_TRY(hipMalloc((void **)&s->part, (4 * PG + 2 * EG) * sizeof(float)));
     s->gemv_scr_n = 2 * dual_gemv_scratch_floats(m, n);
