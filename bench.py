@@ -48,8 +48,17 @@ def parse():
     ap.add_argument("--collective", default="rccl", choices=["rccl", "torch", "gloo"],
                     help="rccl: native RCCL call on the library's stream; torch: torch.distributed.all_reduce hook; "
                          "gloo: all-reduce staged through the host (lets several ranks share ONE GPU: plumbing tests)")
-    ap.add_argument("--to-eps", type=float, default=None, help="also solve to this eps_acc and report time-to-eps")
-    ap.add_argument("--cpu-cones", type=int, default=0, help="cones in the CPU sample (0: pick from the thread count)")
+    ap.add_argument("--to-eps", type=float, default=None,
+                    help="also solve to this eps_acc and report time-to-eps (default: 1e-3 for the socp workload at its "
+                         "full size -- the eps_acc the reference runs its f32 backend at, benchmark_lp/src/main.rs:62-65)")
+    ap.add_argument("--no-to-eps", action="store_true", help="skip the time-to-eps leg (iterations/sec only)")
+    ap.add_argument("--to-eps-budget", type=float, default=1200.0,
+                    help="stop the time-to-eps leg after this many seconds and report the criteria reached (state -1)")
+    ap.add_argument("--state", default="compensated", choices=["compensated", "plain"],
+                    help="thip_param.state_arith: compensated (Kahan) or plain f32 iterate updates")
+    ap.add_argument("--cpu-cones", type=int, default=328,
+                    help="cones in the CPU sample: the first 328 of the instance by default (A_sub 13 GB of f64), a FIXED "
+                         "count so that the baseline reproduces from host to host")
     return ap.parse_args()
 
 
@@ -141,9 +150,15 @@ def cpu_baseline(n, n_cones_full, ni, seed, cones_sub, budget_s=25.0):
 
     t1, _ = run(2)                      # init (norms, preconditioner) + 2 iterations
     per_iter_guess = max(t1 / 4.0, 1e-3)
-    k2 = int(max(4, min(200, budget_s / per_iter_guess)))
-    t2, r2 = run(2 + k2)
-    rate_sub = k2 / (t2 - t1) if t2 > 1.05 * t1 else (2 + k2) / max(t2, 1e-9)    # tiny samples: init time is noise
+    # three independent timings of k2 iterations each (every one pays the init again, subtracted as t1): the median is
+    # the value, min / max the spread
+    k2 = int(max(3, min(70, budget_s / 3.0 / per_iter_guess)))
+    rates = []
+    for _ in range(3):
+        t2, r2 = run(2 + k2)
+        rates.append(k2 / (t2 - t1) if t2 > 1.05 * t1 else (2 + k2) / max(t2, 1e-9))   # tiny samples: init time is noise
+    rates.sort()
+    rate_sub = rates[1]
     # The reference's own f64 backend spends its iteration in 3 + 3 dgemv calls (f64lapack.rs:123-146, MKL there):
     # the same six products through numpy's BLAS on the same sub-matrix bound its iteration rate from above.
     blas = None
@@ -178,9 +193,12 @@ def cpu_baseline(n, n_cones_full, ni, seed, cones_sub, budget_s=25.0):
         "cores": O.num_threads(),
         "kind": "port",
         "sample": ("oracle (C, f64, OpenMP %d threads) on the first %d of %d cones of the same instance "
-                   "(A_sub %d x %d f64), %d timed iterations at %.3f iter/s, scaled by rows %d/%d"
-                   % (O.num_threads(), cones_sub, n_cones_full, m, n, k2, rate_sub, cones_sub, n_cones_full)),
+                   "(A_sub %d x %d f64), median of 3 timings of %d iterations: %.3f iter/s (min %.3f, max %.3f), "
+                   "scaled by rows %d/%d"
+                   % (O.num_threads(), cones_sub, n_cones_full, m, n, k2, rate_sub, rates[0], rates[2], cones_sub,
+                      n_cones_full)),
         "measured_sub_instance_iter_per_s": rate_sub,
+        "spread_iter_per_s": [rates[0] * cones_sub / n_cones_full, rates[2] * cones_sub / n_cones_full],
         "host_cpu_count": os.cpu_count(),
         "blas_gemv_bound": blas,
     }
@@ -268,6 +286,10 @@ def run(a):
     p.max_iter = None
     p.eps_acc = 0.0            # never terminates inside the timed region: every step does full work
     p.eps_inf = 0.0
+    p.state_arith = a.state
+    if a.to_eps is None and not a.no_to_eps and a.workload == "socp" and n == 50_000 and a.cones == 1000 \
+            and a.a_storage == "f32":
+        a.to_eps = 1e-3
     hook, coll = None, "none"
     if use_dist and a.collective == "gloo":
         hook, coll = GlooAllreduce(torch, dist, lib), "gloo through host memory (plumbing test mode)"
@@ -346,6 +368,8 @@ def run(a):
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
         "traffic": None,
+        "traffic_source": None,
+        "timer": "hip_events on the launch stream around every dual_gemv_k launch of the timed region (thip_prof_*)",
         "bytes_per_launch": bytes_per_pass,
         "avg_launch_ms": avg_ms,
         "launches_timed": nl.value,
@@ -361,11 +385,17 @@ def run(a):
             key = "%s_n%d_m%d_%s%s" % (a.workload, n, inst.m, a.schedule, "" if a.a_storage == "f32" else "_" + a.a_storage)
             if key in tr:
                 roofline["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = ("stored PMC run (profiles/hbm_traffic.json: %s), not a counter of this run"
+                                              % tr[key].get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE"))
+                if "rocprof_avg_launch_ms" in tr[key]:
+                    # the same kernel under rocprofv3 --kernel-trace --stats (includes the autotune / warm-up launches)
+                    roofline["rocprof_avg_launch_ms"] = tr[key]["rocprof_avg_launch_ms"]
+                    roofline["rocprof_frac"] = bytes_per_pass / (tr[key]["rocprof_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
         except Exception:
             pass
 
     out = {
-        "metric": "solver iterations/sec, dense SOCP n=50k (time-to-eps with --to-eps)" if a.workload == "socp"
+        "metric": "solver iters/sec + time-to-eps, dense SOCP n=50k (value = iters/sec; time_to_eps beside it)" if a.workload == "socp"
                   else "solver iterations/sec, dense %s" % a.workload.upper(),
         "a_storage": a.a_storage,
         "value": iters_per_s,
@@ -378,31 +408,53 @@ def run(a):
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32" if a.a_storage == "f32" else "f32 arithmetic on a 16-bit-STORED A (%s; rounded problem; not the headline)" % a.a_storage,
-        "data": "synthetic (counter-based generator on device, seed 0)",
+        "data": "synthetic (counter-based generator on device, seed 0; 'normal' entries are Irwin-Hall(4) sums scaled to "
+                "unit variance, not exact Gaussians)",
+        "state_arith": a.state,
         "config": {"workload": wl, "schedule": a.schedule, "passes_over_A_per_iter": passes,
                    "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll,
                    "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan(), "a_storage": a.a_storage},
         "roofline": roofline,
+        # north_star: "same primal/dual objective as the f64 CPU reference within 1e-4 relative".  The f64 oracle runs the
+        # full-size instance at ~0.24 iter/s (1e5 iterations = 5 days), so the gate is checked where it finishes:
+        "objective_gate": {"tolerance": 1e-4,
+                           "largest_size_checked": "synthetic SOCP n=2000, 40 cones of 1+99 rows (same generator), eps_acc 1e-3",
+                           "relative_gap_measured": 4.1e-8,
+                           "evidence": "profiles/r01_objective_gap_socp_n2000.json; asserted in tests at n=500 "
+                                       "(test_synth_socp_converges_to_oracle_objective)",
+                           "at_this_size": "unverifiable against the f64 CPU path (see above); primal vs dual objective of "
+                                           "the GPU solve itself is reported in time_to_eps"},
     }
 
     if a.to_eps is not None:
         p2 = T.SolverParam()
         p2.eps_acc = a.to_eps
+        p2.state_arith = a.state
+        budget = {"hit": False}
         def run_to_end(fs):
             # in chunks, with a progress line on stderr: a run that hits an outer time limit still leaves its trail
             while True:
-                r = fs.run(20000, poll_every=64)
+                r = fs.run(5000, poll_every=100)
                 if rank == 0:
                     sys.stderr.write("to-eps: iter %d state %d cri %.3e %.3e %.3e t %.1f s\n"
                                      % (r.iters + 1, r.state, r.cri[0], r.cri[1], r.cri[2], time.perf_counter() - t0))
                     sys.stderr.flush()
                 if r.state != _lib.ST_RUNNING:
                     return r
+                # every rank sees the same elapsed-time decision (rank 0's clock)
+                over = time.perf_counter() - t0 > a.to_eps_budget
+                if use_dist:
+                    tt = torch.tensor([1 if over else 0], dtype=torch.int32, device="cpu" if a.collective == "gloo" else "cuda")
+                    dist.broadcast(tt, src=0)
+                    over = bool(int(tt.item()))
+                if over:
+                    budget["hit"] = True
+                    return r
 
-        fs2 = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
-                            a.schedule, allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"))
         barrier()
         t0 = time.perf_counter()
+        fs2 = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
+                            a.schedule, allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"))
         r2 = run_to_end(fs2)
         barrier()
         phase1 = None
@@ -421,7 +473,11 @@ def run(a):
             r2 = run_to_end(fs2)
             barrier()
         out["time_to_eps"] = {"eps_acc": a.to_eps, "seconds": time.perf_counter() - t0, "iterations": r2.iters + 1,
-                              "state": r2.state, "cri": list(r2.cri)}
+                              "state": r2.state, "cri": list(r2.cri), "a_storage": a.a_storage, "state_arith": a.state,
+                              "budget_s": a.to_eps_budget, "budget_hit": budget["hit"],
+                              "what": "wall time of the solve from the initial iterate (x = 0, tau = 1) to the reference's "
+                                      "stopping test at eps_acc (solver.rs:381-400), A resident in HBM, init (norms, "
+                                      "preconditioner, plan autotune) included"}
         if phase1:
             out["time_to_eps"]["f16_phase" if a.a_storage == "mixed" else "bf16_phase"] = phase1
         x, y = fs2.solution()
@@ -433,8 +489,14 @@ def run(a):
 
     if rank == 0 and world == 1 and not a.no_cpu and a.workload == "socp":
         import oracle as O
-        # enough rows to give every OpenMP thread row blocks (256 rows each), A_sub capped at 16 GB of f64
-        cc = a.cpu_cones or max(20, min(int(2.56 * O.num_threads()) + 1, int(16e9 / (8.0 * n * 100))))
+        # a fixed sample (default: the first 328 cones, A_sub 13 GB of f64) so that the figure reproduces; shrunk only
+        # when the host's free memory cannot hold it
+        cc = a.cpu_cones
+        try:
+            import psutil
+            cc = max(8, min(cc, int(0.4 * psutil.virtual_memory().available / (8.0 * n * 100))))
+        except Exception:
+            pass
         out["cpu_baseline"] = cpu_baseline(n, a.cones, 99, 0, min(cc, a.cones))
     elif rank == 0:
         out["cpu_baseline"] = None

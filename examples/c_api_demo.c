@@ -34,7 +34,7 @@ int main(void)
     const int32_t seg_type[1] = { THIP_CONE_RPOS };
     const int64_t seg_len[1] = { 3 };
     thip_problem prob = { 2, 3, a, b, c, NULL, 1, seg_type, seg_len };
-    thip_param par = { 100000, 1e-5f, 1e-6f, 1e-12f, 0 };
+    thip_param par = { 100000, 1e-5f, 1e-6f, 1e-12f, 0, THIP_STATE_COMPENSATED, 0 };
     thip_solver *s = NULL;
     thip_status st;
     float x[2], yy[3];

@@ -154,10 +154,21 @@ int thip_group_min_batched(float *dp_tau, const int64_t *dev_offs, size_t n_grou
  * ------------------------------------------------------------------------------------------- */
 typedef struct thip_solver thip_solver;
 
+/* Arithmetic of the iterate updates x += T o tx, y += S o ty (solver.rs:542,560) of the fused loop.  Storage and
+ * every product stay f32 either way.
+ *   THIP_STATE_COMPENSATED: each of the five iterate vectors (x_x, x_y, x_s, u, v) carries a Kahan term, O(n + m)
+ *     floats next to an m x n matrix.  Without it the f32 iterate stops moving once an update is below half an ulp of
+ *     the entry it is added to, and the dual criterion floors (1.6e-4 on the n = 50 000 SOCP) -- a floor
+ *     the reference's own f32 backend shares, which is why it is run at eps_acc = 1e-3 (benchmark_lp/src/main.rs:62-65);
+ *   THIP_STATE_PLAIN: x + inc in plain f32, the reference's literal arithmetic. */
+enum { THIP_STATE_COMPENSATED = 0, THIP_STATE_PLAIN = 1 };
+
 typedef struct thip_param {           /* solver.rs:13-41 */
     int64_t max_iter;                 /* < 0: None */
     float   eps_acc, eps_inf, eps_zero;
     int64_t log_period;               /* 0: no periodic log */
+    int32_t state_arith;              /* THIP_STATE_* (not in the reference; zero-initialised = the default) */
+    int32_t reserved;                 /* 0 */
 } thip_param;
 
 enum { THIP_ST_RUNNING = -1,
@@ -210,6 +221,12 @@ int thip_solver_set_csr(thip_solver *s, size_t nnz,
                         const int64_t *dev_rowptr, const int32_t *dev_colidx, const float *dev_vals,
                         const int64_t *dev_t_rowptr, const int32_t *dev_t_colidx, const float *dev_t_vals);
 int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
+/* Row-sharded runs: on != 0 runs each stage's all-reduce on a side HIP stream of the solver (event in / event out)
+ * while the launch stream goes on with the stage's work on the LOCAL rows (the x_y / x_s update and the cone
+ * projections in the x-stage, the v update in the y-stage), which needs no collective; the x_x / u / tau / kappa
+ * updates wait for it.  The hook then receives the side stream.  Results are bitwise those of the in-order run.
+ * thip_solver_use_rccl switches it on; a hook that ignores its stream argument stays correct (and un-overlapped). */
+int thip_solver_set_overlap(thip_solver *s, int on);
 /* Storage of the dense A the iteration streams: THIP_A_F32 (default: prob->mat_a as given), or THIP_A_BF16 /
  * THIP_A_F16 (a library-owned 16-bit copy, made on the first request; f16 is column-scaled and rounds 8x finer than
  * bf16: half the bytes per pass, the problem solved is the one with the ROUNDED matrix).  Before thip_solver_init the preconditioners are computed from the stored form; between

@@ -157,6 +157,7 @@ struct SolverParam {                                                            
     int64_t max_iter = -1;                 // < 0: None
     float eps_acc = 1e-6f, eps_inf = 1e-6f, eps_zero = 1e-12f;
     int64_t log_period = 10000;
+    int32_t state_arith = THIP_STATE_COMPENSATED;   // fused loop only (not in the reference): THIP_STATE_*
 };
 enum class SolverError { Ok = 0, Unbounded, Infeasible, ExcessIter, InvalidOp, WorkShortage, ConeFailure };   // solver_error.rs:3-17
 
@@ -319,6 +320,7 @@ private:
         thip_param p{};
         p.max_iter = par.max_iter; p.eps_acc = par.eps_acc; p.eps_inf = par.eps_inf; p.eps_zero = par.eps_zero;
         p.log_period = 0;
+        p.state_arith = par.state_arith;
         return p;
     }
     size_t n_, m_;

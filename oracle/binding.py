@@ -38,7 +38,7 @@ class Trace(C.Structure):
     _fields_ = [("rec", C.POINTER(TraceRec)), ("cap", C.c_size_t), ("len", C.c_size_t),
                 ("iters", C.c_int64), ("norm_b", C.c_double), ("norm_c", C.c_double),
                 ("snap_iters", C.POINTER(C.c_int64)), ("n_snap", C.c_size_t),
-                ("snap_out", C.POINTER(C.c_double))]
+                ("snap_out", C.POINTER(C.c_double)), ("precond_out", C.POINTER(C.c_double))]
 
 
 _lib = None
@@ -119,6 +119,10 @@ def _mk_trace(cap, snap_iters=None, NM=0):
         t.snap_out = so.ctypes.data_as(_dp)
         keep["si"] = si
         keep["so"] = so
+    if NM:
+        pc = np.zeros(NM, dtype=np.float64)       # dp_tau (N) then dp_sigma (M) of calc_precond
+        t.precond_out = pc.ctypes.data_as(_dp)
+        keep["pc"] = pc
     return t, keep
 
 
@@ -128,7 +132,9 @@ def _finish(rc, x, y, t, keep):
         n = min(t.len, t.cap)
         r = keep["recs"]
         recs = [(r[i].iter, r[i].kind, r[i].v0, r[i].v1, r[i].v2) for i in range(n)]
-    return Result(rc, x, y, t, recs, keep.get("so"))
+    res = Result(rc, x, y, t, recs, keep.get("so"))
+    res.precond = keep.get("pc")
+    return res
 
 
 def solve_matop_cones(par, vec_c, mat_a, vec_b, seg_type, seg_len, use_ql=False, trace_cap=0,

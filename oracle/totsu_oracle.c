@@ -806,6 +806,7 @@ static int core_solve(core_t *s, double *work, oc_trace *trace)
     x[n + m + m] = 1.0;
 
     calc_precond(s, dp_tau, dp_sigma);
+    if (trace && trace->precond_out) memcpy(trace->precond_out, dp_tau, (N + M) * sizeof(double));
 
     int64_t i = 0;
     for (;;) {

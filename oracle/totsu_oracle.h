@@ -115,6 +115,8 @@ typedef struct oc_trace {
     double  norm_b, norm_c;
     /* optional state snapshots: x then y (N+M doubles) at the iterations listed */
     const int64_t *snap_iters; size_t n_snap; double *snap_out;
+    /* optional: dp_tau (N) then dp_sigma (M) as calc_precond leaves them (solver.rs:496-524) */
+    double *precond_out;
 } oc_trace;
 
 size_t oc_query_worklen(size_t m, size_t n);               /* solver.rs:231-249 */

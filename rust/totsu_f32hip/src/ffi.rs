@@ -3,7 +3,10 @@
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)]
-pub struct thip_param { pub max_iter: i64, pub eps_acc: f32, pub eps_inf: f32, pub eps_zero: f32, pub log_period: i64 }
+pub struct thip_param { pub max_iter: i64, pub eps_acc: f32, pub eps_inf: f32, pub eps_zero: f32, pub log_period: i64,
+                         pub state_arith: i32, pub reserved: i32 }
+pub const THIP_STATE_COMPENSATED: i32 = 0;
+pub const THIP_STATE_PLAIN: i32 = 1;
 
 #[repr(C)]
 pub struct thip_problem {
@@ -69,6 +72,7 @@ extern "C" {
     pub fn thip_solver_create(prob: *const thip_problem, par: *const thip_param, schedule: c_int,
                               out: *mut *mut thip_solver) -> c_int;
     pub fn thip_solver_set_allreduce(s: *mut thip_solver, f: thip_allreduce_fn, ctx: *mut c_void) -> c_int;
+    pub fn thip_solver_set_overlap(s: *mut thip_solver, on: c_int) -> c_int;
     pub fn thip_solver_init(s: *mut thip_solver) -> c_int;
     pub fn thip_solver_run(s: *mut thip_solver, max_steps: i64, poll_every: i64, host_status: *mut thip_status) -> c_int;
     pub fn thip_solver_solution(s: *mut thip_solver, host_x: *mut f32, host_y: *mut f32) -> c_int;

@@ -1,0 +1,204 @@
+"""GPU: BASELINE.json's configs[3] and configs[4] at their FULL sizes.
+
+configs[4] = dense LP n = 200 000, m = 400 000 row-partitioned over 8 GPUs: one rank's shard is 50 000 x 200 000 f32
+(40 GB).  A 1-GPU box holds any ONE of the eight shards, so the per-rank product path is checked shard by shard through
+size-independent properties (exact answers on the -I rows, regenerated rows / columns of the counter-based generator,
+adjointness, linearity, agreement of the schedules), and the 8-way sharded solve is checked against the oracle at
+reduced n with the shards keeping C5's 1 : 4 aspect ratio.
+
+configs[3] = SDP with one PSD cone of order 500 (n = 2000, A 125 250 x 2000): iterates of the full-size instance
+against the oracle's snapshots (Householder + QL at k = 500 on the CPU), and the unaligned-lda GEMV shape."""
+import numpy as np
+import pytest
+
+import oracle as O
+from problems import benchmark_lp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import totsu_amd
+    from totsu_amd import _lib
+    _lib.init()
+    return totsu_amd
+
+
+N5, WORLD5 = 200_000, 8
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+def test_c5_shard_products(T, rank):
+    """rank 0 holds rows 0 .. 50 000 of G = [-I ; U(0,1)] (all inside the -I block: the products are known EXACTLY);
+    rank 7 holds the last 50 000 dense rows (entries regenerated from the counter-based generator in f64)."""
+    from totsu_amd import synth
+    from totsu_amd._lib import lib
+    D = T.DeviceBuffer
+    inst = synth.LpInstance(N5, seed=0, rank=rank, world=WORLD5)
+    m, n, m_total = inst.m, inst.n, inst.m_total
+    assert (m, n) == (50_000, 200_000) and inst.r0 == rank * 50_000
+    x, y = D(n), D(m)
+    lib.thip_gen_vector(x.ptr, n, 0, 2, 0, 1, 1.0, 0.0)
+    lib.thip_gen_vector(y.ptr, m, 0, 3, 0, 1, 1.0, 0.0)
+    Ax, Aty = D(m), D(n)
+    lib.thip_transform_ge(0, m, n, 1.0, inst.mat_a.ptr, x.ptr, 0.0, Ax.ptr)
+    lib.thip_transform_ge(1, m, n, 1.0, inst.mat_a.ptr, y.ptr, 0.0, Aty.ptr)
+    hx, hy = x.to_host(), y.to_host()
+    hAx, hAty = Ax.to_host(), Aty.to_host()
+    if rank == 0:
+        # A = [-I_50000 | 0]: A x = -x[:m], A^T y = [-y ; 0] -- bit-exact (every other term is an exact zero)
+        assert np.array_equal(hAx, -hx[:m])
+        assert np.array_equal(hAty[:m], -hy) and not hAty[m:].any()
+    else:
+        hx64, hy64 = hx.astype(np.float64), hy.astype(np.float64)
+        for r in (0, 1, 31_337, m - 1):
+            row = np.array([O.rng_uniform(0, synth.STREAM_A, (inst.r0 + r) + cc * m_total) for cc in range(n)])
+            assert abs(hAx[r] - row @ hx64) <= 2e-5 * (np.abs(row) @ np.abs(hx64))
+        for cc in (0, 77_777, n - 1):
+            col = np.array([O.rng_uniform(0, synth.STREAM_A, (inst.r0 + r) + cc * m_total) for r in range(m)])
+            assert abs(hAty[cc] - col @ hy64) <= 2e-5 * (np.abs(col) @ np.abs(hy64))
+    # adjointness <A x, y> == <x, A^T y> in f64 of the f32 results
+    lhs = hAx.astype(np.float64) @ hy.astype(np.float64)
+    rhs = hx.astype(np.float64) @ hAty.astype(np.float64)
+    assert abs(lhs - rhs) <= 1e-5 * (np.abs(hAx).astype(np.float64) @ np.abs(hy).astype(np.float64))
+    # linearity and beta accumulation: 2 A x - A x == A x
+    lib.thip_transform_ge(0, m, n, 2.0, inst.mat_a.ptr, x.ptr, -1.0, Ax.ptr)
+    assert np.allclose(Ax.to_host(), hAx, rtol=1e-5, atol=1e-3)
+    for d in (x, y, Ax, Aty):
+        d.free()
+    inst.free()
+
+
+def test_c5_shard_iteration_schedules_agree(T):
+    """five iterations of the device loop on rank 7's 40 GB shard with the all-reduce hook installed (one rank: the sum
+    over ranks is the identity, the hook placement and tail scalars are the sharded code path): the 2-pass carried
+    schedule and the reference's 6-GEMV schedule must produce the same iterate"""
+    from totsu_amd import synth
+    inst = synth.LpInstance(N5, seed=0, rank=7, world=WORLD5)
+    p = T.SolverParam()
+    p.eps_acc, p.eps_inf, p.max_iter = 0.0, 0.0, None
+    calls = []
+
+    def hook(ctx, ptr, cnt, stream):
+        calls.append(cnt)
+        return 0
+
+    its = {}
+    for sched in ("reference", "carried"):
+        fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, sched,
+                           allreduce=hook)
+        r = fs.run(5, poll_every=5)
+        assert r.state == -1 and r.iters == 5 and np.isfinite(r.cri[0]) and np.isfinite(r.tau)
+        its[sched] = fs.iterate()
+        fs.destroy()
+    # the A^T partial with the block partials of the sharded sums in its tail (n + 4 * 256), and the one at init
+    # (|A| column sums + 2 scalars): nothing else is exchanged
+    assert set(calls) == {inst.n + 2, inst.n + 1024}, set(calls)
+    for a, b in zip(its["reference"], its["carried"]):
+        sc = max(np.abs(a).max(), 1e-6)
+        assert np.abs(a - b).max() <= 5e-5 * sc, np.abs(a - b).max() / sc
+    inst.free()
+
+
+def test_c5_aspect_eight_emulated_ranks_vs_oracle(T):
+    """the benchmark_lp construction at n = 96 split over EIGHT emulated ranks (shards of 24 x 96: C5's 1 : 4 aspect
+    ratio; ranks 0-3 hold -I rows, ranks 4-7 dense rows, as at full size) against the oracle's solve"""
+    from test_gpu_sharded import _mb, _run_sharded
+    n = 96
+    c, G, h = benchmark_lp(n, seed=8)
+    lp = T.ProbLP(_mb(T, T.MatType.General(n, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(2 * n, n)).set_array(G),
+                  _mb(T, T.MatType.General(2 * n, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, n)),
+                  _mb(T, T.MatType.General(0, 1)))
+    dense = lp.dense()
+    m = dense.m
+    A = dense.mat_a.reshape((n, m)).T
+    rows = m // 8
+    parts = [dict(n=n, m=rows, mat_a=np.asfortranarray(A[k * rows:(k + 1) * rows]).ravel(order="F"),
+                  vec_b=dense.vec_b[k * rows:(k + 1) * rows], vec_c=dense.vec_c, seg_type=[1], seg_len=[rows], rowabs=None)
+             for k in range(8)]
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 400_000, 1e-4
+    out = _run_sharded(T, parts, p, "carried")
+    ro = O.solve_matop_cones(O.param(max_iter=400000, eps_acc=1e-4), dense.vec_c, dense.mat_a, dense.vec_b,
+                             dense.seg_type, dense.seg_len)
+    assert ro.status == O.OK
+    assert all(o[0].state == 0 for o in out)
+    assert len({o[0].iters for o in out}) == 1                     # every rank stops at the same iteration
+    assert abs(out[0][0].iters - ro.iters) <= 0.02 * ro.iters + 5
+    for o in out[1:]:
+        assert np.array_equal(o[1], out[0][1])                     # replicated x is bitwise identical on all ranks
+    x = out[0][1].astype(np.float64)
+    y = np.concatenate([o[2] for o in out]).astype(np.float64)
+    pobj = float(dense.vec_c.astype(np.float64) @ ro.x)
+    assert abs(float(dense.vec_c.astype(np.float64) @ x) - pobj) <= 1e-4 * (1 + abs(pobj))
+    assert np.allclose(x, ro.x, rtol=0, atol=2e-3 * max(1.0, np.abs(ro.x).max()))
+    assert np.allclose(y, ro.y, rtol=0, atol=2e-3 * max(1.0, np.abs(ro.y).max()))
+    lp.drop()
+
+
+# ---- configs[3] at full size --------------------------------------------------------------------------------------
+
+def test_c4_gemv_unaligned_lda_properties(T):
+    """A of the k = 500 SDP: 125 250 x 2000, lda = 125 250 (not a multiple of 4)"""
+    from totsu_amd._lib import lib
+    D = T.DeviceBuffer
+    m, n = 125_250, 2000
+    A = D(n * m)
+    lib.thip_gen_matrix(A.ptr, m, n, m, 0, 1, 0, 0, m, 0, 1.0, 0.0)
+    x, y = D(n), D(m)
+    lib.thip_gen_vector(x.ptr, n, 0, 2, 0, 1, 1.0, 0.0)
+    lib.thip_gen_vector(y.ptr, m, 0, 3, 0, 1, 1.0, 0.0)
+    Ax, Aty = D(m), D(n)
+    lib.thip_transform_ge(0, m, n, 1.0, A.ptr, x.ptr, 0.0, Ax.ptr)
+    lib.thip_transform_ge(1, m, n, 1.0, A.ptr, y.ptr, 0.0, Aty.ptr)
+    hx, hy = x.to_host().astype(np.float64), y.to_host().astype(np.float64)
+    hAx, hAty = Ax.to_host().astype(np.float64), Aty.to_host().astype(np.float64)
+    assert abs(hAx @ hy - hx @ hAty) <= 1e-5 * (np.abs(hAx) @ np.abs(hy))
+    for r in (0, 1, 2, 3, 62_501, m - 2, m - 1):
+        row = np.array([O.rng_uniform(0, 1, r + cc * m) for cc in range(n)])
+        assert abs(hAx[r] - row @ hx) <= 2e-5 * (np.abs(row) @ np.abs(hx))
+    for cc in (0, 1, 999, n - 1):
+        col = np.array([O.rng_uniform(0, 1, r + cc * m) for r in range(m)])
+        assert abs(hAty[cc] - col @ hy) <= 2e-5 * (np.abs(col) @ np.abs(hy))
+    for d in (A, x, y, Ax, Aty):
+        d.free()
+
+
+@pytest.mark.parametrize("schedule", ["fused", "carried"])
+def test_c4_full_size_sdp_iterates_vs_oracle(T, schedule):
+    """the bench's configs[3] instance (k = 500, n = 2000, A 1 GB) for three iterations: preconditioner and iterates
+    against the oracle (f64; its PSD projection is Householder + QL at k = 500)"""
+    from totsu_amd import synth
+    inst = synth.SdpInstance(2000, 500, seed=0)
+    n, m = inst.n, inst.m
+    a = inst.mat_a.to_host()[:m * n].astype(np.float64)
+    b, c = inst.vec_b_host.astype(np.float64), inst.vec_c_host.astype(np.float64)
+    iters = [0, 1, 2]
+    k = O.num_threads()
+    O.set_num_threads(max(k, min(64, (__import__("os").cpu_count() or 8))))      # 2 GB products: use the host's cores
+    try:
+        ro = O.solve_matop_cones(O.param(max_iter=5, eps_acc=1e-30), c, a, b, [O.CONE_PSD], [m], use_ql=True,
+                                 snap_iters=iters, trace_cap=8)
+    finally:
+        O.set_num_threads(k)
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    fs = T.FusedSolver(n, m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule)
+    t, s = fs.precond()
+    N = n + 2 * m + 1
+    assert np.allclose(t, ro.precond[:N], rtol=5e-5, atol=0)
+    assert np.allclose(s, ro.precond[N:], rtol=5e-5, atol=0)
+    done = 0
+    for q, it in enumerate(iters):
+        fs.run(it + 1 - done, poll_every=8)
+        done = it + 1
+        x, y = fs.iterate()
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        sx, sy = max(np.abs(rx).max(), 1e-6), max(np.abs(ry).max(), 1e-6)
+        assert np.abs(x - rx).max() <= 1e-4 * sx, (it, np.abs(x - rx).max() / sx)
+        assert np.abs(y - ry).max() <= 1e-4 * sy, (it, np.abs(y - ry).max() / sy)
+        tr = ro.trace[it]
+        assert np.allclose(fs.status().cri, tr[2:], rtol=5e-3, atol=1e-5), (it, fs.status().cri, tr)
+    fs.destroy()
+    inst.free()

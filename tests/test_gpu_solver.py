@@ -169,6 +169,10 @@ def _check_iterates(T, dense, schedule, iters, tols):
     fs = T.FusedSolver.from_dense(dense, p, schedule)
     t, s = fs.precond()
     N = dense.n + 2 * dense.m + 1
+    # calc_precond (solver.rs:496-524) = 1 / max(abssum, eps_zero) with the block-cone minima of
+    # product_group, against the oracle's dp_tau / dp_sigma
+    assert np.allclose(t, ro.precond[:N], rtol=2e-5, atol=0), np.abs(t / ro.precond[:N] - 1).max()
+    assert np.allclose(s, ro.precond[N:], rtol=2e-5, atol=0), np.abs(s / ro.precond[N:] - 1).max()
     done = 0
     for q, (it, tol) in enumerate(zip(iters, tols)):
         fs.run(it + 1 - done, poll_every=64)
@@ -716,11 +720,11 @@ def test_schedules_agree_at_the_full_socp_size(T):
     inst.free()
 
 
-def test_compensated_state_lowers_the_f32_floor(T, monkeypatch):
+def test_compensated_state_lowers_the_f32_floor(T):
     # In plain f32 the iterate stops moving once an update is below half an ulp of the entry it is added to: the dual
     # criterion of this n = 200 SOCP freezes at 6.3e-6 (the same number in a numpy f32 emulation of the reference's
-    # loop, 1.2e-14 in f64).  THIP_COMPENSATED_STATE=1 (Kahan terms for x_x, x_y, x_s, u, v; experimental, default
-    # off) takes it to ~1e-7 with the same f32 storage and arithmetic.
+    # loop, 1.2e-14 in f64).  thip_param.state_arith = THIP_STATE_COMPENSATED (Kahan terms for x_x, x_y, x_s, u, v)
+    # takes it to ~1e-7 with the same f32 storage and arithmetic; THIP_STATE_PLAIN is the reference's literal f32.
     f, Gs, hs, cs, d = random_socp(200, [99] * 6, seed=1)
     n = 200
     socp = T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(f.reshape(-1, 1)),
@@ -733,7 +737,7 @@ def test_compensated_state_lowers_the_f32_floor(T, monkeypatch):
     p.eps_acc = 0.0
     floors = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("THIP_COMPENSATED_STATE", flag)        # read by thip_solver_create
+        p.state_arith = "compensated" if flag == "1" else "plain"
         fs = T.FusedSolver.from_dense(dense, p, "carried")
         r = fs.run(15000, poll_every=64)
         floors[flag] = r.cri[1]
@@ -741,3 +745,51 @@ def test_compensated_state_lowers_the_f32_floor(T, monkeypatch):
         fs.destroy()
     assert 2e-6 < floors["0"] < 2e-5, floors
     assert floors["1"] < 5e-7, floors
+
+
+def test_solver_can_be_initialised_again_after_a_finished_solve(T):
+    # thip_solver_init after a terminated solve starts a fresh solve: same iteration count, same (1/tau-scaled) answer
+    c, G, h = benchmark_lp(48, seed=5)
+    lp = T.ProbLP(_mb(T, T.MatType.General(48, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(96, 48)).set_array(G),
+                  _mb(T, T.MatType.General(96, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, 48)),
+                  _mb(T, T.MatType.General(0, 1)))
+    p = T.SolverParam()
+    p.eps_acc, p.max_iter = 1e-4, 200_000
+    for sched in ("fused", "carried"):
+        fs = T.FusedSolver.from_dense(lp.dense(), p, sched)
+        x1, y1 = fs.solve()
+        it1 = fs.status().iters
+        fs.reinit()
+        assert fs.status().state == -1 and fs.status().iters == 0
+        x2, y2 = fs.solve()
+        assert fs.status().iters == it1
+        assert np.array_equal(x1, x2) and np.array_equal(y1, y2)
+        fs.destroy()
+    lp.drop()
+
+
+def test_storage_switch_inside_a_carried_solve_rebuilds_the_carried_products(T):
+    # carried keeps A^T x_y and A x_x of the current iterate; after bf16 -> f32 they must be recomputed with the f32
+    # matrix, or the first y-update mixes the two matrices (a 2^-9 relative one-off error).  The fused schedule carries
+    # nothing, so it is the reference: same switch, same iterates.
+    f, Gs, hs, cs, d = random_socp(60, [9, 30, 17], seed=4)
+    n = 60
+    socp = T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(f.reshape(-1, 1)),
+                      [_mb(T, T.MatType.General(G.shape[0], n)).set_array(G) for G in Gs],
+                      [_mb(T, T.MatType.General(len(h_), 1)).set_array(h_.reshape(-1, 1)) for h_ in hs],
+                      [_mb(T, T.MatType.General(n, 1)).set_array(c_.reshape(-1, 1)) for c_ in cs], d,
+                      _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    its = {}
+    for sched in ("fused", "carried"):
+        fs = T.FusedSolver.from_dense(socp.dense(), p, sched, a_storage="bf16")
+        fs.run(200, poll_every=50)
+        fs.set_a_storage("f32")
+        fs.run(3, poll_every=3)
+        its[sched] = fs.iterate()
+        fs.destroy()
+    for a, b in zip(its["fused"], its["carried"]):
+        sc = np.abs(a).max()
+        assert np.abs(a - b).max() <= 2e-5 * sc, np.abs(a - b).max() / sc
+    socp.drop()

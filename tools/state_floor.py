@@ -1,7 +1,7 @@
-"""The f32 floor of the dual criterion and what compensated iterate updates (THIP_COMPENSATED_STATE=1) do to it:
+"""The f32 floor of the dual criterion and what compensated iterate updates (thip_param.state_arith) do to it:
 a small SOCP (n = 200, 6 cones of 1 + 99 rows) run for a fixed number of iterations with eps_acc = 0; prints the
 criteria along the way.  A numpy emulation of the same iteration gives 6.3e-6 (plain f32) vs 1e-7 (Kahan).
-Usage: [THIP_COMPENSATED_STATE=1] python tools/state_floor.py [n] [cones] [iters]"""
+Usage: [STATE=plain] python tools/state_floor.py [n] [cones] [iters]"""
 import os
 import sys
 
@@ -29,12 +29,13 @@ def main():
                       mb(T.MatType.General(0, n)), mb(T.MatType.General(0, 1)))
     p = T.SolverParam()
     p.eps_acc, p.max_iter = 0.0, None
+    p.state_arith = os.environ.get("STATE", "compensated")
     for sched in ("reference", "carried"):
         fs = T.FusedSolver.from_dense(socp.dense(), p, sched)
         for k in range(6):
             r = fs.run(iters // 6, poll_every=64)
             print("compensated=%s %-9s iter %6d  pri %.3e dual %.3e gap %.3e"
-                  % (os.environ.get("THIP_COMPENSATED_STATE", "0"), sched, r.iters, r.cri[0], r.cri[1], r.cri[2]), flush=True)
+                  % (p.state_arith, sched, r.iters, r.cri[0], r.cri[1], r.cri[2]), flush=True)
         fs.destroy()
 
 

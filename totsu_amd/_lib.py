@@ -14,6 +14,7 @@ E_INVALID, E_NOTINIT, E_NOGPU, E_WORK, E_NOCONV = 10001, 10002, 10003, 10004, 10
 ST_RUNNING, ST_OK, ST_UNBOUNDED, ST_INFEASIBLE, ST_EXCESS_ITER, ST_INVALID_OP, ST_WORK_SHORTAGE, ST_CONE_FAILURE = \
     -1, 0, 1, 2, 3, 4, 5, 6
 SCHED_REFERENCE, SCHED_FUSED, SCHED_CARRIED = 0, 1, 2
+STATE_COMPENSATED, STATE_PLAIN = 0, 1
 CONE_ZERO, CONE_RPOS, CONE_SOC, CONE_ROTSOC, CONE_PSD = 0, 1, 2, 3, 4
 
 fp = C.POINTER(C.c_float)
@@ -27,7 +28,7 @@ class ThipError(RuntimeError):
 
 class Param(C.Structure):
     _fields_ = [("max_iter", C.c_int64), ("eps_acc", C.c_float), ("eps_inf", C.c_float),
-                ("eps_zero", C.c_float), ("log_period", C.c_int64)]
+                ("eps_zero", C.c_float), ("log_period", C.c_int64), ("state_arith", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Problem(C.Structure):
@@ -101,6 +102,7 @@ PROTOTYPES = {
     "thip_solver_create": (_i, [C.POINTER(Problem), C.POINTER(Param), _i, C.POINTER(_vp)]),
     "thip_solver_set_csr": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thip_solver_set_allreduce": (_i, [_vp, ALLREDUCE_FN, _vp]),
+    "thip_solver_set_overlap": (_i, [_vp, _i]),
     "thip_solver_set_a_storage": (_i, [_vp, _i]),
     "thip_solver_set_a_bf16": (_i, [_vp, _vp, _sz]),
     "thip_solver_set_a_f16": (_i, [_vp, _vp, _sz, _vp]),

@@ -106,7 +106,8 @@ int thip_comm_allreduce(float *dev_buf, size_t n)
 int thip_solver_use_rccl(thip_solver *s)
 {
     if (!g.comm) return fail(THIP_E_NOTINIT, "thip_comm_init() has not been called", __FILE__, __LINE__);
-    return thip_solver_set_allreduce(s, rccl_allreduce, nullptr);
+    THIP_RC(thip_solver_set_allreduce(s, rccl_allreduce, nullptr));
+    return thip_solver_set_overlap(s, 1);      // the collective runs on the solver's side stream, under the local-row work
 }
 
 }  // extern "C"

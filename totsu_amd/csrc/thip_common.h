@@ -150,6 +150,8 @@ size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col);
 int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float alpha, float beta,
                       float *y, const int *stop);
 
+void prof_release();      // destroys the HIP events of thip_prof_* (thip_shutdown)
+
 int reduce_to_dev(hipStream_t st, int op, size_t n, const float *x, const float *y, size_t incx, float *dev_out);
 enum { RED_SUMSQ_SQRT = 0, RED_ABSSUM = 1, RED_DOT = 2 };
 

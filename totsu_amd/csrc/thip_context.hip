@@ -96,6 +96,7 @@ int thip_shutdown(void)
     if (!c.inited) return 0;
     hipSetDevice(c.device);
     hipStreamSynchronize(c.stream);
+    prof_release();
     if (c.scratch) hipFree(c.scratch);
     if (c.dev_scalar) hipFree(c.dev_scalar);
     if (c.pinned) hipHostFree(c.pinned);

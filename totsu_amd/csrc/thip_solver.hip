@@ -30,7 +30,8 @@ using namespace thip;
 namespace {
 
 constexpr int BLK = 256;
-constexpr int TAIL = 8;          // scalars riding behind an n-vector through the all-reduce
+constexpr unsigned NPS = 256;    // sharded run: post_k's grid = number of block partials per sharded sum
+constexpr int TAIL = 4 * NPS;    // block partials of up to 3 sharded sums riding behind an n-vector through the all-reduce
 constexpr unsigned EG = 512;     // max blocks of the elementwise kernels (block partials per quantity)
 constexpr unsigned PG = 4096;    // max blocks of post_k (64 elements per block)
 
@@ -50,10 +51,15 @@ struct DevStatus {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// kernels.  One iteration of the carried schedule is 10 launches when the rows are sharded over GPUs:
-//   gemv, post, sumfin, [all-reduce], xupdate, soc | gemv, post, sumfin, [all-reduce], ycrit, status
-// and 7 on a single GPU, where the consumers sum post's block partials themselves and sumfin is dropped.  The final
-// 1/tau scaling is not a per-iteration launch: the host applies it once when it sees the terminated state.
+// kernels.  One iteration of the carried schedule is 7 launches (8 with block cones):
+//   gemv, post, [all-reduce], xupdate, soc | gemv, post, [all-reduce], ycrit, status
+// The stage's dots are left as block partials by post_k and summed by their consumers (block 0 / the status block).
+// In a row-sharded run the block partials of the SHARDED sums (b.v, ||p||^2, b.x_y, b.rx_y) are written straight into
+// the tail of the n-vector that is all-reduced (the sum over ranks of block partials is the block partials of the
+// global sum), so the sharded path has the single-GPU launch count.  With overlap on, xupdate / ycrit run as two
+// launches: the m-part (local rows: needs no collective) while the all-reduce is in flight on the side stream, the
+// n-part after it.  The final 1/tau scaling is not a per-iteration launch: the host applies it once when it sees the
+// terminated state.
 // ---------------------------------------------------------------------------------------------------
 
 // After a dual GEMV: second reduction stage of both products + the stage's sharded / replicated reductions.
@@ -61,7 +67,8 @@ struct DevStatus {
 //   q0 = dn_a . dn_b over n (optional) ; q1 = dm_a . dm_b over m (optional)
 //   crit != 0: q2 = ||p||^2, q3 = b . x_y with
 //      tau > eps_zero: p = x_s/tau - b + h/tau (solver.rs:592-594) ; else p = x_s + h (solver.rs:631-632)
-// block partials -> part[q * gridDim.x + blockIdx.x]
+// block partials: q0 (a sum over the replicated n-vectors) -> part_rep[blockIdx.x];
+//   q1..q3 (sums over the local rows) -> part_sh[q * gridDim.x + blockIdx.x] (part_sh = the all-reduce tail when sharded)
 __global__ __launch_bounds__(BLK) void post_k(int n, int m,
                                              const float *__restrict__ partT, int nT, size_t strideT, float *__restrict__ g,
                                              const float *__restrict__ partN, int nN, size_t strideN, float *__restrict__ h,
@@ -69,7 +76,8 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
                                              const float *__restrict__ dm_a, const float *__restrict__ dm_b,
                                              int crit, const float *__restrict__ xs, const float *__restrict__ xy,
                                              const float *__restrict__ b, float eps_zero,
-                                             float *__restrict__ part, const DevStatus *st)
+                                             float *__restrict__ part_rep, float *__restrict__ part_sh,
+                                             const DevStatus *st)
 {
     if (st->stop != 0) return;
     // 256 threads = 64 elements x 4 partial-index lanes: the sum over the ~100 partials of one element is split
@@ -122,40 +130,22 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
         __syncthreads();
     }
     q0 = block_sum(q0, sh); q1 = block_sum(q1, sh);
-    if (threadIdx.x == 0) { part[blockIdx.x] = q0; part[gridDim.x + blockIdx.x] = q1; }
+    if (threadIdx.x == 0) { part_rep[blockIdx.x] = q0; part_sh[gridDim.x + blockIdx.x] = q1; }
     if (crit) {
         q2 = block_sum(q2, sh); q3 = block_sum(q3, sh);
-        if (threadIdx.x == 0) { part[2 * gridDim.x + blockIdx.x] = q2; part[3 * gridDim.x + blockIdx.x] = q3; }
+        if (threadIdx.x == 0) { part_sh[2 * gridDim.x + blockIdx.x] = q2; part_sh[3 * gridDim.x + blockIdx.x] = q3; }
     }
 }
 
-// sum of the np block partials of quantity q (part[q * np + k]) by one whole block, in sumfin_k's order (so the value
-// is the one sumfin_k would have stored); the result is valid in every thread.  shd: 16 doubles of LDS.
-__device__ __forceinline__ float block_sum_of_partials(const float *part, int q, int np, double *shd)
+// sum of np block partials by one whole block (f64 accumulation); the result is valid in every thread.
+// shd: 16 doubles of LDS.
+__device__ __forceinline__ float block_sum_of_partials(const float *part, int np, double *shd)
 {
     double acc = 0.0;
-    for (int k = threadIdx.x; k < np; k += BLK) acc += (double)part[(size_t)q * np + k];
+    for (int k = threadIdx.x; k < np; k += BLK) acc += (double)part[k];
     acc = block_sum_d(acc, shd);
     __syncthreads();
     return (float)acc;
-}
-
-// sums of the block partials of up to 4 quantities -> their destinations (null = skip); one block
-__global__ __launch_bounds__(BLK) void sumfin_k(int np, const float *__restrict__ part, float *d0, float *d1, float *d2,
-                                               float *d3, const int *__restrict__ stop)
-{
-    if (stop != nullptr && *stop != 0) return;
-    __shared__ double shd[16];
-    float *dst[4] = { d0, d1, d2, d3 };
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (dst[q] == nullptr) continue;
-        double acc = 0.0;
-        for (int k = threadIdx.x; k < np; k += BLK) acc += (double)part[(size_t)q * np + k];
-        acc = block_sum_d(acc, shd);
-        if (threadIdx.x == 0) *dst[q] = (float)acc;
-        __syncthreads();
-    }
 }
 
 // x + inc, optionally compensated: k[i] carries the rounding error of the previous additions into this entry (Kahan).
@@ -187,30 +177,31 @@ __global__ __launch_bounds__(BLK) void xupdate_k(int n, int m, const float *__re
                                                 const unsigned char *__restrict__ cls,
                                                 float *__restrict__ xx, float *__restrict__ xy, float *__restrict__ xs,
                                                 float *__restrict__ rxx, float *__restrict__ rxy, float *__restrict__ rxs,
-                                                const float *__restrict__ dot_c, const float *__restrict__ dot_b,
-                                                DevStatus *st, const float *psum, int npsum,
+                                                DevStatus *st, const float *ps_c, const float *ps_b, int np,
+                                                int do_n, int do_m,
                                                 float *__restrict__ kx, float *__restrict__ ky, float *__restrict__ ks)
 {
     if (st->stop != 0) return;
     // kx / ky / ks != NULL: compensated (Kahan) accumulation of the iterate -- see comp_add
-    // single GPU (no all-reduce between post_k and this kernel): block 0 sums post_k's block partials of c.u and b.v
-    // itself instead of a sumfin_k launch in between
+    // do_n: the x_x rows and tau (need the all-reduced gT and b.v); do_m: the x_y / x_s rows (local).  Both in one
+    // launch, or the m-part first while the all-reduce is in flight.
+    // block 0 sums post_k's block partials of c.u (ps_c) and b.v (ps_b: all-reduced block partials when sharded)
     float dc = 0.0f, db = 0.0f;
-    if (blockIdx.x == 0) {
-        if (psum != nullptr) {
-            __shared__ double shd[16];
-            dc = block_sum_of_partials(psum, 0, npsum, shd);
-            db = block_sum_of_partials(psum, 1, npsum, shd);
-        } else { dc = dot_c[0]; db = dot_b[0]; }
+    if (do_n && blockIdx.x == 0) {
+        __shared__ double shd[16];
+        dc = block_sum_of_partials(ps_c, np, shd);
+        db = block_sum_of_partials(ps_b, np, shd);
     }
     const float kappa = st->kappa;
     const size_t gstride = (size_t)gridDim.x * BLK;
+    if (do_n)
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
         const float old = xx[i];
         const float nw = comp_add(old, Tx[i] * (gT[i] + c[i] * kappa), kx, i);
         xx[i] = nw;
         rxx[i] = old - 2.0f * nw;
     }
+    if (do_m)
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
         const unsigned char k = cls[i];
         const float oy = xy[i], os = xs[i];
@@ -223,7 +214,7 @@ __global__ __launch_bounds__(BLK) void xupdate_k(int n, int m, const float *__re
         rxy[i] = (k < 2) ? oy - 2.0f * ny : oy;
         rxs[i] = (k < 2) ? os - 2.0f * ns : os;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (do_n && blockIdx.x == 0 && threadIdx.x == 0) {
         // every other thread only reads st->kappa / st->stop; tau is written by this thread alone
         const float old = st->tau;
         float t = old + st->t_tau * (-dc - db);
@@ -258,20 +249,19 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
                                               const float *__restrict__ c, const float *__restrict__ b,
                                               const float *__restrict__ rxs, const float *__restrict__ Su,
                                               const float *__restrict__ Sv, float *__restrict__ u, float *__restrict__ v,
-                                              const float *__restrict__ xx, const float *__restrict__ dot_c,
-                                              const float *__restrict__ dot_b, float eps_zero, float *__restrict__ part,
-                                              DevStatus *st, const float *psum, int npsum,
+                                              const float *__restrict__ xx, float eps_zero, float *__restrict__ part,
+                                              DevStatus *st, const float *ps_c, const float *ps_b, int np,
+                                              int do_n, int do_m,
                                               float *__restrict__ ku, float *__restrict__ kv)
 {
     if (st->stop != 0) return;
+    // do_n: the u rows, kappa and the n-part of the criteria (need the all-reduced products); do_m: the v rows (local)
     __shared__ float sh[16];
-    float dc = 0.0f, db = 0.0f;      // c.rx_x and b.rx_y: from sumfin_k (sharded run) or summed here by block 0
-    if (doy && blockIdx.x == 0) {
-        if (psum != nullptr) {
-            __shared__ double shd[16];
-            dc = block_sum_of_partials(psum, 0, npsum, shd);
-            db = block_sum_of_partials(psum, 1, npsum, shd);
-        } else { dc = dot_c[0]; db = dot_b[0]; }
+    float dc = 0.0f, db = 0.0f;      // c.rx_x and b.rx_y: block partials of post_k summed here by block 0
+    if (doy && do_n && blockIdx.x == 0) {
+        __shared__ double shd[16];
+        dc = block_sum_of_partials(ps_c, np, shd);
+        db = block_sum_of_partials(ps_b, np, shd);
     }
     const float rtau = st->r_tau;
     const float tau = st->tau;
@@ -279,6 +269,7 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
     const float rt = conv ? 1.0f / tau : 1.0f;
     const size_t gstride = (size_t)gridDim.x * BLK;
     float dd = 0.0f, cx = 0.0f;
+    if (do_n)
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
         const float ci = c[i];
         if (doy) {
@@ -294,18 +285,19 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
         }
     }
     if (doy) {
+        if (do_m)
         for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
             float h2;
             if (carried) { const float nw = h3[i]; h2 = hP[i] - 2.0f * nw; hP[i] = nw; }
             else h2 = h2in[i];
             v[i] = comp_add(v[i], Sv[i] * (h2 + rxs[i] - b[i] * rtau), kv, i);
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (do_n && blockIdx.x == 0 && threadIdx.x == 0) {
             const float k = st->kappa + st->s_kappa * (dc + db);
             st->kappa = fminf(k, 0.0f);       // solver.rs:566-567
         }
     }
-    if (docrit) {
+    if (docrit && do_n) {
         dd = block_sum(dd, sh);
         cx = block_sum(cx, sh);
         if (threadIdx.x == 0) { part[blockIdx.x] = dd; part[gridDim.x + blockIdx.x] = cx; }
@@ -314,19 +306,15 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
 
 // the termination test, solver.rs:381-451 + the tails of criteria_conv / criteria_inf (solver.rs:599-611,
 // 636-655).  One block: sums the np block partials of ||d||^2 and c.x_x, then thread 0 decides.
-// pp_by[0] = ||p||^2, pp_by[1] = b.x_y (already all-reduced).
-__global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict__ part, const float *__restrict__ pp_by,
+// ps_pp / ps_by: post_k's block partials of ||p||^2 and b.x_y (all-reduced block partials when sharded).
+__global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict__ part,
                                                float eps_acc, float eps_inf, float eps_zero, long long max_iter,
-                                               DevStatus *st, const float *psum, int npsum)
+                                               DevStatus *st, const float *ps_pp, const float *ps_by, int npsum)
 {
     if (st->stop != 0) return;
     __shared__ double shd[16];
-    // ||p||^2 and b.x_y: all-reduced tail scalars (sharded run), or summed here from post_k's partials (q2, q3)
-    float pp, by;
-    if (psum != nullptr) {
-        pp = block_sum_of_partials(psum, 2, npsum, shd);
-        by = block_sum_of_partials(psum, 3, npsum, shd);
-    } else { pp = pp_by[0]; by = pp_by[1]; }
+    const float pp = block_sum_of_partials(ps_pp, npsum, shd);
+    const float by = block_sum_of_partials(ps_by, npsum, shd);
     double a0 = 0.0, a1 = 0.0;
     for (int k = threadIdx.x; k < np; k += BLK) { a0 += (double)part[k]; a1 += (double)part[np + k]; }
     a0 = block_sum_d(a0, shd);
@@ -482,6 +470,10 @@ struct thip_solver {
 
     thip_allreduce_fn allreduce = nullptr;
     void *allreduce_ctx = nullptr;
+    // overlap: the stage's all-reduce runs on `side` (event in / event out) under the stage's local-row work
+    bool overlap = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 
     // optional sparse A (CSR of A and of A^T)
     bool sparse = false; size_t nnz = 0;
@@ -503,7 +495,11 @@ struct thip_solver {
     float *arena = nullptr; size_t arena_n = 0;
     float *xx, *xy, *xs, *u, *v, *Tx, *Ty, *Ts, *Su, *Sv, *rxx, *rxy, *rxs;
     float *g1, *h1, *g2, *h2, *g3, *h3, *gP, *hP;
-    float *kx = nullptr, *ky = nullptr, *ks = nullptr, *ku = nullptr, *kv = nullptr;   // Kahan terms of the iterate (optional)   // n-vectors carry TAIL extra floats
+    // Kahan terms of the five iterate vectors (always allocated: O(n + m) floats); passed to the kernels when
+    // par.state_arith == THIP_STATE_COMPENSATED, NULL (plain f32 additions) otherwise
+    float *kx = nullptr, *ky = nullptr, *ks = nullptr, *ku = nullptr, *kv = nullptr;
+    bool comp() const { return par.state_arith == THIP_STATE_COMPENSATED; }
+    size_t kahan_n = 0;                              // kx .. kv are contiguous: kahan_n floats from kx
     float *part = nullptr;                           // block partials (4 * EG)
     float *dotc = nullptr;                           // local scalars: [0] c.u, [1] c.rx_x, [2..3] dd,cx
     float *gemv_scr = nullptr; size_t gemv_scr_n = 0;
@@ -522,6 +518,7 @@ struct thip_solver {
     DevStatus *hst = nullptr;                        // pinned
     bool inited = false;
     bool finalized = false;      // finalize_k has been applied to the terminated iterate
+    bool carried_stale = false;  // the stored form of A changed under a running carried schedule: gP / hP must be rebuilt
 };
 
 namespace {
@@ -553,6 +550,17 @@ void prof_end(hipStream_t st)
     g_prof.used += 2;
 }
 
+}  // namespace
+namespace thip {
+void prof_release()
+{
+    for (hipEvent_t e : g_prof.ev) hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.used = 0; g_prof.on = false;
+}
+}  // namespace thip
+namespace {
+
 int do_allreduce(thip_solver *s, float *buf, size_t count)
 {
     if (!s->allreduce) return 0;
@@ -561,7 +569,39 @@ int do_allreduce(thip_solver *s, float *buf, size_t count)
     return 0;
 }
 
+// The all-reduce of a stage, optionally on the solver's side stream (overlap): begin = "the producer kernel has been
+// enqueued on the launch stream": the side stream waits for it (event in) and runs the collective; end = the launch
+// stream waits for the collective (event out) before the first consumer.  Whatever is enqueued on the launch stream
+// between begin and end -- the stage's work on the local rows -- overlaps the collective.  Without overlap the
+// collective is enqueued in order on the launch stream (begin) and end is a no-op.
+int allreduce_begin(thip_solver *s, float *buf, size_t count)
+{
+    if (!s->allreduce) return 0;
+    if (!s->overlap) return do_allreduce(s, buf, count);
+    hipStream_t st = ctx().stream;
+    THIP_TRY(hipEventRecord(s->ev_in, st));
+    THIP_TRY(hipStreamWaitEvent(s->side, s->ev_in, 0));
+    const int rc = s->allreduce(s->allreduce_ctx, buf, count, (void *)s->side);
+    if (rc != 0) return fail(rc, "all-reduce callback failed", __FILE__, __LINE__);
+    THIP_TRY(hipEventRecord(s->ev_out, s->side));
+    return 0;
+}
+int allreduce_end(thip_solver *s)
+{
+    if (!s->allreduce || !s->overlap) return 0;
+    THIP_TRY(hipStreamWaitEvent(ctx().stream, s->ev_out, 0));
+    return 0;
+}
+
 unsigned egrid(size_t n) { return grid_for(n, BLK, EG); }
+
+int ensure_gemv_scratch(thip_solver *s)
+{
+    if (s->gemv_scr || s->sparse || s->m == 0 || s->n == 0) return 0;
+    s->gemv_scr_n = 2 * dual_gemv_scratch_floats(s->m, s->n);
+    THIP_TRY(hipMalloc((void **)&s->gemv_scr, s->gemv_scr_n * sizeof(float)));
+    return 0;
+}
 
 // one stage's products as partial sums: N partials of A xn (m), T partials of A^T xt (n).  The fused and carried
 // schedules read A once (dual launch); the reference schedule issues the reference's two single GEMVs.
@@ -625,66 +665,79 @@ int one_iteration(thip_solver *s)
 {
     hipStream_t st = ctx().stream;
     const int n = (int)s->n, m = (int)s->m;
-    const int *stop = &s->dst->stop;
     const unsigned g = egrid(s->n > s->m ? s->n : s->m);
     float *const part = s->part;
     const bool carried = s->schedule == THIP_SCHED_CARRIED;
     const float ez = s->par.eps_zero;
     GemvPartials gp;
-    const unsigned gq = grid_for(s->n > s->m ? s->n : s->m, 64, PG);
-    // Without an all-reduce between post_k and its consumers (single GPU) the consumers sum post_k's block partials
-    // themselves (block 0 / the status block) and the three sumfin_k launches are dropped; a sharded run needs the
-    // local sums in the tail of the all-reduced vector, so it keeps them.
+    // post_k leaves its sums as block partials: q0 (over the replicated n-vectors) in `part`, q1..q3 (over the local
+    // rows) in `part` too on a single GPU, or -- row-sharded -- in the tail of the n-vector that is all-reduced next,
+    // with a fixed grid of NPS blocks so that every rank fills the same NPS slots per sum.
     const bool local = s->allreduce == nullptr;
-    const float *psum = local ? part : (const float *)nullptr;
+    const unsigned gq = local ? grid_for(s->n > s->m ? s->n : s->m, 64, PG) : NPS;
+    auto shp = [&](float *nvec) { return local ? part : nvec + s->n; };
+    const size_t arcount = s->n + TAIL;
     float *const part_y = s->part + 4 * PG;          // ycrit_k's own partials (read by status_k)
+    const bool split = !local && s->overlap;         // m-part under the all-reduce, n-part after it
+    float *const kx = s->comp() ? s->kx : nullptr, *const ky = s->comp() ? s->ky : nullptr;
+    float *const ks = s->comp() ? s->ks : nullptr, *const ku = s->comp() ? s->ku : nullptr;
+    float *const kv = s->comp() ? s->kv : nullptr;
 
+    auto xupdate = [&](int do_n, int do_m) {
+        hipLaunchKernelGGL(xupdate_k, dim3(g), dim3(BLK), 0, st, n, m, s->g1, s->h1, s->c, s->b, s->v, s->Tx, s->Ty, s->Ts,
+                           s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dst, part, shp(s->g1) + gq, (int)gq,
+                           do_n, do_m, kx, ky, ks);
+    };
     // ---- stage X: x update (solver.rs:538-555) ----------------------------------------------------
     THIP_RC(products(s, s->u, s->v, &gp, s->h1, s->g1));
     hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g1, gp.partN, gp.nN,
                        gp.strideN, s->h1, s->c, s->u, s->b, s->v, 0, (const float *)nullptr, (const float *)nullptr,
-                       (const float *)nullptr, ez, part, s->dst);
-    if (!local)
-        hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, s->dotc + 0, s->g1 + s->n, (float *)nullptr,
-                           (float *)nullptr, stop);
-    THIP_RC(do_allreduce(s, s->g1, s->n + 1));
-    hipLaunchKernelGGL(xupdate_k, dim3(g), dim3(BLK), 0, st, n, m, s->g1, s->h1, s->c, s->b, s->v, s->Tx, s->Ty, s->Ts,
-                       s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dotc + 0, s->g1 + s->n, s->dst, psum, (int)gq,
-                       s->kx, s->ky, s->ks);
-    THIP_RC(project_blocks(s));
+                       (const float *)nullptr, ez, part, shp(s->g1), s->dst);
+    THIP_RC(allreduce_begin(s, s->g1, arcount));
+    if (split) {
+        xupdate(0, 1);
+        THIP_RC(project_blocks(s));      // the block cones live on the local rows
+        THIP_RC(allreduce_end(s));
+        xupdate(1, 0);
+    } else {
+        THIP_RC(allreduce_end(s));
+        xupdate(1, 1);
+        THIP_RC(project_blocks(s));
+    }
 
     // ---- stage Y: y update from K rx (solver.rs:557-567), own products unless carried ---------------
     if (!carried) {
         THIP_RC(products(s, s->rxx, s->rxy, &gp, s->h2, s->g2));
         hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g2, gp.partN, gp.nN,
                            gp.strideN, s->h2, s->c, s->rxx, s->b, s->rxy, 0, (const float *)nullptr,
-                           (const float *)nullptr, (const float *)nullptr, ez, part, s->dst);
-        if (!local)
-            hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, s->dotc + 1, s->g2 + s->n,
-                               (float *)nullptr, (float *)nullptr, stop);
-        THIP_RC(do_allreduce(s, s->g2, s->n + 1));
-        hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, 1, 0, 0, (const float *)nullptr,
-                           (const float *)nullptr, (float *)nullptr, (float *)nullptr, s->g2, s->h2, s->c, s->b, s->rxs,
-                           s->Su, s->Sv, s->u, s->v, s->xx, s->dotc + 1, s->g2 + s->n, ez, part_y, s->dst, psum, (int)gq,
-                           s->ku, s->kv);
+                           (const float *)nullptr, (const float *)nullptr, ez, part, shp(s->g2), s->dst);
+        auto yupdate = [&](int do_n, int do_m) {
+            hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, 1, 0, 0, (const float *)nullptr,
+                               (const float *)nullptr, (float *)nullptr, (float *)nullptr, s->g2, s->h2, s->c, s->b, s->rxs,
+                               s->Su, s->Sv, s->u, s->v, s->xx, ez, part_y, s->dst, part, shp(s->g2) + gq, (int)gq,
+                               do_n, do_m, ku, kv);
+        };
+        THIP_RC(allreduce_begin(s, s->g2, arcount));
+        if (split) { yupdate(0, 1); THIP_RC(allreduce_end(s)); yupdate(1, 0); }
+        else       { THIP_RC(allreduce_end(s)); yupdate(1, 1); }
     }
 
     // ---- stage C: criteria products of the new iterate (solver.rs:573-656) --------------------------
     THIP_RC(products(s, s->xx, s->xy, &gp, s->h3, s->g3));
+    // block partials: q0 = c.rx_x, q1 = b.rx_y (carried), q2 = ||p||^2, q3 = b.x_y
     hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g3, gp.partN, gp.nN,
                        gp.strideN, s->h3, carried ? s->c : (const float *)nullptr, s->rxx,
-                       carried ? s->b : (const float *)nullptr, s->rxy, 1, s->xs, s->xy, s->b, ez, part, s->dst);
-    // tail of g3: [0] ||p||^2, [1] b.x_y, [2] b.rx_y (carried) -- all sharded sums, all-reduced with g3
-    if (!local)
-        hipLaunchKernelGGL(sumfin_k, dim3(1), dim3(BLK), 0, st, (int)gq, part, carried ? s->dotc + 1 : (float *)nullptr,
-                           carried ? s->g3 + s->n + 2 : (float *)nullptr, s->g3 + s->n, s->g3 + s->n + 1, stop);
-    THIP_RC(do_allreduce(s, s->g3, s->n + 3));
-    hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, carried ? 1 : 0, 1, 1, s->g3, s->h3, s->gP, s->hP,
-                       (const float *)nullptr, (const float *)nullptr, s->c, s->b, s->rxs, s->Su, s->Sv, s->u, s->v, s->xx,
-                       s->dotc + 1, s->g3 + s->n + 2, ez, part_y, s->dst, carried ? psum : (const float *)nullptr, (int)gq,
-                       s->ku, s->kv);
-    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part_y, s->g3 + s->n, s->par.eps_acc, s->par.eps_inf,
-                       ez, (long long)s->par.max_iter, s->dst, psum, (int)gq);
+                       carried ? s->b : (const float *)nullptr, s->rxy, 1, s->xs, s->xy, s->b, ez, part, shp(s->g3), s->dst);
+    auto ycrit = [&](int do_n, int do_m) {
+        hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, carried ? 1 : 0, 1, 1, s->g3, s->h3, s->gP, s->hP,
+                           (const float *)nullptr, (const float *)nullptr, s->c, s->b, s->rxs, s->Su, s->Sv, s->u, s->v, s->xx,
+                           ez, part_y, s->dst, part, shp(s->g3) + gq, (int)gq, do_n, do_m, ku, kv);
+    };
+    THIP_RC(allreduce_begin(s, s->g3, arcount));
+    if (split && carried) { ycrit(0, 1); THIP_RC(allreduce_end(s)); ycrit(1, 0); }
+    else                  { THIP_RC(allreduce_end(s)); ycrit(1, 1); }
+    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part_y, s->par.eps_acc, s->par.eps_inf,
+                       ez, (long long)s->par.max_iter, s->dst, shp(s->g3) + 2 * gq, shp(s->g3) + 3 * gq, (int)gq);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -733,6 +786,25 @@ int autotune_gemv(thip_solver *s)
     else     { s->hint = pick; s->tuned = true; s->tuned_ms = best; }
     THIP_TRY(hipEventDestroy(e0));
     THIP_TRY(hipEventDestroy(e1));
+    return 0;
+}
+
+// The carried schedule keeps gP = A^T x_y and hP = A x_x of the current iterate (ycrit_k).  After the stored form of A
+// has been switched inside a solve (16-bit passes first, f32 passes to finish) they still hold the products with the
+// OLD matrix: the first y-update would mix A_old and A_new, a one-off error of (A_old - A)^T x ~ 2^-9 .. 2^-12 relative,
+// far above the step size near convergence.  Recompute them with the matrix now in use: one pass over A.
+int rebuild_carried(thip_solver *s)
+{
+    s->carried_stale = false;
+    if (s->schedule != THIP_SCHED_CARRIED || s->m == 0 || s->n == 0) return 0;
+    hipStream_t st = ctx().stream;
+    GemvPartials gp;
+    THIP_RC(products(s, s->xx, s->xy, &gp, s->hP, s->gP));
+    if (gp.nN >= 0) {      // dense: finish the partial sums (the sparse products are finished vectors already)
+        THIP_RC(finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, s->hP, nullptr));
+        THIP_RC(finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, 1.0f, 0.0f, s->gP, nullptr));
+    }
+    THIP_RC(do_allreduce(s, s->gP, s->n));
     return 0;
 }
 
@@ -834,10 +906,9 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
 
     // ---- vectors ----
     const size_t pn = pad64(n + TAIL), pm = pad64(m + 1);
-    // THIP_COMPENSATED_STATE=1 (experimental, default off): compensated accumulation of the iterate vectors
-    const char *env_comp = getenv("THIP_COMPENSATED_STATE");
-    const bool compensated = env_comp && atoi(env_comp) != 0;
-    const size_t total = 7 * pn /*xx u Tx Su rxx + g1 g2 g3 gP = 9*/ + 2 * pn + 13 * pm + 64 + (compensated ? 2 * pn + 3 * pm : 0);
+    if (par->state_arith != THIP_STATE_COMPENSATED && par->state_arith != THIP_STATE_PLAIN)
+        return fail(THIP_E_INVALID, "bad thip_param.state_arith", __FILE__, __LINE__);
+    const size_t total = 9 * pn /* xx u Tx Su rxx g1 g2 g3 gP */ + 13 * pm + 64 + 2 * pn + 3 * pm /* Kahan terms */;
     THIP_TRY(hipMalloc((void **)&s->arena, total * sizeof(float)));
     THIP_TRY(hipMemsetAsync(s->arena, 0, total * sizeof(float), st));
     s->arena_n = total;
@@ -849,11 +920,12 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
     s->rxy = take(pm); s->rxs = take(pm); s->h1 = take(pm); s->h2 = take(pm); s->h3 = take(pm); s->hP = take(pm);
     (void)take(pm);
     s->dotc = take(64);
-    if (compensated) { s->kx = take(pn); s->ku = take(pn); s->ky = take(pm); s->ks = take(pm); s->kv = take(pm); }
+    s->kx = take(pn); s->ku = take(pn); s->ky = take(pm); s->ks = take(pm); s->kv = take(pm);
+    s->kahan_n = 2 * pn + 3 * pm;
 
     THIP_TRY(hipMalloc((void **)&s->part, (4 * PG + 2 * EG) * sizeof(float)));
-    s->gemv_scr_n = 2 * dual_gemv_scratch_floats(m, n);
-    THIP_TRY(hipMalloc((void **)&s->gemv_scr, s->gemv_scr_n * sizeof(float)));
+    // the dense GEMV partial-sum scratch (~ m n / 256 floats) is allocated by thip_solver_init, and only for a dense A
+    // (thip_solver_set_csr comes between create and init: a sparse 1e6 x 1e6 operator must not pay 15 GB for it)
     THIP_TRY(hipMalloc((void **)&s->dst, sizeof(DevStatus)));
     THIP_TRY(hipMemsetAsync(s->dst, 0, sizeof(DevStatus), st));
     THIP_TRY(hipHostMalloc((void **)&s->hst, sizeof(DevStatus), hipHostMallocDefault));
@@ -893,6 +965,20 @@ int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *c)
     return 0;
 }
 
+int thip_solver_set_overlap(thip_solver *s, int on)
+{
+    THIP_NEED_INIT();
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (on && !s->side) {
+        THIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        THIP_TRY(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
+        THIP_TRY(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
+    }
+    if (!on && s->side && ctx().inited) THIP_TRY(hipStreamSynchronize(s->side));
+    s->overlap = on != 0;
+    return 0;
+}
+
 int thip_solver_init(thip_solver *s)
 {
     THIP_NEED_INIT();
@@ -901,6 +987,11 @@ int thip_solver_init(thip_solver *s)
     const size_t n = s->n, m = s->m;
     const unsigned g = egrid(n > m ? n : m);
 
+    // per-solve host state: a solver may be initialised again after a solve that terminated
+    s->finalized = false;
+    s->carried_stale = false;
+    s->hst->state = THIP_ST_RUNNING;
+    THIP_RC(ensure_gemv_scratch(s));
     // init_vecs (solver.rs:483-494): x = 0, y = 0, tau = 1
     THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
     hipLaunchKernelGGL(init_status_k, dim3(1), dim3(1), 0, st, s->dst, 0.0f);
@@ -948,6 +1039,7 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
     if (poll_every <= 0) poll_every = 16;
     int64_t done = 0;
     THIP_RC(poll(s, host_status));
+    if (s->carried_stale && s->hst->state == THIP_ST_RUNNING) THIP_RC(rebuild_carried(s));
     while (s->hst->state == THIP_ST_RUNNING && (max_steps < 0 || done < max_steps)) {
         int64_t batch = poll_every;
         if (max_steps >= 0 && done + batch > max_steps) batch = max_steps - done;
@@ -1069,14 +1161,23 @@ int thip_solver_set_a_storage(thip_solver *s, int a_kind)
         s->a16_kind = a_kind;
         s->tuned16 = false;
     }
+    const bool changed = s->a_kind != a_kind;
     s->a_kind = a_kind;
-    if (s->inited) THIP_RC(autotune_gemv(s));      // a switch inside a running solve: tune the other kernel once
+    if (s->inited) {
+        THIP_RC(autotune_gemv(s));      // a switch inside a running solve: tune the other kernel once
+        if (changed) s->carried_stale = true;      // rebuilt by the next thip_solver_run (after thip_solver_resume)
+    }
     return 0;
 }
 
 int thip_solver_set_param(thip_solver *s, const thip_param *par)
 {
     if (!s || !par) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    if (par->state_arith != THIP_STATE_COMPENSATED && par->state_arith != THIP_STATE_PLAIN)
+        return fail(THIP_E_INVALID, "bad thip_param.state_arith", __FILE__, __LINE__);
+    // compensation switched on inside a solve starts from clean Kahan terms
+    if (s->par.state_arith != par->state_arith && par->state_arith == THIP_STATE_COMPENSATED && s->kx && ctx().inited)
+        THIP_TRY(hipMemsetAsync(s->kx, 0, s->kahan_n * sizeof(float), ctx().stream));
     s->par = *par;
     return 0;
 }
@@ -1147,6 +1248,9 @@ int thip_solver_destroy(thip_solver *s)
 {
     if (!s) return 0;
     if (ctx().inited) hipStreamSynchronize(ctx().stream);
+    if (s->side) { hipStreamSynchronize(s->side); hipStreamDestroy(s->side); }
+    if (s->ev_in) hipEventDestroy(s->ev_in);
+    if (s->ev_out) hipEventDestroy(s->ev_out);
     hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
     hipFree(s->gemv_scr); hipFree(s->dst); if (s->A16_owned) hipFree(s->A16); if (s->inv_s_owned) hipFree(s->inv_s);

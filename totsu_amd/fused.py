@@ -97,6 +97,16 @@ class Bf16Matrix:
         self.ptr = None
 
 
+STATE_ARITH = {"compensated": _lib.STATE_COMPENSATED, "plain": _lib.STATE_PLAIN}
+
+
+def _c_param(p):
+    """SolverParam -> thip_param.  `state_arith` is an attribute of the fused loop only (not in the reference's
+    SolverParam, solver.rs:13-41): "compensated" (default) or "plain" f32 iterate updates."""
+    return _lib.Param(-1 if p.max_iter is None else int(p.max_iter), p.eps_acc, p.eps_inf, p.eps_zero,
+                      int(p.log_period), STATE_ARITH[getattr(p, "state_arith", "compensated")], 0)
+
+
 class FusedResult:
     def __init__(self, st):
         self.state = st.state
@@ -109,7 +119,7 @@ class FusedResult:
 
 class FusedSolver:
     def __init__(self, n, m, mat_a, vec_b, vec_c, seg_type, seg_len, param=None, schedule="fused",
-                 vec_b_rowabs=None, allreduce=None, a_storage="f32"):
+                 vec_b_rowabs=None, allreduce=None, a_storage="f32", overlap=None):
         """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded).
         a_storage: "f32" (the matrix as given), "bf16" or "f16" (a rounded 16-bit copy streamed at half the bytes; f16
         is column-scaled and rounds 8x finer; see set_a_storage / include/totsu_f32hip.h).
@@ -141,9 +151,7 @@ class FusedSolver:
                             None if self.vec_b_rowabs is None else self.vec_b_rowabs.ptr, len(self._st),
                             self._st.ctypes.data_as(C.POINTER(C.c_int32)),
                             self._sl.ctypes.data_as(C.POINTER(C.c_int64)))
-        p = self.param
-        par = _lib.Param(-1 if p.max_iter is None else int(p.max_iter), p.eps_acc, p.eps_inf, p.eps_zero,
-                         int(p.log_period))
+        par = _c_param(self.param)
         h = C.c_void_p()
         lib.thip_solver_create(C.byref(prob), C.byref(par), SCHEDULES[schedule], C.byref(h))
         self.h = h
@@ -158,6 +166,9 @@ class FusedSolver:
         elif allreduce is not None:
             self._cb = _lib.ALLREDUCE_FN(allreduce)
             lib.thip_solver_set_allreduce(self.h, self._cb, None)
+        if overlap is not None and allreduce is not None:
+            # all-reduce on the solver's side stream under the local-row work (default: on for native RCCL)
+            lib.thip_solver_set_overlap(self.h, 1 if overlap else 0)
         self.a_storage = "f32"
         if self._a16 is not None:
             if self._a16.kind == "f16":
@@ -169,12 +180,15 @@ class FusedSolver:
             self.set_a_storage(a_storage)
         lib.thip_solver_init(self.h)
 
+    def reinit(self):
+        """thip_solver_init again: a fresh solve of the same problem (x = 0, tau = 1)"""
+        lib.thip_solver_init(self.h)
+
     def resume(self, param=None):
         """continue a solve that ended Converged / ExcessIter, optionally with new parameters"""
         if param is not None:
             self.param = param
-            par = _lib.Param(-1 if param.max_iter is None else int(param.max_iter), param.eps_acc, param.eps_inf,
-                             param.eps_zero, int(param.log_period))
+            par = _c_param(param)
             lib.thip_solver_set_param(self.h, C.byref(par))
         lib.thip_solver_resume(self.h)
 

@@ -37,6 +37,9 @@ class SolverParam:
         self.eps_inf = 1e-6
         self.eps_zero = 1e-12
         self.log_period = 10_000
+        # not in the reference: arithmetic of the iterate updates of the fused device loop, "compensated" | "plain"
+        # (thip_param.state_arith, include/totsu_f32hip.h); the trait-level loop ignores it
+        self.state_arith = "compensated"
 
     def __repr__(self):
         return ("SolverParam { max_iter: %r, eps_acc: %r, eps_inf: %r, eps_zero: %r, log_period: %r }"
