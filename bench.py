@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--to-eps", type=float, default=None,
                     help="also solve to this eps_acc and report time-to-eps (default: 1e-3 for the socp workload at its "
                          "full size -- the eps_acc the reference runs its f32 backend at, benchmark_lp/src/main.rs:62-65)")
+    ap.add_argument("--overlap", default="on", choices=["on", "off"],
+                    help="N > 1: all-reduce on the solver's side stream under the local-row work (thip_solver_set_overlap)")
     ap.add_argument("--no-to-eps", action="store_true", help="skip the time-to-eps leg (iterations/sec only)")
     ap.add_argument("--to-eps-budget", type=float, default=1200.0,
                     help="stop the time-to-eps leg after this many seconds and report the criteria reached (state -1)")
@@ -329,7 +331,8 @@ def run(a):
         if hook is None:
             hook, coll = TorchAllreduce(torch, dist), "torch.distributed.all_reduce hook (nccl)"
     fs = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, a.schedule,
-                       allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"))
+                       allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"),
+                       overlap=(a.overlap == "on") if hook is not None and a.collective != "gloo" else None)
 
     def barrier():
         if use_dist:
@@ -412,7 +415,7 @@ def run(a):
                 "unit variance, not exact Gaussians)",
         "state_arith": a.state,
         "config": {"workload": wl, "schedule": a.schedule, "passes_over_A_per_iter": passes,
-                   "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll,
+                   "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll, "overlap": (a.overlap if hook is not None else None),
                    "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan(), "a_storage": a.a_storage},
         "roofline": roofline,
         # north_star: "same primal/dual objective as the f64 CPU reference within 1e-4 relative".  The f64 oracle runs the
@@ -454,7 +457,8 @@ def run(a):
         barrier()
         t0 = time.perf_counter()
         fs2 = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
-                            a.schedule, allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"))
+                            a.schedule, allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"),
+                            overlap=(a.overlap == "on") if hook is not None and a.collective != "gloo" else None)
         r2 = run_to_end(fs2)
         barrier()
         phase1 = None
