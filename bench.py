@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--to-eps", type=float, default=None,
                     help="also solve to this eps_acc and report time-to-eps (default: 1e-3 for the socp workload at its "
                          "full size -- the eps_acc the reference runs its f32 backend at, benchmark_lp/src/main.rs:62-65)")
-    ap.add_argument("--overlap", default="on", choices=["on", "off"],
-                    help="N > 1: all-reduce on the solver's side stream under the local-row work (thip_solver_set_overlap)")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: all-reduce on the solver's side stream under the local-row work (thip_solver_set_overlap); "
+                         "auto = time both during the warm-up and keep the faster")
     ap.add_argument("--no-to-eps", action="store_true", help="skip the time-to-eps leg (iterations/sec only)")
     ap.add_argument("--to-eps-budget", type=float, default=1200.0,
                     help="stop the time-to-eps leg after this many seconds and report the criteria reached (state -1)")
@@ -332,13 +333,33 @@ def run(a):
             hook, coll = TorchAllreduce(torch, dist), "torch.distributed.all_reduce hook (nccl)"
     fs = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, a.schedule,
                        allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"),
-                       overlap=(a.overlap == "on") if hook is not None and a.collective != "gloo" else None)
+                       overlap=None)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    overlap_pick = None
+    if hook is not None and a.collective != "gloo":
+        if a.overlap == "auto":
+            # untimed: 3 x 20 iterations each way (max over ranks), keep the faster -- like the GEMV plan autotune
+            best = {}
+            for mode in (0, 1, 0, 1, 0, 1):
+                lib.thip_solver_set_overlap(fs.h, mode)
+                barrier()
+                t0 = time.perf_counter()
+                fs.run(20, poll_every=20)
+                barrier()
+                best[mode] = min(best.get(mode, 1e30), time.perf_counter() - t0)
+            tt = torch.tensor([best[0], best[1]], dtype=torch.float64, device="cuda")
+            if use_dist:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            overlap_pick = "on" if float(tt[1]) < float(tt[0]) else "off"
+            a.warmup_extra = 120
+        else:
+            overlap_pick = a.overlap
+        lib.thip_solver_set_overlap(fs.h, 1 if overlap_pick == "on" else 0)
     fs.run(a.warmup, poll_every=max(a.warmup, 1))
     barrier()
     lib.thip_prof_enable(1)
@@ -354,7 +375,7 @@ def run(a):
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if a.collective == "gloo" else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert r.state == _lib.ST_RUNNING and r.iters == a.warmup + a.steps, (r.state, r.iters)
+    assert r.state == _lib.ST_RUNNING and r.iters == a.warmup + a.steps + getattr(a, "warmup_extra", 0), (r.state, r.iters)
     assert math.isfinite(r.tau) and math.isfinite(r.cri[0]), "iterate blew up"
 
     passes, bytes_per_pass = fs.passes()
@@ -415,7 +436,7 @@ def run(a):
                 "unit variance, not exact Gaussians)",
         "state_arith": a.state,
         "config": {"workload": wl, "schedule": a.schedule, "passes_over_A_per_iter": passes,
-                   "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll, "overlap": (a.overlap if hook is not None else None),
+                   "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll, "overlap": overlap_pick,
                    "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan(), "a_storage": a.a_storage},
         "roofline": roofline,
         # north_star: "same primal/dual objective as the f64 CPU reference within 1e-4 relative".  The f64 oracle runs the
@@ -458,7 +479,7 @@ def run(a):
         t0 = time.perf_counter()
         fs2 = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
                             a.schedule, allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"),
-                            overlap=(a.overlap == "on") if hook is not None and a.collective != "gloo" else None)
+                            overlap=(overlap_pick == "on") if overlap_pick is not None else None)
         r2 = run_to_end(fs2)
         barrier()
         phase1 = None

@@ -225,7 +225,10 @@ int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
  * while the launch stream goes on with the stage's work on the LOCAL rows (the x_y / x_s update and the cone
  * projections in the x-stage, the v update in the y-stage), which needs no collective; the x_x / u / tau / kappa
  * updates wait for it.  The hook then receives the side stream.  Results are bitwise those of the in-order run.
- * thip_solver_use_rccl switches it on; a hook that ignores its stream argument stays correct (and un-overlapped). */
+ * Off by default: it costs two more launches and two cross-stream event hand-offs per stage (+27 us per iteration
+ * measured at world size 1), so it pays only where the collective's latency exceeds that -- time both (bench.py
+ * --overlap auto does).  May be switched between thip_solver_run calls.  A hook that ignores its stream argument
+ * stays correct (and un-overlapped). */
 int thip_solver_set_overlap(thip_solver *s, int on);
 /* Storage of the dense A the iteration streams: THIP_A_F32 (default: prob->mat_a as given), or THIP_A_BF16 /
  * THIP_A_F16 (a library-owned 16-bit copy, made on the first request; f16 is column-scaled and rounds 8x finer than

@@ -36,7 +36,7 @@ def _split_rows(dense, T, cut_seg):
     return parts
 
 
-def _run_sharded(T, parts, param, schedule, max_steps=-1):
+def _run_sharded(T, parts, param, schedule, max_steps=-1, overlap=None):
     from totsu_amd._lib import lib
     barrier = threading.Barrier(len(parts))
     bufs = [None] * len(parts)
@@ -64,7 +64,7 @@ def _run_sharded(T, parts, param, schedule, max_steps=-1):
         try:
             p = parts[rank]
             fs = T.FusedSolver(p["n"], p["m"], p["mat_a"], p["vec_b"], p["vec_c"], p["seg_type"], p["seg_len"], param,
-                               schedule, vec_b_rowabs=p["rowabs"], allreduce=make_hook(rank))
+                               schedule, vec_b_rowabs=p["rowabs"], allreduce=make_hook(rank), overlap=overlap)
             r = fs.run(max_steps, poll_every=32)
             x, y = fs.solution()
             out[rank] = (r, x, y, fs.iterate())
@@ -220,3 +220,26 @@ def test_bench_prints_one_json_line_with_native_rccl_in_the_loop():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert "RCCL" in d["config"]["collective"] and d["n_gpus"] == 1
+
+
+@pytest.mark.parametrize("schedule", ["fused", "carried"])
+def test_overlapped_allreduce_is_bitwise_the_in_order_run(T, schedule):
+    # thip_solver_set_overlap: the x / y updates run as an m-part (local rows, under the collective) and an n-part
+    # (after it); the arithmetic per element is unchanged, so the iterates must be bitwise those of the in-order run
+    n, cones = 36, [7, 20, 33, 4]
+    f, Gs, hs, cs, d = random_socp(n, cones, seed=11)
+    socp = T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(f.reshape(-1, 1)),
+                      [_mb(T, T.MatType.General(g.shape[0], n)).set_array(g) for g in Gs],
+                      [_mb(T, T.MatType.General(len(v), 1)).set_array(v.reshape(-1, 1)) for v in hs],
+                      [_mb(T, T.MatType.General(n, 1)).set_array(v.reshape(-1, 1)) for v in cs], d,
+                      _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+    parts = _split_rows(socp.dense(), T, 2)
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    a = _run_sharded(T, parts, p, schedule, max_steps=300, overlap=False)
+    b = _run_sharded(T, parts, p, schedule, max_steps=300, overlap=True)
+    for (ra, _, _, (xa, ya)), (rb, _, _, (xb, yb)) in zip(a, b):
+        assert ra.iters == rb.iters == 300
+        assert np.array_equal(xa, xb) and np.array_equal(ya, yb)
+        assert ra.cri == rb.cri
+    socp.drop()

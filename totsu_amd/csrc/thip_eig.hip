@@ -19,6 +19,7 @@
 #include "thip_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 using namespace thip;
 
@@ -341,6 +342,81 @@ __global__ __launch_bounds__(GNW * 64) void gemm_k(int n, int ld, float alpha, c
     }
 }
 
+// The same two products with every operand load of a wave issued BEFORE its first MFMA (ld <= 512: a wave's K range is
+// ld / 8 <= 64).  gemm_k above prefetches one slab of 8 ahead, i.e. a wave walks its K range in ld / 64 dependent L2
+// round trips (~0.7 us each: the 6-7 us of an 8.7 us launch that are neither MFMA issue nor launch ramp).  Here:
+//   * GEN: operand a is read ALONG k, as the general factor is stored: a(i, k) = Gen[(i0 + i) * ld + k], one dwordx4 per
+//     lane per 8 k: lane (h = l >> 5, i = l & 31) gets k = 8 q + 4 h + t, t < 4.  An MFMA may pair ANY two k values as
+//     long as a and b agree, so MFMA (q, t) takes k = 8 q + t on lanes 0-31 and k = 8 q + 4 + t on lanes 32-63: no LDS
+//     transposition.  (Not for the X X^T products: X = S is symmetric only to round-off, and S^T S^T instead of the Gram
+//     matrix S S^T loses the damping of antisymmetric round-off that makes the left-multiplied iteration stable.)
+//   * every other operand: row k = 8 q + 4 h + t, coalesced along the tile (one dword per lane per MFMA);
+//   * all of a wave's loads are in flight at once (<= 64 VGPRs at ld = 512), then KW / 2 MFMAs.
+// The summation order over k differs from gemm_k's (both are fixed, so results stay bitwise reproducible and the
+// symmetric products stay bitwise symmetric: the mirrored tile swaps a and b, and the products commute).
+template <bool GEN, int KW>
+__global__ __launch_bounds__(GNW * 64) void gemm_pre_k(int n, int ld, float alpha, const float *__restrict__ X,
+                                                       const float *__restrict__ Y, float beta, const float *D, float gamma,
+                                                       float *C, const int *__restrict__ stop, size_t ws)
+{
+    if (stop != nullptr && *stop != 0) return;
+    X += blockIdx.z * ws; Y += blockIdx.z * ws; C += blockIdx.z * ws;
+    if (D) D += blockIdx.z * ws;
+    __shared__ float red[GNW - 1][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * GT, j0 = blockIdx.y * GT;
+    const int kb = wave * KW, h = lane >> 5, li = lane & 31;
+    // GEN: X symmetric (b), Y general (a, along k).  !GEN: a(i, k) = X(i, k) = Xmem[k * ld + i], b(k, j) = Y(j, k).
+    const float *pa = GEN ? Y + (size_t)(i0 + li) * ld + kb + 4 * h : X + (size_t)(kb + 4 * h) * ld + i0 + li;
+    const float *pb = (GEN ? X : Y) + (size_t)(kb + 4 * h) * ld + j0 + li;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int NQ = KW / 8;
+    f32x4_t av[NQ];
+    float bv[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if constexpr (GEN) av[q] = *reinterpret_cast<const f32x4_t *>(pa + 8 * q);
+        else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[q][t] = pa[(size_t)(8 * q + t) * ld];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[q][t] = pb[(size_t)(8 * q + t) * ld];
+    // left alone the scheduler sinks the loads between the MFMAs to save registers (38 VGPRs, one or two loads in
+    // flight): nothing may cross this point
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t], acc, 0, 0, 0);
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int tj = j0 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ti = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = acc[r];
+#pragma unroll
+            for (int w = 0; w < GNW - 1; ++w) v += red[w][r][lane];
+            v *= alpha;
+            const size_t o = (size_t)ti * ld + tj;
+            if (beta != 0.0f) v = fmaf(beta, D[o], v);
+            if (ti == tj && ti < n) v += gamma;
+            C[o] = v;
+        }
+    }
+}
+
 // S = M / ||M||_F  (sc[0] = ||M||_F); exact zero matrix stays zero
 __global__ void scale_by_fro_k(size_t tot, const float *__restrict__ M, const float *__restrict__ sc,
                                float *__restrict__ S, const int *__restrict__ stop, size_t ws)
@@ -372,8 +448,27 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
          float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0)
 {
     dim3 g(ld / GT, ld / GT, nb);
-    if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
+    static const int mode = getenv("THIP_GEMM_MODE") ? atoi(getenv("THIP_GEMM_MODE")) : 1;   // 0: gemm_k (experiments)
+#define THIP_GEMM_PRE(KW)                                                                                                   \
+    do {                                                                                                                    \
+        if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW>), g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);  \
+        else     hipLaunchKernelGGL((gemm_pre_k<false, KW>), g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
+    } while (0)
+    if (mode != 0 && ld <= 512) {
+        switch (ld / GNW) {
+        case 8: THIP_GEMM_PRE(8); break;
+        case 16: THIP_GEMM_PRE(16); break;
+        case 24: THIP_GEMM_PRE(24); break;
+        case 32: THIP_GEMM_PRE(32); break;
+        case 40: THIP_GEMM_PRE(40); break;
+        case 48: THIP_GEMM_PRE(48); break;
+        case 56: THIP_GEMM_PRE(56); break;
+        default: THIP_GEMM_PRE(64); break;
+        }
+    }
+    else if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
     else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
+#undef THIP_GEMM_PRE
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -451,19 +546,40 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
                        k.part, stop, ws, ps);
     hipLaunchKernelGGL(shift_k, dim3(1, 1, nb), dim3(BLK), 0, st, ni, ld, (int)g, k.part, M, k.sc, 0, stop, ws);
     hipLaunchKernelGGL(scale_by_fro_k, dim3(g, 1, nb), dim3(BLK), 0, st, tot, M, k.sc, S, stop, ws);
-    // phase 1: quintic with a steep slope at 0 (3.4445 x - 4.7750 x^3 + 2.0315 x^5 maps (0, 1] into ~[0.7, 1.2] and
-    // multiplies tiny singular values by 3.44 per step): 13 steps lift relative eigenvalues >= 1e-7 into the band.
-    // Three GEMMs per step, the polynomial folded into the second one's epilogue:
+    // sign(M) = the polar factor of S = M / ||M||_F by the polar iteration S <- p_k(S S^T) S with odd quintics
+    // p_k(x) = a x + b x^3 + c x^5.  Three GEMMs per step, the polynomial folded into the second one's epilogue:
     //   Y = S S^T ;  T = c Y Y^T + b Y + a I ;  S <- T S
-    for (int it = 0; it < 13; ++it) {
+    // Phase 1 (lifting, 11 steps): ONE polynomial, the LP solution of "maximise the gain s subject to p(x) >= s x on
+    // [0, lo / s], lo <= p(x) <= hi on [lo / s, hi]" for the band [lo, hi] = [0.3, 1.7]: every singular value below the
+    // band grows by s = 4.06 per step and a value inside the band STAYS inside (tools/polar_coeffs.py).  Step 0 takes
+    // x <= 1 and may scale its argument by 1.7.  Relative eigenvalues >= 1e-7 are inside the band after 11 steps.
+    // (The unconstrained minimax composition -- "Polar Express", Amsel et al. 2025 -- is two steps shorter, but its
+    // early polynomials equioscillate between ~0 and 2: an already-large eigenvalue can be thrown back to 1e-6, below
+    // the absolute round-off of the evaluation.  Measured: 3e-5 |X| error on rank-deficient inputs instead of 2e-8.)
+    // Phase 2 (3 steps): minimax polynomials of 1 on [0.3, 1.7] -> [0.73, 1.27] -> [0.985, 1.015] -> 1 +- 2e-5.
+    // Phase 3: one Newton-Schulz step x (3 - x^2) / 2 squares the remaining error.  14 x 3 + 2 = 44 GEMMs (round 1: 13
+    // steps of 3.4445 x - 4.7750 x^3 + 2.0315 x^5, band [0.7, 1.2], and 5 Newton-Schulz steps = 49).
+    static const int sched = getenv("THIP_POLAR_SCHED") ? atoi(getenv("THIP_POLAR_SCHED")) : 1;
+    static const float LIFT[3] = { 4.08273337f, -3.88521879f, 0.97526957f };
+    static const float TAILC[3][3] = {
+        { 2.647997920f, -1.945904487f, 0.440483961f },
+        { 1.967564378f, -1.351306898f, 0.386705679f },
+        { 1.884943743f, -1.269148602f, 0.384197480f },
+    };
+    const int nq = sched == 0 ? 13 : 14;
+    for (int it = 0; it < nq; ++it) {
+        float a, b, c;
+        if (sched == 0) { a = 3.4445f; b = -4.7750f; c = 2.0315f; }
+        else if (it == 0) { a = LIFT[0] * 1.7f; b = LIFT[1] * 4.913f; c = LIFT[2] * 14.19857f; }     // p(1.7 x)
+        else if (it < 11) { a = LIFT[0]; b = LIFT[1]; c = LIFT[2]; }
+        else { a = TAILC[it - 11][0]; b = TAILC[it - 11][1]; c = TAILC[it - 11][2]; }
         THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop, nb, ws));
-        THIP_RC(gemm(st, false, ni, ld, 2.0315f, Y, Y, -4.7750f, Y, 3.4445f, T, stop, nb, ws));
+        THIP_RC(gemm(st, false, ni, ld, c, Y, Y, b, Y, a, T, stop, nb, ws));
         THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));
         float *tmp = S; S = Z; Z = tmp;
     }
-    // phase 2: Newton-Schulz x (3 - x^2) / 2, quadratic convergence to exactly +-1 from the band
-    //   T = -0.5 S S^T + 1.5 I ;  S <- T S
-    for (int it = 0; it < 5; ++it) {
+    // Newton-Schulz x (3 - x^2) / 2:  T = -0.5 S S^T + 1.5 I ;  S <- T S
+    for (int it = 0; it < (sched == 0 ? 5 : 1); ++it) {
         THIP_RC(gemm(st, false, ni, ld, -0.5f, S, S, 0.0f, nullptr, 1.5f, T, stop, nb, ws));
         THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));
         float *tmp = S; S = Z; Z = tmp;

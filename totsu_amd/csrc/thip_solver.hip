@@ -62,6 +62,23 @@ struct DevStatus {
 // terminated state.
 // ---------------------------------------------------------------------------------------------------
 
+// sum over k = k0, k0 + 4, k0 + 8, .. < np of p[k * stride] in f64 with eight independent loads in flight per lane:
+// the second reduction stage is a latency chain over ~100-200 partials per element, not a bandwidth problem
+__device__ __forceinline__ double sum_partials4(const float *__restrict__ p, size_t stride, int k0, int np)
+{
+    double s[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+    int k = k0;
+    for (; k + 28 < np; k += 32) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = p[(size_t)(k + 4 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += (double)a[u];
+    }
+    for (; k < np; k += 4) s[0] += (double)p[(size_t)k * stride];
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
 // After a dual GEMV: second reduction stage of both products + the stage's sharded / replicated reductions.
 //   g[i] = sum_k partT[k][i] (n) ; h[i] = sum_k partN[k][i] (m)
 //   q0 = dn_a . dn_b over n (optional) ; q1 = dm_a . dm_b over m (optional)
@@ -94,8 +111,7 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
     for (size_t i0 = blockIdx.x * (size_t)64; i0 < (size_t)n; i0 += gstride) {
         const size_t i = i0 + e;
         double sd = 0.0;
-        if (i < (size_t)n)
-            for (int k = kq; k < nT; k += 4) sd += (double)partT[(size_t)k * strideT + i];
+        if (i < (size_t)n) sd = sum_partials4(partT + i, strideT, kq, nT);
         if (kq > 0) comb[kq - 1][e] = sd;
         __syncthreads();
         if (kq == 0 && i < (size_t)n) {
@@ -109,8 +125,7 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
     for (size_t i0 = blockIdx.x * (size_t)64; i0 < (size_t)m; i0 += gstride) {
         const size_t i = i0 + e;
         double sd = 0.0;
-        if (i < (size_t)m)
-            for (int k = kq; k < nN; k += 4) sd += (double)partN[(size_t)k * strideN + i];
+        if (i < (size_t)m) sd = sum_partials4(partN + i, strideN, kq, nN);
         if (kq > 0) comb[kq - 1][e] = sd;
         __syncthreads();
         if (kq == 0 && i < (size_t)m) {
@@ -509,9 +524,12 @@ struct thip_solver {
     int a_kind = THIP_A_F32; uint16_t *A16 = nullptr; size_t ld16 = 0; bool A16_owned = false; int a16_kind = 0;
     float *inv_s = nullptr; bool inv_s_owned = false;
     GemvHint hint16{0, 0}; bool tuned16 = false; float tuned16_ms = 0.0f;
+    // f32 with m % 4 != 0 (e.g. the k = 500 SDP: m = 125 250): a library-owned copy with the leading dimension padded to a
+    // multiple of 4 gives the 16-byte-load kernel instead of the scalar one (made by thip_solver_init for A < 4 GB)
+    float *Apad = nullptr; size_t ldpad = 0;
     bool is16() const { return a_kind != THIP_A_F32; }
-    const void *amat() const { return is16() ? (const void *)A16 : (const void *)A; }
-    size_t alda() const { return is16() ? ld16 : m; }
+    const void *amat() const { return is16() ? (const void *)A16 : (Apad ? (const void *)Apad : (const void *)A); }
+    size_t alda() const { return is16() ? ld16 : (Apad ? ldpad : m); }
     const float *ainv() const { return a_kind == THIP_A_F16 ? inv_s : nullptr; }
     const GemvHint *ahint() const { return is16() ? (tuned16 ? &hint16 : nullptr) : (tuned ? &hint : nullptr); }
     DevStatus *dst = nullptr;
@@ -992,6 +1010,17 @@ int thip_solver_init(thip_solver *s)
     s->carried_stale = false;
     s->hst->state = THIP_ST_RUNNING;
     THIP_RC(ensure_gemv_scratch(s));
+    // THIP_LDA_PAD = floats the padded leading dimension is a multiple of (default 32 = 128 bytes: every column then
+    // starts on a cache-line boundary; 0 = never copy)
+    const size_t padto = getenv("THIP_LDA_PAD") ? (size_t)atoi(getenv("THIP_LDA_PAD")) : 32;
+    if (!s->sparse && s->A && !s->Apad && padto > 0 && m % padto != 0 && n > 0
+        && m * n * sizeof(float) < ((size_t)8 << 30)) {
+        s->ldpad = (m + padto - 1) / padto * padto;
+        THIP_TRY(hipMalloc((void **)&s->Apad, s->ldpad * n * sizeof(float)));
+        THIP_TRY(hipMemsetAsync(s->Apad, 0, s->ldpad * n * sizeof(float), st));
+        THIP_TRY(hipMemcpy2DAsync(s->Apad, s->ldpad * sizeof(float), s->A, m * sizeof(float), m * sizeof(float), n,
+                                  hipMemcpyDeviceToDevice, st));
+    }
     // init_vecs (solver.rs:483-494): x = 0, y = 0, tau = 1
     THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
     hipLaunchKernelGGL(init_status_k, dim3(1), dim3(1), 0, st, s->dst, 0.0f);
@@ -1253,7 +1282,7 @@ int thip_solver_destroy(thip_solver *s)
     if (s->ev_out) hipEventDestroy(s->ev_out);
     hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
-    hipFree(s->gemv_scr); hipFree(s->dst); if (s->A16_owned) hipFree(s->A16); if (s->inv_s_owned) hipFree(s->inv_s);
+    hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->Apad); if (s->A16_owned) hipFree(s->A16); if (s->inv_s_owned) hipFree(s->inv_s);
     if (s->hst) hipHostFree(s->hst);
     delete s;
     return 0;
