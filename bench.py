@@ -54,6 +54,14 @@ def parse():
     ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: all-reduce on the solver's side stream under the local-row work (thip_solver_set_overlap); "
                          "auto = time both during the warm-up and keep the faster")
+    ap.add_argument("--path", default="fused", choices=["fused", "trait"],
+                    help="fused: the device-resident loop (the product's hot path).  trait: the compiled trait-level host "
+                         "(examples/trait_host.cpp over include/totsu_f32hip.hpp): Solver::solve call by call through the "
+                         "reference's composite operators, one L:: call per reference call -- what an UNCHANGED caller "
+                         "gets without the Hip* alias types; N = 1, lp / socp workloads")
+    ap.add_argument("--trait-cones", default="reference", choices=["reference", "device"],
+                    help="--path trait: the reference's literal cone code (host loop over get_mut / get + norm + scale per "
+                         "cone) or the device-side projections (thip_proj_*)")
     ap.add_argument("--no-to-eps", action="store_true", help="skip the time-to-eps leg (iterations/sec only)")
     ap.add_argument("--to-eps-budget", type=float, default=1200.0,
                     help="stop the time-to-eps leg after this many seconds and report the criteria reached (state -1)")
@@ -207,6 +215,45 @@ def cpu_baseline(n, n_cones_full, ni, seed, cones_sub, budget_s=25.0):
     }
 
 
+def run_trait(a, inst, n, wl, t_gen, rank):
+    """--path trait: iterations/sec of the trait-level drop-in (no fused loop, no alias types) on the same instance"""
+    import ctypes as C
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.workload in ("lp", "socp")
+    so = os.path.join(ROOT, "totsu_amd", "lib", "libtotsu_trait_host.so")
+    if not os.path.exists(so):
+        raise ImportError("%s is missing -- run __graft_entry__.build()" % so)
+    host = C.CDLL(so)
+    out = (C.c_double * 2)()
+    ref = 1 if a.trait_cones == "reference" else 0
+    m = inst.m
+    if a.workload == "lp":
+        host.thost_lp.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        rc = host.thost_lp(n, m, inst.mat_a.ptr, inst.vec_b.ptr, inst.vec_c.ptr, a.steps, ref, out)
+    else:
+        host.thost_socp.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                    C.c_void_p]
+        rc = host.thost_socp(n, a.cones, 99, inst.mat_a.ptr, inst.vec_b.ptr, inst.vec_c.ptr, a.steps, ref, out)
+    assert rc == 0, "trait host failed (%d)" % rc
+    sec = out[0]
+    phys = 6 * 4.0 * m * n            # the reference's op sequence: 6 GEMV passes over A per iteration
+    res = {
+        "metric": "solver iters/sec, trait-level drop-in path (Solver::solve call by call; NOT the headline)",
+        "path": "trait", "trait_cones": a.trait_cones,
+        "value": 1.0 / sec, "unit": "iter/s", "n_gpus": 1, "steps": a.steps, "warmup": max(a.steps // 4, 1),
+        "ms_per_step": 1e3 * sec, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (counter-based generator on device, seed 0)",
+        "config": {"workload": wl, "schedule": "reference op sequence, one C-ABI call per LinAlg call",
+                   "host": "examples/trait_host.cpp (compiled C++ over include/totsu_f32hip.hpp)",
+                   "init_seconds": out[1], "gen_seconds": round(t_gen, 3)},
+        "roofline": {"bound": "hbm", "achieved": phys / sec / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": phys / sec / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "what": "6 passes x 4 m n bytes per iteration / wall time per iteration (whole loop, not one kernel)"},
+        "cpu_baseline": None,
+    }
+    inst.free()
+    return res, rank, (lambda: None)
+
+
 def main():
     a = parse()
     # RCCL prints a version banner on stdout when a communicator is created: keep fd 1 clean for the ONE JSON line
@@ -285,6 +332,8 @@ def run(a):
     lib.thip_sync()
     t_gen = time.perf_counter() - t_gen0
 
+    if a.path == "trait":
+        return run_trait(a, inst, n, wl, t_gen, rank)
     p = T.SolverParam()
     p.max_iter = None
     p.eps_acc = 0.0            # never terminates inside the timed region: every step does full work

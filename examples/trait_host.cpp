@@ -1,0 +1,116 @@
+// trait_host.cpp -- a COMPILED host over include/totsu_f32hip{,_prob}.hpp that drives the solver the way an unchanged
+// totsu / totsu_core would: `Solver::solve((op_c, op_a, op_b, cone, work))` with the reference's composite operators
+// (ProbLPOpA lp.rs:76-98, ProbSOCPOpA socp.rs:77-130: one transform_ge per block and product) and, with cones = 1, the
+// reference's literal cone code (ConeRPos: host loop over get_mut, cone_rpos.rs:38-45; ConeSOC: get + norm + scale +
+// set per cone, cone_soc.rs:38-65).  One `L::` call per reference call, every one through the C ABI.
+// Built as a shared library so that bench.py (--path trait) can time it on the instance it generated on the device:
+// it measures what the drop-in gets WITHOUT the Hip* aliases, next to the fused number.
+#include <chrono>
+#include <cstdio>
+
+#include <hip/hip_runtime.h>
+
+#include "totsu_f32hip_prob.hpp"
+
+using namespace totsu;
+
+namespace {
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// seconds of a solve that stops after `iters` iterations (ExcessIter)
+double timed(Solver &s, const Operator &c, const Operator &a, const Operator &b, Cone &cone, Slice work, int64_t iters, int *bad)
+{
+    s.par.max_iter = iters;
+    s.par.eps_acc = 0.f; s.par.eps_inf = 0.f;
+    chk(thip_sync());
+    const double t0 = now();
+    const SolverError e = s.solve(c, a, b, cone, work);
+    chk(thip_sync());
+    const double t1 = now();
+    if (e != SolverError::ExcessIter) *bad = 1;
+    return t1 - t0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// LP in the benchmark_lp shape (lp.rs operators): A = G (m x n, device, column-major), no equality rows.
+// ref_cones != 0: ConeRPos as the reference's host loop.  out[0] = seconds per iteration, out[1] = seconds of init.
+int thost_lp(size_t n, size_t m, float *dev_a, float *dev_b, float *dev_c, int64_t iters, int ref_cones, double *out)
+{
+    try {
+        OpVec op_c(MatOp(n, 1, Slice{ dev_c, n }));
+        OpStack2 op_a(MatOp(m, n, Slice{ dev_a, m * n }), MatOp(0, n, Slice{ nullptr, 0 }));
+        OpStack2 op_b(MatOp(m, 1, Slice{ dev_b, m }), MatOp(0, 1, Slice{ nullptr, 0 }));
+        ConeRPos rp; ConeRPosRef rpr; ConeZero zero;
+        ConeProduct cone;
+        cone.blocks.push_back({ ref_cones ? (Cone *)&rpr : (Cone *)&rp, m });
+        cone.blocks.push_back({ &zero, 0 });
+        DeviceVec work(Solver::query_worklen(m, n));
+        Solver s;
+        int bad = 0;
+        const int64_t k1 = iters / 4 > 0 ? iters / 4 : 1;
+        const double t1 = timed(s, op_c, op_a, op_b, cone, work.slice(), k1, &bad);
+        const double t2 = timed(s, op_c, op_a, op_b, cone, work.slice(), k1 + iters, &bad);
+        out[0] = (t2 - t1) / (double)iters;
+        out[1] = t1 - k1 * out[0];
+        return bad;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "thost_lp: %s\n", e.what());
+        return -1;
+    }
+}
+
+// SOCP with n_cones cones of 1 + ni rows: dev_a is the STACKED matrix (m x n, rows of cone i = [-c_i^T ; -G_i]), dev_b the
+// stacked right-hand side [d_i ; h_i].  The reference holds one MatOp per c_i / G_i / h_i (its own contiguous array
+// each), so the blocks are first copied out of the stacked matrix (device-side strided copies, outside the timing).
+int thost_socp(size_t n, size_t n_cones, size_t ni, float *dev_a, float *dev_b, float *dev_c, int64_t iters, int ref_cones,
+               double *out)
+{
+    try {
+        const size_t rows = 1 + ni, m = n_cones * rows;
+        hipStream_t st = (hipStream_t)thip_get_stream();
+        DeviceVec gall(n_cones * ni * n), call(n_cones * n);
+        std::vector<float> hb(m);
+        chk(thip_d2h(hb.data(), dev_b, m));
+        std::vector<MatOp> og, oc, oh;
+        std::vector<float> d(n_cones);
+        for (size_t i = 0; i < n_cones; ++i) {
+            float *gi = gall.slice().p + i * ni * n, *ci = call.slice().p + i * n;
+            // G_i = -(rows i*rows+1 .. of A): a strided 2-D copy, then the sign
+            if (hipMemcpy2DAsync(gi, ni * sizeof(float), dev_a + i * rows + 1, m * sizeof(float), ni * sizeof(float), n,
+                                 hipMemcpyDeviceToDevice, st) != hipSuccess) return -2;
+            if (hipMemcpy2DAsync(ci, sizeof(float), dev_a + i * rows, m * sizeof(float), sizeof(float), n,
+                                 hipMemcpyDeviceToDevice, st) != hipSuccess) return -2;
+            og.push_back(MatOp(ni, n, Slice{ gi, ni * n }));
+            oc.push_back(MatOp(n, 1, Slice{ ci, n }));
+            oh.push_back(MatOp(ni, 1, Slice{ dev_b + i * rows + 1, ni }));
+            d[i] = hb[i * rows];
+        }
+        chk(thip_scale(n_cones * ni * n, -1.f, gall.slice().p));
+        chk(thip_scale(n_cones * n, -1.f, call.slice().p));
+        OpVec op_c(MatOp(n, 1, Slice{ dev_c, n }));
+        ProbSOCPOpA op_a(og, oc, MatOp(0, n, Slice{ nullptr, 0 }));
+        ProbSOCPOpB op_b(oh, d, MatOp(0, 1, Slice{ nullptr, 0 }));
+        ConeSOC soc; ConeSOCRef socr; ConeZero zero;
+        ConeProduct cone;
+        for (size_t i = 0; i < n_cones; ++i) cone.blocks.push_back({ ref_cones ? (Cone *)&socr : (Cone *)&soc, rows });
+        cone.blocks.push_back({ &zero, 0 });
+        DeviceVec work(Solver::query_worklen(m, n));
+        Solver s;
+        int bad = 0;
+        const int64_t k1 = iters / 4 > 0 ? iters / 4 : 1;
+        const double t1 = timed(s, op_c, op_a, op_b, cone, work.slice(), k1, &bad);
+        const double t2 = timed(s, op_c, op_a, op_b, cone, work.slice(), k1 + iters, &bad);
+        out[0] = (t2 - t1) / (double)iters;
+        out[1] = t1 - k1 * out[0];
+        return bad;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "thost_socp: %s\n", e.what());
+        return -1;
+    }
+}
+
+}  // extern "C"

@@ -132,6 +132,13 @@ int thip_absadd_sympack(size_t n, const float *mat, float *y);
 /* calc_precond host loops, solver.rs:501-506: x[i] = 1 / max(x[i], eps_zero) */
 int thip_recip_max(size_t n, float eps_zero, float *x);
 
+/* Stacking the blocks of a composite operator into ONE column-major matrix on the device (what
+ * ProbLPOpA / ProbSOCPOpA / ProbSDPOpA are, lp.rs:76-98, socp.rs:77-130, sdp.rs:75-97, seen as a single MatOp):
+ * dst(r, c) = sign * src(r, c) for an n_row x n_col column-major block (lda = n_row), dst pointing at the block's first
+ * row inside a matrix of leading dimension ld_dst; transposed != 0: src is an n_col-vector written as ONE row (the
+ * -c_i^T rows of socp.rs:88-93). */
+int thip_copy_block(int transposed, size_t n_row, size_t n_col, float sign, const float *src, float *dst, size_t ld_dst);
+
 /* Cone projections (totsu_core/src/cone_*.rs) on device-resident vectors */
 enum { THIP_CONE_ZERO = 0, THIP_CONE_RPOS = 1, THIP_CONE_SOC = 2, THIP_CONE_ROTSOC = 3, THIP_CONE_PSD = 4 };
 int thip_proj_zero(int dual_cone, size_t n, float *x);          /* cone_zero.rs:38-44 */

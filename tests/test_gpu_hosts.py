@@ -1,0 +1,36 @@
+"""GPU: the compiled hosts over the C ABI that stand in for the Rust crate (no cargo here):
+examples/hip_prob_demo (the Hip* alias builders of include/totsu_f32hip_prob.hpp dispatching to the fused loop, and the
+same problems call by call through the reference's composite operators and literal cones) and the trait-level host that
+`bench.py --path trait` times."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_hip_prob_alias_demo():
+    exe = os.path.join(ROOT, "examples", "hip_prob_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe, "3000", "400"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert sum("OK" in ln for ln in lines if ln.startswith("kat")) == 4 and not any("MISMATCH" in ln for ln in lines)
+    # the mirror cache: 1 cone => f, G, h, c uploaded once each although as_op() is taken twice per G_i (socp.rs:450,463)
+    assert any(ln.startswith("kat socp") and "uploads 4" in ln for ln in lines), r.stdout
+    d = json.loads(lines[-1])
+    assert d["ratio"] >= 0.9, d                      # the alias route IS the fused loop
+
+
+@pytest.mark.parametrize("args", [["--workload", "lp", "--size", "600"], ["--workload", "socp", "--size", "300", "--cones", "6"]])
+@pytest.mark.parametrize("cones", ["reference", "device"])
+def test_trait_level_host_runs_and_reports(args, cones):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--path", "trait", "--trait-cones", cones,
+                        "--steps", "40", "--no-cpu"] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["path"] == "trait" and d["value"] > 0 and d["trait_cones"] == cones

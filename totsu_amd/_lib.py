@@ -87,6 +87,7 @@ PROTOTYPES = {
     "thip_absadd_rows": (_i, [_sz, _sz, _vp, _vp]),
     "thip_absadd_sympack": (_i, [_sz, _vp, _vp]),
     "thip_recip_max": (_i, [_sz, _f, _vp]),
+    "thip_copy_block": (_i, [_i, _sz, _sz, _f, _vp, _vp, _sz]),
     "thip_proj_zero": (_i, [_i, _sz, _vp]),
     "thip_proj_rpos": (_i, [_sz, _vp]),
     "thip_proj_soc": (_i, [_sz, _vp]),

@@ -203,6 +203,32 @@ int thip_recip_max(size_t n, float eps_zero, float *x)
     return 0;
 }
 
+namespace {
+// dst(r0 + r, c) = sign * src(r, c) for an n_row x n_col column-major block (lda = n_row) written into the rows of a
+// taller column-major matrix (leading dimension ld_dst); transposed: src is an n_col-vector used as ONE row
+__global__ void copy_block_k(int transposed, size_t n_row, size_t n_col, float sign, const float *__restrict__ src,
+                             float *__restrict__ dst, size_t ld_dst)
+{
+    const size_t tot = n_row * n_col;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) {
+        const size_t c = i / n_row, r = i - c * n_row;
+        dst[c * ld_dst + r] = sign * (transposed ? src[c] : src[i]);
+    }
+}
+}  // namespace
+
+int thip_copy_block(int transposed, size_t n_row, size_t n_col, float sign, const float *src, float *dst, size_t ld_dst)
+{
+    THIP_NEED_INIT();
+    if (transposed) n_row = 1;
+    if (n_row == 0 || n_col == 0) return 0;
+    if (ld_dst < n_row) return fail(THIP_E_INVALID, "ld_dst < n_row", __FILE__, __LINE__);
+    hipLaunchKernelGGL(copy_block_k, dim3(grid_for(n_row * n_col, BLK, 16384)), dim3(BLK), 0, ctx().stream, transposed,
+                       n_row, n_col, sign, src, dst, ld_dst);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int thip_norm_dev(size_t n, const float *x, float *dev_out)
 {
     THIP_NEED_INIT();
