@@ -75,6 +75,15 @@ int thip_transform_di(size_t n, float alpha, const float *d, const float *x,
  * linalg_ex.rs:23 (cublasSgemv, f32cuda.rs:144-171) */
 int thip_transform_ge(int transpose, size_t n_row, size_t n_col, float alpha, const float *mat,
                       const float *x, float beta, float *y);
+/* Small calls are DEFERRED and batched: thip_transform_ge on matrices <= 64 MB, thip_scale / thip_add on vectors <= 1024
+ * long.  A composite operator issues them per block (ProbSOCPOpA / ProbSOCPOpB, socp.rs:77-130,194-246: 5000 per product
+ * at BASELINE configs[2]); the library records them and runs the record -- one grouped launch per kind of product plus
+ * one finishing launch -- as soon as ANY other entry point is called or a new call would read or overwrite a pending
+ * result, so call order is still what every caller observes.  Contributions to the same y are summed in a fixed order of
+ * their own (last-bit differences from sequential accumulation).  thip_set_lazy_gemv(0) (or THIP_LAZY_GEMV=0) restores
+ * one launch per call. */
+int thip_set_lazy_gemv(int on);
+int thip_lazy_gemv_stats(int64_t *host_deferred, int64_t *host_flushes);
 /* y = alpha * S x + beta * y, S symmetric, packed upper by columns.  linalg_ex.rs:37 (cublasSspmv, f32cuda.rs:174-187) */
 int thip_transform_sp(size_t n, float alpha, const float *mat, const float *x, float beta, float *y);
 /* Reduced-precision STORAGE of a dense operator (not part of the reference's trait surface):

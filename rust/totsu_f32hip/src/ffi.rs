@@ -63,6 +63,10 @@ extern "C" {
     pub fn thip_absadd_cols(n_row: usize, n_col: usize, mat: *const f32, tau: *mut f32) -> c_int;
     pub fn thip_absadd_rows(n_row: usize, n_col: usize, mat: *const f32, sigma: *mut f32) -> c_int;
     pub fn thip_recip_max(n: usize, eps_zero: f32, x: *mut f32) -> c_int;
+    pub fn thip_copy_block(transposed: c_int, n_row: usize, n_col: usize, sign: f32, src: *const f32, dst: *mut f32,
+                           ld_dst: usize) -> c_int;
+    pub fn thip_set_lazy_gemv(on: c_int) -> c_int;
+    pub fn thip_lazy_gemv_stats(host_deferred: *mut i64, host_flushes: *mut i64) -> c_int;
     pub fn thip_proj_zero(dual_cone: c_int, n: usize, x: *mut f32) -> c_int;
     pub fn thip_proj_rpos(n: usize, x: *mut f32) -> c_int;
     pub fn thip_proj_soc(n: usize, x: *mut f32) -> c_int;

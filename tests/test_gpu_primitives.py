@@ -249,3 +249,110 @@ def test_soc_batched_moreau_decomposition_at_configs2_layout(L, rot):
     norms = np.linalg.norm(p.reshape(ncone, ln), axis=1) * np.linalg.norm(q.reshape(ncone, ln), axis=1)
     assert np.all(np.abs(dots) <= 1e-5 * (norms + 1e-30) + 1e-30)
     od.free()
+
+
+# ---- deferred / grouped transform_ge (thip_lazy.hip) ----------------------------------------------------------------
+import ctypes as C      # noqa: E402
+
+
+def _dev(L, a):
+    return L.Sl.new_mut(np.ascontiguousarray(a, dtype=np.float32).copy())
+
+
+def _blocks(rng, n, nis):
+    return [rng.standard_normal((ni, n)).astype(np.float32) for ni in nis]
+
+
+@pytest.mark.parametrize("lazy", [1, 0])
+def test_grouped_block_products_match_numpy(L, lazy):
+    """the call pattern of ProbSOCPOpA::op / ::trans_op (socp.rs:77-130): one transform_ge per c_i (n x 1, transposed /
+    plain) and per G_i, outputs = consecutive slices of one vector (op) or ONE accumulated vector (trans_op)"""
+    from totsu_amd._lib import lib
+    rng = np.random.default_rng(5)
+    n, nis = 300, [99, 1, 7, 260, 33, 99, 2, 513]
+    Gs, cs = _blocks(rng, n, nis), [rng.standard_normal(n).astype(np.float32) for _ in nis]
+    m = sum(1 + k for k in nis)
+    D = lambda a: _dev(L, np.asfortranarray(a).ravel(order="F"))
+    dG, dc = [D(g) for g in Gs], [D(c) for c in cs]
+    x, ym = rng.standard_normal(n).astype(np.float32), rng.standard_normal(m).astype(np.float32)
+    dx, dy = _dev(L, x), _dev(L, ym)
+    lib.thip_set_lazy_gemv(lazy)
+    d0, f0 = C.c_int64(), C.c_int64()
+    lib.thip_lazy_gemv_stats(C.byref(d0), C.byref(f0))
+    alpha, beta = -0.7, 0.3
+    done, ref = 0, ym.astype(np.float64).copy()
+    for g, c, dg, dcc in zip(Gs, cs, dG, dc):
+        ni = g.shape[0]
+        lib.thip_transform_ge(1, n, 1, -alpha, dcc.dev(), dx.dev(), beta, dy.dev() + 4 * done)
+        lib.thip_transform_ge(0, ni, n, -alpha, dg.dev(), dx.dev(), beta, dy.dev() + 4 * (done + 1))
+        ref[done] = beta * ref[done] - alpha * (c.astype(np.float64) @ x)
+        ref[done + 1:done + 1 + ni] = beta * ref[done + 1:done + 1 + ni] - alpha * (g.astype(np.float64) @ x)
+        done += 1 + ni
+    got = dy.get_ref().copy()            # a download: runs whatever is pending
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    # trans_op: y_n = beta y_n + sum_i ( -alpha c_i x_i[0] - alpha G_i^T x_i[1:] )
+    yn = rng.standard_normal(n).astype(np.float32)
+    dyn = _dev(L, yn)
+    lib.thip_scale(n, beta, dyn.dev())
+    refn = beta * yn.astype(np.float64)
+    done = 0
+    for g, c, dg, dcc in zip(Gs, cs, dG, dc):
+        ni = g.shape[0]
+        lib.thip_transform_ge(0, n, 1, -alpha, dcc.dev(), dy.dev() + 4 * done, 1.0, dyn.dev())
+        lib.thip_transform_ge(1, ni, n, -alpha, dg.dev(), dy.dev() + 4 * (done + 1), 1.0, dyn.dev())
+        refn += -alpha * c.astype(np.float64) * got[done] - alpha * (g.astype(np.float64).T @ got[done + 1:done + 1 + ni])
+        done += 1 + ni
+    gotn = dyn.get_ref().copy()
+    assert np.allclose(gotn, refn, rtol=2e-5, atol=2e-5 * np.abs(refn).max())
+    # ProbSOCPOpB::trans_op (socp.rs:219-246): one number accumulates a scale, and per cone an add and a dot
+    hs = [rng.standard_normal(k).astype(np.float32) for k in nis]
+    dh = [_dev(L, h) for h in hs]
+    ds = _dev(L, np.array([0.37], np.float32))
+    lib.thip_scale(1, beta, ds.dev())
+    refs = beta * 0.37
+    done = 0
+    for i, (h, dhh) in enumerate(zip(hs, dh)):
+        ni = len(h)
+        lib.thip_add(1, alpha * (i + 1.5), dy.dev() + 4 * done, ds.dev())
+        lib.thip_transform_ge(1, ni, 1, alpha, dhh.dev(), dy.dev() + 4 * (done + 1), 1.0, ds.dev())
+        refs += alpha * (i + 1.5) * float(got[done]) + alpha * float(h.astype(np.float64) @ got[done + 1:done + 1 + ni])
+        done += 1 + ni
+    gots = float(ds.get_ref()[0])
+    assert abs(gots - refs) <= 2e-5 * (1 + abs(refs)), (gots, refs)
+    d1, f1 = C.c_int64(), C.c_int64()
+    lib.thip_lazy_gemv_stats(C.byref(d1), C.byref(f1))
+    if lazy:
+        # 4 + 2 recorded calls per block, the two scales: three grouped flushes in all
+        assert d1.value - d0.value == 6 * len(nis) + 2 and f1.value - f0.value == 3
+    else:
+        assert d1.value == d0.value
+    lib.thip_set_lazy_gemv(1)
+    for s in dG + dc + dh + [dx, dy, dyn, ds]:
+        s.drop()
+
+
+def test_deferred_products_respect_data_hazards(L):
+    """a product that reads (or overwrites) what a pending one writes must see it done: y1 = A x ; y2 = B y1 ;
+    x <- C y2 (overwrites an input of the first) ; y1 <- 2 y1 + A x"""
+    from totsu_amd._lib import lib
+    rng = np.random.default_rng(6)
+    k = 40
+    A, B, Cm = (rng.standard_normal((k, k)).astype(np.float32) for _ in range(3))
+    x = rng.standard_normal(k).astype(np.float32)
+    D = lambda a: _dev(L, np.asfortranarray(a).ravel(order="F"))
+    dA, dB, dC = D(A), D(B), D(Cm)
+    dx, y1, y2 = _dev(L, x), _dev(L, np.zeros(k, np.float32)), _dev(L, np.zeros(k, np.float32))
+    lib.thip_set_lazy_gemv(1)
+    lib.thip_transform_ge(0, k, k, 1.0, dA.dev(), dx.dev(), 0.0, y1.dev())
+    lib.thip_transform_ge(0, k, k, 1.0, dB.dev(), y1.dev(), 0.0, y2.dev())        # RAW on y1
+    lib.thip_transform_ge(1, k, k, 1.0, dC.dev(), y2.dev(), 0.0, dx.dev())        # RAW on y2, WAR on x
+    lib.thip_transform_ge(0, k, k, 1.0, dA.dev(), dx.dev(), 2.0, y1.dev())        # WAW on y1, RAW on x
+    r1 = A.astype(np.float64) @ x
+    r2 = B.astype(np.float64) @ r1
+    rx = Cm.astype(np.float64).T @ r2
+    r1b = 2.0 * r1 + A.astype(np.float64) @ rx
+    assert np.allclose(y2.get_ref(), r2, rtol=1e-4, atol=1e-4 * np.abs(r2).max())
+    assert np.allclose(dx.get_ref(), rx, rtol=1e-4, atol=1e-4 * np.abs(rx).max())
+    assert np.allclose(y1.get_ref(), r1b, rtol=1e-4, atol=1e-4 * np.abs(r1b).max())
+    for s in (dA, dB, dC, dx, y1, y2):
+        s.drop()

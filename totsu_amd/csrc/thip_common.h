@@ -25,6 +25,14 @@ struct Ctx {
 };
 
 Ctx &ctx();
+// deferred small GEMVs (thip_lazy.hip)
+bool lazy_pending();
+int  lazy_flush();
+int  lazy_push(int transpose, size_t n_row, size_t n_col, float alpha, const float *mat, const float *x, float beta,
+               float *y, int *deferred);
+int  lazy_push_scale(size_t n, float alpha, float *x, int *deferred);
+int  lazy_push_add(size_t n, float alpha, const float *x, float *y, int *deferred);
+void lazy_release();      // frees the queue's device memory (thip_shutdown)
 int  fail(int code, const char *what, const char *file, int line);
 int  need_init();
 // returns a scratch buffer of at least n floats (grows with hipMalloc; not inside graph capture)
@@ -42,7 +50,14 @@ int  scratch(size_t n, float **out);
         if (rc__ != 0) return rc__;                                               \
     } while (0)
 
+// every entry point first runs what thip_transform_ge has deferred (thip_lazy.hip), so that stream order == call order
 #define THIP_NEED_INIT()                                                          \
+    do {                                                                          \
+        if (!::thip::ctx().inited) return ::thip::need_init();                    \
+        if (::thip::lazy_pending()) { int rcl__ = ::thip::lazy_flush(); if (rcl__ != 0) return rcl__; } \
+    } while (0)
+
+#define THIP_NEED_INIT_NOFLUSH()                                                  \
     do {                                                                          \
         if (!::thip::ctx().inited) return ::thip::need_init();                    \
     } while (0)
@@ -139,6 +154,10 @@ struct GemvPartials {
     const float *partN; int nN; size_t strideN;   // outN[r] = sum_{k<nN} partN[k*strideN + r]
     const float *partT; int nT; size_t strideT;   // outT[c] = sum_{k<nT} partT[k*strideT + c]
 };
+// descriptor of one matrix of a grouped launch: column-major nr x nc, lda = nr; x = the input vector (nc long for N,
+// nr long for T); part = where the partial sums go; cpc = columns per chunk
+struct GroupDesc { const float *A; const float *x; float *part; int nr, nc, cpc, pad; };
+int grouped_gemv(hipStream_t st, const GroupDesc *dev_tab, int n_desc, int max_tiles, int max_chunks, bool transposed);
 struct GemvHint { int nj; int target_blocks; };        // tiling override: row groups per lane, grid size
 const GemvHint *gemv_candidates(int *count);           // plans worth timing on a given matrix
 int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,

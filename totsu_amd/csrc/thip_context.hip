@@ -97,6 +97,7 @@ int thip_shutdown(void)
     hipSetDevice(c.device);
     hipStreamSynchronize(c.stream);
     prof_release();
+    lazy_release();
     if (c.scratch) hipFree(c.scratch);
     if (c.dev_scalar) hipFree(c.dev_scalar);
     if (c.pinned) hipHostFree(c.pinned);
@@ -115,7 +116,11 @@ int thip_set_stream(void *hip_stream)
     return 0;
 }
 
-void *thip_get_stream(void) { return (void *)ctx().stream; }
+void *thip_get_stream(void)
+{
+    if (ctx().inited && lazy_pending()) lazy_flush();      // the caller may enqueue its own work behind ours
+    return (void *)ctx().stream;
+}
 
 int thip_sync(void)
 {

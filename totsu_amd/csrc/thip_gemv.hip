@@ -332,6 +332,70 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const E *__restrict__ A, size
     }
 }
 
+// Many small GEMVs in ONE launch (thip_lazy.hip: the deferred transform_ge calls of a composite operator, e.g. the 2000
+// block products of ProbSOCPOpA::op / ::trans_op, socp.rs:77-130): blockIdx.z picks a descriptor.  The blocks are
+// short (99 rows at BASELINE configs[2]) and start anywhere, so the unit of work is ONE WAVE: 128 rows (two per lane:
+// l and l + 64) x a chunk of d.cpc columns, 8 columns = 16 guarded dword loads per lane in flight; the four waves of a
+// workgroup take four consecutive column chunks of the same row tile and never synchronise.  A 99-row block keeps
+// 99 / 128 of the lanes of EVERY wave busy (a 256-row tile would idle two waves of four and leave 3 KB per workgroup in
+// flight instead of 16).  Partial sums: N -> part[chunk * nr + r]; T -> part[tile * nc + c] (8 columns reduced across
+// the wave by the transpose-reduce butterfly, staged in LDS, stored coalesced).
+constexpr int GROWS = 128;      // rows per wave tile
+template <bool DO_T>
+__global__ __launch_bounds__(BLK) void grouped_gemv_k(const GroupDesc *__restrict__ tab)
+{
+    const GroupDesc d = tab[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x, chunk = blockIdx.y * 4 + wave;
+    __shared__ float ldsT[DO_T ? 4 * MAXCW : 4];
+    if (tile * GROWS >= d.nr || chunk * d.cpc >= d.nc) return;
+    const int r0 = tile * GROWS + lane, r1 = r0 + 64;
+    const bool ok0 = r0 < d.nr, ok1 = r1 < d.nr;
+    const int c0 = chunk * d.cpc, c1 = min(d.nc, c0 + d.cpc);
+    const float *__restrict__ A = d.A;
+    const size_t lda = (size_t)d.nr;
+    float xt0 = 0.0f, xt1 = 0.0f, acc0 = 0.0f, acc1 = 0.0f;
+    if constexpr (DO_T) { xt0 = ok0 ? d.x[r0] : 0.0f; xt1 = ok1 ? d.x[r1] : 0.0f; }
+    float *lw = ldsT + wave * (DO_T ? MAXCW : 1);
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+        float a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float *col = A + (size_t)(c + u) * lda;
+            a0[u] = ok0 ? __builtin_nontemporal_load(col + r0) : 0.0f;
+            a1[u] = ok1 ? __builtin_nontemporal_load(col + r1) : 0.0f;
+        }
+        if constexpr (!DO_T) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float xs = d.x[c + u]; acc0 = fmaf(a0[u], xs, acc0); acc1 = fmaf(a1[u], xs, acc1); }
+        } else {
+            float p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = fmaf(a0[u], xt0, a1[u] * xt1);
+            const float r = multi_reduce<8>(p, lane);
+            if ((lane & 7) == 0) lw[c - c0 + (lane >> 3)] = r;
+        }
+    }
+    for (; c < c1; ++c) {
+        const float *col = A + (size_t)c * lda;
+        const float a0 = ok0 ? col[r0] : 0.0f, a1 = ok1 ? col[r1] : 0.0f;
+        if constexpr (!DO_T) { const float xs = d.x[c]; acc0 = fmaf(a0, xs, acc0); acc1 = fmaf(a1, xs, acc1); }
+        else { const float r = wave_sum(fmaf(a0, xt0, a1 * xt1)); if (lane == 0) lw[c - c0] = r; }
+    }
+    if constexpr (!DO_T) {
+        float *dst = d.part + (size_t)chunk * d.nr;
+        if (ok0) dst[r0] = acc0;
+        if (ok1) dst[r1] = acc1;
+    } else {
+        // this wave's LDS writes are visible to itself after the wait (no cross-wave sharing)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float *dst = d.part + (size_t)tile * d.nc + c0;
+        for (int t = lane; t < c1 - c0; t += 64) dst[t] = lw[t];
+    }
+}
+
 // second stage: y[i] = alpha * sum_k part[k*stride + i] + beta * y[i]
 __global__ void finalize_k(size_t n, const float *__restrict__ part, int np, size_t stride, float alpha, float beta,
                            float *__restrict__ y, const int *__restrict__ stop)
@@ -592,6 +656,16 @@ int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *m
     return 0;
 }
 
+int grouped_gemv(hipStream_t st, const GroupDesc *dev_tab, int n_desc, int max_tiles, int max_chunks, bool transposed)
+{
+    if (n_desc <= 0) return 0;
+    dim3 g(max_tiles, max_chunks, n_desc);
+    if (transposed) hipLaunchKernelGGL(grouped_gemv_k<true>, g, dim3(BLK), 0, st, dev_tab);
+    else            hipLaunchKernelGGL(grouped_gemv_k<false>, g, dim3(BLK), 0, st, dev_tab);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float alpha, float beta,
                       float *y, const int *stop)
 {
@@ -649,11 +723,15 @@ extern "C" {
 int thip_transform_ge(int transpose, size_t n_row, size_t n_col, float alpha, const float *mat, const float *x,
                       float beta, float *y)
 {
-    THIP_NEED_INIT();
+    THIP_NEED_INIT_NOFLUSH();
     // zero-sized operands: MatOp::op_impl never calls transform_ge then (matop.rs:79-85); be lenient anyway
     const size_t ylen = transpose ? n_col : n_row;
     if (ylen == 0) return 0;
     if (n_row == 0 || n_col == 0) return thip_scale(ylen, beta, y);
+    // small products are deferred and batched (thip_lazy.hip); anything else runs now, after what is pending
+    int deferred = 0;
+    THIP_RC(lazy_push(transpose, n_row, n_col, alpha, mat, x, beta, y, &deferred));
+    if (deferred) return 0;
     if (transpose)
         return dual_gemv(ctx().stream, n_row, n_col, mat, n_row, nullptr, 0.f, 0.f, nullptr, x, alpha, beta, y, false, nullptr);
     return dual_gemv(ctx().stream, n_row, n_col, mat, n_row, x, alpha, beta, y, nullptr, 0.f, 0.f, nullptr, false, nullptr);

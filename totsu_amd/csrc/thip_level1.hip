@@ -154,8 +154,13 @@ int thip_copy(size_t n, const float *x, float *y)
 
 int thip_scale(size_t n, float alpha, float *x)
 {
-    THIP_NEED_INIT();
+    THIP_NEED_INIT_NOFLUSH();
     if (n == 0) return 0;
+    // short vectors join the deferred record (thip_lazy.hip: ProbSOCPOpB scales and adds one number per cone,
+    // socp.rs:194-246); anything else runs now, after what is pending
+    int deferred = 0;
+    THIP_RC(lazy_push_scale(n, alpha, x, &deferred));
+    if (deferred) return 0;
     if (alpha == 0.0f) {
         // exact zero fill (also clears NaN/Inf of an uninitialised work buffer; solver.rs:490-491)
         THIP_TRY(hipMemsetAsync(x, 0, n * sizeof(float), ctx().stream));
@@ -169,8 +174,11 @@ int thip_scale(size_t n, float alpha, float *x)
 
 int thip_add(size_t n, float alpha, const float *x, float *y)
 {
-    THIP_NEED_INIT();
+    THIP_NEED_INIT_NOFLUSH();
     if (n == 0) return 0;
+    int deferred = 0;
+    THIP_RC(lazy_push_add(n, alpha, x, y, &deferred));
+    if (deferred) return 0;
     hipLaunchKernelGGL(add_k, dim3(grid_for(n, BLK, MAXB)), dim3(BLK), 0, ctx().stream, n, alpha, x, y);
     THIP_LAUNCH_CHECK();
     return 0;
