@@ -76,7 +76,7 @@ def test_cone_psd_kat(L):
     assert c2.proj(False, sl) is False
 
 
-@pytest.mark.parametrize("k", [2, 5, 40, 64, 65, 130])
+@pytest.mark.parametrize("k", [2, 5, 32, 33, 40, 64, 65, 130, 257, 500])     # > 32: Householder + QL engine
 def test_map_eig_sqrt_and_closure(L, k):
     # MatBuild::sqrt (matbuild/mod.rs:219-245) and an arbitrary host closure through the two-phase path
     rng = np.random.default_rng(k)
@@ -133,3 +133,40 @@ def test_mfma_gemm_symmetric_times_general(L, n, ld):
     assert np.all(np.abs(got - ref) <= 2e-6 * scale)
     for d in (dA, dB, dD, dC):
         d.free()
+
+
+def test_general_eigen_engine_time_and_orthogonality(L):
+    """k = 500 through the two-phase closure path (thip_eig_decompose -> host closure -> thip_eig_rebuild): eigenvalues
+    against numpy, reconstruction of the matrix with the identity closure, and the time (Jacobi took 51 ms)"""
+    import time
+    k = 500
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal((k, k))
+    s = (b + b.T) / 2
+    packed = np.array([s[r, c] for c in range(k) for r in range(c + 1)], dtype=np.float32)
+    work = L.Sl.new_mut(np.zeros(L.map_eig_worklen(k), dtype=np.float32))
+    seen = []
+    sl = L.Sl.new_mut(packed.copy())
+    L.map_eig(sl, None, 1e-12, work, lambda e: (seen.append(e), e)[1])
+    got = sl.get_ref().copy()
+    w = np.linalg.eigvalsh(s)
+    assert np.abs(np.sort(np.array(seen)) - w).max() <= 2e-5 * np.abs(w).max()
+    assert np.abs(got - packed).max() <= 2e-5 * np.abs(w).max()          # Z diag(w) Z^T == M: Z orthogonal, w right
+    sl.drop()
+    sl = L.Sl.new_mut(packed.copy())
+    L.map_eig(sl, None, 1e-12, work, "sqrt_pos")
+    L.sync()
+    ts = []
+    for _ in range(3):
+        sl2 = L.Sl.new_mut(packed.copy())
+        sl2.dev()
+        L.sync()
+        t0 = time.perf_counter()
+        L.map_eig(sl2, None, 1e-12, work, "sqrt_pos")
+        L.sync()
+        ts.append(time.perf_counter() - t0)
+        sl2.drop()
+    print("map_eig(sqrt) k=500: %.2f ms" % (1e3 * min(ts)))
+    assert min(ts) < 0.025
+    sl.drop()
+    work.drop()

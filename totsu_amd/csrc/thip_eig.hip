@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 using namespace thip;
 
@@ -473,6 +474,287 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// engine (3): Householder tridiagonalisation + implicit QL -- the general eigen-decomposition for n > 32
+// (BASELINE.json north_star: "symmetric eigendecomposition (Householder tridiag + QR)"; the routine the reference
+// calls is dsyevr / cusolver syevdx, f64lapack.rs:78-108, f32cuda.rs:253-263).  O(n) dependent steps instead of the
+// O(n * sweeps) of the Jacobi engine:
+//   1. Q^T M Q = T, n - 2 reflectors, two launches per reflector (tri_pv_k: the reflector v_j and p = tau A v, one wave
+//      per column of the L2-resident trailing matrix; tri_upd_k: w = p - (tau p.v / 2) v and the symmetric rank-2 update
+//      A -= v w^T + w v^T, full square so that a "row" stays a contiguous column);
+//   2. Z = Q formed column by column (form_q_k: one wave per column applies all reflectors, no global step);
+//   3. d, e visit the host: implicit-shift QL in f64 (the O(n^2) scalar recurrence of tql2) which only RECORDS its
+//      Givens rotations, one (c, s) pair each, grouped in sweeps of adjacent pairs;
+//   4. rot_apply_k replays the record on Z: rows are independent, one lane per row, the 64 rows of a workgroup live
+//      in LDS ([column][row], conflict-free), the entry carried from one rotation of a sweep to the next in a register;
+//   5. the rebuild V diag(e) V^T is a GEMM on the matrix cores (gemm(false): X Y^T with X = V diag(e)).
+// ---------------------------------------------------------------------------------------------------
+constexpr int TRI_MAXN = 2048;
+
+__global__ __launch_bounds__(BLK) void tri_pv_k(int n, int ld, int j, const float *__restrict__ G, float *__restrict__ Vh,
+                                               float *__restrict__ p, float *__restrict__ d, float *__restrict__ e,
+                                               float *__restrict__ tau)
+{
+    __shared__ float vsh[TRI_MAXN];
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = n - j - 1;
+    const float *x = G + (size_t)j * ld + j + 1;
+    // LAPACK slarfg: beta = -sign(alpha) ||x||, tau = (beta - alpha) / beta, v = [1 ; x[1:] / (alpha - beta)]
+    float ss = 0.0f;
+    for (int i = 1 + tid; i < L; i += BLK) { const float t = x[i]; ss = fmaf(t, t, ss); }
+    ss = block_sum(ss, red);
+    const float alpha = x[0];
+    const float xnorm = sqrtf(ss);
+    float t = 0.0f, beta = alpha, scale = 0.0f;
+    if (xnorm != 0.0f) {
+        beta = -copysignf(hypotf(alpha, xnorm), alpha);
+        t = (beta - alpha) / beta;
+        scale = 1.0f / (alpha - beta);
+    }
+    for (int i = tid; i < L; i += BLK) vsh[i] = i == 0 ? 1.0f : x[i] * scale;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < L; i += BLK) Vh[(size_t)j * ld + j + 1 + i] = vsh[i];
+        if (tid == 0) { d[j] = G[(size_t)j * ld + j]; e[j] = beta; tau[j] = t; }
+    }
+    const int c = blockIdx.x * 4 + wave;            // column j + 1 + c of the trailing matrix
+    if (c < L) {
+        const float *col = G + (size_t)(j + 1 + c) * ld + j + 1;
+        float sacc = 0.0f;
+        for (int r = lane; r < L; r += 64) sacc = fmaf(col[r], vsh[r], sacc);
+        sacc = wave_sum(sacc);
+        if (lane == 0) p[c] = t * sacc;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void tri_upd_k(int n, int ld, int j, float *__restrict__ G, const float *__restrict__ Vh,
+                                                const float *__restrict__ p, const float *__restrict__ tau)
+{
+    __shared__ float vsh[TRI_MAXN];
+    __shared__ float wsh[TRI_MAXN];
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    const int L = n - j - 1;
+    const float t = tau[j];
+    if (t == 0.0f) return;                           // H = I
+    float acc = 0.0f;
+    for (int i = tid; i < L; i += BLK) {
+        const float vi = Vh[(size_t)j * ld + j + 1 + i], pi = p[i];
+        vsh[i] = vi; wsh[i] = pi;
+        acc = fmaf(pi, vi, acc);
+    }
+    acc = block_sum(acc, red);
+    const float k = -0.5f * t * acc;
+    for (int i = tid; i < L; i += BLK) wsh[i] = fmaf(k, vsh[i], wsh[i]);
+    __syncthreads();
+    for (int cc = 0; cc < 4; ++cc) {
+        const int c = blockIdx.x * 4 + cc;
+        if (c >= L) break;
+        float *col = G + (size_t)(j + 1 + c) * ld + j + 1;
+        const float wc = wsh[c], vc = vsh[c];
+        for (int r = tid; r < L; r += BLK) col[r] = col[r] - (vsh[r] * wc + wsh[r] * vc);
+    }
+}
+
+// the 2 x 2 tail (and the whole of n <= 2)
+__global__ void tri_fin_k(int n, int ld, const float *__restrict__ G, float *__restrict__ d, float *__restrict__ e)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (n == 1) { d[0] = G[0]; e[0] = 0.0f; return; }
+    d[n - 2] = G[(size_t)(n - 2) * ld + n - 2];
+    d[n - 1] = G[(size_t)(n - 1) * ld + n - 1];
+    e[n - 2] = G[(size_t)(n - 2) * ld + n - 1];
+    e[n - 1] = 0.0f;
+}
+
+// Z(:, c) = H_0 H_1 .. H_{n-3} e_c, one wave per column (zero padded to ld x ld)
+__global__ __launch_bounds__(BLK) void form_q_k(int n, int ld, const float *__restrict__ Vh, const float *__restrict__ tau,
+                                               float *__restrict__ Z)
+{
+    __shared__ float qs[4][TRI_MAXN];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= ld) return;
+    float *q = qs[wave];
+    for (int r = lane; r < n; r += 64) q[r] = (r == c) ? 1.0f : 0.0f;
+    if (c < n) {
+        for (int j = n - 3; j >= 0; --j) {
+            const int L = n - j - 1;
+            if (j + 1 + L <= c) continue;            // never true; kept for clarity
+            const float t = tau[j];
+            if (t == 0.0f) continue;
+            const float *v = Vh + (size_t)j * ld + j + 1;
+            float sacc = 0.0f;
+            for (int r = lane; r < L; r += 64) sacc = fmaf(v[r], q[j + 1 + r], sacc);
+            sacc = wave_sum(sacc) * t;
+            for (int r = lane; r < L; r += 64) q[j + 1 + r] = fmaf(-sacc, v[r], q[j + 1 + r]);
+        }
+    }
+    for (int r = lane; r < ld; r += 64) Z[(size_t)c * ld + r] = (r < n && c < n) ? q[r] : 0.0f;
+}
+
+struct RotSweep { int start, count, off, pad; };     // rotations on columns (i, i + 1), i = start, start - 1, ..
+
+// replays the QL rotations on the rows of Z: RB rows per workgroup in LDS as zs[column][row], one lane per row.
+// The replay is a chain: every rotation needs the entry its predecessor left.  Rows are independent but LDS holds
+// only ~64 of them per CU, and ONE wave issues ~8 instructions per rotation at one instruction per ~8 cycles.  So the
+// RW waves of a workgroup work on the SAME rows and take the sweeps round-robin (wave w: sweeps w, w + RW, ..), as a
+// software pipeline: sweep q + 1 follows sweep q down the columns and may touch column c only after sweep q has
+// moved below it.  Progress of sweep q lives in LDS slot q & 7 as the key (q << 12) | (4095 - (lowest index done + 1)),
+// published with atomicMax: keys only grow -- within a sweep as it descends, and from sweep q to the sweep q + 8 that
+// reuses the slot -- so a late writer can never hide a newer sweep, and a reader that finds a LARGER sweep number in the
+// slot knows its predecessor finished long ago.
+constexpr int RW = 4;
+template <int RB>
+__global__ __launch_bounds__(64 * RW) void rot_apply_k(int n, int ld, float *__restrict__ Z, const float2 *__restrict__ rot,
+                                                      const RotSweep *__restrict__ sw, int nsw)
+{
+    extern __shared__ float zs[];
+    __shared__ int prog[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool act = lane < RB;
+    const int row = blockIdx.x * RB + lane;
+    const bool ok = act && row < n;
+    if (threadIdx.x < 8) prog[threadIdx.x] = -1;
+    for (int c = wave; c < n; c += RW) if (act) zs[c * RB + lane] = ok ? Z[(size_t)c * ld + row] : 0.0f;
+    __syncthreads();
+    volatile int *vprog = prog;
+    // The (c, s) pairs: each lane fetches ONE pair of the next 64 rotations (a coalesced load: one memory round trip per
+    // 64 rotations) and the pairs are broadcast from lane u with v_readlane; the block after the one being replayed is
+    // already in flight.
+    for (int q = wave; q < nsw; q += RW) {
+        const RotSweep w = sw[q];
+        float2 mine = lane < min(64, w.count) ? rot[w.off + lane] : make_float2(1.0f, 0.0f);
+        if (lane == 0) atomicMax(&prog[q & 7], q << 12);         // sweep q: nothing done yet (done + 1 = 4095)
+        int i = w.start;
+        bool first = true;
+        float hi = 0.0f;
+        for (int t0 = 0; t0 < w.count; t0 += 64) {
+            const int nb = min(64, w.count - t0);
+            float2 next = make_float2(1.0f, 0.0f);
+            if (t0 + 64 < w.count && lane < min(64, w.count - t0 - 64)) next = rot[w.off + t0 + 64 + lane];
+            for (int u = 0; u < nb; u += 8) {
+                const int m8 = min(8, nb - u);
+                // columns i - m8 + 1 .. i + 1 are touched: the previous sweep must be below them
+                if (q > 0) {
+                    const int need = i - m8 + 1;
+                    for (;;) {
+                        const int v = vprog[(q - 1) & 7];
+                        const int tag = v >> 12;
+                        if (tag > q - 1 || (tag == q - 1 && (4095 - (v & 4095)) - 1 < need)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (first) { hi = act ? zs[(i + 1) * RB + lane] : 0.0f; first = false; }
+                if (m8 == 8) {
+                    float lo[8], nh[8];
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) lo[v] = act ? zs[(i - v) * RB + lane] : 0.0f;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), u + v));
+                        const float sn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), u + v));
+                        // the only loop-carried value is hi: ONE dependent FMA per rotation on that chain
+                        const float cl = c * lo[v], sl = sn * lo[v];
+                        nh[v] = fmaf(c, hi, sl);                       // s z_i + c z_{i+1}
+                        hi = fmaf(-sn, hi, cl);                        // c z_i - s z_{i+1}
+                    }
+                    if (act) {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) zs[(i - v + 1) * RB + lane] = nh[v];
+                    }
+                    i -= 8;
+                } else {
+                    for (int v = 0; v < m8; ++v, --i) {
+                        const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), u + v));
+                        const float sn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), u + v));
+                        const float lo = act ? zs[i * RB + lane] : 0.0f;
+                        if (act) zs[(i + 1) * RB + lane] = fmaf(c, hi, sn * lo);
+                        hi = fmaf(-sn, hi, c * lo);
+                    }
+                }
+                // column i + 1 is still in a register (hi): everything above it is final for this sweep
+                const bool last = t0 + u + m8 >= w.count;
+                if (last && act) zs[(i + 1) * RB + lane] = hi;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) atomicMax(&prog[q & 7], (q << 12) | (4095 - (last ? 0 : (i + 2))));   // done = i + 1 (last: -1)
+            }
+            mine = next;
+        }
+    }
+    __syncthreads();
+    if (ok)
+        for (int c = wave; c < n; c += RW) Z[(size_t)c * ld + row] = zs[c * RB + lane];
+}
+
+// X(:, i) = e_i V(:, i)   (ld x ld, padding stays zero)
+__global__ void scale_cols_k(int ld, const float *__restrict__ V, const float *__restrict__ e, int n, float *__restrict__ X)
+{
+    const size_t tot = (size_t)ld * ld;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) {
+        const int c = (int)(i / ld);
+        X[i] = c < n ? e[c] * V[i] : 0.0f;
+    }
+}
+
+// packed(r, c) = C(r, c), r <= c, diag / scale
+__global__ void pack_sym_k(int n, int ld, const float *__restrict__ Cm, int has_scale, float scale, float *__restrict__ packed)
+{
+    const int c = blockIdx.y;
+    for (int r = blockIdx.x * BLK + threadIdx.x; r <= c; r += gridDim.x * BLK) {
+        float v = 0.5f * (Cm[(size_t)c * ld + r] + Cm[(size_t)r * ld + c]);
+        if (r == c && has_scale) v = v / scale;
+        packed[(size_t)c * (c + 1) / 2 + r] = v;
+    }
+}
+
+// implicit-shift QL on the tridiagonal (d, e) in f64 (EISPACK tql2 / NR tqli recurrence); every Givens rotation is
+// recorded as (c, s), grouped in sweeps.  Returns false if an eigenvalue needs more than 60 iterations.
+template <typename Emit>
+bool ql_record(int n, std::vector<double> &d, std::vector<double> &e, std::vector<float2> &rot, std::vector<RotSweep> &sweeps,
+               size_t chunk_rotations, Emit emit)
+{
+    const double eps = 1.1102230246251565e-16;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0, m;
+        do {
+            for (m = l; m < n - 1; ++m) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= eps * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 60) return false;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::sqrt(g * g + 1.0);
+                g = d[m] - d[l] + e[l] / (g + std::copysign(r, g));
+                double s = 1.0, c = 1.0, p = 0.0;
+                RotSweep sw{ m - 1, 0, (int)rot.size(), 0 };
+                int i;
+                for (i = m - 1; i >= l; --i) {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    e[i + 1] = r = std::sqrt(f * f + g * g);     // |f|, |g| <= ||T||: no overflow guard needed in f64
+                    if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
+                    s = f / r; c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    d[i + 1] = g + (p = s * r);
+                    g = c * r - b;
+                    rot.push_back(make_float2((float)c, (float)s));
+                    sw.count += 1;
+                }
+                if (sw.count) sweeps.push_back(sw);
+                // hand the record to the device in chunks: the replay of chunk k runs while the host computes chunk k + 1
+                if (rot.size() >= chunk_rotations) { if (!emit()) return false; rot.clear(); sweeps.clear(); }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p; e[l] = g; e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    return true;
+}
+
 struct Work {
     float *G, *V, *S, *Y, *Z;      // ld x ld each
     float *w, *e;                  // ld each
@@ -491,9 +773,14 @@ Work carve(float *work, size_t n)
     return k;
 }
 
+int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_scale, float scale, const Work &k, int map_kind);
+constexpr int TRI_MIN_N = 32;        // above: Householder + QL (host-facing calls); up to here the one-workgroup Jacobi
+
 int decompose(hipStream_t st, size_t n, const float *packed, int has_scale, float scale, const Work &k,
               int map_kind, const int *stop)
 {
+    if (n > (size_t)TRI_MIN_N && stop == nullptr && !getenv("THIP_EIG_JACOBI"))
+        return decompose_tridiag(st, n, packed, has_scale, scale, k, map_kind);
     const int ni = (int)n, ld = (int)np_of(n);
     const unsigned g = grid_for((size_t)ld * ld, BLK, 512);
     hipLaunchKernelGGL(unpack_k, dim3(g), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, k.G, k.V, k.part, stop);
@@ -523,8 +810,108 @@ int decompose(hipStream_t st, size_t n, const float *packed, int has_scale, floa
     return 0;
 }
 
+template <int RB>
+int launch_rot(hipStream_t st, int n, int ld, float *Z, const float2 *rot, const RotSweep *sw, int nsw)
+{
+    const size_t lds = (size_t)n * RB * sizeof(float);
+    THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rot_apply_k<RB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rot_apply_k<RB>, dim3((n + RB - 1) / RB), dim3(64 * RW), lds, st, n, ld, Z, rot, sw, nsw);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// M = Z diag(w) Z^T by Householder tridiagonalisation + QL; eigenvectors -> k.V (columns), eigenvalues -> k.w, and for
+// map_kind 0 / 1 the mapped values -> k.e.  SYNC (d and e visit the host).
+int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_scale, float scale, const Work &k, int map_kind)
+{
+    const int ni = (int)n, ld = (int)np_of(n);
+    if (ni > TRI_MAXN) return fail(THIP_E_INVALID, "map_eig: order above 2048", __FILE__, __LINE__);
+    const unsigned g = grid_for((size_t)ld * ld, BLK, 512);
+    hipLaunchKernelGGL(unpack_k, dim3(g), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, k.G, (float *)nullptr, k.part,
+                       (const int *)nullptr);
+    float *d = k.Y, *e = k.Y + ld, *tau = k.Y + 2 * (size_t)ld, *p = k.Y + 3 * (size_t)ld, *Vh = k.S;
+    for (int j = 0; j + 2 < ni; ++j) {
+        const unsigned blocks = (unsigned)((ni - j - 1 + 3) / 4);
+        hipLaunchKernelGGL(tri_pv_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, p, d, e, tau);
+        hipLaunchKernelGGL(tri_upd_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, p, tau);
+    }
+    hipLaunchKernelGGL(tri_fin_k, dim3(1), dim3(64), 0, st, ni, ld, k.G, d, e);
+    THIP_LAUNCH_CHECK();
+    std::vector<float> hde(2 * (size_t)ld);
+    THIP_TRY(hipMemcpyAsync(hde.data(), d, 2 * (size_t)ld * sizeof(float), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(form_q_k, dim3((unsigned)((ld + 3) / 4)), dim3(BLK), 0, st, ni, ld, Vh, tau, k.V);   // runs under the host QL
+    THIP_LAUNCH_CHECK();
+    THIP_TRY(hipStreamSynchronize(st));
+    std::vector<double> dd(ni), ee(ni, 0.0);
+    for (int i = 0; i < ni; ++i) { dd[i] = hde[i]; if (i + 1 < ni) ee[i] = hde[ld + i]; }
+    // The record goes to the device in chunks of >= 16k rotations (whole sweeps): two device buffers alternate, an event
+    // each says "the replay that read this buffer has finished".
+    const size_t chunk = 16384, cap_rot = chunk + (size_t)ni + 8, cap_sw = chunk / 2 + 16;
+    const size_t per = 2 * cap_rot + 4 * cap_sw;             // floats per buffer (float2 pairs, then 16-byte sweep records)
+    float *scr = nullptr;
+    THIP_RC(scratch(2 * per + 64, &scr));
+    hipEvent_t ev[2] = { nullptr, nullptr };
+    int which = 0, rc = 0;
+    std::vector<float2> rot;
+    std::vector<RotSweep> sweeps;
+    rot.reserve(cap_rot);
+    auto emit = [&]() -> bool {
+        if (sweeps.empty()) return true;
+        if (sweeps.size() > cap_sw) { rc = fail(THIP_E_NOCONV, "QL: too many short sweeps", __FILE__, __LINE__); return false; }
+        float *buf = scr + (size_t)which * per;
+        float2 *drot = reinterpret_cast<float2 *>(buf);
+        RotSweep *dsw = reinterpret_cast<RotSweep *>(buf + 2 * cap_rot);
+        if (ev[which] == nullptr) { if (hipEventCreateWithFlags(&ev[which], hipEventDisableTiming) != hipSuccess) { rc = -1; return false; } }
+        else if (hipEventSynchronize(ev[which]) != hipSuccess) { rc = -1; return false; }
+        const int off0 = sweeps[0].off;
+        for (RotSweep &w : sweeps) w.off -= off0;            // offsets relative to the chunk
+        if (hipMemcpyAsync(drot, rot.data(), rot.size() * sizeof(float2), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(dsw, sweeps.data(), sweeps.size() * sizeof(RotSweep), hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1; return false; }
+        // pageable sources: the copies are staged before the calls return, the vectors may be reused
+        int r2;
+        if ((size_t)ni * 64 * sizeof(float) <= 150 * 1024) r2 = launch_rot<64>(st, ni, ld, k.V, drot, dsw, (int)sweeps.size());
+        else if ((size_t)ni * 32 * sizeof(float) <= 150 * 1024) r2 = launch_rot<32>(st, ni, ld, k.V, drot, dsw, (int)sweeps.size());
+        else r2 = launch_rot<16>(st, ni, ld, k.V, drot, dsw, (int)sweeps.size());
+        if (r2 != 0) { rc = r2; return false; }
+        hipEventRecord(ev[which], st);
+        which ^= 1;
+        return true;
+    };
+    const bool conv = ql_record(ni, dd, ee, rot, sweeps, chunk, emit);
+    if (conv) emit();
+    THIP_TRY(hipStreamSynchronize(st));
+    for (int b = 0; b < 2; ++b) if (ev[b]) hipEventDestroy(ev[b]);
+    if (rc != 0) return rc > 0 ? rc : fail(THIP_E_INVALID, "QL replay: HIP call failed", __FILE__, __LINE__);
+    if (!conv) return fail(THIP_E_NOCONV, "QL iteration did not converge", __FILE__, __LINE__);
+    std::vector<float> hw(2 * (size_t)ld, 0.0f);
+    for (int i = 0; i < ni; ++i) {
+        const float lam = (float)dd[i];
+        hw[i] = lam;
+        if (map_kind == 0) hw[ld + i] = lam > 0.0f ? lam : 0.0f;
+        else if (map_kind == 1) hw[ld + i] = lam > 0.0f ? std::sqrt(lam) : 0.0f;
+    }
+    // k.w and k.e are adjacent (carve): one upload
+    THIP_TRY(hipMemcpyAsync(k.w, hw.data(), 2 * (size_t)ld * sizeof(float), hipMemcpyHostToDevice, st));
+    THIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// packed <- V diag(e) V^T on the matrix cores: X = V diag(e), C = X V^T (gemm(false)), then the symmetric pack
+int rebuild_mfma(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k)
+{
+    const int ni = (int)n, ld = (int)np_of(n);
+    const unsigned g = grid_for((size_t)ld * ld, BLK, 512);
+    hipLaunchKernelGGL(scale_cols_k, dim3(g), dim3(BLK), 0, st, ld, k.V, k.e, ni, k.S);
+    THIP_RC(gemm(st, false, ni, ld, 1.0f, k.S, k.V, 0.0f, nullptr, 0.0f, k.Z, nullptr));
+    dim3 gp((unsigned)((n + BLK - 1) / BLK), (unsigned)n);
+    hipLaunchKernelGGL(pack_sym_k, gp, dim3(BLK), 0, st, ni, ld, k.Z, has_scale, scale, packed);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
 int rebuild(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop)
 {
+    if (n > (size_t)TRI_MIN_N && stop == nullptr) return rebuild_mfma(st, n, packed, has_scale, scale, k);
     const int ni = (int)n, ld = (int)np_of(n);
     dim3 g((unsigned)((n + BLK - 1) / BLK), (unsigned)n);
     hipLaunchKernelGGL(rebuild_k, g, dim3(BLK), 0, st, ni, ld, k.V, k.e, has_scale, scale, packed, stop);
