@@ -793,3 +793,38 @@ def test_storage_switch_inside_a_carried_solve_rebuilds_the_carried_products(T):
         sc = np.abs(a).max()
         assert np.abs(a - b).max() <= 2e-5 * sc, np.abs(a - b).max() / sc
     socp.drop()
+
+
+def test_literal_reference_cones_over_the_hip_backend(T):
+    """the trait-level loop with the reference's literal cone code (host loop over get_mut, get + norm + scale + set,
+    map_eig with a host closure) over F32HIP -- no device fast path -- reproduces the known answers"""
+    import totsu_amd.cone as cone_mod
+    L = T.F32HIP
+    cone_mod.DEVICE_FAST_PATHS = False
+    try:
+        # nostd_cortex-m LP (ConeRPos through get_mut): x = [2, 2]
+        lp = T.ProbLP(_mb(T, T.MatType.General(2, 1)).iter_colmaj([-1., 0.]), _mb(T, T.MatType.General(3, 2)).iter_colmaj([4., -1., -1., -1., 4., -1.]),
+                      _mb(T, T.MatType.General(3, 1)).iter_colmaj([6., 6., 1.]), _mb(T, T.MatType.General(0, 2)), _mb(T, T.MatType.General(0, 1)))
+        x, _ = _par(T.Solver(L), max_iter=100_000, eps_acc=1e-5).solve(lp.problem())
+        assert np.allclose(x, [2., 2.], atol=1e-3)
+        lp.drop()
+        # totsu/tests/socp.rs test_socp1 (ConeSOC through get / norm / scale / set): x = [-1, -1]
+        n = 2
+        socp = T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).iter_colmaj([1., 1.]), [_mb(T, T.MatType.General(2, 2)).iter_colmaj([1., 0., 0., 1.])],
+                          [_mb(T, T.MatType.General(2, 1))], [_mb(T, T.MatType.General(n, 1))], [2. ** 0.5],
+                          _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+        x, _ = _par(T.Solver(L), max_iter=100_000, eps_acc=1e-5).solve(socp.problem())
+        assert np.allclose(x, [-1., -1.], atol=1e-3)
+        socp.drop()
+        # totsu_core/tests/solver.rs (ConePSD through map_eig with the host closure e > 0 -> Some(e)): x = -2
+        op_c = T.MatOp(L, T.MatType.General(1, 1), np.array([1.], np.float32))
+        op_a = T.MatOp(L, T.MatType.General(3, 1), np.array([0., -1. * 1.41421356, -3.], np.float32))
+        op_b = T.MatOp(L, T.MatType.General(3, 1), np.array([1., 0., 10.], np.float32))
+        sv = _par(T.Solver(L), max_iter=100_000, eps_acc=1e-5)
+        cone_w = np.zeros(T.ConePSD.query_worklen(L, 3), dtype=np.float32)
+        cone = T.ConePSD(L, cone_w, sv.param.eps_zero)
+        work = np.zeros(T.Solver.query_worklen(op_a.size()), dtype=np.float32)
+        x, _ = sv.solve((op_c, op_a, op_b, cone, work))
+        assert abs(x[0] + 2.0) <= 1e-3
+    finally:
+        cone_mod.DEVICE_FAST_PATHS = True

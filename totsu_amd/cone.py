@@ -7,8 +7,14 @@ import math
 from ._lib import lib
 
 
+# False: every cone runs the reference's LITERAL sequence of SliceLike / LinAlg calls on any backend (ConeRPos: a host
+# loop over get_mut(); ConeSOC: get + norm + scale + set; ConePSD: map_eig with a host closure) -- what an unchanged
+# totsu_core executes over the F32HIP backend.  True (default): the device projections (thip_proj_*) on F32HIP.
+DEVICE_FAST_PATHS = True
+
+
 def _is_hip(L):
-    return getattr(L, "name", "") == "F32HIP"
+    return DEVICE_FAST_PATHS and getattr(L, "name", "") == "F32HIP"
 
 
 class ConeZero:
