@@ -52,11 +52,23 @@ fn register<'a>(mut s: F32HIPSlice) -> &'a mut F32HIPSlice {
     })
 }
 
+thread_local! {
+    // read-only mirrors keyed by the host array: `MatBuild::as_op()` is taken twice per G_i by ProbSOCP::problem
+    // (socp.rs:450,463) and once per `problem()` call by every builder -- one upload per array, shared while alive
+    // (totsu_f32cuda uploads on every new_ref, f32cuda_slice.rs:89-113).  The C++ twin is `MirrorCache`.
+    static MIRRORS: RefCell<std::collections::HashMap<(usize, usize), std::rc::Weak<Root>>> = RefCell::new(Default::default());
+}
+
 fn new_root<'a>(host: *mut f32, n: usize, mutable: bool) -> &'a mut F32HIPSlice {
+    if !mutable {
+        let hit = MIRRORS.with(|m| m.borrow().get(&(host as usize, n)).and_then(|w| w.upgrade()));
+        if let Some(root) = hit { return register(F32HIPSlice { root, off: 0, len: n, is_root: true, slot: 0 }); }
+    }
     let mut dev = std::ptr::null_mut();
     chk(unsafe { thip_alloc(n, &mut dev) });
     if n > 0 { chk(unsafe { thip_h2d(dev, host, n) }); }
     let root = Rc::new(Root { dev, host, n, mutable, dirty: RefCell::new(Vec::new()) });
+    if !mutable { MIRRORS.with(|m| { m.borrow_mut().insert((host as usize, n), Rc::downgrade(&root)); }); }
     register(F32HIPSlice { root, off: 0, len: n, is_root: true, slot: 0 })
 }
 

@@ -25,6 +25,11 @@ pub struct thip_status {
 pub enum thip_solver {}
 pub type thip_allreduce_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, dev_buf: *mut f32, n: usize, stream: *mut c_void) -> c_int>;
 
+pub const THIP_CONE_ZERO: i32 = 0;
+pub const THIP_CONE_RPOS: i32 = 1;
+pub const THIP_CONE_SOC: i32 = 2;
+pub const THIP_CONE_ROTSOC: i32 = 3;
+pub const THIP_CONE_PSD: i32 = 4;
 pub const THIP_SCHED_REFERENCE: c_int = 0;
 pub const THIP_SCHED_FUSED: c_int = 1;
 pub const THIP_SCHED_CARRIED: c_int = 2;

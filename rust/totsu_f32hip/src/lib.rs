@@ -16,10 +16,12 @@ pub mod ffi;
 pub mod f32hip;
 pub mod f32hip_slice;
 pub mod cones;
+pub mod prob;
 
 pub use f32hip::F32HIP;
 pub use f32hip_slice::F32HIPSlice;
 pub use cones::{HipConePSD, HipConeRPos, HipConeSOC};
+pub use prob::{FusedSolver, HipProbLP, HipProbSOCP, HipSolver};
 
 /// Selects the GPU (cuda_mgr.rs:30-60 hard-codes device 0; any device here).  Call once per thread before use.
 pub fn init(device: i32) { ffi::chk(unsafe { ffi::thip_init(device) }); }
