@@ -557,6 +557,79 @@ __global__ __launch_bounds__(BLK) void tri_upd_k(int n, int ld, int j, float *__
     }
 }
 
+// One launch per reflector: step j applies the rank-2 update of step j - 1 to the columns it owns WHILE it forms
+// p_j = tau_j A v_j from them.  Every workgroup first rebuilds, redundantly, what it needs of step j - 1 (w_{j-1} from
+// p_{j-1} and v_{j-1}) and the updated column j (-> d_j, the reflector v_j, tau_j, e_j): O(n) work per workgroup against
+// a launch boundary saved per step.  Column c's update is local to the workgroup that owns c, and p_j[c] = column c . v_j
+// by symmetry, so nothing crosses workgroups inside the launch.  Step 0 has no pending update (first != 0).
+__global__ __launch_bounds__(BLK) void tri_step_k(int n, int ld, int j, int first, float *__restrict__ G, float *__restrict__ Vh,
+                                                 const float *__restrict__ p_prev, float *__restrict__ p_out,
+                                                 float *__restrict__ d, float *__restrict__ e, float *__restrict__ tau)
+{
+    __shared__ float vp[TRI_MAXN];      // v_{j-1}, indices j .. n-1  (local 0 .. Lp-1)
+    __shared__ float wp[TRI_MAXN];      // w_{j-1}
+    __shared__ float vsh[TRI_MAXN];     // v_j, indices j+1 .. n-1   (local 0 .. L-1)
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Lp = n - j, L = n - j - 1;
+    float tprev = 0.0f;
+    if (!first) {
+        tprev = tau[j - 1];
+        float acc = 0.0f;
+        for (int i = tid; i < Lp; i += BLK) {
+            const float vi = Vh[(size_t)(j - 1) * ld + j + i], pi = p_prev[i];
+            vp[i] = vi; wp[i] = pi;
+            acc = fmaf(pi, vi, acc);
+        }
+        acc = block_sum(acc, red);
+        const float kk = -0.5f * tprev * acc;
+        for (int i = tid; i < Lp; i += BLK) wp[i] = fmaf(kk, vp[i], wp[i]);
+        __syncthreads();
+    }
+    const bool upd = !first && tprev != 0.0f;
+    // column j after the pending update (local row r <-> global row j + r); x = its rows below the diagonal
+    const float *cj = G + (size_t)j * ld + j;
+    const float w0 = upd ? wp[0] : 0.0f, v0 = upd ? vp[0] : 0.0f;
+    float ss = 0.0f;
+    for (int i = tid; i < Lp; i += BLK) {
+        float x = cj[i];
+        if (upd) x -= vp[i] * w0 + wp[i] * v0;
+        if (i >= 1) { vsh[i - 1] = x; if (i >= 2) ss = fmaf(x, x, ss); }
+        else if (blockIdx.x == 0) d[j] = x;
+    }
+    ss = block_sum(ss, red);
+    __syncthreads();
+    const float alpha = vsh[0];
+    const float xnorm = sqrtf(ss);
+    float t = 0.0f, beta = alpha, scale = 0.0f;
+    if (xnorm != 0.0f) {
+        beta = -copysignf(hypotf(alpha, xnorm), alpha);
+        t = (beta - alpha) / beta;
+        scale = 1.0f / (alpha - beta);
+    }
+    __syncthreads();
+    for (int i = tid; i < L; i += BLK) vsh[i] = i == 0 ? 1.0f : vsh[i] * scale;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < L; i += BLK) Vh[(size_t)j * ld + j + 1 + i] = vsh[i];
+        if (tid == 0) { e[j] = beta; tau[j] = t; }
+    }
+    // own columns: one wave per column c (trailing block of step j: global column j + 1 + c)
+    const int c = blockIdx.x * 4 + wave;
+    if (c < L) {
+        float *col = G + (size_t)(j + 1 + c) * ld + j + 1;
+        const float wc = upd ? wp[c + 1] : 0.0f, vc = upd ? vp[c + 1] : 0.0f;
+        float sacc = 0.0f;
+        for (int r = lane; r < L; r += 64) {
+            float a = col[r];
+            if (upd) { a -= vp[r + 1] * wc + wp[r + 1] * vc; col[r] = a; }
+            sacc = fmaf(a, vsh[r], sacc);
+        }
+        sacc = wave_sum(sacc);
+        if (lane == 0) p_out[c] = t * sacc;
+    }
+}
+
 // the 2 x 2 tail (and the whole of n <= 2)
 __global__ void tri_fin_k(int n, int ld, const float *__restrict__ G, float *__restrict__ d, float *__restrict__ e)
 {
@@ -830,10 +903,21 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
     hipLaunchKernelGGL(unpack_k, dim3(g), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, k.G, (float *)nullptr, k.part,
                        (const int *)nullptr);
     float *d = k.Y, *e = k.Y + ld, *tau = k.Y + 2 * (size_t)ld, *p = k.Y + 3 * (size_t)ld, *Vh = k.S;
+    float *pbuf[2] = { p, p + ld };            // p_{j-1} is read while p_j is written
+    static const bool two_launch = getenv("THIP_TRIDIAG_TWO_LAUNCH") != nullptr;
     for (int j = 0; j + 2 < ni; ++j) {
         const unsigned blocks = (unsigned)((ni - j - 1 + 3) / 4);
-        hipLaunchKernelGGL(tri_pv_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, p, d, e, tau);
-        hipLaunchKernelGGL(tri_upd_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, p, tau);
+        if (two_launch) {
+            hipLaunchKernelGGL(tri_pv_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, p, d, e, tau);
+            hipLaunchKernelGGL(tri_upd_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, p, tau);
+        } else {
+            hipLaunchKernelGGL(tri_step_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, j == 0 ? 1 : 0, k.G, Vh, pbuf[(j + 1) & 1],
+                               pbuf[j & 1], d, e, tau);
+        }
+    }
+    if (!two_launch && ni >= 3) {              // the last reflector's update of the 2 x 2 tail is still pending
+        const int j = ni - 3;
+        hipLaunchKernelGGL(tri_upd_k, dim3((unsigned)((ni - j - 1 + 3) / 4)), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, pbuf[j & 1], tau);
     }
     hipLaunchKernelGGL(tri_fin_k, dim3(1), dim3(64), 0, st, ni, ld, k.G, d, e);
     THIP_LAUNCH_CHECK();
