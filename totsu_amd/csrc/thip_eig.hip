@@ -355,17 +355,56 @@ __global__ __launch_bounds__(GNW * 64) void gemm_k(int n, int ld, float alpha, c
 //   * all of a wave's loads are in flight at once (<= 64 VGPRs at ld = 512), then KW / 2 MFMAs.
 // The summation order over k differs from gemm_k's (both are fixed, so results stay bitwise reproducible and the
 // symmetric products stay bitwise symmetric: the mirrored tile swaps a and b, and the products commute).
-template <bool GEN, int KW>
-__global__ __launch_bounds__(GNW * 64) void gemm_pre_k(int n, int ld, float alpha, const float *__restrict__ X,
-                                                       const float *__restrict__ Y, float beta, const float *D, float gamma,
-                                                       float *C, const int *__restrict__ stop, size_t ws)
+// NW waves per workgroup split K NW ways.  tools/gemm_floor.hip (a dependent chain of launches that add one phase at a
+// time, 512^3): empty launch 2.4 us, + flag and operand loads 2.9, + the MFMAs 7.4 with 8 waves (2 per SIMD) but 6.1
+// with 4 waves (1 per SIMD, 64 MFMAs each), + the LDS reduction +0.1-0.3: the launch is bounded by MFMA ISSUE (about
+// twice the 1.7 us that 64 instructions of 64 cycles per SIMD take at 2.4 GHz), not by operand latency.  Hence NW = 4,
+// and SYM: a product whose result is symmetric (X Y^T with X = Y, or both symmetric polynomials of one matrix) computes
+// only the 136 tiles on and below the diagonal of the 16 x 16 tile grid and writes each off-diagonal tile twice, the
+// mirror image through an LDS transposition -- half the MFMAs, and bitwise symmetry by construction.
+// XMAP (a 1-D grid of nt * nt * nb workgroups): PMC counters of the chain (profiles/r02_sdp_k500_pmc_fetch.txt) show
+// 8-9 MiB of FETCH_SIZE and 1.6e5 L2 misses per launch against 4 MB of distinct operands: what bounds a launch is the
+// REPLICATION of the operands into the eight XCD L2s (every launch reads what another XCD's launch just wrote), not
+// MFMA issue -- halving the tiles (SYM) left the duration at 12 us.  Workgroup b runs on XCD b % 8, so the mapping
+// gives each XCD ONE item (nb = 2: XCDs 0-3 the first matrix, 4-7 the second) and inside it a compact block of the
+// tile grid (nt / 2 x nt / 2, or nt / 2 x nt / 4 when 8 XCDs share one item): an XCD then pulls 1 MB of operand panels
+// per launch instead of 2.2.  Pure placement: any mapping gives the same bits.  MEASURED SLOWER (13.6 vs 12.1 us per
+// launch; 921 vs 989 iter/s on the k = 500 SDP), so the premise is wrong somewhere -- the placement of a 1-D grid may not
+// be b % 8, or the replication is not what bounds the launch either.  Kept as THIP_GEMM_MODE=3 for the record.
+template <bool GEN, int KW, int NW, bool SYM, bool XMAP = false>
+__global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha, const float *__restrict__ X,
+                                                      const float *__restrict__ Y, float beta, const float *D, float gamma,
+                                                      float *C, const int *__restrict__ stop, size_t ws, int nb = 1)
 {
+    static_assert(!(GEN && SYM), "the symmetric shortcut is for X Y^T products");
+    static_assert(!(XMAP && SYM), "one mapping at a time");
     if (stop != nullptr && *stop != 0) return;
-    X += blockIdx.z * ws; Y += blockIdx.z * ws; C += blockIdx.z * ws;
-    if (D) D += blockIdx.z * ws;
-    __shared__ float red[GNW - 1][16][64];
+    int bi = blockIdx.x, bj = blockIdx.y, bz = blockIdx.z;
+    if constexpr (XMAP) {
+        const int nt = ld / GT;
+        const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+        const int G = 8 / nb;                         // XCDs per item: 8 or 4
+        const int GJ = G == 8 ? 4 : 2;                // blocks across: 2 x 4 or 2 x 2
+        const int BJ = nt / GJ;
+        bz = xcd / G;
+        const int g = xcd % G;
+        bi = (g / GJ) * (nt / 2) + slot / BJ;
+        bj = (g % GJ) * BJ + slot % BJ;
+    }
+    X += bz * ws; Y += bz * ws; C += bz * ws;
+    if (D) D += bz * ws;
+    __shared__ float red[NW - 1][16][64];
+    __shared__ float tr[SYM ? 32 : 1][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * GT, j0 = blockIdx.y * GT;
+    if constexpr (SYM) {
+        // blockIdx.x = t runs over the lower triangle: t = bi (bi + 1) / 2 + bj, bj <= bi
+        const int t = blockIdx.x;
+        bi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        while (bi * (bi + 1) / 2 > t) --bi;
+        bj = t - bi * (bi + 1) / 2;
+    }
+    const int i0 = bi * GT, j0 = bj * GT;
     const int kb = wave * KW, h = lane >> 5, li = lane & 31;
     // GEN: X symmetric (b), Y general (a, along k).  !GEN: a(i, k) = X(i, k) = Xmem[k * ld + i], b(k, j) = Y(j, k).
     const float *pa = GEN ? Y + (size_t)(i0 + li) * ld + kb + 4 * h : X + (size_t)(kb + 4 * h) * ld + i0 + li;
@@ -403,17 +442,34 @@ __global__ __launch_bounds__(GNW * 64) void gemm_pre_k(int n, int ld, float alph
     __syncthreads();
     if (wave == 0) {
         const int tj = j0 + (lane & 31);
+        float vv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ti = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             float v = acc[r];
 #pragma unroll
-            for (int w = 0; w < GNW - 1; ++w) v += red[w][r][lane];
+            for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
             v *= alpha;
             const size_t o = (size_t)ti * ld + tj;
             if (beta != 0.0f) v = fmaf(beta, D[o], v);
             if (ti == tj && ti < n) v += gamma;
             C[o] = v;
+            vv[r] = v;
+        }
+        if constexpr (SYM) {
+            if (bi != bj) {
+                // the mirror tile: element (ti, tj) of this tile goes to Cmem[(j0 + tj) * ld + i0 + ti]; through LDS so
+                // that the 32 lanes of a store walk along ti
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tr[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = vv[r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tjl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);      // row of the mirror tile
+                    C[(size_t)(j0 + tjl) * ld + i0 + (lane & 31)] = tr[lane & 31][tjl];
+                }
+            }
         }
     }
 }
@@ -449,27 +505,68 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
          float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0)
 {
     dim3 g(ld / GT, ld / GT, nb);
-    static const int mode = getenv("THIP_GEMM_MODE") ? atoi(getenv("THIP_GEMM_MODE")) : 1;   // 0: gemm_k (experiments)
-#define THIP_GEMM_PRE(KW)                                                                                                   \
+    // THIP_GEMM_MODE: 0 = gemm_k (slab prefetch, 8 waves); 1 = loads up front, 8 waves; 2 (default) = loads up front,
+    // 4 waves, symmetric results from the lower triangle of tiles
+    static const int mode = getenv("THIP_GEMM_MODE") ? atoi(getenv("THIP_GEMM_MODE")) : 2;
+    const int nt = ld / GT;
+#define THIP_GEMM_PRE8(KW)                                                                                                  \
     do {                                                                                                                    \
-        if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW>), g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);  \
-        else     hipLaunchKernelGGL((gemm_pre_k<false, KW>), g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
+        if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 8, false>), g, dim3(512), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);  \
+        else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 8, false>), g, dim3(512), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
     } while (0)
-    if (mode != 0 && ld <= 512) {
+#define THIP_GEMM_PRE4(KW)                                                                                                  \
+    do {                                                                                                                    \
+        if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false>), g, dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);  \
+        else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, true>), dim3(nt * (nt + 1) / 2, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
+    } while (0)
+#define THIP_GEMM_PREX(KW)                                                                                                  \
+    do {                                                                                                                    \
+        if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false, true>), dim3(nt * nt * nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, nb);  \
+        else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, false, true>), dim3(nt * nt * nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, nb); \
+    } while (0)
+    // mode 3 (experiment, NOT the default: measured 921 iter/s on the k = 500 SDP against 989 for mode 2): XCD-blocked
+    // placement; needs nb in {1, 2} and a tile grid that splits evenly over the XCDs
+    const bool xok = (nb == 1 && nt % 4 == 0) || (nb == 2 && nt % 2 == 0 && nt >= 4);
+    if (mode == 3 && ld <= 512 && xok) {
+        switch (ld / 4) {
+        case 32: THIP_GEMM_PREX(32); break;
+        case 48: THIP_GEMM_PREX(48); break;
+        case 64: THIP_GEMM_PREX(64); break;
+        case 80: THIP_GEMM_PREX(80); break;
+        case 96: THIP_GEMM_PREX(96); break;
+        case 112: THIP_GEMM_PREX(112); break;
+        default: THIP_GEMM_PREX(128); break;
+        }
+    }
+    else if (mode >= 2 && ld <= 512) {
+        switch (ld / 4) {
+        case 16: THIP_GEMM_PRE4(16); break;
+        case 32: THIP_GEMM_PRE4(32); break;
+        case 48: THIP_GEMM_PRE4(48); break;
+        case 64: THIP_GEMM_PRE4(64); break;
+        case 80: THIP_GEMM_PRE4(80); break;
+        case 96: THIP_GEMM_PRE4(96); break;
+        case 112: THIP_GEMM_PRE4(112); break;
+        default: THIP_GEMM_PRE4(128); break;
+        }
+    }
+    else if (mode != 0 && ld <= 512) {
         switch (ld / GNW) {
-        case 8: THIP_GEMM_PRE(8); break;
-        case 16: THIP_GEMM_PRE(16); break;
-        case 24: THIP_GEMM_PRE(24); break;
-        case 32: THIP_GEMM_PRE(32); break;
-        case 40: THIP_GEMM_PRE(40); break;
-        case 48: THIP_GEMM_PRE(48); break;
-        case 56: THIP_GEMM_PRE(56); break;
-        default: THIP_GEMM_PRE(64); break;
+        case 8: THIP_GEMM_PRE8(8); break;
+        case 16: THIP_GEMM_PRE8(16); break;
+        case 24: THIP_GEMM_PRE8(24); break;
+        case 32: THIP_GEMM_PRE8(32); break;
+        case 40: THIP_GEMM_PRE8(40); break;
+        case 48: THIP_GEMM_PRE8(48); break;
+        case 56: THIP_GEMM_PRE8(56); break;
+        default: THIP_GEMM_PRE8(64); break;
         }
     }
     else if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
     else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
-#undef THIP_GEMM_PRE
+#undef THIP_GEMM_PRE8
+#undef THIP_GEMM_PRE4
+#undef THIP_GEMM_PREX
     THIP_LAUNCH_CHECK();
     return 0;
 }
