@@ -1171,8 +1171,28 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
     const size_t ws = thip_map_eig_worklen(n);
     if (worklen < ws * (size_t)nbatch) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
     const Work k = carve(work, n);
-    if (map_kind == 0 && n > POLAR_MIN_N)
+    if (map_kind == 0 && n > POLAR_MIN_N) {
+        // THIP_PSD_TWO_STREAMS=1 (experiment): the two matrices of a pair as two independent chains on two streams
+        // instead of one chain of z = 2 launches
+        static const bool two = getenv("THIP_PSD_TWO_STREAMS") && atoi(getenv("THIP_PSD_TWO_STREAMS")) != 0;
+        if (two && nbatch == 2) {
+            Ctx &c = ctx();
+            if (!c.side) {
+                THIP_TRY(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+                THIP_TRY(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+                THIP_TRY(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+            }
+            THIP_TRY(hipEventRecord(c.ev_fork, st));
+            THIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0));
+            THIP_RC(polar_project(st, n, packed, has_scale, scale_diag, k, stop, 1, ws, pstride));
+            const Work k1 = carve(work + ws, n);
+            THIP_RC(polar_project(c.side, n, packed + pstride, has_scale, scale_diag, k1, stop, 1, ws, pstride));
+            THIP_TRY(hipEventRecord(c.ev_join, c.side));
+            THIP_TRY(hipStreamWaitEvent(st, c.ev_join, 0));
+            return 0;
+        }
         return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride);
+    }
     for (int z = 0; z < nbatch; ++z) {          // the Jacobi engine works on one matrix at a time
         THIP_RC(decompose(st, n, packed + z * pstride, has_scale, scale_diag, k, map_kind, stop));
         THIP_RC(rebuild(st, n, packed + z * pstride, has_scale, scale_diag, k, stop));
