@@ -356,3 +356,47 @@ def test_deferred_products_respect_data_hazards(L):
     assert np.allclose(y1.get_ref(), r1b, rtol=1e-4, atol=1e-4 * np.abs(r1b).max())
     for s in (dA, dB, dC, dx, y1, y2):
         s.drop()
+
+
+def test_grouped_products_at_scale_match_the_stacked_matrix(L):
+    """200 blocks of 99 x 20 000 (+ 200 row vectors), 1.6 GB: the block-by-block products of a composite operator through
+    the deferred / grouped path against ONE transform_ge on the stacked matrix (the fused loop's form), both directions"""
+    from totsu_amd._lib import lib
+    from totsu_amd.fused import DeviceBuffer as D
+    n, nb, ni = 20_000, 200, 99
+    rows = 1 + ni
+    m = nb * rows
+    A = D(m * n)
+    lib.thip_gen_matrix(A.ptr, m, n, m, 0, 1, 0, 0, m, 1, 1.0, 0.0)
+    x, y = D(n), D(m)
+    lib.thip_gen_vector(x.ptr, n, 0, 2, 0, 1, 1.0, 0.0)
+    lib.thip_gen_vector(y.ptr, m, 0, 3, 0, 1, 1.0, 0.0)
+    # per-block copies (own contiguous arrays, as the reference's MatOps hold them): row 0 of a block -> c_i, rows 1.. -> G_i
+    G, Cv = D(nb * ni * n), D(nb * n)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy2D.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    lib.thip_sync()
+    for i in range(nb):
+        assert hip.hipMemcpy2D(G.ptr + 4 * i * ni * n, 4 * ni, A.ptr + 4 * (i * rows + 1), 4 * m, 4 * ni, n, 3) == 0
+        assert hip.hipMemcpy2D(Cv.ptr + 4 * i * n, 4, A.ptr + 4 * (i * rows), 4 * m, 4, n, 3) == 0
+    lib.thip_set_lazy_gemv(1)
+    # op: y_blk = A_blk x
+    out, ref = D(m, zero=True), D(m, zero=True)
+    for i in range(nb):
+        lib.thip_transform_ge(1, n, 1, 1.0, Cv.ptr + 4 * i * n, x.ptr, 0.0, out.ptr + 4 * i * rows)
+        lib.thip_transform_ge(0, ni, n, 1.0, G.ptr + 4 * i * ni * n, x.ptr, 0.0, out.ptr + 4 * (i * rows + 1))
+    lib.thip_transform_ge(0, m, n, 1.0, A.ptr, x.ptr, 0.0, ref.ptr)        # 1.6 GB: runs at once, after the record
+    a, b = out.to_host(), ref.to_host()
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
+    # trans_op: z = sum_blk A_blk^T y_blk
+    outn, refn = D(n, zero=True), D(n, zero=True)
+    lib.thip_scale(n, 0.0, outn.ptr)
+    for i in range(nb):
+        lib.thip_transform_ge(0, n, 1, 1.0, Cv.ptr + 4 * i * n, y.ptr + 4 * i * rows, 1.0, outn.ptr)
+        lib.thip_transform_ge(1, ni, n, 1.0, G.ptr + 4 * i * ni * n, y.ptr + 4 * (i * rows + 1), 1.0, outn.ptr)
+    lib.thip_transform_ge(1, m, n, 1.0, A.ptr, y.ptr, 0.0, refn.ptr)
+    a, b = outn.to_host(), refn.to_host()
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
+    for d in (A, x, y, G, Cv, out, ref, outn, refn):
+        d.free()
