@@ -71,6 +71,29 @@ static int kats()
             bad += !ok;
         }
     }
+    {   // totsu/tests/sdp.rs test_sdp1: min x0 + x1 s.t. x0 F0 + x1 F1 + F2 <= 0 -> x = [3, 4]
+        MatBuild c(2, 1), a(0, 2), b(0, 1);
+        c.iter_colmaj({ 1, 1 });
+        std::vector<SymPack> syms(3, SymPack(2));
+        syms[0].iter_rowmaj({ -1, 0, 0, 0 });
+        syms[1].iter_rowmaj({ 0, 0, 0, -1 });
+        syms[2].iter_rowmaj({ 3, 0, 0, 4 });
+        for (int route = 0; route < 2; ++route) {
+            HipProbSDP sdp(c, syms, a, b, 1e-12f);
+            sdp.cones = route == 0 ? ConeImpl::Reference : ConeImpl::Device;
+            Problem pr = sdp.problem();
+            Solver s;
+            s.par.max_iter = 100000; s.par.eps_acc = 1e-5f;
+            SolveInfo info;
+            const SolverError e = solve(s, pr, &info, route == 1);
+            const std::vector<float> w = pr.work->to_host();
+            const bool ok = e == SolverError::Ok && std::fabs(w[0] - 3.f) <= 1e-3f && std::fabs(w[1] - 4.f) <= 1e-3f && info.fused == (route == 1);
+            printf("kat sdp  %-28s status %d iters %lld x = [%.5f, %.5f] uploads %zu  %s\n",
+                   route ? "HipProbSDP -> fused loop" : "composite ops, reference cones", (int)e, (long long)info.iters, w[0], w[1],
+                   sdp.cache.uploads, ok ? "OK" : "MISMATCH");
+            bad += !ok;
+        }
+    }
     return bad;
 }
 

@@ -2,7 +2,7 @@
 // totsu_f32hip.hpp (itself layered only on the C ABI): `MatBuild` (totsu/src/matbuild/mod.rs:11-40, General only),
 // `ProbLP` (totsu/src/problem/lp.rs:222-338) and `ProbSOCP` (socp.rs:336-474) with their composite operators and cones,
 // restated block for block, and the two things SURVEY.md 8(f1) asks of the binding crate:
-//   * `HipProbLP` / `HipProbSOCP`: the same builders (same constructor arguments, same `problem()`), whose `problem()`
+//   * `HipProbLP` / `HipProbSOCP` / `HipProbSDP`: the same builders (same constructor arguments, same `problem()`), whose `problem()`
 //     additionally carries a DENSE DESCRIPTION of itself -- so that `solve(Solver &, Problem &)` can hand the problem
 //     to the device-resident loop (FusedSolver) instead of driving it call by call: an unchanged caller gets the fused
 //     rate by changing one type name;
@@ -61,19 +61,21 @@ struct OpVec : Operator {
     void absadd_rows(Slice s) const override { vec.absadd_rows(s); }
 };
 
-// two row-stacked blocks sharing the columns: ProbLPOpA (lp.rs:50-115), ProbLPOpB (lp.rs:119-191)
+// two row-stacked blocks sharing the columns: ProbLPOpA (lp.rs:50-115), ProbLPOpB (lp.rs:119-191), ProbSDPOpA
+// (sdp.rs:49-114), ProbSDPOpB (sdp.rs:118-190: the first block enters with -alpha, sf = -1)
 struct OpStack2 : Operator {
     MatOp first, second;
-    OpStack2(MatOp f, MatOp s) : first(f), second(s) {}
+    float sf;
+    OpStack2(MatOp f, MatOp s, float sign_first = 1.f) : first(f), second(s), sf(sign_first) {}
     std::pair<size_t, size_t> size() const override { return { first.nr + second.nr, first.nc }; }
     void op(float a, Slice x, float b, Slice y) const override
     {
-        first.op(a, x, b, y.sub(0, first.nr));
+        first.op(sf * a, x, b, y.sub(0, first.nr));
         second.op(a, x, b, y.sub(first.nr, second.nr));
     }
     void trans_op(float a, Slice x, float b, Slice y) const override
     {
-        first.trans_op(a, x.sub(0, first.nr), b, y);
+        first.trans_op(sf * a, x.sub(0, first.nr), b, y);
         second.trans_op(a, x.sub(first.nr, second.nr), 1.f, y);
     }
     void absadd_cols(Slice t) const override { first.absadd_cols(t); second.absadd_cols(t); }
@@ -358,6 +360,77 @@ protected:
     ConeZero zero_;
 };
 
+// ---- ProbSDP (sdp.rs:222-332) ----------------------------------------------------------------------------------------
+// MatType::SymPack(k): the upper triangle by columns (matbuild/mod.rs:254-279)
+struct SymPack {
+    size_t k = 0;
+    std::vector<float> array;
+    SymPack() {}
+    explicit SymPack(size_t k_) : k(k_), array(k_ * (k_ + 1) / 2, 0.f) {}
+    void set(size_t r, size_t c, float v) { if (r > c) std::swap(r, c); array[c * (c + 1) / 2 + r] = v; }
+    SymPack &iter_rowmaj(const std::vector<float> &v)             // set_iter_rowmaj on the full k x k matrix: later entries win
+    {
+        size_t i = 0;
+        for (size_t r = 0; r < k; ++r) for (size_t c = 0; c < k && i < v.size(); ++c) set(r, c, v[i++]);
+        return *this;
+    }
+    // scale_nondiag(sqrt 2) + reshape_colvec (sdp.rs:271-274): svec
+    std::vector<float> svec() const
+    {
+        std::vector<float> o(array);
+        const float s2 = std::sqrt(2.f);
+        for (size_t c = 0; c < k; ++c) for (size_t r = 0; r < c; ++r) o[c * (c + 1) / 2 + r] *= s2;
+        return o;
+    }
+};
+
+class ProbSDP {
+public:
+    ProbSDP(const MatBuild &vec_c, const std::vector<SymPack> &syms_f, const MatBuild &mat_a, const MatBuild &vec_b, float eps_zero)
+        : c_(vec_c), a_(mat_a), b_(vec_b), eps_zero_(eps_zero)
+    {
+        const size_t n = c_.nr, p = b_.nr;
+        if (c_.nc != 1 || syms_f.size() != n + 1 || a_.size() != std::make_pair(p, n) || b_.nc != 1) throw std::invalid_argument("ProbSDP: sizes");
+        const size_t k = syms_f[0].k;
+        for (auto &f : syms_f) if (f.k != k) throw std::invalid_argument("ProbSDP: orders differ");
+        sk_ = k * (k + 1) / 2;
+        symmat_f_ = MatBuild(sk_, n);                                                     // sdp.rs:276-281
+        for (size_t c = 0; c < n; ++c) { const std::vector<float> v = syms_f[c].svec(); std::copy(v.begin(), v.end(), symmat_f_.array.begin() + c * sk_); }
+        symvec_f_n_ = MatBuild(sk_, 1);
+        symvec_f_n_.array = syms_f[n].svec();
+    }
+    virtual ~ProbSDP() {}
+    ConeImpl cones = ConeImpl::Device;
+    MirrorCache cache;
+
+    virtual Problem problem()                                                           // sdp.rs:299-331
+    {
+        const size_t n = c_.nr, p = b_.nr;
+        Problem pr;
+        pr.op_c.reset(new OpVec(MatOp(n, 1, cache.get(c_))));
+        pr.op_a.reset(new OpStack2(MatOp(sk_, n, cache.get(symmat_f_)), MatOp(p, n, cache.get(a_))));
+        pr.op_b.reset(new OpStack2(MatOp(sk_, 1, cache.get(symvec_f_n_)), MatOp(p, 1, cache.get(b_)), -1.f));
+        w_cone_.reset(new DeviceVec(ConePSD::query_worklen(sk_)));
+        if (cones == ConeImpl::Device) psd_.reset(new ConePSD(w_cone_->slice(), eps_zero_));
+        else psd_.reset(new ConePSDRef(w_cone_->slice(), eps_zero_));
+        auto *cone = new ConeProduct();
+        cone->blocks.push_back({ psd_.get(), sk_ });
+        cone->blocks.push_back({ &zero_, p });
+        pr.cone.reset(cone);
+        pr.work.reset(new DeviceVec(Solver::query_worklen(sk_ + p, n)));
+        return pr;
+    }
+
+protected:
+    const MatBuild &c_, &a_, &b_;
+    MatBuild symmat_f_, symvec_f_n_;
+    size_t sk_ = 0;
+    float eps_zero_;
+    std::unique_ptr<DeviceVec> w_cone_;
+    std::unique_ptr<Cone> psd_;
+    ConeZero zero_;
+};
+
 // ---- Hip* aliases: the same builders + a dense description of themselves -------------------------------------------------
 class HipProbLP : public ProbLP {
 public:
@@ -403,6 +476,27 @@ public:
         d->seg_type.push_back(THIP_CONE_ZERO); d->seg_len.push_back((int64_t)p);
         d->m += p;
         d->c = cache.get(f_);
+        pr.dense = std::move(d);
+        return pr;
+    }
+};
+
+class HipProbSDP : public ProbSDP {
+public:
+    using ProbSDP::ProbSDP;
+    Problem problem() override
+    {
+        Problem pr = ProbSDP::problem();
+        const size_t n = c_.nr, p = b_.nr;
+        std::unique_ptr<DenseDesc> d(new DenseDesc());
+        d->n = n; d->m = sk_ + p;
+        d->blocks.push_back({ cache.get(symmat_f_), sk_, 1.f, false });
+        d->blocks.push_back({ cache.get(a_), p, 1.f, false });
+        for (float v : symvec_f_n_.array) { d->b.push_back(-v); d->b_rowabs.push_back(std::fabs(v)); }   // b = [-svec(F_n) ; b], sdp.rs:152
+        for (float v : b_.array) { d->b.push_back(v); d->b_rowabs.push_back(std::fabs(v)); }
+        d->c = cache.get(c_);
+        d->seg_type = { THIP_CONE_PSD, THIP_CONE_ZERO };
+        d->seg_len = { (int64_t)sk_, (int64_t)p };
         pr.dense = std::move(d);
         return pr;
     }

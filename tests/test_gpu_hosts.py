@@ -19,7 +19,7 @@ def test_hip_prob_alias_demo():
     r = subprocess.run([exe, "3000", "400"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.strip().splitlines()
-    assert sum("OK" in ln for ln in lines if ln.startswith("kat")) == 4 and not any("MISMATCH" in ln for ln in lines)
+    assert sum("OK" in ln for ln in lines if ln.startswith("kat")) == 6 and not any("MISMATCH" in ln for ln in lines)
     # the mirror cache: 1 cone => f, G, h, c uploaded once each although as_op() is taken twice per G_i (socp.rs:450,463)
     assert any(ln.startswith("kat socp") and "uploads 4" in ln for ln in lines), r.stdout
     d = json.loads(lines[-1])
