@@ -1010,11 +1010,17 @@ int thip_solver_init(thip_solver *s)
     s->carried_stale = false;
     s->hst->state = THIP_ST_RUNNING;
     THIP_RC(ensure_gemv_scratch(s));
-    // THIP_LDA_PAD = floats the padded leading dimension is a multiple of (default 32 = 128 bytes: every column then
-    // starts on a cache-line boundary; 0 = never copy)
-    const size_t padto = getenv("THIP_LDA_PAD") ? (size_t)atoi(getenv("THIP_LDA_PAD")) : 32;
+    // THIP_LDA_PAD = floats the padded leading dimension is a multiple of (default 16 = 64 bytes; 0 = never copy).
+    // Measured on row shards of the 50 000-column SOCP: columns of 50 000 B (m = 12 500) 6.32 -> 6.79 TB/s and of
+    // 100 000 B (m = 25 000) 6.3 -> 6.7 TB/s once padded; columns of 200 000 B (m = 50 000: a multiple of 64 B but not
+    // of 128) gain nothing from a 128-byte pitch -- so 64 bytes is the pitch that matters
+    const size_t padto = getenv("THIP_LDA_PAD") ? (size_t)atoi(getenv("THIP_LDA_PAD")) : 16;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    // the copy doubles the footprint of A: made when it leaves two thirds of the free HBM untouched (a 40 GB shard of
+    // BASELINE configs[4] on a 288 GB part: yes)
     if (!s->sparse && s->A && !s->Apad && padto > 0 && m % padto != 0 && n > 0
-        && m * n * sizeof(float) < ((size_t)8 << 30)) {
+        && ((m + padto) * n * sizeof(float)) < free_b / 3) {
         s->ldpad = (m + padto - 1) / padto * padto;
         THIP_TRY(hipMalloc((void **)&s->Apad, s->ldpad * n * sizeof(float)));
         THIP_TRY(hipMemsetAsync(s->Apad, 0, s->ldpad * n * sizeof(float), st));
