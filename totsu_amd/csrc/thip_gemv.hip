@@ -107,19 +107,21 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
             xsv[u] = ((ABS || !DO_N) ? 1.0f : xn[c + u]) * isv[u];
         }
         if constexpr (FULL) {
-            // All K * NJ loads are issued back to back and each column is consumed as soon as ITS loads have landed
-            // (explicit vmcnt waits).  Left to itself the compiler either keeps every widened value alive (115+ VGPRs)
-            // or, once the updates are pinned per column, splits the loads into two groups of four.
+            // All K * NJ loads are issued back to back and each column is consumed as soon as ITS loads have landed.
+            // Left to itself the compiler either keeps every widened value alive (115+ VGPRs) or, once the updates are
+            // pinned per column, splits the loads into two groups of four: the scheduling barrier below keeps the load
+            // block together, and the compiler's own waitcnt insertion then counts the loads down column by column
+            // (round 1 issued them from inline asm with hand-written vmcnt waits, which the compiler could not see).
 #pragma unroll
             for (int u = 0; u < K; ++u) {
                 const E *col = A + (size_t)(c + u) * lda + r_first;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const E *src = col + j * (BLK * VW);
-                    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(raw[u][j]) : "v"(src));
-                    else              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw[u][j]) : "v"(src));
+                    const u32x4_t *src = reinterpret_cast<const u32x4_t *>(col + j * (BLK * VW));
+                    raw[u][j] = NT ? __builtin_nontemporal_load(src) : *src;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         } else {
 #pragma unroll
             for (int u = 0; u < K; ++u) {
@@ -148,11 +150,6 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
             const f32x2_t xs2 = { xsv[u], xsv[u] };
             f32x2_t s2 = { 0.0f, 0.0f };
-            if constexpr (FULL) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw[u][j]) : "n"((K - 1 - u) * NJ));
-            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
