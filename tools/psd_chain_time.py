@@ -31,6 +31,6 @@ for k in (128, 256, 500):
         L.map_eig(sl, sq2, 1e-12, work, "pos")
     L.sync()
     dt = (time.perf_counter() - t0) / reps
-    print("k=%d PSD projection: %.3f ms  err/|x| %.2e  (THIP_GEMM_MODE=%s)" % (k, 1e3 * dt, err, os.environ.get("THIP_GEMM_MODE", "1")))
+    print("k=%d PSD projection: %.3f ms  err/|x| %.2e  (THIP_GEMM_MODE=%s)" % (k, 1e3 * dt, err, os.environ.get("THIP_GEMM_MODE", "default")))
     sl.drop()
     work.drop()

@@ -22,9 +22,6 @@ struct Ctx {
     size_t       stage_bytes = 0;
     hipEvent_t   stage_ev[2] = { nullptr, nullptr };   // "the DMA out of half k has finished"
     int          num_cu = 256;
-    // a second stream for work that is independent of the launch stream's (the second matrix of a PSD projection pair)
-    hipStream_t  side = nullptr;
-    hipEvent_t   ev_fork = nullptr, ev_join = nullptr;
 };
 
 Ctx &ctx();

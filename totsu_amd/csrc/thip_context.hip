@@ -103,9 +103,6 @@ int thip_shutdown(void)
     if (c.pinned) hipHostFree(c.pinned);
     if (c.stage) hipHostFree(c.stage);
     for (int k = 0; k < 2; ++k) if (c.stage_ev[k]) hipEventDestroy(c.stage_ev[k]);
-    if (c.side) { hipStreamSynchronize(c.side); hipStreamDestroy(c.side); }
-    if (c.ev_fork) hipEventDestroy(c.ev_fork);
-    if (c.ev_join) hipEventDestroy(c.ev_join);
     if (c.own_stream) hipStreamDestroy(c.own_stream);
     c = Ctx();
     return 0;

@@ -362,37 +362,16 @@ __global__ __launch_bounds__(GNW * 64) void gemm_k(int n, int ld, float alpha, c
 // and SYM: a product whose result is symmetric (X Y^T with X = Y, or both symmetric polynomials of one matrix) computes
 // only the 136 tiles on and below the diagonal of the 16 x 16 tile grid and writes each off-diagonal tile twice, the
 // mirror image through an LDS transposition -- half the MFMAs, and bitwise symmetry by construction.
-// XMAP (a 1-D grid of nt * nt * nb workgroups): PMC counters of the chain (profiles/r02_sdp_k500_pmc_fetch.txt) show
-// 8-9 MiB of FETCH_SIZE and 1.6e5 L2 misses per launch against 4 MB of distinct operands: what bounds a launch is the
-// REPLICATION of the operands into the eight XCD L2s (every launch reads what another XCD's launch just wrote), not
-// MFMA issue -- halving the tiles (SYM) left the duration at 12 us.  Workgroup b runs on XCD b % 8, so the mapping
-// gives each XCD ONE item (nb = 2: XCDs 0-3 the first matrix, 4-7 the second) and inside it a compact block of the
-// tile grid (nt / 2 x nt / 2, or nt / 2 x nt / 4 when 8 XCDs share one item): an XCD then pulls 1 MB of operand panels
-// per launch instead of 2.2.  Pure placement: any mapping gives the same bits.  MEASURED SLOWER (13.6 vs 12.1 us per
-// launch; 921 vs 989 iter/s on the k = 500 SDP), so the premise is wrong somewhere -- the placement of a 1-D grid may not
-// be b % 8, or the replication is not what bounds the launch either.  Kept as THIP_GEMM_MODE=3 for the record.
-template <bool GEN, int KW, int NW, bool SYM, bool XMAP = false>
+template <bool GEN, int KW, int NW, bool SYM>
 __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha, const float *__restrict__ X,
                                                       const float *__restrict__ Y, float beta, const float *D, float gamma,
-                                                      float *C, const int *__restrict__ stop, size_t ws, int nb = 1)
+                                                      float *C, const int *__restrict__ stop, size_t ws)
 {
     static_assert(!(GEN && SYM), "the symmetric shortcut is for X Y^T products");
-    static_assert(!(XMAP && SYM), "one mapping at a time");
     if (stop != nullptr && *stop != 0) return;
-    int bi = blockIdx.x, bj = blockIdx.y, bz = blockIdx.z;
-    if constexpr (XMAP) {
-        const int nt = ld / GT;
-        const int lin = blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-        const int G = 8 / nb;                         // XCDs per item: 8 or 4
-        const int GJ = G == 8 ? 4 : 2;                // blocks across: 2 x 4 or 2 x 2
-        const int BJ = nt / GJ;
-        bz = xcd / G;
-        const int g = xcd % G;
-        bi = (g / GJ) * (nt / 2) + slot / BJ;
-        bj = (g % GJ) * BJ + slot % BJ;
-    }
-    X += bz * ws; Y += bz * ws; C += bz * ws;
-    if (D) D += bz * ws;
+    int bi = blockIdx.x, bj = blockIdx.y;
+    X += blockIdx.z * ws; Y += blockIdx.z * ws; C += blockIdx.z * ws;
+    if (D) D += blockIdx.z * ws;
     __shared__ float red[NW - 1][16][64];
     __shared__ float tr[SYM ? 32 : 1][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -505,40 +484,16 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
          float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0)
 {
     dim3 g(ld / GT, ld / GT, nb);
-    // THIP_GEMM_MODE: 0 = gemm_k (slab prefetch, 8 waves); 1 = loads up front, 8 waves; 2 (default) = loads up front,
-    // 4 waves, symmetric results from the lower triangle of tiles
+    // ld <= 512: gemm_pre_k (loads up front, 4 waves, symmetric results from the lower triangle of tiles); larger orders,
+    // or THIP_GEMM_MODE=0: gemm_k (slab prefetch, 8 waves, any ld)
     static const int mode = getenv("THIP_GEMM_MODE") ? atoi(getenv("THIP_GEMM_MODE")) : 2;
     const int nt = ld / GT;
-#define THIP_GEMM_PRE8(KW)                                                                                                  \
-    do {                                                                                                                    \
-        if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 8, false>), g, dim3(512), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);  \
-        else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 8, false>), g, dim3(512), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
-    } while (0)
 #define THIP_GEMM_PRE4(KW)                                                                                                  \
     do {                                                                                                                    \
         if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false>), g, dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);  \
         else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, true>), dim3(nt * (nt + 1) / 2, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
     } while (0)
-#define THIP_GEMM_PREX(KW)                                                                                                  \
-    do {                                                                                                                    \
-        if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false, true>), dim3(nt * nt * nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, nb);  \
-        else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, false, true>), dim3(nt * nt * nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, nb); \
-    } while (0)
-    // mode 3 (experiment, NOT the default: measured 921 iter/s on the k = 500 SDP against 989 for mode 2): XCD-blocked
-    // placement; needs nb in {1, 2} and a tile grid that splits evenly over the XCDs
-    const bool xok = (nb == 1 && nt % 4 == 0) || (nb == 2 && nt % 2 == 0 && nt >= 4);
-    if (mode == 3 && ld <= 512 && xok) {
-        switch (ld / 4) {
-        case 32: THIP_GEMM_PREX(32); break;
-        case 48: THIP_GEMM_PREX(48); break;
-        case 64: THIP_GEMM_PREX(64); break;
-        case 80: THIP_GEMM_PREX(80); break;
-        case 96: THIP_GEMM_PREX(96); break;
-        case 112: THIP_GEMM_PREX(112); break;
-        default: THIP_GEMM_PREX(128); break;
-        }
-    }
-    else if (mode >= 2 && ld <= 512) {
+    if (mode >= 2 && ld <= 512) {
         switch (ld / 4) {
         case 16: THIP_GEMM_PRE4(16); break;
         case 32: THIP_GEMM_PRE4(32); break;
@@ -550,23 +505,9 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
         default: THIP_GEMM_PRE4(128); break;
         }
     }
-    else if (mode != 0 && ld <= 512) {
-        switch (ld / GNW) {
-        case 8: THIP_GEMM_PRE8(8); break;
-        case 16: THIP_GEMM_PRE8(16); break;
-        case 24: THIP_GEMM_PRE8(24); break;
-        case 32: THIP_GEMM_PRE8(32); break;
-        case 40: THIP_GEMM_PRE8(40); break;
-        case 48: THIP_GEMM_PRE8(48); break;
-        case 56: THIP_GEMM_PRE8(56); break;
-        default: THIP_GEMM_PRE8(64); break;
-        }
-    }
     else if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
     else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
-#undef THIP_GEMM_PRE8
 #undef THIP_GEMM_PRE4
-#undef THIP_GEMM_PREX
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -576,9 +517,9 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
 // (BASELINE.json north_star: "symmetric eigendecomposition (Householder tridiag + QR)"; the routine the reference
 // calls is dsyevr / cusolver syevdx, f64lapack.rs:78-108, f32cuda.rs:253-263).  O(n) dependent steps instead of the
 // O(n * sweeps) of the Jacobi engine:
-//   1. Q^T M Q = T, n - 2 reflectors, two launches per reflector (tri_pv_k: the reflector v_j and p = tau A v, one wave
-//      per column of the L2-resident trailing matrix; tri_upd_k: w = p - (tau p.v / 2) v and the symmetric rank-2 update
-//      A -= v w^T + w v^T, full square so that a "row" stays a contiguous column);
+//   1. Q^T M Q = T, n - 2 reflectors, ONE launch per reflector (tri_step_k: applies the symmetric rank-2 update of the
+//      previous reflector, A -= v w^T + w v^T on the full trailing square so that a "row" stays a contiguous column, to the
+//      columns it owns while it forms the next reflector v_j and p = tau A v from them, one wave per column);
 //   2. Z = Q formed column by column (form_q_k: one wave per column applies all reflectors, no global step);
 //   3. d, e visit the host: implicit-shift QL in f64 (the O(n^2) scalar recurrence of tql2) which only RECORDS its
 //      Givens rotations, one (c, s) pair each, grouped in sweeps of adjacent pairs;
@@ -587,43 +528,6 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
 //   5. the rebuild V diag(e) V^T is a GEMM on the matrix cores (gemm(false): X Y^T with X = V diag(e)).
 // ---------------------------------------------------------------------------------------------------
 constexpr int TRI_MAXN = 2048;
-
-__global__ __launch_bounds__(BLK) void tri_pv_k(int n, int ld, int j, const float *__restrict__ G, float *__restrict__ Vh,
-                                               float *__restrict__ p, float *__restrict__ d, float *__restrict__ e,
-                                               float *__restrict__ tau)
-{
-    __shared__ float vsh[TRI_MAXN];
-    __shared__ float red[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = n - j - 1;
-    const float *x = G + (size_t)j * ld + j + 1;
-    // LAPACK slarfg: beta = -sign(alpha) ||x||, tau = (beta - alpha) / beta, v = [1 ; x[1:] / (alpha - beta)]
-    float ss = 0.0f;
-    for (int i = 1 + tid; i < L; i += BLK) { const float t = x[i]; ss = fmaf(t, t, ss); }
-    ss = block_sum(ss, red);
-    const float alpha = x[0];
-    const float xnorm = sqrtf(ss);
-    float t = 0.0f, beta = alpha, scale = 0.0f;
-    if (xnorm != 0.0f) {
-        beta = -copysignf(hypotf(alpha, xnorm), alpha);
-        t = (beta - alpha) / beta;
-        scale = 1.0f / (alpha - beta);
-    }
-    for (int i = tid; i < L; i += BLK) vsh[i] = i == 0 ? 1.0f : x[i] * scale;
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        for (int i = tid; i < L; i += BLK) Vh[(size_t)j * ld + j + 1 + i] = vsh[i];
-        if (tid == 0) { d[j] = G[(size_t)j * ld + j]; e[j] = beta; tau[j] = t; }
-    }
-    const int c = blockIdx.x * 4 + wave;            // column j + 1 + c of the trailing matrix
-    if (c < L) {
-        const float *col = G + (size_t)(j + 1 + c) * ld + j + 1;
-        float sacc = 0.0f;
-        for (int r = lane; r < L; r += 64) sacc = fmaf(col[r], vsh[r], sacc);
-        sacc = wave_sum(sacc);
-        if (lane == 0) p[c] = t * sacc;
-    }
-}
 
 __global__ __launch_bounds__(BLK) void tri_upd_k(int n, int ld, int j, float *__restrict__ G, const float *__restrict__ Vh,
                                                 const float *__restrict__ p, const float *__restrict__ tau)
@@ -1001,18 +905,12 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
                        (const int *)nullptr);
     float *d = k.Y, *e = k.Y + ld, *tau = k.Y + 2 * (size_t)ld, *p = k.Y + 3 * (size_t)ld, *Vh = k.S;
     float *pbuf[2] = { p, p + ld };            // p_{j-1} is read while p_j is written
-    static const bool two_launch = getenv("THIP_TRIDIAG_TWO_LAUNCH") != nullptr;
     for (int j = 0; j + 2 < ni; ++j) {
         const unsigned blocks = (unsigned)((ni - j - 1 + 3) / 4);
-        if (two_launch) {
-            hipLaunchKernelGGL(tri_pv_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, p, d, e, tau);
-            hipLaunchKernelGGL(tri_upd_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, p, tau);
-        } else {
-            hipLaunchKernelGGL(tri_step_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, j == 0 ? 1 : 0, k.G, Vh, pbuf[(j + 1) & 1],
-                               pbuf[j & 1], d, e, tau);
-        }
+        hipLaunchKernelGGL(tri_step_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, j == 0 ? 1 : 0, k.G, Vh, pbuf[(j + 1) & 1],
+                           pbuf[j & 1], d, e, tau);
     }
-    if (!two_launch && ni >= 3) {              // the last reflector's update of the 2 x 2 tail is still pending
+    if (ni >= 3) {              // the last reflector's update of the 2 x 2 tail is still pending
         const int j = ni - 3;
         hipLaunchKernelGGL(tri_upd_k, dim3((unsigned)((ni - j - 1 + 3) / 4)), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, pbuf[j & 1], tau);
     }
@@ -1127,18 +1025,15 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
     // Phase 2 (3 steps): minimax polynomials of 1 on [0.3, 1.7] -> [0.73, 1.27] -> [0.985, 1.015] -> 1 +- 2e-5.
     // Phase 3: one Newton-Schulz step x (3 - x^2) / 2 squares the remaining error.  14 x 3 + 2 = 44 GEMMs (round 1: 13
     // steps of 3.4445 x - 4.7750 x^3 + 2.0315 x^5, band [0.7, 1.2], and 5 Newton-Schulz steps = 49).
-    static const int sched = getenv("THIP_POLAR_SCHED") ? atoi(getenv("THIP_POLAR_SCHED")) : 1;
     static const float LIFT[3] = { 4.08273337f, -3.88521879f, 0.97526957f };
     static const float TAILC[3][3] = {
         { 2.647997920f, -1.945904487f, 0.440483961f },
         { 1.967564378f, -1.351306898f, 0.386705679f },
         { 1.884943743f, -1.269148602f, 0.384197480f },
     };
-    const int nq = sched == 0 ? 13 : 14;
-    for (int it = 0; it < nq; ++it) {
+    for (int it = 0; it < 14; ++it) {
         float a, b, c;
-        if (sched == 0) { a = 3.4445f; b = -4.7750f; c = 2.0315f; }
-        else if (it == 0) { a = LIFT[0] * 1.7f; b = LIFT[1] * 4.913f; c = LIFT[2] * 14.19857f; }     // p(1.7 x)
+        if (it == 0) { a = LIFT[0] * 1.7f; b = LIFT[1] * 4.913f; c = LIFT[2] * 14.19857f; }     // p(1.7 x)
         else if (it < 11) { a = LIFT[0]; b = LIFT[1]; c = LIFT[2]; }
         else { a = TAILC[it - 11][0]; b = TAILC[it - 11][1]; c = TAILC[it - 11][2]; }
         THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop, nb, ws));
@@ -1147,7 +1042,7 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
         float *tmp = S; S = Z; Z = tmp;
     }
     // Newton-Schulz x (3 - x^2) / 2:  T = -0.5 S S^T + 1.5 I ;  S <- T S
-    for (int it = 0; it < (sched == 0 ? 5 : 1); ++it) {
+    {
         THIP_RC(gemm(st, false, ni, ld, -0.5f, S, S, 0.0f, nullptr, 1.5f, T, stop, nb, ws));
         THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));
         float *tmp = S; S = Z; Z = tmp;
@@ -1172,25 +1067,6 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
     if (worklen < ws * (size_t)nbatch) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
     const Work k = carve(work, n);
     if (map_kind == 0 && n > POLAR_MIN_N) {
-        // THIP_PSD_TWO_STREAMS=1 (experiment): the two matrices of a pair as two independent chains on two streams
-        // instead of one chain of z = 2 launches
-        static const bool two = getenv("THIP_PSD_TWO_STREAMS") && atoi(getenv("THIP_PSD_TWO_STREAMS")) != 0;
-        if (two && nbatch == 2) {
-            Ctx &c = ctx();
-            if (!c.side) {
-                THIP_TRY(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
-                THIP_TRY(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
-                THIP_TRY(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
-            }
-            THIP_TRY(hipEventRecord(c.ev_fork, st));
-            THIP_TRY(hipStreamWaitEvent(c.side, c.ev_fork, 0));
-            THIP_RC(polar_project(st, n, packed, has_scale, scale_diag, k, stop, 1, ws, pstride));
-            const Work k1 = carve(work + ws, n);
-            THIP_RC(polar_project(c.side, n, packed + pstride, has_scale, scale_diag, k1, stop, 1, ws, pstride));
-            THIP_TRY(hipEventRecord(c.ev_join, c.side));
-            THIP_TRY(hipStreamWaitEvent(st, c.ev_join, 0));
-            return 0;
-        }
         return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride);
     }
     for (int z = 0; z < nbatch; ++z) {          // the Jacobi engine works on one matrix at a time
