@@ -135,11 +135,11 @@ def test_mfma_gemm_symmetric_times_general(L, n, ld):
         d.free()
 
 
-def test_general_eigen_engine_time_and_orthogonality(L):
-    """k = 500 through the two-phase closure path (thip_eig_decompose -> host closure -> thip_eig_rebuild): eigenvalues
-    against numpy, reconstruction of the matrix with the identity closure, and the time (Jacobi took 51 ms)"""
+@pytest.mark.parametrize("k", [500, 700, 1300])      # 64 / 32 / 16 rows of Z per workgroup in the rotation replay
+def test_general_eigen_engine_time_and_orthogonality(L, k):
+    """the two-phase closure path (thip_eig_decompose -> host closure -> thip_eig_rebuild): eigenvalues against numpy,
+    reconstruction of the matrix with the identity closure, and at k = 500 the time (Jacobi took 51 ms)"""
     import time
-    k = 500
     rng = np.random.default_rng(3)
     b = rng.standard_normal((k, k))
     s = (b + b.T) / 2
@@ -166,7 +166,7 @@ def test_general_eigen_engine_time_and_orthogonality(L):
         L.sync()
         ts.append(time.perf_counter() - t0)
         sl2.drop()
-    print("map_eig(sqrt) k=500: %.2f ms" % (1e3 * min(ts)))
-    assert min(ts) < 0.025
+    print("map_eig(sqrt) k=%d: %.2f ms" % (k, 1e3 * min(ts)))
+    assert k != 500 or min(ts) < 0.025
     sl.drop()
     work.drop()
