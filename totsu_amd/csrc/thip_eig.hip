@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 using namespace thip;
@@ -929,6 +930,14 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
     const size_t per = 2 * cap_rot + 4 * cap_sw;             // floats per buffer (float2 pairs, then 16-byte sweep records)
     float *scr = nullptr;
     THIP_RC(scratch(2 * per + 64, &scr));
+    // pinned staging for the uploads, one half per device buffer (the same event guards both)
+    static float *pin = nullptr; static size_t pin_floats = 0;
+    if (pin_floats < 2 * per) {
+        if (pin) THIP_TRY(hipHostFree(pin));
+        pin = nullptr; pin_floats = 0;
+        THIP_TRY(hipHostMalloc((void **)&pin, 2 * per * sizeof(float), hipHostMallocDefault));
+        pin_floats = 2 * per;
+    }
     hipEvent_t ev[2] = { nullptr, nullptr };
     int which = 0, rc = 0;
     std::vector<float2> rot;
@@ -944,9 +953,11 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
         else if (hipEventSynchronize(ev[which]) != hipSuccess) { rc = -1; return false; }
         const int off0 = sweeps[0].off;
         for (RotSweep &w : sweeps) w.off -= off0;            // offsets relative to the chunk
-        if (hipMemcpyAsync(drot, rot.data(), rot.size() * sizeof(float2), hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(dsw, sweeps.data(), sweeps.size() * sizeof(RotSweep), hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1; return false; }
-        // pageable sources: the copies are staged before the calls return, the vectors may be reused
+        float *hbuf = pin + (size_t)which * per;
+        memcpy(hbuf, rot.data(), rot.size() * sizeof(float2));
+        memcpy(hbuf + 2 * cap_rot, sweeps.data(), sweeps.size() * sizeof(RotSweep));
+        if (hipMemcpyAsync(drot, hbuf, rot.size() * sizeof(float2), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(dsw, hbuf + 2 * cap_rot, sweeps.size() * sizeof(RotSweep), hipMemcpyHostToDevice, st) != hipSuccess) { rc = -1; return false; }
         int r2;
         if ((size_t)ni * 64 * sizeof(float) <= 150 * 1024) r2 = launch_rot<64>(st, ni, ld, k.V, drot, dsw, (int)sweeps.size());
         else if ((size_t)ni * 32 * sizeof(float) <= 150 * 1024) r2 = launch_rot<32>(st, ni, ld, k.V, drot, dsw, (int)sweeps.size());

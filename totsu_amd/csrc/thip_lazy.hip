@@ -25,6 +25,7 @@
 #include "thip_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -71,6 +72,7 @@ struct Queue {
     char *pin[2] = { nullptr, nullptr }; size_t pin_bytes[2] = { 0, 0 }; hipEvent_t pin_ev[2] = { nullptr, nullptr };
     int pin_next = 0;
     long long flushes = 0, deferred = 0;
+    std::atomic<bool> pending{ false };                     // read without the lock by every entry point
 } Q;
 
 bool overlap(uintptr_t a0, uintptr_t a1, uintptr_t b0, uintptr_t b1) { return a0 < b1 && b0 < a1; }
@@ -133,6 +135,7 @@ size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 void reset_queue()
 {
+    Q.pending.store(false, std::memory_order_relaxed);
     Q.groups.clear(); Q.target.clear(); Q.n_members = 0;
     Q.xlo = Q.ylo = ~(uintptr_t)0; Q.xhi = Q.yhi = 0;
 }
@@ -306,6 +309,7 @@ int push_locked(float *y, size_t len, float beta, const Member &m, int *deferred
         if (has_a) { Q.xlo = std::min(Q.xlo, a0); Q.xhi = std::max(Q.xhi, a1); }
     }
     Q.deferred += 1;
+    Q.pending.store(true, std::memory_order_relaxed);
     *deferred = 1;
     return 0;
 }
@@ -324,7 +328,7 @@ bool lazy_on()
 
 namespace thip {
 
-bool lazy_pending() { return !Q.groups.empty(); }
+bool lazy_pending() { return Q.pending.load(std::memory_order_relaxed); }
 
 int lazy_flush()
 {
