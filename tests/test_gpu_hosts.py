@@ -34,3 +34,18 @@ def test_trait_level_host_runs_and_reports(args, cones):
     assert r.returncode == 0, r.stdout + r.stderr
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["path"] == "trait" and d["value"] > 0 and d["trait_cones"] == cones
+
+
+def test_f64_certificate_tool_on_a_small_instance():
+    """tools/c3_f64_certificate.py (the full-size objective gate of bench.py's `objective_gate`) on n = 500: the GPU's
+    f32 answer, evaluated in f64 on the host with the regenerated matrix, is primal feasible, dual feasible to eps and
+    has a duality gap far inside 1e-4"""
+    env = dict(os.environ, C3_N="500", C3_CONES="10")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c3_f64_certificate.py"), "1e-4"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    pt = json.loads(r.stdout.strip().splitlines()[-1])["points"][0]
+    assert pt["state"] == 0
+    assert pt["gap_rel"] <= 1e-4 and pt["dual_residual_rel"] <= 1.2e-4
+    assert pt["primal_cone_violation_rel_to_norm_b"] <= 1e-5 and pt["dual_cone_violation_max"] <= 1e-5
+    assert abs(pt["dual_residual_rel"] - pt["gpu_criteria_f32"][1]) <= 0.05 * pt["gpu_criteria_f32"][1] + 1e-6
