@@ -369,6 +369,7 @@ int lazy_push_scale(size_t n, float alpha, float *x, int *deferred)
     std::lock_guard<std::mutex> lock(Q.mu);
     *deferred = 0;
     if (!lazy_on() || n > LAZY_MAX_VEC || n == 0) return flush_locked();
+    if (alpha == 1.0f) { *deferred = 1; return 0; }          // x <- 1 x: nothing to record
     Member m{};
     m.kind = K_SCALE;
     return push_locked(x, n, alpha, m, deferred);
