@@ -400,3 +400,70 @@ def test_grouped_products_at_scale_match_the_stacked_matrix(L):
     assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
     for d in (A, x, y, G, Cv, out, ref, outn, refn):
         d.free()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_deferred_execution_fuzz_against_eager(L, seed):
+    """random sequences of transform_ge / scale / add on random (overlapping) windows of three vectors, with matrices
+    and vectors of every shape class (matrix, row vector, column vector): deferred + grouped execution must give what
+    one launch per call gives (same values up to the order of f32 additions)"""
+    from totsu_amd._lib import lib
+    rng = np.random.default_rng(100 + seed)
+    NV = 700
+    mats = []
+    for _ in range(10):
+        nr, nc = int(rng.choice([1, 1, 3, 17, 64, 130, 300])), int(rng.choice([1, 1, 5, 40, 129, 260]))
+        mats.append((nr, nc, rng.standard_normal((nr, nc)).astype(np.float32)))
+    dm = [_dev(L, np.asfortranarray(a).ravel(order="F")) for _, _, a in mats]
+    init = [rng.standard_normal(NV).astype(np.float32) for _ in range(3)]
+    ops = []
+    for _ in range(120):
+        kind = rng.choice(["ge", "ge", "ge", "scale", "add"])
+        if kind == "ge":
+            k = int(rng.integers(len(mats)))
+            nr, nc, _ = mats[k]
+            tr = int(rng.integers(2))
+            xin, yout = (nr, nc) if tr else (nc, nr)
+            vi, vo = int(rng.integers(3)), int(rng.integers(3))
+            ox, oy = int(rng.integers(0, NV - xin + 1)), int(rng.integers(0, NV - yout + 1))
+            if vi == vo and ox < oy + yout and oy < ox + xin:
+                continue                      # a product must not alias its own input and output (as in the reference)
+            ops.append(("ge", k, tr, float(rng.choice([1.0, -0.5, 0.25])), vi, ox, float(rng.choice([0.0, 1.0, 1.0, 0.5])), vo, oy))
+        elif kind == "scale":
+            ln = int(rng.choice([1, 7, 300]))
+            ops.append(("scale", float(rng.choice([0.0, 0.5, 1.0, -1.0])), int(rng.integers(3)), int(rng.integers(0, NV - ln + 1)), ln))
+        else:
+            ln = int(rng.choice([1, 9, 200]))
+            vi, vo = int(rng.integers(3)), int(rng.integers(3))
+            ox, oy = int(rng.integers(0, NV - ln + 1)), int(rng.integers(0, NV - ln + 1))
+            if vi == vo and ox != oy and ox < oy + ln and oy < ox + ln:
+                continue
+            ops.append(("add", float(rng.choice([1.0, -2.0, 0.125])), vi, ox, vo, oy, ln))
+
+    def run(lazy):
+        lib.thip_set_lazy_gemv(lazy)
+        vs = [_dev(L, v) for v in init]
+        for op in ops:
+            if op[0] == "ge":
+                _, k, tr, al, vi, ox, be, vo, oy = op
+                nr, nc, _ = mats[k]
+                lib.thip_transform_ge(tr, nr, nc, al, dm[k].dev(), vs[vi].dev() + 4 * ox, be, vs[vo].dev() + 4 * oy)
+            elif op[0] == "scale":
+                _, al, vi, ox, ln = op
+                lib.thip_scale(ln, al, vs[vi].dev() + 4 * ox)
+            else:
+                _, al, vi, ox, vo, oy, ln = op
+                lib.thip_add(ln, al, vs[vi].dev() + 4 * ox, vs[vo].dev() + 4 * oy)
+        out = [v.get_ref().copy() for v in vs]
+        for v in vs:
+            v.drop()
+        return out
+
+    eager, lazy = run(0), run(1)
+    lib.thip_set_lazy_gemv(1)
+    for a, b in zip(eager, lazy):
+        assert np.all(np.isfinite(a)) == np.all(np.isfinite(b))
+        sc = max(1.0, float(np.abs(a[np.isfinite(a)]).max()) if np.isfinite(a).any() else 1.0)
+        assert np.allclose(a, b, rtol=2e-4, atol=2e-4 * sc, equal_nan=True), np.nanmax(np.abs(a - b)) / sc
+    for d in dm:
+        d.drop()
