@@ -24,6 +24,15 @@ __global__ __launch_bounds__(NW * 64) void k(const float *__restrict__ X, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
     if (PHASE == 1) { if (tid == 0) C[(size_t)i0 * LD + j0] = 1.0f; return; }
+    if (PHASE == 6) {                    // the MFMAs alone: operands from registers, no operand loads
+        f32x16 acc6;
+        for (int r = 0; r < 16; ++r) acc6[r] = 0.0f;
+        float a6 = 1.0f + tid * 1e-6f, b6 = 0.5f;
+#pragma unroll
+        for (int q = 0; q < LD / NW / 2; ++q) acc6 = __builtin_amdgcn_mfma_f32_32x32x2f32(a6, b6, acc6, 0, 0, 0);
+        if (acc6[0] == 12345.678f) C[0] = acc6[1];
+        return;
+    }
     const int kb = wave * KW, h = lane >> 5, li = lane & 31;
     const float *pa = X + (size_t)(kb + 4 * h) * LD + i0 + li;
     const float *pb = Y + (size_t)(kb + 4 * h) * LD + j0 + li;
@@ -37,6 +46,15 @@ __global__ __launch_bounds__(NW * 64) void k(const float *__restrict__ X, const 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    if (PHASE == 5) {                    // all operand loads of every wave, kept alive by a store per wave; no MFMA
+        float s5 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s5 += av[q][t] * bv[q][t];
+        if (s5 == 12345.678f) C[(size_t)(i0 + li) * LD + j0 + wave] = s5;
+        return;
+    }
     if (PHASE == 2) {
         float s = 0.0f;
 #pragma unroll
@@ -111,6 +129,10 @@ int main()
     printf("4 waves/WG:  empty %.2f  flag+store %.2f  +loads %.2f  +mfma %.2f  +lds-reduce %.2f\n",
            chain<0, 4>(st, A, B, Cc, stop, 1), chain<1, 4>(st, A, B, Cc, stop, 1), chain<2, 4>(st, A, B, Cc, stop, 1),
            chain<3, 4>(st, A, B, Cc, stop, 1), chain<4, 4>(st, A, B, Cc, stop, 1));
+    printf("4 waves/WG, z = 1: loads only (all waves) %.2f  mfma only %.2f ;  z = 2: loads only %.2f  mfma only %.2f  full %.2f\n",
+           chain<5, 4>(st, A, B, Cc, stop, 1), chain<6, 4>(st, A, B, Cc, stop, 1), chain<5, 4>(st, A, B, Cc, stop, 2),
+           chain<6, 4>(st, A, B, Cc, stop, 2), chain<4, 4>(st, A, B, Cc, stop, 2));
+    printf("8 waves/WG, z = 2: loads only %.2f  mfma only %.2f\n", chain<5, 8>(st, A, B, Cc, stop, 2), chain<6, 8>(st, A, B, Cc, stop, 2));
     printf("grid z = 2 (the batched pair), 8 waves: +loads %.2f  +mfma %.2f  full %.2f ; 4 waves: full %.2f\n",
            chain<2, 8>(st, A, B, Cc, stop, 2), chain<3, 8>(st, A, B, Cc, stop, 2), chain<4, 8>(st, A, B, Cc, stop, 2),
            chain<4, 4>(st, A, B, Cc, stop, 2));

@@ -454,6 +454,125 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
     }
 }
 
+// gemm_pre_k with a 32 x 64 block of the result per workgroup, for launches in which one 32 x 32 tile per workgroup would
+// put more than one workgroup on a CU (the batched pair of 512^3 products: 512 tiles, or 272 for the symmetric shape, on
+// 256 CUs).  tools/gemm_phases.hip (device-clock stamps inside the kernel) shows what bounds such a launch:
+//   * operand loads: a wave may have 64 vector loads in flight, an L2 round trip under this load is ~1 us, so four
+//     waves of dword loads (256 B per instruction) pull 64 KB per us into a CU, and the 128 KB of a tile take 1.4 us;
+//   * the SECOND workgroup of a CU gets its operands at 4-6 us, not 2.8; its 1.8 us of MFMAs (64 x 64 cycles, issue
+//     bound) and its store follow: 8.4 us for the two against 4.8 for a single tile.
+// Here the two accumulators of a wave are the EVEN and the ODD columns of the 64-wide strip, so operand b is one dwordx2
+// per lane (512 B per instruction, half as many instructions in flight for the same bytes) and the result leaves as
+// dwordx2; operand a is shared (192 KB per workgroup instead of 2 x 128); the loads run DEP slabs of 8 k ahead of the
+// MFMAs (as many as fit in the 64 slots) instead of all up front, so the first MFMA issues after one round trip and not
+// after the wave has been allowed to issue its last load; and no CU holds more waves than SIMDs.  All four waves take
+// part in the epilogue (four accumulator registers each).  Per element the order of every sum is that of gemm_pre_k:
+// the results are bitwise the same.  SYM: the block covers tiles (bi, 2p) and (bi, 2p + 1) of the lower triangle; in
+// the last block of an even row the second tile lies above the diagonal and is computed but not stored.
+template <bool GEN, int KW, bool SYM>
+__global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, const float *__restrict__ X,
+                                                   const float *__restrict__ Y, float beta, const float *D, float gamma,
+                                                   float *C, const int *__restrict__ stop, size_t ws)
+{
+    static_assert(!(GEN && SYM), "the symmetric shortcut is for X Y^T products");
+    if (stop != nullptr && *stop != 0) return;
+    constexpr int NW = 4;
+    int bi, bj;
+    if constexpr (SYM) {
+        // blockIdx.x runs over the blocks of the lower triangle: tile row bi holds bi / 2 + 1 of them
+        int t = blockIdx.x;
+        bi = 0;
+        while (t >= bi / 2 + 1) { t -= bi / 2 + 1; ++bi; }
+        bj = 2 * t;
+    } else {
+        bi = blockIdx.x;
+        bj = 2 * blockIdx.y;
+    }
+    X += blockIdx.z * ws; Y += blockIdx.z * ws; C += blockIdx.z * ws;
+    if (D) D += blockIdx.z * ws;
+    __shared__ float red[NW][2][16][64];
+    __shared__ float tr[SYM ? 32 : 1][65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = bi * GT, j0 = bj * GT;
+    const int kb = wave * KW, h = lane >> 5, li = lane & 31;
+    const float *pa = GEN ? Y + (size_t)(i0 + li) * ld + kb + 4 * h : X + (size_t)(kb + 4 * h) * ld + i0 + li;
+    const float *pb = (GEN ? X : Y) + (size_t)(kb + 4 * h) * ld + j0 + 2 * li;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    constexpr int NQ = KW / 8;
+    constexpr int DEP = (GEN ? 12 : 8) < NQ ? (GEN ? 12 : 8) : NQ;
+    f32x4_t av[NQ];
+    f32x2_t bv[NQ][4];
+    auto load = [&](const int q) {
+        if constexpr (GEN) av[q] = *reinterpret_cast<const f32x4_t *>(pa + 8 * q);
+        else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[q][t] = pa[(size_t)(8 * q + t) * ld];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[q][t] = *reinterpret_cast<const f32x2_t *>(pb + (size_t)(8 * q + t) * ld);
+    };
+#pragma unroll
+    for (int q = 0; q < DEP; ++q) load(q);
+    f32x16 acce, acco;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acce[r] = acco[r] = 0.0f;
+    // nothing may cross these points: left alone the scheduler sinks every load to its first use
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acce = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][0], acce, 0, 0, 0);
+            acco = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][1], acco, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + DEP < NQ) load(q + DEP);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[wave][0][r][lane] = acce[r]; red[wave][1][r][lane] = acco[r]; }
+    __syncthreads();
+    // wave w finishes accumulator registers 4 w .. 4 w + 3 of both column sets: rows (r & 3) + 8 w + 4 h
+    const int tj = j0 + 2 * li;                               // this lane's columns tj, tj + 1
+    const bool colok = !SYM || tj < (bi + 1) * GT;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * wave + rr;
+        const int tl = rr + 8 * wave + 4 * h;
+        const int ti = i0 + tl;
+        float ve = red[0][0][r][lane], vo = red[0][1][r][lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { ve += red[w][0][r][lane]; vo += red[w][1][r][lane]; }
+        ve *= alpha; vo *= alpha;
+        const size_t o = (size_t)ti * ld + tj;
+        if (beta != 0.0f) {
+            const f32x2_t d = *reinterpret_cast<const f32x2_t *>(D + o);
+            ve = fmaf(beta, d[0], ve); vo = fmaf(beta, d[1], vo);
+        }
+        if (ti < n) {
+            if (ti == tj) ve += gamma;
+            if (ti == tj + 1) vo += gamma;
+        }
+        if (colok) {
+            f32x2_t v2;
+            v2[0] = ve; v2[1] = vo;
+            *reinterpret_cast<f32x2_t *>(C + o) = v2;
+        }
+        if constexpr (SYM) { tr[tl][2 * li] = ve; tr[tl][2 * li + 1] = vo; }
+    }
+    if constexpr (SYM) {
+        // the mirror image of the tiles strictly below the diagonal: element (ti, tj) also goes to Cmem[tj * ld + ti];
+        // through LDS so that the 32 lanes of a store walk along ti.  Wave w: rows j0 + 16 w .. + 15 of the image.
+        __syncthreads();
+#pragma unroll
+        for (int sI = 0; sI < 8; ++sI) {
+            const int jj = 16 * wave + 2 * sI + h;
+            if (bj + (jj >> 5) < bi) C[(size_t)(j0 + jj) * ld + i0 + li] = tr[li][jj];
+        }
+    }
+}
+
 // S = M / ||M||_F  (sc[0] = ||M||_F); exact zero matrix stays zero
 __global__ void scale_by_fro_k(size_t tot, const float *__restrict__ M, const float *__restrict__ sc,
                                float *__restrict__ S, const int *__restrict__ stop, size_t ws)
@@ -485,13 +604,20 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
          float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0)
 {
     dim3 g(ld / GT, ld / GT, nb);
-    // ld <= 512: gemm_pre_k (loads up front, 4 waves, symmetric results from the lower triangle of tiles); larger orders,
-    // or THIP_GEMM_MODE=0: gemm_k (slab prefetch, 8 waves, any ld)
-    static const int mode = getenv("THIP_GEMM_MODE") ? atoi(getenv("THIP_GEMM_MODE")) : 2;
+    // ld <= 512: gemm_pre_k (loads up front, 4 waves, symmetric results from the lower triangle of tiles), or its
+    // two-tile form when there are more tiles than CUs; larger orders, or THIP_GEMM_MODE=0: gemm_k (slab prefetch, 8
+    // waves, any ld).  THIP_GEMM_MODE=2: one tile per workgroup whatever the count.
+    static const int mode = getenv("THIP_GEMM_MODE") ? atoi(getenv("THIP_GEMM_MODE")) : 3;
     const int nt = ld / GT;
+    const int tiles = (gen ? nt * nt : nt * (nt + 1) / 2) * nb;
+    const bool pairs = mode >= 3 && tiles > ctx().num_cu && nt % 2 == 0;
+    int npair = 0;
+    for (int bi = 0; bi < nt; ++bi) npair += bi / 2 + 1;
 #define THIP_GEMM_PRE4(KW)                                                                                                  \
     do {                                                                                                                    \
-        if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false>), g, dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);  \
+        if (pairs && gen) hipLaunchKernelGGL((gemm_pre2_k<true, KW, false>), dim3(nt, nt / 2, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
+        else if (pairs)   hipLaunchKernelGGL((gemm_pre2_k<false, KW, true>), dim3(npair, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
+        else if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false>), g, dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);  \
         else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, true>), dim3(nt * (nt + 1) / 2, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
     } while (0)
     if (mode >= 2 && ld <= 512) {
