@@ -24,13 +24,14 @@ for k in (128, 256, 500):
     sl = L.Sl.new_mut(packed.copy())
     L.map_eig(sl, sq2, 1e-12, work, "pos")
     err = np.abs(sl.get_ref() - pref).max() / np.linalg.norm(packed)
-    reps = 50
-    L.sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        L.map_eig(sl, sq2, 1e-12, work, "pos")
-    L.sync()
-    dt = (time.perf_counter() - t0) / reps
+    reps, dt = 50, float("inf")
+    for _ in range(5):                      # best of 5: a host hiccup in one batch of launches is not the chain's time
+        L.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            L.map_eig(sl, sq2, 1e-12, work, "pos")
+        L.sync()
+        dt = min(dt, (time.perf_counter() - t0) / reps)
     print("k=%d PSD projection: %.3f ms  err/|x| %.2e  (THIP_GEMM_MODE=%s)" % (k, 1e3 * dt, err, os.environ.get("THIP_GEMM_MODE", "default")))
     sl.drop()
     work.drop()

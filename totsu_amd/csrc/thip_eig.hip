@@ -353,7 +353,7 @@ __global__ __launch_bounds__(GNW * 64) void gemm_k(int n, int ld, float alpha, c
 //     transposition.  (Not for the X X^T products: X = S is symmetric only to round-off, and S^T S^T instead of the Gram
 //     matrix S S^T loses the damping of antisymmetric round-off that makes the left-multiplied iteration stable.)
 //   * every other operand: row k = 8 q + 4 h + t, coalesced along the tile (one dword per lane per MFMA);
-//   * all of a wave's loads are in flight at once (<= 64 VGPRs at ld = 512), then KW / 2 MFMAs.
+//   * a wave's loads are in flight 8 slabs of 8 k (GEN: 12) ahead of its KW / 2 MFMAs.
 // The summation order over k differs from gemm_k's (both are fixed, so results stay bitwise reproducible and the
 // symmetric products stay bitwise symmetric: the mirrored tile swaps a and b, and the products commute).
 // NW waves per workgroup split K NW ways.  tools/gemm_floor.hip (a dependent chain of launches that add one phase at a
@@ -391,30 +391,37 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
     const float *pb = (GEN ? X : Y) + (size_t)(kb + 4 * h) * ld + j0 + li;
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     constexpr int NQ = KW / 8;
+    // the loads run DEP slabs of 8 k ahead of the MFMAs: as many as fit in the 64 slots a wave has for loads in flight
+    // (all of them up to ld = 256).  Issued all up front, the 65th stalls the wave until the first returns, and the
+    // first MFMA waits behind the last load's ISSUE (tools/gemm_phases.hip).
+    constexpr int DEP = (GEN ? 12 : 8) < NQ ? (GEN ? 12 : 8) : NQ;
     f32x4_t av[NQ];
     float bv[NQ][4];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+    auto load = [&](const int q) {
         if constexpr (GEN) av[q] = *reinterpret_cast<const f32x4_t *>(pa + 8 * q);
         else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) av[q][t] = pa[(size_t)(8 * q + t) * ld];
         }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int t = 0; t < 4; ++t) bv[q][t] = pb[(size_t)(8 * q + t) * ld];
-    // left alone the scheduler sinks the loads between the MFMAs to save registers (38 VGPRs, one or two loads in
-    // flight): nothing may cross this point
-    __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int q = 0; q < DEP; ++q) load(q);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // left alone the scheduler sinks the loads between the MFMAs to save registers (38 VGPRs, one or two loads in
+    // flight): nothing may cross these points
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int q = 0; q < NQ; ++q) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + DEP < NQ) load(q + DEP);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
