@@ -171,6 +171,132 @@ __global__ __launch_bounds__(256) void kpair(const float *__restrict__ X, const 
     }
 }
 
+// the 32 x 64 block kernel as shipped (gemm_pre2_k of thip_eig.hip, symmetric-operand shape, full grid): even / odd column
+// accumulators, operand b as dwordx2, loads DEP slabs ahead.  Stamps: t0 entry, t1 MFMAs done, t2 partial sums in LDS and
+// workgroup barrier passed, t3 stored.  grid (16, 8, nz)
+template <int DEP>
+__global__ __launch_bounds__(256) void kblock(const float *__restrict__ X, const float *__restrict__ Y, float *C, unsigned long long *ts, const int ld)
+{
+    const unsigned long long t0 = wall_clock64();
+    X += (size_t)blockIdx.z * LD * ld; Y += (size_t)blockIdx.z * LD * ld; C += (size_t)blockIdx.z * LD * ld;
+    __shared__ float red[NW][2][16][64];
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 64;
+    const int kb = wave * KW, h = lane >> 5, li = lane & 31;
+    const float *pa = X + (size_t)(kb + 4 * h) * ld + i0 + li;
+    const float *pb = Y + (size_t)(kb + 4 * h) * ld + j0 + 2 * li;
+    float av[NQ][4];
+    f32x2_t bv[NQ][4];
+    auto load = [&](const int q) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { av[q][t] = pa[(size_t)(8 * q + t) * ld]; bv[q][t] = *reinterpret_cast<const f32x2_t *>(pb + (size_t)(8 * q + t) * ld); }
+    };
+#pragma unroll
+    for (int q = 0; q < DEP; ++q) load(q);
+    f32x16 acce, acco;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acce[r] = acco[r] = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acce = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][0], acce, 0, 0, 0);
+            acco = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][1], acco, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + DEP < NQ) load(q + DEP);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[wave][0][r][lane] = acce[r]; red[wave][1][r][lane] = acco[r]; }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = wall_clock64();
+    __syncthreads();
+    const unsigned long long t2 = wall_clock64();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = 4 * wave + rr;
+        float ve = red[0][0][r][lane], vo = red[0][1][r][lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { ve += red[w][0][r][lane]; vo += red[w][1][r][lane]; }
+        f32x2_t v2;
+        v2[0] = ve * 1e-3f; v2[1] = vo * 1e-3f;
+        *reinterpret_cast<f32x2_t *>(C + (size_t)(i0 + rr + 8 * wave + 4 * h) * ld + j0 + 2 * li) = v2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t3 = wall_clock64();
+    if (ts != nullptr && tid == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        ts[4 * b] = t0; ts[4 * b + 1] = t1; ts[4 * b + 2] = t2; ts[4 * b + 3] = t3;
+    }
+}
+
+// the same with NWV waves splitting K (8: two waves per SIMD)
+// the 32 x 64 block kernel as shipped (gemm_pre2_k of thip_eig.hip, symmetric-operand shape, full grid): even / odd column
+// accumulators, operand b as dwordx2, loads DEP slabs ahead.  Stamps: t0 entry, t1 MFMAs done, t2 partial sums in LDS and
+// workgroup barrier passed, t3 stored.  grid (16, 8, nz)
+template <int DEP, int NWV>
+__global__ __launch_bounds__(NWV * 64) void kblockw(const float *__restrict__ X, const float *__restrict__ Y, float *C, unsigned long long *ts, const int ld)
+{
+    const unsigned long long t0 = wall_clock64();
+    X += (size_t)blockIdx.z * LD * ld; Y += (size_t)blockIdx.z * LD * ld; C += (size_t)blockIdx.z * LD * ld;
+    constexpr int KWv = LD / NWV, NQv = KWv / 8;
+    __shared__ float red[NWV][2][16][64];
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 64;
+    const int kb = wave * KWv, h = lane >> 5, li = lane & 31;
+    const float *pa = X + (size_t)(kb + 4 * h) * ld + i0 + li;
+    const float *pb = Y + (size_t)(kb + 4 * h) * ld + j0 + 2 * li;
+    float av[NQv][4];
+    f32x2_t bv[NQv][4];
+    auto load = [&](const int q) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { av[q][t] = pa[(size_t)(8 * q + t) * ld]; bv[q][t] = *reinterpret_cast<const f32x2_t *>(pb + (size_t)(8 * q + t) * ld); }
+    };
+#pragma unroll
+    for (int q = 0; q < DEP; ++q) load(q);
+    f32x16 acce, acco;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acce[r] = acco[r] = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQv; ++q) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acce = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][0], acce, 0, 0, 0);
+            acco = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][1], acco, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + DEP < NQv) load(q + DEP);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[wave][0][r][lane] = acce[r]; red[wave][1][r][lane] = acco[r]; }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = wall_clock64();
+    __syncthreads();
+    const unsigned long long t2 = wall_clock64();
+#pragma unroll
+    for (int rr = 0; rr < 16 / NWV; ++rr) {
+        const int r = (16 / NWV) * wave + rr;
+        float ve = red[0][0][r][lane], vo = red[0][1][r][lane];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) { ve += red[w][0][r][lane]; vo += red[w][1][r][lane]; }
+        f32x2_t v2;
+        v2[0] = ve * 1e-3f; v2[1] = vo * 1e-3f;
+        *reinterpret_cast<f32x2_t *>(C + (size_t)(i0 + (r & 3) + 8 * (r >> 2) + 4 * h) * ld + j0 + 2 * li) = v2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t3 = wall_clock64();
+    if (ts != nullptr && tid == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        ts[4 * b] = t0; ts[4 * b + 1] = t1; ts[4 * b + 2] = t2; ts[4 * b + 3] = t3;
+    }
+}
+
 int main()
 {
     hipStream_t st;
@@ -183,9 +309,9 @@ int main()
     hipMemcpy(Cc, h.data(), 2 * sq * 4, hipMemcpyHostToDevice);
     for (int ld : { 512 })
     for (int place = 0; place <= 0; ++place)        // 1: dynamic LDS sized so that exactly nz workgroups fit a CU
-    for (int chains : { 6, 8 })
+    for (int chains : { 10, 12, 13 })
     for (int nz = 2; nz <= 2; ++nz) {
-        auto kern = chains == 1 ? k<1> : chains == 6 ? kpair<0> : chains == 7 ? kpair<1> : kpair<2>;
+        auto kern = chains == 1 ? k<1> : chains == 6 ? kpair<0> : chains == 7 ? kpair<1> : chains == 8 ? kpair<2> : chains == 9 ? kblock<8> : chains == 10 ? kblock<6> : chains == 11 ? kblock<16> : chains == 12 ? kblockw<8, 8> : kblockw<4, 8>;
         const bool pr = chains >= 6;
         const int nwg = (pr ? 128 : 256) * nz;
         const size_t dyn = place ? (nz == 1 ? 100 : 48) * 1024 : 0;
@@ -194,11 +320,11 @@ int main()
         hipEvent_t e0, ev1; hipEventCreate(&e0); hipEventCreate(&ev1);
         const int reps = 100;
         for (int warm = 0; warm < 200; ++warm)
-            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(16, pr ? 8 : 16, nz), dim3(NW * 64), dyn, st, bufs[i % 3], bufs[(i + 1) % 3], bufs[(i + 2) % 3], nullptr, ld);
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(16, pr ? 8 : 16, nz), dim3((chains >= 12 ? 8 : NW) * 64), dyn, st, bufs[i % 3], bufs[(i + 1) % 3], bufs[(i + 2) % 3], nullptr, ld);
         hipEventRecord(e0, st);
         for (int i = 0; i < reps; ++i) {
             unsigned long long *t = (i >= 50 && i < 53) ? ts + (size_t)(i - 50) * nwg * 4 : nullptr;
-            hipLaunchKernelGGL(kern, dim3(16, pr ? 8 : 16, nz), dim3(NW * 64), dyn, st, bufs[i % 3], bufs[(i + 1) % 3], bufs[(i + 2) % 3], t, ld);
+            hipLaunchKernelGGL(kern, dim3(16, pr ? 8 : 16, nz), dim3((chains >= 12 ? 8 : NW) * 64), dyn, st, bufs[i % 3], bufs[(i + 1) % 3], bufs[(i + 2) % 3], t, ld);
         }
         hipEventRecord(ev1, st); hipEventSynchronize(ev1);
         float ms; hipEventElapsedTime(&ms, e0, ev1);
@@ -219,7 +345,7 @@ int main()
                ld, place, chains, nz, us_per_launch, (double)(s2 - s0) / 2 / tpu, d_load / nwg / tpu, d_mfma / nwg / tpu, d_store / nwg / tpu,
                (double)(smax - s1) / tpu, (double)(e1 - s1) / tpu, (double)(long long)(s2 - e1) / tpu);
         {
-            const char *names[5] = { "start", "loads", "mfma", "reduce+store", "end" };
+            const char *names[5] = { "start", "phase 1", "phase 2", "phase 3", "end" };
             for (int w = 0; w < 5; ++w) {
                 std::vector<double> v;
                 for (int b = 0; b < nwg; ++b)

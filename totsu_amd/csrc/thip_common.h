@@ -22,6 +22,7 @@ struct Ctx {
     size_t       stage_bytes = 0;
     hipEvent_t   stage_ev[2] = { nullptr, nullptr };   // "the DMA out of half k has finished"
     int          num_cu = 256;
+    int         *never_stop = nullptr;  // a device int that stays 0: the stop flag of launches outside a solver loop
 };
 
 Ctx &ctx();

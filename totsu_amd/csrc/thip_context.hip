@@ -79,6 +79,8 @@ int thip_init(int device)
     THIP_TRY(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     c.stream = c.own_stream;
     THIP_TRY(hipMalloc((void **)&c.dev_scalar, 64 * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&c.never_stop, sizeof(int)));
+    THIP_TRY(hipMemset(c.never_stop, 0, sizeof(int)));
     THIP_TRY(hipHostMalloc((void **)&c.pinned, 64 * sizeof(float), hipHostMallocDefault));
     c.stage_bytes = 8u << 20;
     THIP_TRY(hipHostMalloc(&c.stage, 2 * c.stage_bytes, hipHostMallocDefault));
@@ -100,6 +102,8 @@ int thip_shutdown(void)
     lazy_release();
     if (c.scratch) hipFree(c.scratch);
     if (c.dev_scalar) hipFree(c.dev_scalar);
+    if (c.never_stop) hipFree(c.never_stop);
+    c.never_stop = nullptr;
     if (c.pinned) hipHostFree(c.pinned);
     if (c.stage) hipHostFree(c.stage);
     for (int k = 0; k < 2; ++k) if (c.stage_ev[k]) hipEventDestroy(c.stage_ev[k]);

@@ -369,7 +369,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
                                                       float *C, const int *__restrict__ stop, size_t ws)
 {
     static_assert(!(GEN && SYM), "the symmetric shortcut is for X Y^T products");
-    if (stop != nullptr && *stop != 0) return;
+    // the stop flag is fetched now and looked at just before the first store: tested here, every launch of the chain
+    // would start with an L2 round trip on which all of its operand loads wait
+    const int halted = *stop;                   // never null: gemm() passes ctx().never_stop
     int bi = blockIdx.x, bj = blockIdx.y;
     X += blockIdx.z * ws; Y += blockIdx.z * ws; C += blockIdx.z * ws;
     if (D) D += blockIdx.z * ws;
@@ -427,6 +429,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
         for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
     }
     __syncthreads();
+    if (halted != 0) return;
     if (wave == 0) {
         const int tj = j0 + (lane & 31);
         float vv[16];
@@ -482,7 +485,9 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
                                                    float *C, const int *__restrict__ stop, size_t ws)
 {
     static_assert(!(GEN && SYM), "the symmetric shortcut is for X Y^T products");
-    if (stop != nullptr && *stop != 0) return;
+    // the stop flag is fetched now and looked at just before the first store: tested here, every launch of the chain
+    // would start with an L2 round trip on which all of its operand loads wait
+    const int halted = *stop;                   // never null: gemm() passes ctx().never_stop
     constexpr int NW = 4;
     int bi, bj;
     if constexpr (SYM) {
@@ -540,6 +545,7 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
 #pragma unroll
     for (int r = 0; r < 16; ++r) { red[wave][0][r][lane] = acce[r]; red[wave][1][r][lane] = acco[r]; }
     __syncthreads();
+    if (halted != 0) return;
     // wave w finishes accumulator registers 4 w .. 4 w + 3 of both column sets: rows (r & 3) + 8 w + 4 h
     const int tj = j0 + 2 * li;                               // this lane's columns tj, tj + 1
     const bool colok = !SYM || tj < (bi + 1) * GT;
@@ -611,6 +617,7 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
          float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0)
 {
     dim3 g(ld / GT, ld / GT, nb);
+    if (stop == nullptr) stop = ctx().never_stop;
     // ld <= 512: gemm_pre_k (loads up front, 4 waves, symmetric results from the lower triangle of tiles), or its
     // two-tile form when there are more tiles than CUs; larger orders, or THIP_GEMM_MODE=0: gemm_k (slab prefetch, 8
     // waves, any ld).  THIP_GEMM_MODE=2: one tile per workgroup whatever the count.
