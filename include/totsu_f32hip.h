@@ -284,6 +284,13 @@ int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_byte
  * with A symmetric and B arbitrary, all ld x ld column-major, ld a multiple of 64, zero padded beyond n */
 int thip_test_gemm_sym(int n, int ld, float alpha, const float *A, const float *B, float beta, const float *D,
                        float gamma, float *C);
+/* the same for either shape and either kernel of the chain, nb matrices per launch (item i at offset i * ld * ld of every
+ * operand).  shape 0: C = alpha * X^T * Y + beta * D + gamma * I_n, for operands whose result is symmetric (X = Y, or
+ * both symmetric and commuting) -- only the lower triangle of tiles is computed, the rest mirrored; shape 1 =
+ * thip_test_gemm_sym (X symmetric, Y general).  kernel 0: the library's choice; 1: one 32 x 32 tile per workgroup;
+ * 2: 32 x 64 blocks (what the library picks when a launch has more tiles than the device has CUs) */
+int thip_test_gemm_chain(int shape, int kernel, int n, int ld, int nb, float alpha, const float *X, const float *Y,
+                         float beta, const float *D, float gamma, float *C);
 
 /* the GEMV tiling chosen by the create-time autotune (rows groups per lane, grid size, its measured ms); 0 = heuristic */
 int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, float *host_ms);

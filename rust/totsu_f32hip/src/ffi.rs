@@ -140,6 +140,8 @@ extern "C" {
     pub fn thip_prof_read(host_launches: *mut i64, host_total_ms: *mut f64) -> c_int;
     pub fn thip_test_gemm_sym(n: c_int, ld: c_int, alpha: f32, a: *const f32, b: *const f32, beta: f32, d: *const f32,
                               gamma: f32, c: *mut f32) -> c_int;
+    pub fn thip_test_gemm_chain(shape: c_int, kernel: c_int, n: c_int, ld: c_int, nb: c_int, alpha: f32, x: *const f32,
+                                y: *const f32, beta: f32, d: *const f32, gamma: f32, c: *mut f32) -> c_int;
 }
 
 pub const THIP_A_F32: c_int = 0;

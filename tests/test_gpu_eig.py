@@ -135,6 +135,56 @@ def test_mfma_gemm_symmetric_times_general(L, n, ld):
         d.free()
 
 
+@pytest.mark.parametrize("ld", [64, 128, 192, 256, 320, 384, 448, 512])
+@pytest.mark.parametrize("shape", [0, 1])
+def test_mfma_gemm_both_kernels_every_k_split(L, ld, shape):
+    """the chain's GEMM through both of its kernels -- one 32 x 32 tile per workgroup, and the 32 x 64 block form the
+    library picks when a launch has more tiles than CUs -- for every instantiated K split (ld / 4 = 16 ... 128), three
+    matrices per launch: each against f64 numpy, the two against each other BITWISE (per element both keep the same
+    order of every sum), and for the symmetric shape the result bitwise symmetric"""
+    from totsu_amd._lib import lib
+    from totsu_amd.fused import DeviceBuffer
+    nb, n = 3, ld - 13
+    rng = np.random.default_rng(1000 * shape + ld)
+    X = rng.standard_normal((nb, ld, ld)).astype(np.float32)
+    Y = rng.standard_normal((nb, ld, ld)).astype(np.float32)
+    D = rng.standard_normal((nb, ld, ld)).astype(np.float32)
+    if shape == 0:
+        Y = X.copy()                          # X^T X: symmetric whatever X is
+        D = D + D.transpose(0, 2, 1)
+    else:
+        X = X + X.transpose(0, 2, 1)          # symmetric times general
+    for M in (X, Y, D):
+        M[:, n:, :] = 0
+        M[:, :, n:] = 0
+    # memory is column-major: element (r, c) of item i at i * ld * ld + c * ld + r
+    up = lambda M: DeviceBuffer.from_host(np.ascontiguousarray(M.transpose(0, 2, 1)).ravel())
+    dX, dY, dD = up(X), up(Y), up(D)
+    eye = np.zeros((ld, ld))
+    eye[:n, :n] = np.eye(n)
+    X64, Y64 = X.astype(np.float64), Y.astype(np.float64)
+    if shape == 0:
+        # shape 0 contracts the FIRST index of both operands as stored: C_mem[i][j] = sum_k X_mem[k][i] Y_mem[k][j]
+        Xm, Ym = X64.transpose(0, 2, 1), Y64.transpose(0, 2, 1)          # X_mem as a row-major array
+        ref_mem = 0.5 * np.einsum("bki,bkj->bij", Xm, Ym) - 2.0 * D.transpose(0, 2, 1) + 3.0 * eye
+        scale = 0.5 * np.einsum("bki,bkj->bij", np.abs(Xm), np.abs(Ym)) + 2.0 * np.abs(D.transpose(0, 2, 1)) + 3.0
+    else:
+        ref_mem = (0.5 * X64 @ Y64 - 2.0 * D + 3.0 * eye).transpose(0, 2, 1)
+        scale = (0.5 * np.abs(X64) @ np.abs(Y64) + 2.0 * np.abs(D) + 3.0).transpose(0, 2, 1)
+    got = {}
+    for kernel in (1, 2):
+        dC = DeviceBuffer(nb * ld * ld)
+        assert lib.thip_test_gemm_chain(shape, kernel, n, ld, nb, 0.5, dX.ptr, dY.ptr, -2.0, dD.ptr, 3.0, dC.ptr) == 0
+        got[kernel] = dC.to_host().reshape((nb, ld, ld))
+        dC.free()
+        assert np.all(np.abs(got[kernel] - ref_mem) <= 2e-6 * scale), kernel
+        if shape == 0:
+            assert np.array_equal(got[kernel], got[kernel].transpose(0, 2, 1)), kernel
+    assert np.array_equal(got[1], got[2])
+    for d in (dX, dY, dD):
+        d.free()
+
+
 @pytest.mark.parametrize("k", [500, 700, 1300])      # 64 / 32 / 16 rows of Z per workgroup in the rotation replay
 def test_general_eigen_engine_time_and_orthogonality(L, k):
     """the two-phase closure path (thip_eig_decompose -> host closure -> thip_eig_rebuild): eigenvalues against numpy,

@@ -120,6 +120,7 @@ PROTOTYPES = {
     "thip_solver_destroy": (_i, [_vp]),
     "thip_solver_passes": (_i, [_vp, C.POINTER(_i), C.POINTER(_sz)]),
     "thip_test_gemm_sym": (_i, [_i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
+    "thip_test_gemm_chain": (_i, [_i, _i, _i, _i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_solver_gemv_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),
     "thip_prof_enable": (_i, [_i]),
     "thip_prof_read": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

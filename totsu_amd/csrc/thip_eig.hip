@@ -612,6 +612,7 @@ __global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const fl
     }
 }
 
+static int g_force_kernel = 0;     // thip_test_gemm_chain: 1 = one tile per workgroup, 2 = 32 x 64 blocks, 0 = by tile count
 // gen == false: C = alpha X Y^T + beta D + gamma I (symmetric result); gen == true: C = alpha X Y + ... (X symmetric)
 int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, const float *Y, float beta, const float *D,
          float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0)
@@ -624,7 +625,7 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
     static const int mode = getenv("THIP_GEMM_MODE") ? atoi(getenv("THIP_GEMM_MODE")) : 3;
     const int nt = ld / GT;
     const int tiles = (gen ? nt * nt : nt * (nt + 1) / 2) * nb;
-    const bool pairs = mode >= 3 && tiles > ctx().num_cu && nt % 2 == 0;
+    const bool pairs = g_force_kernel != 0 ? g_force_kernel == 2 && nt % 2 == 0 : mode >= 3 && tiles > ctx().num_cu && nt % 2 == 0;
     int npair = 0;
     for (int bi = 0; bi < nt; ++bi) npair += bi / 2 + 1;
 #define THIP_GEMM_PRE4(KW)                                                                                                  \
@@ -1237,6 +1238,18 @@ int thip_test_gemm_sym(int n, int ld, float alpha, const float *A, const float *
     THIP_NEED_INIT();
     // gen form: C = alpha A B + beta D + gamma I with A symmetric, B arbitrary
     return gemm(ctx().stream, true, n, ld, alpha, A, B, beta, D, gamma, C, nullptr);
+}
+
+int thip_test_gemm_chain(int shape, int kernel, int n, int ld, int nb, float alpha, const float *X, const float *Y,
+                         float beta, const float *D, float gamma, float *C)
+{
+    THIP_NEED_INIT();
+    if (ld <= 0 || ld % 64 != 0 || ld > 512 || n < 0 || n > ld || nb < 1 || kernel < 0 || kernel > 2 || (shape != 0 && shape != 1))
+        return fail(THIP_E_INVALID, "thip_test_gemm_chain: ld a multiple of 64 up to 512, n <= ld, nb >= 1", __FILE__, __LINE__);
+    g_force_kernel = kernel;
+    const int rc = gemm(ctx().stream, shape == 1, n, ld, alpha, X, Y, beta, D, gamma, C, nullptr, nb, (size_t)ld * ld);
+    g_force_kernel = 0;
+    return rc;
 }
 
 size_t thip_map_eig_worklen(size_t n)
