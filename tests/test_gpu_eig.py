@@ -36,7 +36,7 @@ def _rand_sym(k, seed, rank_def=False):
     return s
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 9, 33, 64, 65, 100, 200, 500])
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 6, 9, 20, 21, 32, 33, 48, 63, 64, 65, 100, 200, 500])
 @pytest.mark.parametrize("rank_def", [False, True])
 def test_psd_projection(L, k, rank_def):
     from totsu_amd import ConePSD
@@ -60,6 +60,81 @@ def test_psd_projection(L, k, rank_def):
     sl.drop()
     cone.drop()
     assert np.abs(again - got).max() <= 2e-5 * np.linalg.norm(x)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 6, 12, 40, 64, 100])        # one-workgroup polar chain / chain of launches
+def test_psd_projection_at_every_scale_and_on_special_matrices(L, k):
+    """scale invariance down to subnormal entries (a slack block on its way to zero gets there: the reciprocal of a
+    subnormal norm is infinite, the squares of 1e-25 are not f32 numbers) and up to 1e15, and the matrices a converged
+    iterate produces: zero, +-identity, rank one of either sign, diagonal"""
+    from totsu_amd import ConePSD
+    rng = np.random.default_rng(k)
+    b = rng.standard_normal((k, k))
+    s = (b + b.T) / 2
+    v = rng.standard_normal((k, 1))
+    e0 = np.zeros((k, k))
+    e0[0, 0] = 1.0
+    cases = [("random", s, 2e-5), ("1e-18", s * 1e-18, 2e-5), ("1e-25", s * 1e-25, 2e-5), ("1e15", s * 1e15, 2e-5),
+             ("subnormal 1e-40", s * 1e-40, 1e-3), ("subnormal 3e-44", s * 3e-44, 0.2),
+             ("zero", np.zeros((k, k)), 0.0), ("identity", np.eye(k), 2e-5), ("-identity", -np.eye(k), 2e-5),
+             ("rank one", v @ v.T, 2e-5), ("-rank one", -(v @ v.T), 2e-5), ("diagonal", np.diag(rng.standard_normal(k)), 2e-5),
+             ("e0 e0^T", e0, 2e-5)]
+    w = np.zeros(ConePSD.query_worklen(L, k * (k + 1) // 2), dtype=np.float32)
+    for tag, mat, tol in cases:
+        x = _packed(mat)
+        ev, z = np.linalg.eigh(mat.astype(np.float64))
+        ref = _packed((z * np.maximum(ev, 0)) @ z.T).astype(np.float64)
+        cone = ConePSD(L, w, 1e-12)
+        sl = L.Sl.new_mut(x.copy())
+        assert cone.proj(False, sl)
+        got = sl.get_ref().copy()
+        sl.drop()
+        cone.drop()
+        assert np.all(np.isfinite(got)), tag
+        assert np.abs(got - ref).max() <= tol * np.linalg.norm(x.astype(np.float64)), (tag, np.abs(got - ref).max())
+
+
+def test_psd_projection_band_edge_regression(L):
+    """tests/golden/psd_k20_band_edge_iterate.npy: the x_y / x_s blocks of iteration 122 of the (12, 20) synthetic SDP,
+    captured from this library's own loop.  A singular value of the second one reaches the interior maximum of the
+    lifting polynomial; with a polynomial that returned values up to the edge of what it accepts (p(1.7) = 1.7, slope 11)
+    round-off pushed it over the edge and the projection came back as NaN.  Also a sweep of spectra placed ON the
+    polynomial's extrema and edges, through the one-workgroup kernel (k <= 64) and the chain of launches."""
+    import os
+    from totsu_amd import ConePSD
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "psd_k20_band_edge_iterate.npy"))
+    k = 20
+    w = np.zeros(ConePSD.query_worklen(L, k * (k + 1) // 2), dtype=np.float32)
+    for z in range(2):
+        ref = O.proj(O.CONE_PSD, d[z].astype(np.float64), use_ql=True)
+        cone = ConePSD(L, w, 1e-12)
+        sl = L.Sl.new_mut(d[z].copy())
+        assert cone.proj(False, sl)
+        got = sl.get_ref().copy()
+        sl.drop()
+        cone.drop()
+        assert np.all(np.isfinite(got))
+        assert np.abs(got - ref).max() <= 2e-6 * np.linalg.norm(d[z])
+    # spectra on a fine grid of relative magnitudes: every |lambda| / ||M||_F between 1e-7 and 1 gets hit closely,
+    # including the values that map onto the polynomial's extrema after one or more steps
+    rng = np.random.default_rng(5)
+    for k in (24, 72):
+        w = np.zeros(ConePSD.query_worklen(L, k * (k + 1) // 2), dtype=np.float32)
+        q, _ = np.linalg.qr(rng.standard_normal((k, k)))
+        for trial in range(150):
+            mag = np.exp(rng.uniform(np.log(1e-6), 0.0, k)) * rng.choice([-1.0, 1.0], k)
+            mag[0] = 1.0                                        # one dominant value fixes the scale
+            mat = (q * mag) @ q.T
+            x = _packed(mat)
+            ref = _packed((q * np.maximum(mag, 0)) @ q.T).astype(np.float64)
+            cone = ConePSD(L, w, 1e-12)
+            sl = L.Sl.new_mut(x.copy())
+            assert cone.proj(False, sl)
+            got = sl.get_ref().copy()
+            sl.drop()
+            cone.drop()
+            assert np.all(np.isfinite(got)), (k, trial)
+            assert np.abs(got - ref).max() <= 2e-6 * np.linalg.norm(x), (k, trial, np.abs(got - ref).max())
 
 
 def test_cone_psd_kat(L):

@@ -75,3 +75,32 @@ for it in range(5):
 s=4.0616
 import math
 print("lifting steps from 1e-7*1.7:", math.log(0.3/(1.7e-7))/math.log(s))
+# ---- lifting polynomial with a MARGIN between what it accepts and what it returns.  With p <= hi on (0, hi] the LP
+# solution has p(hi) = hi: an unstable fixed point (p'(1.7) = 11).  A singular value that reaches the interior maximum
+# lands on it, and round-off decides whether it leaves downwards or upwards -- upwards is an overflow within 7 steps
+# (seen: a 20 x 20 iterate of tests/test_gpu_solver.py::test_synth_sdp_converges_to_oracle_objective).  So: accept
+# (0, hi_in], return values in [lo_out, hi_out] with hi_out < hi_in and lo_out > lo_in.
+print("---- lifting polynomial with margin")
+def feasible_m(lo_in, lo_out, hi_in, hi_out, s):
+    V = lambda x: np.stack([x, x**3, x**5], 1)
+    x1 = np.linspace(0, hi_in, 6001)[1:]
+    A = [V(x1)]; b = [np.full(len(x1), hi_out)]                                   # p <= hi_out on (0, hi_in]
+    x2 = np.linspace(lo_in / s, hi_in, 6001); A.append(-V(x2)); b.append(np.full(len(x2), -lo_out))   # p >= lo_out
+    x3 = np.linspace(0, lo_in / s, 3001)[1:]; A.append(-V(x3)); b.append(-s * x3)  # p >= s x below
+    A = np.concatenate(A); b = np.concatenate(b)
+    r = linprog(np.zeros(3), A_ub=A, b_ub=b, bounds=[(None, None)] * 3, method="highs")
+    return (r.status == 0), (r.x if r.status == 0 else None)
+def best_m(lo_in, lo_out, hi_in, hi_out):
+    a, bb = 1.5, 20.0; co = None
+    for _ in range(50):
+        m = (a + bb) / 2
+        ok, c = feasible_m(lo_in, lo_out, hi_in, hi_out, m)
+        if ok: a = m; co = c
+        else: bb = m
+    return a, co
+for lo_in, lo_out, hi_in, hi_out in [(0.3, 0.3, 1.7, 1.7), (0.3, 0.303, 1.7, 1.69), (0.3, 0.305, 1.7, 1.68), (0.3, 0.31, 1.7, 1.67), (0.3, 0.32, 1.7, 1.65)]:
+    s, co = best_m(lo_in, lo_out, hi_in, hi_out)
+    xs = np.linspace(lo_in, hi_in, 200001); p = co[0] * xs + co[1] * xs**3 + co[2] * xs**5
+    dp = co[0] + 3 * co[1] * hi_in**2 + 5 * co[2] * hi_in**4
+    print("accept (0, %.2f], return [%.2f, %.2f] (below %.2f: gain): s = %.4f coef %.8f %.8f %.8f  image of [lo_in, hi_in] = [%.5f, %.5f]  p'(hi_in) = %.2f  steps from 1.7e-7: %.2f"
+          % (hi_in, lo_out, hi_out, lo_in, s, co[0], co[1], co[2], p.min(), p.max(), dp, math.log(lo_in / 1.7e-7) / math.log(s)))

@@ -1,6 +1,6 @@
 """Time of ConePSD::proj through the matrix-core polar chain (thip_proj_psd) at k = 128 / 256 / 500, and its error
 against numpy's eigh.  THIP_GEMM_MODE=0 selects the slab-prefetch GEMM (round 1), default = loads-up-front GEMM.
-Usage: [THIP_GEMM_MODE=0] python tools/psd_chain_time.py"""
+Usage: [THIP_GEMM_MODE=0] [THIP_POLAR_SMALL=0] python tools/psd_chain_time.py [k ...]"""
 import os
 import sys
 import time
@@ -12,7 +12,8 @@ from totsu_amd import F32HIP as L, _lib     # noqa: E402
 
 _lib.init()
 rng = np.random.default_rng(0)
-for k in (128, 256, 500):
+KS = [int(a) for a in sys.argv[1:]] or [128, 256, 500]
+for k in KS:
     b = rng.standard_normal((k, k))
     s = (b + b.T) / 2
     w, z = np.linalg.eigh(s)

@@ -29,7 +29,9 @@ namespace {
 
 constexpr int BLK = 256;
 constexpr int SMALL_N = 64;          // largest order the single-workgroup Jacobi kernel holds in LDS
-constexpr int POLAR_MIN_N = 20;      // from here on the MFMA polar chain (~0.3 ms flat) beats it for PSD projections
+constexpr int POLAR_MIN_N = 20;      // from here on the MFMA polar chain (~0.2 ms flat) beats it for PSD projections
+constexpr int POLAR_SMALL_MIN_N = 1; // orders 1 .. 64: the polar chain inside one workgroup, 29-75 us (Jacobi: 16-21 us up to order 4, 31 at 5,
+                                     // 200 at 16 -- and not scale invariant: its column products underflow for entries of 1e-18)
 constexpr int MAX_SWEEPS = 18;
 
 __host__ __device__ inline size_t np_of(size_t n) { return (n + 63) / 64 * 64; }
@@ -82,8 +84,8 @@ __global__ void unpack_k(int n, int ld, const float *__restrict__ packed, int ha
     if (stop != nullptr && *stop != 0) return;
     packed += (ptrdiff_t)blockIdx.z * ps; G += blockIdx.z * ws; part += blockIdx.z * ws;
     if (V) V += blockIdx.z * ws;
-    __shared__ float sh[16];
-    float acc = 0.0f;
+    __shared__ double shd[16];
+    double acc = 0.0;
     const size_t tot = (size_t)ld * ld;
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) {
         const int r = (int)(i % ld), c = (int)(i / ld);
@@ -92,13 +94,15 @@ __global__ void unpack_k(int n, int ld, const float *__restrict__ packed, int ha
             const int lo = r < c ? r : c, hi = r < c ? c : r;
             v = packed[(size_t)hi * (hi + 1) / 2 + lo];
             if (r == c && has_scale) v *= scale;
-            acc = fmaf(v, v, acc);
+            acc += (double)v * (double)v;
         }
         G[i] = v;
         if (V) V[i] = (r == c && r < n) ? 1.0f : 0.0f;
     }
-    acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+    // the block's 2-norm, not its sum of squares: representable in f32 whenever the entries are (the squares of a
+    // block of 1e-25s are not, and a norm of 0 for a nonzero matrix makes the projection return M / 2)
+    acc = block_sum_d(acc, shd);
+    if (threadIdx.x == 0) part[blockIdx.x] = (float)sqrt(acc);
 }
 
 // sc[0] = ||M||_F, sc[1] = sigma = 1.01 ||M||_F + tiny ; G += sigma I (when shift != 0)
@@ -109,7 +113,7 @@ __global__ void shift_k(int n, int ld, int np, const float *__restrict__ part, f
     part += blockIdx.z * ws; G += blockIdx.z * ws; sc += blockIdx.z * ws;
     __shared__ double shd[16];
     double acc = 0.0;
-    for (int k = threadIdx.x; k < np; k += blockDim.x) acc += (double)part[k];
+    for (int k = threadIdx.x; k < np; k += blockDim.x) acc += (double)part[k] * (double)part[k];
     acc = block_sum_d(acc, shd);
     const float fro = (float)sqrt(acc);
     const float sigma = 1.01f * fro + 1.0e-30f;
@@ -592,9 +596,9 @@ __global__ void scale_by_fro_k(size_t tot, const float *__restrict__ M, const fl
 {
     if (stop != nullptr && *stop != 0) return;
     M += blockIdx.z * ws; sc += blockIdx.z * ws; S += blockIdx.z * ws;
+    // a division per element: 1 / f overflows for a subnormal norm, and 0 * inf would poison the iterate
     const float f = sc[0];
-    const float inv = f > 0.0f ? 1.0f / f : 0.0f;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) S[i] = M[i] * inv;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) S[i] = f > 0.0f ? M[i] / f : 0.0f;
 }
 
 // packed(r,c) = (M + MS)(r,c) / 2 symmetrised, diag / scale
@@ -609,6 +613,113 @@ __global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const fl
         float v = 0.5f * (M[o1] + 0.5f * (MS[o1] + MS[o2]));
         if (r == c && has_scale) v = v / scale;
         packed[(size_t)c * (c + 1) / 2 + r] = v;
+    }
+}
+
+// The whole PSD projection of a matrix of order n <= 64 in ONE workgroup, one launch for a batch (blockIdx.x = item):
+// unpack, Frobenius norm, the 45-product polar chain of polar_project() below and the symmetrised pack, all operands in
+// LDS.  At these orders the chain of launches is nothing but launch boundaries (45 x 4.4 us = 0.2 ms at any n <= 128;
+// the reference's own SDP example, partitioning_sdp, has order 48), while the products themselves are (n / 2) MFMAs per
+// wave: four waves, one 32 x 32 quadrant of the result each (one MFMA wave per SIMD), K runs over the
+// n columns that are not padding.  Matrices are row-major with a pitch of 65 words: the a operand (a row per lane) and
+// the b operand of either shape (a row per lane for X X^T, consecutive words for Sym * Gen) are conflict-free.
+// Y = S S^T and T = c Y Y + b Y + a I come out bitwise symmetric (the mirrored element sums the same products in the
+// same order), Z = T S is the left-multiplied update.
+constexpr int PSN = 64, PSP = 65;
+typedef float ps_mat[PSN][PSP];
+
+// C = alpha * (FORM 0: A B^T, FORM 1: A B) + beta * D + gamma * I_n on this wave's quadrant; nk = number of MFMA steps
+template <int FORM>
+__device__ __forceinline__ void ps_gemm(ps_mat &C, const ps_mat &A, const ps_mat &B, const ps_mat *D, float alpha, float beta,
+                                        float gamma, int n, int nk, int qi, int qj, int h, int li, bool live)
+{
+    if (live) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float *pa = &A[32 * qi + li][h];
+        const float *pb = FORM == 0 ? &B[32 * qj + li][h] : &B[h][32 * qj + li];
+        constexpr int SB = FORM == 0 ? 2 : 2 * PSP;
+        // nk is a multiple of 4 (columns n .. 63 are zero padding inside the arrays)
+        for (int s0 = 0; s0 < nk; s0 += 4) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = pa[2 * (s0 + u)]; bv[u] = pb[SB * (s0 + u)]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * qi + (r & 3) + 8 * (r >> 2) + 4 * h, j = 32 * qj + li;
+            float v = alpha * acc[r];
+            if (D != nullptr) v = fmaf(beta, (*D)[i][j], v);
+            if (i == j && i < n) v += gamma;
+            C[i][j] = v;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void polar_small_k(int n, float *__restrict__ packed, int has_scale, float scale,
+                                                     const int *__restrict__ stop, ptrdiff_t ps)
+{
+    if (stop != nullptr && *stop != 0) return;
+    packed += (ptrdiff_t)blockIdx.x * ps;
+    __shared__ ps_mat M, S0, S1, Y, T;
+    __shared__ double shd[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = wave >> 1, qj = wave & 1, h = lane >> 5, li = lane & 31;
+    // a quadrant that is all padding is neither computed nor read (its operands' padding stays zero from here on)
+    const bool live = 32 * qi < n && 32 * qj < n;
+    const int nk = ((n + 1) / 2 + 3) / 4 * 4;
+    double acc = 0.0;
+    for (int e = tid; e < PSN * PSN; e += 256) {
+        const int r = e & 63, c = e >> 6;
+        float v = 0.0f;
+        if (r < n && c < n) {
+            const int lo = r < c ? r : c, hi = r < c ? c : r;
+            v = packed[(size_t)hi * (hi + 1) / 2 + lo];
+            if (r == c && has_scale) v *= scale;
+            acc += (double)v * (double)v;
+        }
+        M[r][c] = v;
+        S1[r][c] = 0.0f; Y[r][c] = 0.0f; T[r][c] = 0.0f;
+    }
+    acc = block_sum_d(acc, shd);
+    const float fro = (float)sqrt(acc);
+    // a DIVISION per element, not a multiplication by 1 / fro: the reciprocal of a subnormal norm is infinite (a slack
+    // block on its way to zero gets there), and 0 * inf poisons the iterate.  The exact zero matrix stays zero.
+    for (int e = tid; e < PSN * PSN; e += 256) S0[e >> 6][e & 63] = fro > 0.0f ? M[e >> 6][e & 63] / fro : 0.0f;
+    __syncthreads();
+    ps_mat *S = &S0, *Z = &S1;
+    // the schedule of polar_project(): 11 lifting quintics (the first on 1.7 x), 3 minimax quintics, 1 Newton-Schulz
+    const float LIFT[3] = { 4.02942496f, -3.82532605f, 0.95951948f };
+    const float TAILC[3][3] = {
+        { 2.647997920f, -1.945904487f, 0.440483961f },
+        { 1.967564378f, -1.351306898f, 0.386705679f },
+        { 1.884943743f, -1.269148602f, 0.384197480f },
+    };
+    for (int it = 0; it < 14; ++it) {
+        float a, b, c;
+        if (it == 0) { a = LIFT[0] * 1.7f; b = LIFT[1] * 4.913f; c = LIFT[2] * 14.19857f; }
+        else if (it < 11) { a = LIFT[0]; b = LIFT[1]; c = LIFT[2]; }
+        else { a = TAILC[it - 11][0]; b = TAILC[it - 11][1]; c = TAILC[it - 11][2]; }
+        ps_gemm<0>(Y, *S, *S, nullptr, 1.0f, 0.0f, 0.0f, n, nk, qi, qj, h, li, live);
+        ps_gemm<1>(T, Y, Y, &Y, c, b, a, n, nk, qi, qj, h, li, live);
+        ps_gemm<1>(*Z, T, *S, nullptr, 1.0f, 0.0f, 0.0f, n, nk, qi, qj, h, li, live);
+        ps_mat *t = S; S = Z; Z = t;
+    }
+    ps_gemm<0>(T, *S, *S, nullptr, -0.5f, 0.0f, 1.5f, n, nk, qi, qj, h, li, live);
+    ps_gemm<1>(*Z, T, *S, nullptr, 1.0f, 0.0f, 0.0f, n, nk, qi, qj, h, li, live);
+    { ps_mat *t = S; S = Z; Z = t; }
+    ps_gemm<1>(*Z, M, *S, nullptr, 1.0f, 0.0f, 0.0f, n, nk, qi, qj, h, li, live);       // M sign(M)
+    for (int e = tid; e < PSN * PSN; e += 256) {
+        const int r = e & 63, c = e >> 6;
+        if (r <= c && c < n) {
+            float v = 0.5f * (M[r][c] + 0.5f * ((*Z)[r][c] + (*Z)[c][r]));
+            if (r == c && has_scale) v = v / scale;
+            packed[(size_t)c * (c + 1) / 2 + r] = v;
+        }
     }
 }
 
@@ -1169,15 +1280,19 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
     //   Y = S S^T ;  T = c Y Y^T + b Y + a I ;  S <- T S
     // Phase 1 (lifting, 11 steps): ONE polynomial, the LP solution of "maximise the gain s subject to p(x) >= s x on
     // [0, lo / s], lo <= p(x) <= hi on [lo / s, hi]" for the band [lo, hi] = [0.3, 1.7]: every singular value below the
-    // band grows by s = 4.06 per step and a value inside the band STAYS inside (tools/polar_coeffs.py).  Step 0 takes
+    // band grows by s per step and a value inside the band STAYS inside (tools/polar_coeffs.py).  Step 0 takes
     // x <= 1 and may scale its argument by 1.7.  Relative eigenvalues >= 1e-7 are inside the band after 11 steps.
+    // The polynomial ACCEPTS (0, 1.7] and RETURNS [0.305, 1.68] (gain s = 3.94 below 0.3): with "returns <= 1.7" the LP
+    // solution has p(1.7) = 1.7, a fixed point with p' = 11 -- a singular value that reaches the interior maximum
+    // lands on it and round-off decides which way it leaves; upwards is an overflow within seven steps (it happened:
+    // a 20 x 20 iterate of test_synth_sdp_converges_to_oracle_objective, through the one-workgroup kernel's order of sums).
     // (The unconstrained minimax composition -- "Polar Express", Amsel et al. 2025 -- is two steps shorter, but its
     // early polynomials equioscillate between ~0 and 2: an already-large eigenvalue can be thrown back to 1e-6, below
     // the absolute round-off of the evaluation.  Measured: 3e-5 |X| error on rank-deficient inputs instead of 2e-8.)
     // Phase 2 (3 steps): minimax polynomials of 1 on [0.3, 1.7] -> [0.73, 1.27] -> [0.985, 1.015] -> 1 +- 2e-5.
     // Phase 3: one Newton-Schulz step x (3 - x^2) / 2 squares the remaining error.  14 x 3 + 2 = 44 GEMMs (round 1: 13
     // steps of 3.4445 x - 4.7750 x^3 + 2.0315 x^5, band [0.7, 1.2], and 5 Newton-Schulz steps = 49).
-    static const float LIFT[3] = { 4.08273337f, -3.88521879f, 0.97526957f };
+    static const float LIFT[3] = { 4.02942496f, -3.82532605f, 0.95951948f };
     static const float TAILC[3][3] = {
         { 2.647997920f, -1.945904487f, 0.440483961f },
         { 1.967564378f, -1.351306898f, 0.386705679f },
@@ -1218,6 +1333,14 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
     const size_t ws = thip_map_eig_worklen(n);
     if (worklen < ws * (size_t)nbatch) return fail(THIP_E_WORK, "map_eig work too short", __FILE__, __LINE__);
     const Work k = carve(work, n);
+    // THIP_POLAR_SMALL=0: the chain of launches at every order; THIP_POLAR_SMALL_MIN=n: lowest order of the one-workgroup form
+    static const int small_on = getenv("THIP_POLAR_SMALL") ? atoi(getenv("THIP_POLAR_SMALL")) : 1;
+    static const int small_min = getenv("THIP_POLAR_SMALL_MIN") ? atoi(getenv("THIP_POLAR_SMALL_MIN")) : POLAR_SMALL_MIN_N;
+    if (map_kind == 0 && small_on && n <= PSN && (int)n >= small_min) {
+        hipLaunchKernelGGL(polar_small_k, dim3(nbatch), dim3(256), 0, st, (int)n, packed, has_scale, scale_diag, stop, pstride);
+        THIP_LAUNCH_CHECK();
+        return 0;
+    }
     if (map_kind == 0 && n > POLAR_MIN_N) {
         return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride);
     }
