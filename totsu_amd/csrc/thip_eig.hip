@@ -629,9 +629,9 @@ constexpr int PSN = 64, PSP = 65;
 typedef float ps_mat[PSN][PSP];
 
 // C = alpha * (FORM 0: A B^T, FORM 1: A B) + beta * D + gamma * I_n on this wave's quadrant; nk = number of MFMA steps
-template <int FORM>
+template <int FORM, int NK>
 __device__ __forceinline__ void ps_gemm(ps_mat &C, const ps_mat &A, const ps_mat &B, const ps_mat *D, float alpha, float beta,
-                                        float gamma, int n, int nk, int qi, int qj, int h, int li, bool live)
+                                        float gamma, int n, int qi, int qj, int h, int li, bool live)
 {
     if (live) {
         f32x16 acc;
@@ -640,14 +640,13 @@ __device__ __forceinline__ void ps_gemm(ps_mat &C, const ps_mat &A, const ps_mat
         const float *pa = &A[32 * qi + li][h];
         const float *pb = FORM == 0 ? &B[32 * qj + li][h] : &B[h][32 * qj + li];
         constexpr int SB = FORM == 0 ? 2 : 2 * PSP;
-        // nk is a multiple of 4 (columns n .. 63 are zero padding inside the arrays)
-        for (int s0 = 0; s0 < nk; s0 += 4) {
-            float av[4], bv[4];
+        // NK MFMA steps, a multiple of 4 (columns n .. 63 are zero padding inside the arrays), unrolled: the LDS reads
+        // of later steps are in flight under the MFMAs of earlier ones
+        float av[NK], bv[NK];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { av[u] = pa[2 * (s0 + u)]; bv[u] = pb[SB * (s0 + u)]; }
+        for (int u = 0; u < NK; ++u) { av[u] = pa[2 * u]; bv[u] = pb[SB * u]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-        }
+        for (int u = 0; u < NK; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 32 * qi + (r & 3) + 8 * (r >> 2) + 4 * h, j = 32 * qj + li;
@@ -660,6 +659,7 @@ __device__ __forceinline__ void ps_gemm(ps_mat &C, const ps_mat &A, const ps_mat
     __syncthreads();
 }
 
+template <int NK>
 __global__ __launch_bounds__(256) void polar_small_k(int n, float *__restrict__ packed, int has_scale, float scale,
                                                      const int *__restrict__ stop, ptrdiff_t ps)
 {
@@ -671,7 +671,6 @@ __global__ __launch_bounds__(256) void polar_small_k(int n, float *__restrict__ 
     const int qi = wave >> 1, qj = wave & 1, h = lane >> 5, li = lane & 31;
     // a quadrant that is all padding is neither computed nor read (its operands' padding stays zero from here on)
     const bool live = 32 * qi < n && 32 * qj < n;
-    const int nk = ((n + 1) / 2 + 3) / 4 * 4;
     double acc = 0.0;
     for (int e = tid; e < PSN * PSN; e += 256) {
         const int r = e & 63, c = e >> 6;
@@ -704,15 +703,15 @@ __global__ __launch_bounds__(256) void polar_small_k(int n, float *__restrict__ 
         if (it == 0) { a = LIFT[0] * 1.7f; b = LIFT[1] * 4.913f; c = LIFT[2] * 14.19857f; }
         else if (it < 11) { a = LIFT[0]; b = LIFT[1]; c = LIFT[2]; }
         else { a = TAILC[it - 11][0]; b = TAILC[it - 11][1]; c = TAILC[it - 11][2]; }
-        ps_gemm<0>(Y, *S, *S, nullptr, 1.0f, 0.0f, 0.0f, n, nk, qi, qj, h, li, live);
-        ps_gemm<1>(T, Y, Y, &Y, c, b, a, n, nk, qi, qj, h, li, live);
-        ps_gemm<1>(*Z, T, *S, nullptr, 1.0f, 0.0f, 0.0f, n, nk, qi, qj, h, li, live);
+        ps_gemm<0, NK>(Y, *S, *S, nullptr, 1.0f, 0.0f, 0.0f, n, qi, qj, h, li, live);
+        ps_gemm<1, NK>(T, Y, Y, &Y, c, b, a, n, qi, qj, h, li, live);
+        ps_gemm<1, NK>(*Z, T, *S, nullptr, 1.0f, 0.0f, 0.0f, n, qi, qj, h, li, live);
         ps_mat *t = S; S = Z; Z = t;
     }
-    ps_gemm<0>(T, *S, *S, nullptr, -0.5f, 0.0f, 1.5f, n, nk, qi, qj, h, li, live);
-    ps_gemm<1>(*Z, T, *S, nullptr, 1.0f, 0.0f, 0.0f, n, nk, qi, qj, h, li, live);
+    ps_gemm<0, NK>(T, *S, *S, nullptr, -0.5f, 0.0f, 1.5f, n, qi, qj, h, li, live);
+    ps_gemm<1, NK>(*Z, T, *S, nullptr, 1.0f, 0.0f, 0.0f, n, qi, qj, h, li, live);
     { ps_mat *t = S; S = Z; Z = t; }
-    ps_gemm<1>(*Z, M, *S, nullptr, 1.0f, 0.0f, 0.0f, n, nk, qi, qj, h, li, live);       // M sign(M)
+    ps_gemm<1, NK>(*Z, M, *S, nullptr, 1.0f, 0.0f, 0.0f, n, qi, qj, h, li, live);       // M sign(M)
     for (int e = tid; e < PSN * PSN; e += 256) {
         const int r = e & 63, c = e >> 6;
         if (r <= c && c < n) {
@@ -1337,7 +1336,19 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
     static const int small_on = getenv("THIP_POLAR_SMALL") ? atoi(getenv("THIP_POLAR_SMALL")) : 1;
     static const int small_min = getenv("THIP_POLAR_SMALL_MIN") ? atoi(getenv("THIP_POLAR_SMALL_MIN")) : POLAR_SMALL_MIN_N;
     if (map_kind == 0 && small_on && n <= PSN && (int)n >= small_min) {
-        hipLaunchKernelGGL(polar_small_k, dim3(nbatch), dim3(256), 0, st, (int)n, packed, has_scale, scale_diag, stop, pstride);
+        // NK = MFMA steps per product: ceil(n / 2) rounded up to a multiple of 4
+#define THIP_PS(NK) hipLaunchKernelGGL(polar_small_k<NK>, dim3(nbatch), dim3(256), 0, st, (int)n, packed, has_scale, scale_diag, stop, pstride)
+        switch (((int)n + 7) / 8) {
+        case 0: case 1: THIP_PS(4); break;
+        case 2: THIP_PS(8); break;
+        case 3: THIP_PS(12); break;
+        case 4: THIP_PS(16); break;
+        case 5: THIP_PS(20); break;
+        case 6: THIP_PS(24); break;
+        case 7: THIP_PS(28); break;
+        default: THIP_PS(32); break;
+        }
+#undef THIP_PS
         THIP_LAUNCH_CHECK();
         return 0;
     }
