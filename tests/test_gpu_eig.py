@@ -94,6 +94,34 @@ def test_psd_projection_at_every_scale_and_on_special_matrices(L, k):
         assert np.abs(got - ref).max() <= tol * np.linalg.norm(x.astype(np.float64)), (tag, np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("k", [3, 8, 24, 32, 40, 100])          # one-workgroup Jacobi up to 32, Householder + QL above
+@pytest.mark.parametrize("scale", [1e-18, 1.0, 1e15])
+def test_map_eig_closure_path_is_scale_invariant(L, k, scale):
+    """the host-closure path (linalg_ex.rs:64-65) at small and large scales: eigenvalues seen by the closure against
+    numpy, and the rebuilt matrix with a closure that keeps the upper half of the spectrum"""
+    rng = np.random.default_rng(100 + k)
+    b = rng.standard_normal((k, k))
+    s = (b + b.T) / 2 * scale
+    w_ref, z = np.linalg.eigh(s.astype(np.float32).astype(np.float64))
+    cut = np.median(w_ref)
+    packed = np.array([s[r, c] for c in range(k) for r in range(c + 1)], dtype=np.float32)
+    work = L.Sl.new_mut(np.zeros(L.map_eig_worklen(k), dtype=np.float32))
+    seen = []
+    sl = L.Sl.new_mut(packed.copy())
+    L.map_eig(sl, None, 1e-12, work, lambda e: (seen.append(e), e if e > cut else None)[1])
+    got = sl.get_ref().copy()
+    sl.drop()
+    work.drop()
+    assert len(seen) == k and np.all(np.isfinite(got))
+    assert np.abs(np.sort(np.array(seen, dtype=np.float64)) - w_ref).max() <= 2e-5 * np.abs(w_ref).max()
+    want = (z * np.where(w_ref > cut, w_ref, 0.0)) @ z.T
+    wp = np.array([want[rr, c] for c in range(k) for rr in range(c + 1)])
+    # eigenvalues next to the cut may fall on either side of it: compare away from the cut by the projector's slack
+    gap = np.abs(w_ref - cut).min()
+    if gap > 1e-4 * np.abs(w_ref).max():
+        assert np.abs(got - wp).max() <= 1e-4 * np.abs(w_ref).max()
+
+
 def test_psd_projection_band_edge_regression(L):
     """tests/golden/psd_k20_band_edge_iterate.npy: the x_y / x_s blocks of iteration 122 of the (12, 20) synthetic SDP,
     captured from this library's own loop.  A singular value of the second one reaches the interior maximum of the

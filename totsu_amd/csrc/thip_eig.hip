@@ -122,6 +122,15 @@ __global__ void shift_k(int n, int ld, int np, const float *__restrict__ part, f
         for (int i = threadIdx.x; i < n; i += blockDim.x) G[(size_t)i * ld + i] += sigma;
 }
 
+// G <- G / sigma = M / sigma + I: the one-sided Jacobi works on products of columns, which underflow for a matrix of
+// 1e-18s and overflow for one of 1e+20s; normalised, every entry is O(1) whatever the scale of M (eigvals_k undoes it)
+__global__ void normalise_k(size_t tot, float *__restrict__ G, const float *__restrict__ sc, const int *__restrict__ stop)
+{
+    if (stop != nullptr && *stop != 0) return;
+    const float sigma = sc[1];
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) G[i] = G[i] / sigma;
+}
+
 // n <= 64: whole decomposition in one workgroup, G and V staged in LDS
 __global__ __launch_bounds__(BLK) void jacobi_small_k(int n, int ld, float *__restrict__ Gg, float *__restrict__ Vg,
                                                      const int *__restrict__ stop)
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(BLK) void eigvals_k(int n, int ld, const float *__r
     }
     acc = wave_sum(acc); nv = wave_sum(nv);
     if (lane == 0) {
-        const float lam = acc / nv - sc[1];
+        const float lam = (acc / nv - 1.0f) * sc[1];           // G = M / sigma + I (normalise_k)
         w[i] = lam;
         // map_kind 0: e > 0 -> e (cone_psd.rs:69-76); 1: e > 0 -> sqrt(e) (matbuild/mod.rs:231-238); < 0: host-supplied
         if (map_kind == 0) e[i] = lam > 0.0f ? lam : 0.0f;
@@ -1111,6 +1120,7 @@ int decompose(hipStream_t st, size_t n, const float *packed, int has_scale, floa
     const unsigned g = grid_for((size_t)ld * ld, BLK, 512);
     hipLaunchKernelGGL(unpack_k, dim3(g), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, k.G, k.V, k.part, stop);
     hipLaunchKernelGGL(shift_k, dim3(1), dim3(BLK), 0, st, ni, ld, (int)g, k.part, k.G, k.sc, 1, stop);
+    hipLaunchKernelGGL(normalise_k, dim3(g), dim3(BLK), 0, st, (size_t)ld * ld, k.G, k.sc, stop);
     if (n <= SMALL_N) {
         hipLaunchKernelGGL(jacobi_small_k, dim3(1), dim3(BLK), 0, st, ni, ld, k.G, k.V, stop);
     } else {
