@@ -89,11 +89,18 @@ __device__ __forceinline__ float elt_f32(f16elt v) { return (float)v; }
 __device__ __forceinline__ unsigned raw16(bf16raw v) { return v; }
 __device__ __forceinline__ unsigned raw16(f16elt v) { return (unsigned)__builtin_bit_cast(unsigned short, v); }
 
-template <typename E, int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS, bool NT, bool FULL>
+// FULL: every load of the tile is in bounds, no guards.  CLAMP (with FULL): the same unguarded code for a PARTIAL last row
+// tile -- row group j of this lane loads from rofs[j], which is its own row where that exists and the tile's first row
+// where it does not (one cache line for all such lanes: no extra HBM traffic); what the stray values would contribute is
+// nullified by x_T = 0 on those rows and by the guarded store of the N sums.  The guarded form of a partial tile runs
+// at a fraction of the rate (m = 125 250: 184 -> 163 us per launch).
+template <typename E, int VW, int NJ, int K, bool DO_N, bool DO_T, bool ABS, bool NT, bool FULL, bool CLAMP = false>
 __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m, int r_first, int c, int cc,
                                      const float *__restrict__ xn, const float (&xtv)[NJ][VW],
-                                     float (&accN)[NJ][VW], float *ldsT_wave, int lane, const float *__restrict__ inv_s)
+                                     float (&accN)[NJ][VW], float *ldsT_wave, int lane, const float *__restrict__ inv_s,
+                                     const int (&rofs)[NJ])
 {
+    static_assert(FULL || !CLAMP, "CLAMP is a form of FULL");
     constexpr bool F16 = IsF16<E>::v;
     if constexpr (VW == 8) {
         // bf16 storage: 8 rows per 16-byte load.  The raw dwords stay in registers and are widened (one shift or
@@ -114,10 +121,10 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
             // (round 1 issued them from inline asm with hand-written vmcnt waits, which the compiler could not see).
 #pragma unroll
             for (int u = 0; u < K; ++u) {
-                const E *col = A + (size_t)(c + u) * lda + r_first;
+                const E *col = A + (size_t)(c + u) * lda + (CLAMP ? 0 : r_first);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const u32x4_t *src = reinterpret_cast<const u32x4_t *>(col + j * (BLK * VW));
+                    const u32x4_t *src = reinterpret_cast<const u32x4_t *>(col + (CLAMP ? rofs[j] : j * (BLK * VW)));
                     raw[u][j] = NT ? __builtin_nontemporal_load(src) : *src;
                 }
             }
@@ -198,7 +205,7 @@ __device__ __forceinline__ void step(const E *__restrict__ A, size_t lda, int m,
         const E *col = A + (size_t)(c + u) * lda;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int r = r_first + j * (BLK * VW);
+            const int r = CLAMP ? rofs[j] : r_first + j * (BLK * VW);
             if constexpr (VW == 4) {
                 if (FULL || r + 4 <= m) {
                     typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const E *__restrict__ A, size
                                                    float *__restrict__ partN, size_t strideN,
                                                    float *__restrict__ partT, size_t strideT,
                                                    int cols_per_chunk, const int *__restrict__ stop,
-                                                   const float *__restrict__ inv_s)
+                                                   const float *__restrict__ inv_s, int m_load)
 {
     if (stop != nullptr && *stop != 0) return;
     __shared__ float ldsT[DO_T ? 4 * MAXCW : 4];
@@ -289,16 +296,31 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const E *__restrict__ A, size
 
     float *ldsT_wave = ldsT + wave * (DO_T ? MAXCW : 1);
     int c = c0;
+    int rofs[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rofs[j] = 0;
     if ((tile + 1) * TILE <= m) {
         for (; c + KU <= c1; c += KU)
-            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s);
+            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s, rofs);
         for (; c < c1; ++c)
-            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s);
+            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s, rofs);
+    } else if (VW > 1 && m_load > 0) {
+        // the partial last tile, unguarded: m_load = the rows that may be loaded with whole vectors (m if it is a multiple
+        // of VW, else roundup(m, VW) when the rows m .. lda - 1 are the library's own zeros)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = r_first + j * (BLK * VW);
+            rofs[j] = (r + VW <= m_load) ? r : tile * TILE;
+        }
+        for (; c + KU <= c1; c += KU)
+            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, true, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s, rofs);
+        for (; c < c1; ++c)
+            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, true, true>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s, rofs);
     } else {
         for (; c + KU <= c1; c += KU)
-            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s);
+            step<E, VW, NJ, KU, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s, rofs);
         for (; c < c1; ++c)
-            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s);
+            step<E, VW, NJ, 1, DO_N, DO_T, ABS, NT, false>(A, lda, m, r_first, c, c - c0, xn, xtv, accN, ldsT_wave, lane, inv_s, rofs);
     }
 
     if constexpr (DO_N) {
@@ -440,6 +462,7 @@ __global__ void sp_absadd_k(int n, const float *__restrict__ sp, float *__restri
 struct Plan {
     int vw, nj, ku, nt;
     int tiles, chunks, cols_per_chunk;
+    int m_load = 0;             // > 0: rows of the partial last tile that whole vectors may load (dual_gemv_k)
     size_t strideN, strideT;
 };
 
@@ -514,10 +537,10 @@ void launch_cfg(const Plan &p, hipStream_t st, const E *A, size_t lda, int m, in
     do {                                                                                                      \
         if (p.nt)                                                                                             \
             hipLaunchKernelGGL((dual_gemv_k<E, VW, NJ, KU, DO_N, DO_T, ABS, true>), g, b, 0, st, A, lda, m, n, xn, xt, \
-                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop, inv_s);            \
+                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop, inv_s, p.m_load);  \
         else                                                                                                  \
             hipLaunchKernelGGL((dual_gemv_k<E, VW, NJ, KU, DO_N, DO_T, ABS, false>), g, b, 0, st, A, lda, m, n, xn, xt, \
-                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop, inv_s);            \
+                               partN, p.strideN, partT, p.strideT, p.cols_per_chunk, stop, inv_s, p.m_load);  \
     } while (0)
     if (p.vw == VV) {
         if (p.nj == 4) THIP_GEMV_LAUNCH(VV, 4, 2);
@@ -627,7 +650,7 @@ size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col)
 int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
                        const float *xn, const float *xt, bool do_n, bool do_t, bool abs_mode,
                        float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
-                       const GemvHint *hint, int a_kind, const float *inv_s)
+                       const GemvHint *hint, int a_kind, const float *inv_s, bool pad_zero)
 {
     if (n_row == 0 || n_col == 0 || (!do_n && !do_t)) {
         out->partN = out->partT = nullptr; out->nN = out->nT = 0; out->strideN = out->strideT = 0;
@@ -637,7 +660,14 @@ int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *m
     const bool bf16 = a_kind == THIP_A_BF16, f16 = a_kind == THIP_A_F16;
     if (f16 && inv_s == nullptr) return fail(THIP_E_INVALID, "f16 storage needs the per-column scales", __FILE__, __LINE__);
     const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (lda % ((bf16 || f16) ? 8 : 4) == 0);
-    const Plan p = make_plan(n_row, n_col, vec_ok ? ((bf16 || f16) ? 8 : 4) : 1, hint);
+    Plan p = make_plan(n_row, n_col, vec_ok ? ((bf16 || f16) ? 8 : 4) : 1, hint);
+    {
+        // the partial last row tile runs unguarded when every vector it needs exists: m a multiple of the vector width,
+        // or the rows m .. lda - 1 are the library's own zeros.  THIP_GEMV_CLAMP=0: the guarded form
+        static const int clamp_on = getenv("THIP_GEMV_CLAMP") ? atoi(getenv("THIP_GEMV_CLAMP")) : 1;
+        const size_t m_up = round_up(n_row, (size_t)p.vw);
+        if (clamp_on && p.vw > 1 && (n_row % p.vw == 0 || (pad_zero && lda >= m_up))) p.m_load = (int)m_up;
+    }
     const size_t needN = do_n ? (size_t)p.chunks * p.strideN : 0;
     const size_t needT = do_t ? (size_t)p.tiles * p.strideT : 0;
     if (needN + needT > scratch_floats) return fail(THIP_E_WORK, "gemv scratch too small", __FILE__, __LINE__);

@@ -530,6 +530,8 @@ struct thip_solver {
     bool is16() const { return a_kind != THIP_A_F32; }
     const void *amat() const { return is16() ? (const void *)A16 : (Apad ? (const void *)Apad : (const void *)A); }
     size_t alda() const { return is16() ? ld16 : (Apad ? ldpad : m); }
+    // rows m .. alda() - 1 of the matrix in use are zeros written by this library (its padded f32 copy, or a 16-bit copy it made)
+    bool apadz() const { return is16() ? A16_owned : Apad != nullptr; }
     const float *ainv() const { return a_kind == THIP_A_F16 ? inv_s : nullptr; }
     const GemvHint *ahint() const { return is16() ? (tuned16 ? &hint16 : nullptr) : (tuned ? &hint : nullptr); }
     DevStatus *dst = nullptr;
@@ -644,16 +646,16 @@ int products(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp,
         GemvPartials a, b;
         const size_t half = s->gemv_scr_n / 2;
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), nullptr, xt, false, true, false, s->gemv_scr, half, &a, stop, s->ahint(), s->a_kind, s->ainv()));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), nullptr, xt, false, true, false, s->gemv_scr, half, &a, stop, s->ahint(), s->a_kind, s->ainv(), s->apadz()));
         prof_end(st);
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, nullptr, true, false, false, s->gemv_scr + half, half, &b, stop, s->ahint(), s->a_kind, s->ainv()));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, nullptr, true, false, false, s->gemv_scr + half, half, &b, stop, s->ahint(), s->a_kind, s->ainv(), s->apadz()));
         prof_end(st);
         gp->partT = a.partT; gp->nT = a.nT; gp->strideT = a.strideT;
         gp->partN = b.partN; gp->nN = b.nN; gp->strideN = b.strideN;
     } else {
         prof_begin(st);
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, gp, stop, s->ahint(), s->a_kind, s->ainv()));
+        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), xn, xt, true, true, false, s->gemv_scr, s->gemv_scr_n, gp, stop, s->ahint(), s->a_kind, s->ainv(), s->apadz()));
         prof_end(st);
     }
     return 0;
@@ -780,14 +782,14 @@ int autotune_gemv(thip_solver *s)
     GemvHint pick{0, 0};
     for (int w = 0; w < 3; ++w)         // clocks and caches settle before anything is timed
         THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
-                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind, s->ainv()));
+                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind, s->ainv(), s->apadz()));
     // inputs: the iterate if the loop is already running (storage switch), else zeros -- timing does not depend on them
     for (int i = 0; i < nc; ++i) {
         float ms = 1e30f;
         for (int rep = 0; rep < 5; ++rep) {
             THIP_TRY(hipEventRecord(e0, st));
             THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
-                                       s->gemv_scr_n, &gp, nullptr, &c[i], s->a_kind, s->ainv()));
+                                       s->gemv_scr_n, &gp, nullptr, &c[i], s->a_kind, s->ainv(), s->apadz()));
             // the second reduction stage is part of the price of a plan (finer grids leave more partials to post_k):
             // time it too, into g2 / h2, which every schedule rewrites before reading
             THIP_RC(finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, s->h2, nullptr));
@@ -1047,7 +1049,7 @@ int thip_solver_init(thip_solver *s)
         // solver-owned scratch (several solvers may share the context, e.g. one per thread)
         GemvPartials gp;
         THIP_RC(dual_gemv_partials(st, m, n, s->amat(), s->alda(), nullptr, nullptr, true, true, true, s->gemv_scr,
-                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind, s->ainv()));
+                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind, s->ainv(), s->apadz()));
         THIP_RC(finalize_partials(st, m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, rowabs, nullptr));
         THIP_RC(finalize_partials(st, n, gp.partT, gp.nT, gp.strideT, 1.0f, 0.0f, colabs, nullptr));
     }
