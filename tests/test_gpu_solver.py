@@ -223,6 +223,41 @@ def test_iterates_sdp(T, schedule, k):
     _check_iterates(T, sdp.dense(), schedule, [0, 1, 9, 49], [5e-5, 5e-5, 3e-4, 3e-3])
 
 
+@pytest.mark.parametrize("schedule", ["fused", "carried"])
+def test_iterates_many_psd_cones(T, schedule):
+    """several PSD cones in one problem: orders <= 64 are projected group by group (all cones of one order, x_y and x_s,
+    in ONE launch over a table of offsets), the order-70 cone by the chain of launches; a nonnegative segment in between
+    moves the offsets off any regular stride"""
+    from totsu_amd.problem import _Dense
+    from totsu_amd import _lib
+    n = 5
+    orders = [3, 6, 6, 12, 6, 33, 70, 12, 1]
+    blocks, bs, st, sl = [], [], [], []
+    c0 = None
+    for q, k in enumerate(orders):
+        c, syms = random_sdp(n, k, seed=10 + q)
+        sdp = T.ProbSDP(_mb(T, T.MatType.General(n, 1)).set_array(c.reshape(-1, 1)),
+                        [_mb(T, T.MatType.SymPack(k)).set_array(sy) for sy in syms],
+                        _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)), 1e-12)
+        d = sdp.dense()
+        sk = k * (k + 1) // 2
+        blocks.append(np.asarray(d.mat_a, dtype=np.float32).reshape((n, d.m)).T[:sk])
+        bs.append(np.asarray(d.vec_b, dtype=np.float32)[:sk])
+        st.append(_lib.CONE_PSD)
+        sl.append(sk)
+        c0 = np.asarray(d.vec_c, dtype=np.float32) if c0 is None else c0 + np.asarray(d.vec_c, dtype=np.float32)
+        sdp.drop()
+        if q == 2:                                             # 7 nonnegative rows after the third cone
+            rng = np.random.default_rng(99)
+            blocks.append(rng.standard_normal((7, n)).astype(np.float32))
+            bs.append(np.abs(rng.standard_normal(7)).astype(np.float32) + 1.0)
+            st.append(_lib.CONE_RPOS)
+            sl.append(7)
+    a = np.asfortranarray(np.vstack(blocks))
+    dense = _Dense(n, a.shape[0], a.ravel(order="F"), np.concatenate(bs), c0 / len(orders), st, sl)
+    _check_iterates(T, dense, schedule, [0, 1, 9, 49], [5e-5, 5e-5, 3e-4, 3e-3])
+
+
 def test_trait_level_equals_fused_on_lp(T):
     c, G, h = benchmark_lp(25, seed=4)
     mk = lambda: T.ProbLP(_mb(T, T.MatType.General(25, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(50, 25)).set_array(G),

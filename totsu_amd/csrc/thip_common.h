@@ -186,6 +186,11 @@ int group_min_batched(hipStream_t st, float *t, const int64_t *dev_begs, const i
 // nbatch matrices per call: packed + z * pstride each, work holds nbatch * thip_map_eig_worklen(n) floats
 int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale_diag, float eps_zero,
                     float *work, size_t worklen, int map_kind, const int *stop, int nbatch = 1, ptrdiff_t pstride = 0);
+// PSD projection of `count` matrices of the SAME order n <= thip_psd_small_max() in one launch: matrix (i, z) is at
+// base + dev_offs[i] + z * pstride, z < nbatch (the x_y and x_s blocks of cone i)
+int eig_psd_project_small(hipStream_t st, size_t n, float *base, const int64_t *dev_offs, int count, int has_scale,
+                          float scale_diag, const int *stop, int nbatch, ptrdiff_t pstride);
+size_t psd_small_max();
 
 // counter-based generator, identical integer function to oracle/totsu_oracle.c:oc_rng_hash
 __host__ __device__ __forceinline__ uint64_t rng_hash(uint64_t seed, uint64_t stream, uint64_t idx)

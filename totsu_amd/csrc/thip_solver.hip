@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <vector>
 
 using namespace thip;
@@ -504,6 +505,9 @@ struct thip_solver {
     int64_t *rot_beg = nullptr, *rot_end = nullptr; size_t n_rot = 0, rot_max = 0;
     int64_t *grp_beg = nullptr, *grp_end = nullptr; size_t n_grp = 0, grp_max = 0;
     std::vector<std::pair<int64_t, int64_t>> psd;  // (offset, packed length)
+    // PSD cones of order <= 64, grouped by order: one launch projects the x_y and x_s blocks of every cone of a group
+    struct PsdGroup { size_t k; int count; int64_t *dev_offs; };
+    std::vector<PsdGroup> psd_groups;
     float *psd_work = nullptr; size_t psd_worklen = 0;
 
     // device vectors (one arena)
@@ -670,9 +674,12 @@ int project_blocks(thip_solver *s)
     THIP_RC(soc_batched2(st, s->xy, s->xs, s->rxy, s->rxs, s->rot_beg, s->rot_end, s->n_rot, 1, s->rot_max, stop));
     if (!s->psd.empty()) {
         // the x_y and x_s blocks of a cone go through the projection chain together (2 items per launch)
+        for (auto &g : s->psd_groups)
+            THIP_RC(eig_psd_project_small(st, g.k, s->xy, g.dev_offs, g.count, 1, std::sqrt(2.0f), stop, 2, s->xs - s->xy));
         for (auto &pr : s->psd) {
             const size_t sn = (size_t)pr.second;
             const size_t k = (size_t)((std::sqrt((double)(8 * sn + 1)) - 1.0) / 2.0 + 0.5);
+            if (k <= psd_small_max()) continue;           // went with its group
             THIP_RC(eig_psd_project(st, k, s->xy + pr.first, 1, std::sqrt(2.0f), s->par.eps_zero, s->psd_work,
                                     s->psd_worklen, 0, stop, 2, s->xs - s->xy));
         }
@@ -919,6 +926,18 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
     THIP_RC(up64(gb, &s->grp_beg)); THIP_RC(up64(ge, &s->grp_end));
     THIP_TRY(hipMalloc((void **)&s->cls, cls.size()));
     THIP_TRY(hipMemcpy(s->cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
+    {
+        std::map<size_t, std::vector<int64_t>> by_order;
+        for (auto &pr : s->psd) {
+            const size_t k = (size_t)((std::sqrt((double)(8 * pr.second + 1)) - 1.0) / 2.0 + 0.5);
+            if (k <= psd_small_max()) by_order[k].push_back(pr.first);
+        }
+        for (auto &kv : by_order) {
+            thip_solver::PsdGroup g{ kv.first, (int)kv.second.size(), nullptr };
+            THIP_RC(up64(kv.second, &g.dev_offs));
+            s->psd_groups.push_back(g);
+        }
+    }
     if (psd_kmax) {
         s->psd_worklen = 2 * thip_map_eig_worklen(psd_kmax);
         THIP_TRY(hipMalloc((void **)&s->psd_work, s->psd_worklen * sizeof(float)));
@@ -1289,6 +1308,7 @@ int thip_solver_destroy(thip_solver *s)
     if (s->ev_in) hipEventDestroy(s->ev_in);
     if (s->ev_out) hipEventDestroy(s->ev_out);
     hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
+    for (auto &g : s->psd_groups) hipFree(g.dev_offs);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
     hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->Apad); if (s->A16_owned) hipFree(s->A16); if (s->inv_s_owned) hipFree(s->inv_s);
     if (s->hst) hipHostFree(s->hst);
