@@ -188,8 +188,10 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
                     float *work, size_t worklen, int map_kind, const int *stop, int nbatch = 1, ptrdiff_t pstride = 0);
 // PSD projection of `count` matrices of the SAME order n <= thip_psd_small_max() in one launch: matrix (i, z) is at
 // base + dev_offs[i] + z * pstride, z < nbatch (the x_y and x_s blocks of cone i)
+// rx != nullptr: also rx <- rx - 2 x on the projected entries (rx + dev_offs[i] + z * rx_stride)
 int eig_psd_project_small(hipStream_t st, size_t n, float *base, const int64_t *dev_offs, int count, int has_scale,
-                          float scale_diag, const int *stop, int nbatch, ptrdiff_t pstride);
+                          float scale_diag, const int *stop, int nbatch, ptrdiff_t pstride, float *rx = nullptr,
+                          ptrdiff_t rx_stride = 0);
 size_t psd_small_max();
 
 // counter-based generator, identical integer function to oracle/totsu_oracle.c:oc_rng_hash

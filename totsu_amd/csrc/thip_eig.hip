@@ -671,11 +671,13 @@ __device__ __forceinline__ void ps_gemm(ps_mat &C, const ps_mat &A, const ps_mat
 template <int NK>
 __global__ __launch_bounds__(256) void polar_small_k(int n, float *__restrict__ packed, int has_scale, float scale,
                                                      const int *__restrict__ stop, ptrdiff_t ps,
-                                                     const int64_t *__restrict__ offs)
+                                                     const int64_t *__restrict__ offs, float *__restrict__ rx, ptrdiff_t rps)
 {
     if (stop != nullptr && *stop != 0) return;
     // blockIdx.x: which matrix of a table of offsets (cones of one order), blockIdx.y: which item of its batch
     packed += (offs != nullptr ? (ptrdiff_t)offs[blockIdx.x] : 0) + (ptrdiff_t)blockIdx.y * ps;
+    // rx != nullptr (the fused loop): the reflection rx <- rx - 2 x of the projected rows rides in the pack
+    if (rx != nullptr) rx += (offs != nullptr ? (ptrdiff_t)offs[blockIdx.x] : 0) + (ptrdiff_t)blockIdx.y * rps;
     __shared__ ps_mat M, S0, S1, Y, T;
     __shared__ double shd[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -728,7 +730,9 @@ __global__ __launch_bounds__(256) void polar_small_k(int n, float *__restrict__ 
         if (r <= c && c < n) {
             float v = 0.5f * (M[r][c] + 0.5f * ((*Z)[r][c] + (*Z)[c][r]));
             if (r == c && has_scale) v = v / scale;
-            packed[(size_t)c * (c + 1) / 2 + r] = v;
+            const size_t o = (size_t)c * (c + 1) / 2 + r;
+            packed[o] = v;
+            if (rx != nullptr) rx[o] = rx[o] - 2.0f * v;
         }
     }
 }
@@ -1343,12 +1347,12 @@ size_t psd_small_max()
 }
 
 int eig_psd_project_small(hipStream_t st, size_t n, float *base, const int64_t *dev_offs, int count, int has_scale,
-                          float scale_diag, const int *stop, int nbatch, ptrdiff_t pstride)
+                          float scale_diag, const int *stop, int nbatch, ptrdiff_t pstride, float *rx, ptrdiff_t rx_stride)
 {
     if (n == 0 || count <= 0 || nbatch <= 0) return 0;
     if (n > (size_t)PSN) return fail(THIP_E_INVALID, "eig_psd_project_small: order above 64", __FILE__, __LINE__);
     // NK = MFMA steps per product: ceil(n / 2) rounded up to a multiple of 4
-#define THIP_PS(NK) hipLaunchKernelGGL(polar_small_k<NK>, dim3(count, nbatch), dim3(256), 0, st, (int)n, base, has_scale, scale_diag, stop, pstride, dev_offs)
+#define THIP_PS(NK) hipLaunchKernelGGL(polar_small_k<NK>, dim3(count, nbatch), dim3(256), 0, st, (int)n, base, has_scale, scale_diag, stop, pstride, dev_offs, rx, rx_stride)
     switch (((int)n + 7) / 8) {
     case 0: case 1: THIP_PS(4); break;
     case 2: THIP_PS(8); break;
@@ -1376,7 +1380,7 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
     static const int small_on = getenv("THIP_POLAR_SMALL") ? atoi(getenv("THIP_POLAR_SMALL")) : 1;
     static const int small_min = getenv("THIP_POLAR_SMALL_MIN") ? atoi(getenv("THIP_POLAR_SMALL_MIN")) : POLAR_SMALL_MIN_N;
     if (map_kind == 0 && small_on && n <= PSN && (int)n >= small_min) {
-        return eig_psd_project_small(st, n, packed, nullptr, 1, has_scale, scale_diag, stop, nbatch, pstride);
+        return eig_psd_project_small(st, n, packed, nullptr, 1, has_scale, scale_diag, stop, nbatch, pstride, nullptr, 0);
     }
     if (map_kind == 0 && n > POLAR_MIN_N) {
         return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride);
