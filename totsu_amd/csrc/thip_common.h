@@ -185,7 +185,10 @@ int group_min_batched(hipStream_t st, float *t, const int64_t *dev_begs, const i
 
 // nbatch matrices per call: packed + z * pstride each, work holds nbatch * thip_map_eig_worklen(n) floats
 int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale_diag, float eps_zero,
-                    float *work, size_t worklen, int map_kind, const int *stop, int nbatch = 1, ptrdiff_t pstride = 0);
+                    float *work, size_t worklen, int map_kind, const int *stop, int nbatch = 1, ptrdiff_t pstride = 0,
+                    float *rx = nullptr, ptrdiff_t rx_stride = 0);
+// rx != nullptr (only where psd_project_takes_rx(n)): also rx <- rx - 2 x on the projected entries
+bool psd_project_takes_rx(size_t n);
 // PSD projection of `count` matrices of the SAME order n <= thip_psd_small_max() in one launch: matrix (i, z) is at
 // base + dev_offs[i] + z * pstride, z < nbatch (the x_y and x_s blocks of cone i)
 // rx != nullptr: also rx <- rx - 2 x on the projected entries (rx + dev_offs[i] + z * rx_stride)

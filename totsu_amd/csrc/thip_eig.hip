@@ -599,29 +599,38 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
     }
 }
 
-// S = M / ||M||_F  (sc[0] = ||M||_F); exact zero matrix stays zero
-__global__ void scale_by_fro_k(size_t tot, const float *__restrict__ M, const float *__restrict__ sc,
-                               float *__restrict__ S, const int *__restrict__ stop, size_t ws)
+// S = M / ||M||_F; the exact zero matrix stays zero.  ||M||_F from unpack_k's block 2-norms (part, np of them), summed by
+// EVERY workgroup for itself (np <= 512 floats from L2: cheaper than a launch that does it once)
+__global__ __launch_bounds__(BLK) void scale_by_fro_k(size_t tot, const float *__restrict__ M, const float *__restrict__ part, int np,
+                                                     float *__restrict__ S, const int *__restrict__ stop, size_t ws)
 {
     if (stop != nullptr && *stop != 0) return;
-    M += blockIdx.z * ws; sc += blockIdx.z * ws; S += blockIdx.z * ws;
+    M += blockIdx.z * ws; part += blockIdx.z * ws; S += blockIdx.z * ws;
+    __shared__ double shd[16];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < np; k += BLK) acc += (double)part[k] * (double)part[k];
+    acc = block_sum_d(acc, shd);
     // a division per element: 1 / f overflows for a subnormal norm, and 0 * inf would poison the iterate
-    const float f = sc[0];
+    const float f = (float)sqrt(acc);
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) S[i] = f > 0.0f ? M[i] / f : 0.0f;
 }
 
 // packed(r,c) = (M + MS)(r,c) / 2 symmetrised, diag / scale
 __global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const float *__restrict__ MS, int has_scale,
-                            float scale, float *__restrict__ packed, const int *__restrict__ stop, size_t ws, ptrdiff_t ps)
+                            float scale, float *__restrict__ packed, const int *__restrict__ stop, size_t ws, ptrdiff_t ps,
+                            float *__restrict__ rx, ptrdiff_t rps)
 {
     if (stop != nullptr && *stop != 0) return;
     M += blockIdx.z * ws; MS += blockIdx.z * ws; packed += (ptrdiff_t)blockIdx.z * ps;
+    if (rx != nullptr) rx += (ptrdiff_t)blockIdx.z * rps;       // the fused loop's reflection rx <- rx - 2 x rides along
     const int c = blockIdx.y;
     for (int r = blockIdx.x * BLK + threadIdx.x; r <= c; r += gridDim.x * BLK) {
         const size_t o1 = (size_t)c * ld + r, o2 = (size_t)r * ld + c;
         float v = 0.5f * (M[o1] + 0.5f * (MS[o1] + MS[o2]));
         if (r == c && has_scale) v = v / scale;
-        packed[(size_t)c * (c + 1) / 2 + r] = v;
+        const size_t o = (size_t)c * (c + 1) / 2 + r;
+        packed[o] = v;
+        if (rx != nullptr) rx[o] = rx[o] - 2.0f * v;
     }
 }
 
@@ -1280,7 +1289,7 @@ int rebuild(hipStream_t st, size_t n, float *packed, int has_scale, float scale,
 // vectors ps floats apart): the chain is launch-bound (8.7 us per 512^3 GEMM on 256 workgroups), so the x_y and x_s
 // projections of one iteration share its 50+ launches
 int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop,
-                  int nb, size_t ws, ptrdiff_t ps)
+                  int nb, size_t ws, ptrdiff_t ps, float *rx, ptrdiff_t rps)
 {
     const int ni = (int)n, ld = (int)np_of(n);
     const size_t tot = (size_t)ld * ld;
@@ -1288,8 +1297,7 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
     float *M = k.G, *S = k.S, *Y = k.Y, *Z = k.Z, *T = k.V;
     hipLaunchKernelGGL(unpack_k, dim3(g, 1, nb), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, M, (float *)nullptr,
                        k.part, stop, ws, ps);
-    hipLaunchKernelGGL(shift_k, dim3(1, 1, nb), dim3(BLK), 0, st, ni, ld, (int)g, k.part, M, k.sc, 0, stop, ws);
-    hipLaunchKernelGGL(scale_by_fro_k, dim3(g, 1, nb), dim3(BLK), 0, st, tot, M, k.sc, S, stop, ws);
+    hipLaunchKernelGGL(scale_by_fro_k, dim3(g, 1, nb), dim3(BLK), 0, st, tot, M, k.part, (int)g, S, stop, ws);
     // sign(M) = the polar factor of S = M / ||M||_F by the polar iteration S <- p_k(S S^T) S with odd quintics
     // p_k(x) = a x + b x^3 + c x^5.  Three GEMMs per step, the polynomial folded into the second one's epilogue:
     //   Y = S S^T ;  T = c Y Y^T + b Y + a I ;  S <- T S
@@ -1331,7 +1339,7 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
     }
     THIP_RC(gemm(st, true, ni, ld, 1.0f, M, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));      // M sign(M)
     dim3 gp((unsigned)((n + BLK - 1) / BLK), (unsigned)n, nb);
-    hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop, ws, ps);
+    hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop, ws, ps, rx, rps);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1368,8 +1376,14 @@ int eig_psd_project_small(hipStream_t st, size_t n, float *base, const int64_t *
     return 0;
 }
 
+bool psd_project_takes_rx(size_t n)
+{
+    return n <= psd_small_max() || n > (size_t)POLAR_MIN_N;
+}
+
 int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale_diag, float eps_zero,
-                    float *work, size_t worklen, int map_kind, const int *stop, int nbatch, ptrdiff_t pstride)
+                    float *work, size_t worklen, int map_kind, const int *stop, int nbatch, ptrdiff_t pstride,
+                    float *rx, ptrdiff_t rx_stride)
 {
     (void)eps_zero;   // F32CUDA ignores eps_zero as well (f32cuda.rs:196); f32 round-off is the floor
     if (n == 0 || nbatch <= 0) return 0;
@@ -1380,10 +1394,10 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
     static const int small_on = getenv("THIP_POLAR_SMALL") ? atoi(getenv("THIP_POLAR_SMALL")) : 1;
     static const int small_min = getenv("THIP_POLAR_SMALL_MIN") ? atoi(getenv("THIP_POLAR_SMALL_MIN")) : POLAR_SMALL_MIN_N;
     if (map_kind == 0 && small_on && n <= PSN && (int)n >= small_min) {
-        return eig_psd_project_small(st, n, packed, nullptr, 1, has_scale, scale_diag, stop, nbatch, pstride, nullptr, 0);
+        return eig_psd_project_small(st, n, packed, nullptr, 1, has_scale, scale_diag, stop, nbatch, pstride, rx, rx_stride);
     }
     if (map_kind == 0 && n > POLAR_MIN_N) {
-        return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride);
+        return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride, rx, rx_stride);
     }
     for (int z = 0; z < nbatch; ++z) {          // the Jacobi engine works on one matrix at a time
         THIP_RC(decompose(st, n, packed + z * pstride, has_scale, scale_diag, k, map_kind, stop));

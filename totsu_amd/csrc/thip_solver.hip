@@ -674,21 +674,25 @@ int project_blocks(thip_solver *s)
     THIP_RC(soc_batched2(st, s->xy, s->xs, s->rxy, s->rxs, s->rot_beg, s->rot_end, s->n_rot, 1, s->rot_max, stop));
     if (!s->psd.empty()) {
         // the x_y and x_s blocks of a cone go through the projection chain together (2 items per launch)
-        // every PSD cone small: the reflection of the projected rows rides in the projection kernel's pack
-        size_t n_small = 0;
-        for (auto &g : s->psd_groups) n_small += (size_t)g.count;
-        const bool fold = n_small == s->psd.size();
+        // the reflection rx <- rx - 2 x of the projected rows rides in the projection kernels' pack when every cone's
+        // engine takes it (the polar kernels do)
+        bool fold = true;
+        for (auto &pr : s->psd) {
+            const size_t k = (size_t)((std::sqrt((double)(8 * pr.second + 1)) - 1.0) / 2.0 + 0.5);
+            fold = fold && psd_project_takes_rx(k);
+        }
         for (auto &g : s->psd_groups)
             THIP_RC(eig_psd_project_small(st, g.k, s->xy, g.dev_offs, g.count, 1, std::sqrt(2.0f), stop, 2, s->xs - s->xy,
                                           fold ? s->rxy : nullptr, s->rxs - s->rxy));
-        if (fold) return 0;
         for (auto &pr : s->psd) {
             const size_t sn = (size_t)pr.second;
             const size_t k = (size_t)((std::sqrt((double)(8 * sn + 1)) - 1.0) / 2.0 + 0.5);
             if (k <= psd_small_max()) continue;           // went with its group
             THIP_RC(eig_psd_project(st, k, s->xy + pr.first, 1, std::sqrt(2.0f), s->par.eps_zero, s->psd_work,
-                                    s->psd_worklen, 0, stop, 2, s->xs - s->xy));
+                                    s->psd_worklen, 0, stop, 2, s->xs - s->xy, fold ? s->rxy + pr.first : nullptr,
+                                    s->rxs - s->rxy));
         }
+        if (fold) return 0;
         hipLaunchKernelGGL(rx_psd_k, dim3(egrid(s->m)), dim3(BLK), 0, st, (int)s->m, s->cls, s->xy, s->xs, s->rxy, s->rxs, s->dst);
     }
     return 0;
