@@ -212,7 +212,7 @@ def test_iterates_socp(T, schedule):
     _check_iterates(T, socp.dense(), schedule, [0, 1, 9, 99], [2e-5, 2e-5, 1e-4, 2e-3])
 
 
-@pytest.mark.parametrize("k", [9, 24])     # 9: Jacobi engine; 24: matrix-core polar chain, x_y and x_s batched per launch
+@pytest.mark.parametrize("k", [9, 24, 70])     # 9, 24: the one-workgroup polar kernel (x_y and x_s in one launch); 70: the chain of launches
 @pytest.mark.parametrize("schedule", ["fused", "carried"])
 def test_iterates_sdp(T, schedule, k):
     n = 6
