@@ -74,6 +74,20 @@ SHAPES = [(1, 1), (3, 2), (4, 4), (99, 50), (100, 64), (256, 33), (1024, 17), (1
           (100_000, 1), (1, 100_000), (2, 70_001), (300_001, 3)]
 
 
+@pytest.mark.parametrize("scale", [1e-30, 1e-25, 1e-18, 1.0, 1e15, 1e18])
+def test_norm_is_scale_invariant(L, scale):
+    """LinAlg::norm through nrm2 in the reference's backends (f64lapack.rs, f32cuda.rs) neither underflows nor
+    overflows on the squares: a vector of 1e-25s has the norm 1e-25 sqrt(n), not 0"""
+    rng = np.random.default_rng(7)
+    for n in (1, 99, 5000, 300_000):
+        x = (rng.standard_normal(n) * scale).astype(np.float32)
+        sx = L.Sl.new_ref(x)
+        want = float(np.linalg.norm(x.astype(np.float64)))
+        got = L.norm(sx)
+        sx.drop()
+        assert np.isfinite(got) and abs(got - want) <= 1e-5 * want, (n, got, want)
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 def test_transform_ge(L, shape):
     nr, nc = shape

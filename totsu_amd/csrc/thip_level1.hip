@@ -48,15 +48,28 @@ template <int OP>
 __global__ void reduce1_k(size_t n, const float *__restrict__ x, const float *__restrict__ y, size_t incx,
                           float *__restrict__ part)
 {
-    __shared__ float sh[16];
-    float acc = 0.0f;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
-        if (OP == RED_SUMSQ_SQRT) { const float v = x[i]; acc += v * v; }
-        else if (OP == RED_ABSSUM) { acc += fabsf(x[i * incx]); }
-        else { acc += x[i] * y[i]; }
+    if constexpr (OP == RED_SUMSQ_SQRT) {
+        // LinAlg::norm is scale invariant in the reference (nrm2 of BLAS / cuBLAS, f64lapack.rs, f32cuda.rs): the squares are
+        // accumulated in f64 and a block hands on its 2-NORM, which is an f32 number whenever the entries are (the squares
+        // of a vector of 1e-25s are not)
+        __shared__ double shd[16];
+        double acc = 0.0;
+        for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+            const double v = (double)x[i];
+            acc += v * v;
+        }
+        acc = block_sum_d(acc, shd);
+        if (threadIdx.x == 0) part[blockIdx.x] = (float)sqrt(acc);
+    } else {
+        __shared__ float sh[16];
+        float acc = 0.0f;
+        for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+            if (OP == RED_ABSSUM) { acc += fabsf(x[i * incx]); }
+            else { acc += x[i] * y[i]; }
+        }
+        acc = block_sum(acc, sh);
+        if (threadIdx.x == 0) part[blockIdx.x] = acc;
     }
-    acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
 // stage 2: one block, double accumulation of the (<= MAXB) partials
@@ -65,7 +78,7 @@ __global__ void reduce2_k(int np, const float *__restrict__ part, float *__restr
 {
     __shared__ double shd[16];
     double acc = 0.0;
-    for (int i = threadIdx.x; i < np; i += BLK) acc += (double)part[i];
+    for (int i = threadIdx.x; i < np; i += BLK) acc += (OP == RED_SUMSQ_SQRT) ? (double)part[i] * (double)part[i] : (double)part[i];
     acc = block_sum_d(acc, shd);
     if (threadIdx.x == 0) out[0] = (OP == RED_SUMSQ_SQRT) ? (float)sqrt(acc) : (float)acc;
 }
