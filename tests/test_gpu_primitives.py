@@ -184,6 +184,27 @@ def test_cones_single(L):
                     r.drop()
 
 
+@pytest.mark.parametrize("scale", [1e-30, 1e-25, 1e-18, 1e15])
+def test_soc_projection_is_scale_invariant(L, scale):
+    """cone_soc.rs:47 takes LinAlg::norm (nrm2): the branch taken and the scaling factor do not depend on the scale of x"""
+    from totsu_amd import ConeRotSOC, ConeSOC
+    rng = np.random.default_rng(6)
+    for n in (2, 3, 100, 2049):
+        x = rng.standard_normal(n)
+        for cone, typ in ((ConeSOC(L), O.CONE_SOC), (ConeRotSOC(L), O.CONE_ROTSOC)):
+            for shift in (-3.0, 0.0, 3.0):
+                xx = x.copy()
+                xx[0] += shift * np.linalg.norm(x)
+                if typ == O.CONE_ROTSOC:
+                    xx[1] += shift * np.linalg.norm(x)
+                xs = (xx * scale).astype(np.float32)
+                r, s = _sl(L, xs, 1)
+                assert cone.proj(False, s)
+                ref = O.proj(typ, xs.astype(np.float64), dual_cone=False)
+                assert np.allclose(s.get_ref(), ref, rtol=2e-5, atol=2e-5 * np.abs(xs).max()), (n, typ, shift)
+                r.drop()
+
+
 def test_soc_batched_ragged(L):
     import ctypes as C
     from totsu_amd._lib import lib

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(BLK) void soc_k(float *__restrict__ x0, float *__re
                                              int rotated, int64_t single_len, const int *__restrict__ stop)
 {
     if (stop != nullptr && *stop != 0) return;
-    __shared__ float sh[16];
+    __shared__ double shd[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t total = x1 ? 2 * n_cones : n_cones;
     int64_t cone = BLOCKWISE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
@@ -64,14 +64,15 @@ __global__ __launch_bounds__(BLK) void soc_k(float *__restrict__ x0, float *__re
         s0 = x[beg];
     }
 
-    // ||v||^2 over x[beg+1 .. end)
-    float acc = 0.0f;
+    // ||v|| over x[beg+1 .. end): the reference takes LinAlg::norm (cone_soc.rs:47), an nrm2 that neither underflows nor
+    // overflows on the squares -- here the squares are f64
+    double acc = 0.0;
     for (int64_t i = beg + 1 + gid; i < end; i += gsz) {
-        const float t = (rotated && i == beg + 1) ? v1 : x[i];
-        acc = fmaf(t, t, acc);
+        const double t = (double)((rotated && i == beg + 1) ? v1 : x[i]);
+        acc += t * t;
     }
-    const float sumsq = BLOCKWISE ? block_sum(acc, sh) : wave_sum(acc);
-    const float norm_v = sqrtf(sumsq);
+    const double sumsq = BLOCKWISE ? block_sum_d(acc, shd) : wave_sum_d(acc);
+    const float norm_v = (float)sqrt(sumsq);
 
     // cone_soc.rs:49-61
     float f, s_new;
