@@ -499,11 +499,11 @@ def run(a):
                                            "EVALUATED in f64 on the host with A regenerated from the counter-based generator "
                                            "(tools/c3_f64_certificate.py, profiles/r02_c3_f64_certificate.json): at eps 1e-3 primal "
                                            "feasible (cone violation 0), dual residual 9.99982e-4 (the GPU's own f32 criterion: "
-                                           "9.99982e-4), primal objective -6788.43619 vs dual -6788.42484 = 1.7e-6 relative, so the "
-                                           "optimal value is bracketed to 1.7e-6; at eps 1e-4: dual residual 9.9997e-5, bracket 6.1e-7",
-                           "f64_certificate_at_full_size": {"eps_acc": 1e-3, "objective_bracket_rel": 1.67e-6,
+                                           "9.99982e-4), primal objective -6788.43605 vs dual -6788.42825 = 1.15e-6 relative, so the "
+                                           "optimal value is bracketed to 1.2e-6; at eps 1e-4: dual residual 9.9998e-5, bracket 5.9e-7",
+                           "f64_certificate_at_full_size": {"eps_acc": 1e-3, "objective_bracket_rel": 1.15e-6,
                                                             "dual_residual_rel_f64": 9.99982e-4,
-                                                            "primal_cone_violation": 0.0, "gap_rel": 8.36e-7}},
+                                                            "primal_cone_violation": 0.0, "gap_rel": 5.75e-7}},
     }
 
     if a.to_eps is not None:
