@@ -549,7 +549,7 @@ def test_cpp_trait_mirror_host():
     assert r.stdout.count("OK") == 4 and "fused-lp" in r.stdout
 
 
-@pytest.mark.parametrize("grid", [(2, 3), (3, 4)])
+@pytest.mark.parametrize("grid", [(2, 3), (3, 4), (8, 6)])       # (8, 6): the size of the reference's example, PSD order 48
 def test_partitioning_sdp_gpu_vs_oracle(T, grid):
     # BASELINE.json configs[3] template (examples/partitioning_sdp): PSD cone + equality rows through ProbSDP
     from problems import partitioning_sdp
