@@ -226,6 +226,7 @@ typedef int (*thip_allreduce_fn)(void *ctx, float *dev_buf, size_t n, void *hip_
 int thip_comm_unique_id(uint8_t *host_id128);
 int thip_comm_init(int rank, int world, const uint8_t *host_id128);
 int thip_comm_allreduce(float *dev_buf, size_t n);       /* in-place float sum over the ranks, on the context stream */
+int thip_comm_count(int *host_ranks);                    /* ranks of the live communicator, read back from RCCL (ncclCommCount); 0 = none */
 int thip_comm_destroy(void);
 int thip_solver_use_rccl(thip_solver *s);                /* before thip_solver_init */
 

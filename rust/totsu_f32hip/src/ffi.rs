@@ -128,6 +128,7 @@ extern "C" {
     pub fn thip_comm_unique_id(host_id128: *mut u8) -> c_int;
     pub fn thip_comm_init(rank: c_int, world: c_int, host_id128: *const u8) -> c_int;
     pub fn thip_comm_allreduce(dev_buf: *mut f32, n: usize) -> c_int;
+    pub fn thip_comm_count(host_ranks: *mut c_int) -> c_int;
     pub fn thip_comm_destroy() -> c_int;
     pub fn thip_solver_use_rccl(s: *mut thip_solver) -> c_int;
 

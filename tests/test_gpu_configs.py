@@ -202,3 +202,60 @@ def test_c4_full_size_sdp_iterates_vs_oracle(T, schedule):
         assert np.allclose(fs.status().cri, tr[2:], rtol=5e-3, atol=1e-5), (it, fs.status().cri, tr)
     fs.destroy()
     inst.free()
+
+
+# ---- configs[2] at the full n ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("schedule", ["fused", "carried"])
+def test_c3_first_328_cones_at_full_n_iterates_vs_oracle(T, schedule):
+    """BASELINE configs[2] at its full n = 50 000: the standalone problem made of the first 328 of the 1000 cones (A_sub
+    32 800 x 50 000, 6.6 GB f32 on the GPU, 13 GB f64 in the oracle -- the sub-instance bench.py's cpu_baseline leg
+    times).  Preconditioner (solver.rs:496-524), iterates after iterations 0, 1, 2 (solver.rs:526-571) and the criteria
+    triple (solver.rs:573-612) against the f64 oracle on the SAME inputs: the HIP path compared with the restated
+    reference at the headline's column count, not with itself."""
+    import math
+    import os
+    from totsu_amd import synth
+    from totsu_amd._lib import lib
+    n, cones_full, sub, ni = 50_000, 1000, 328, 99
+    rows = 1 + ni
+    inst = synth.SocpInstance(n, cones_full, ni, seed=0, first_cones=sub)
+    m = inst.m
+    assert m == sub * rows and inst.m_total == cones_full * rows
+    k = O.num_threads()
+    O.set_num_threads(max(k, min(128, (os.cpu_count() or 8))))
+    try:
+        a = O.gen_matrix(m, n, 0, synth.STREAM_A, 0, 0, inst.m_total, 1, -1.0 / math.sqrt(n))
+        # the device holds the same entries: whole columns 0, 17 and n - 1, bit for bit
+        col = T.DeviceBuffer(m)
+        for cc in (0, 17, n - 1):
+            lib.thip_copy(m, inst.mat_a.ptr + 4 * cc * m, col.ptr)
+            assert np.array_equal(col.to_host()[:m].astype(np.float64), np.asarray(a)[cc * m:(cc + 1) * m]), cc
+        col.free()
+        b, c = inst.vec_b_host.astype(np.float64), inst.vec_c_host.astype(np.float64)
+        iters = [0, 1, 2]
+        ro = O.solve_matop_cones(O.param(max_iter=5, eps_acc=1e-30), c, a, b, [O.CONE_SOC] * sub, [rows] * sub,
+                                 snap_iters=iters, trace_cap=8)
+    finally:
+        O.set_num_threads(k)
+    del a
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    fs = T.FusedSolver(n, m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule)
+    t, s = fs.precond()
+    N = n + 2 * m + 1
+    assert np.allclose(t, ro.precond[:N], rtol=5e-5, atol=0), np.abs(t / ro.precond[:N] - 1).max()
+    assert np.allclose(s, ro.precond[N:], rtol=5e-5, atol=0), np.abs(s / ro.precond[N:] - 1).max()
+    done = 0
+    for q, it in enumerate(iters):
+        fs.run(it + 1 - done, poll_every=8)
+        done = it + 1
+        x, y = fs.iterate()
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        sx, sy = max(np.abs(rx).max(), 1e-6), max(np.abs(ry).max(), 1e-6)
+        assert np.abs(x - rx).max() <= 1e-4 * sx, (it, np.abs(x - rx).max() / sx)
+        assert np.abs(y - ry).max() <= 1e-4 * sy, (it, np.abs(y - ry).max() / sy)
+        tr = ro.trace[it]
+        assert np.allclose(fs.status().cri, tr[2:], rtol=5e-3, atol=1e-5), (it, fs.status().cri, tr)
+    fs.destroy()
+    inst.free()

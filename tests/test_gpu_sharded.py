@@ -203,6 +203,53 @@ def test_bench_two_processes_share_one_gpu_and_reproduce_single_process():
     assert abs(t1["dual_obj"] - t2["dual_obj"]) <= 1e-4 * (1 + abs(t1["dual_obj"]))
 
 
+def test_bench_gpus_flag_spawns_the_ranks_itself():
+    # the driver's own command: `python bench.py --gpus N ...` with no launcher and no WORLD_SIZE must start the N ranks
+    # itself (the flag was parsed and ignored).  On this 1-GPU box the two ranks share the GPU, so the
+    # all-reduce falls back to the gloo-staged transport by itself; the line must say n_gpus == 2 and reproduce the
+    # 1-rank objectives, and the f64 re-evaluation of THIS run's answer must be in the line for both.
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--size", "2000", "--cones", "40", "--steps", "5", "--warmup", "1", "--no-cpu", "--to-eps", "1e-3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True,
+                        text=True, timeout=900, env=env, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--collective", "gloo"] + common,
+                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    lines1 = [l for l in r1.stdout.splitlines() if l.strip()]
+    lines2 = [l for l in r2.stdout.splitlines() if l.strip()]
+    assert len(lines1) == 1 and len(lines2) == 1, (lines1, lines2)
+    d1, d2 = json.loads(lines1[0]), json.loads(lines2[0])
+    assert d1["n_gpus"] == 1 and d2["n_gpus"] == 2 and d2["physical_gpus"] == 1
+    assert d2["config"]["rows_per_gpu"] == 2000 and "gloo" in d2["config"]["collective"]
+    t1, t2 = d1["time_to_eps"], d2["time_to_eps"]
+    assert t1["state"] == t2["state"] == 0
+    assert abs(t1["iterations"] - t2["iterations"]) <= max(3, 0.01 * t1["iterations"]), (t1, t2)
+    assert abs(t1["primal_obj"] - t2["primal_obj"]) <= 1e-4 * (1 + abs(t1["primal_obj"]))
+    assert abs(t1["dual_obj"] - t2["dual_obj"]) <= 1e-4 * (1 + abs(t1["dual_obj"]))
+    for d in (d1, d2):
+        g = d["objective_gate"]["this_run"]
+        assert g is not None and "error" not in g, g
+        # the f64 re-evaluation agrees with the solver's own f32 criteria: dual residual at eps, primal inside the cone
+        assert g["dual_residual_rel_f64"] <= 1.05e-3 and g["primal_cone_violation_rel_to_norm_b"] <= 1e-5, g
+        assert g["gap_rel"] <= 1e-3, g
+        assert abs(g["primal_obj_f64"] - d["time_to_eps"]["primal_obj"]) <= 1e-5 * (1 + abs(g["primal_obj_f64"]))
+    g1, g2 = d1["objective_gate"]["this_run"], d2["objective_gate"]["this_run"]
+    assert abs(g1["primal_obj_f64"] - g2["primal_obj_f64"]) <= 1e-4 * (1 + abs(g1["primal_obj_f64"]))
+    # without --collective the shared GPU is detected and the transport switched (the driver passes no such flag)
+    r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size", "1500", "--cones", "30",
+                         "--steps", "3", "--warmup", "1", "--no-cpu", "--no-to-eps"], capture_output=True, text=True,
+                        timeout=900, env=env, cwd=root)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    d3 = json.loads([l for l in r3.stdout.splitlines() if l.strip()][0])
+    assert d3["n_gpus"] == 2 and "gloo" in d3["config"]["collective"] and d3["rccl_ranks"] is None
+
+
 def test_bench_prints_one_json_line_with_native_rccl_in_the_loop():
     # RCCL writes a version banner through C stdio when a communicator is created; it must not land on stdout next
     # to the ONE JSON line of the bench contract (it used to: flushed from libc's buffer at exit)
@@ -220,6 +267,7 @@ def test_bench_prints_one_json_line_with_native_rccl_in_the_loop():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert "RCCL" in d["config"]["collective"] and d["n_gpus"] == 1
+    assert d["rccl_ranks"] == 1          # read back from the communicator (ncclCommCount)
 
 
 @pytest.mark.parametrize("schedule", ["fused", "carried"])

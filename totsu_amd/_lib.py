@@ -100,6 +100,7 @@ PROTOTYPES = {
     "thip_comm_unique_id": (_i, [C.POINTER(C.c_uint8)]),
     "thip_comm_init": (_i, [_i, _i, C.POINTER(C.c_uint8)]),
     "thip_comm_allreduce": (_i, [_vp, _sz]),
+    "thip_comm_count": (_i, [C.POINTER(_i)]),
     "thip_comm_destroy": (_i, []),
     "thip_solver_use_rccl": (_i, [_vp]),
     "thip_solver_create": (_i, [C.POINTER(Problem), C.POINTER(Param), _i, C.POINTER(_vp)]),

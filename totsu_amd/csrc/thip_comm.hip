@@ -20,6 +20,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -40,6 +41,7 @@ int load_rccl()
     g.AllReduce = (decltype(g.AllReduce))dlsym(g.handle, "ncclAllReduce");
     g.CommDestroy = (decltype(g.CommDestroy))dlsym(g.handle, "ncclCommDestroy");
     g.GetErrorString = (decltype(g.GetErrorString))dlsym(g.handle, "ncclGetErrorString");
+    g.CommCount = (decltype(g.CommCount))dlsym(g.handle, "ncclCommCount");
     if (!g.GetUniqueId || !g.CommInitRank || !g.AllReduce || !g.CommDestroy)
         return fail(THIP_E_INVALID, "librccl lacks a required symbol", __FILE__, __LINE__);
     return 0;
@@ -95,6 +97,16 @@ int thip_comm_destroy(void)
     const ncclResult_t r = g.CommDestroy(g.comm);
     g.comm = nullptr;
     return r == ncclSuccess ? 0 : nccl_fail(r, "ncclCommDestroy");
+}
+
+int thip_comm_count(int *host_ranks)
+{
+    if (!host_ranks) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    *host_ranks = 0;
+    if (!g.comm) return 0;                 // no communicator: 0 ranks, not an error
+    if (!g.CommCount) return fail(THIP_E_INVALID, "librccl lacks ncclCommCount", __FILE__, __LINE__);
+    const ncclResult_t r = g.CommCount(g.comm, host_ranks);
+    return r == ncclSuccess ? 0 : nccl_fail(r, "ncclCommCount");
 }
 
 int thip_comm_allreduce(float *dev_buf, size_t n)

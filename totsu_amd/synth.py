@@ -41,11 +41,18 @@ def _gen(n, seed, stream, idx0, kind, scale=1.0, shift=0.0):
 class SocpInstance:
     """device-resident row shard of the synthetic SOCP"""
 
-    def __init__(self, n, n_cones, ni=99, seed=0, rank=0, world=1, allreduce_host=None):
+    def __init__(self, n, n_cones, ni=99, seed=0, rank=0, world=1, allreduce_host=None, first_cones=None):
+        """first_cones: build the STANDALONE problem made of the first `first_cones` cones of the n_cones-cone instance
+        (same matrix entries -- the generator's index still runs over all n_cones * (1 + ni) rows -- with the objective
+        formed from these rows alone): the sub-instance bench.py's cpu_baseline leg times, and the one the full-n parity
+        test compares with the oracle."""
         _lib.ensure_init()
         self.n, self.n_cones, self.ni, self.seed = n, n_cones, ni, seed
         rows = 1 + ni
         c0, c1 = shard_cones(n_cones, world, rank)
+        if first_cones is not None:
+            assert world == 1 and 0 < first_cones <= n_cones
+            c0, c1 = 0, first_cones
         self.c0, self.c1 = c0, c1
         self.m_total = n_cones * rows
         self.m = (c1 - c0) * rows
