@@ -54,9 +54,11 @@ def parse():
     ap.add_argument("--to-eps", type=float, default=None,
                     help="also solve to this eps_acc and report time-to-eps (default: 1e-3 for the socp workload at its "
                          "full size -- the eps_acc the reference runs its f32 backend at, benchmark_lp/src/main.rs:62-65)")
-    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off"],
-                    help="N > 1: all-reduce on the solver's side stream under the local-row work (thip_solver_set_overlap); "
-                         "auto = time both during the warm-up and keep the faster")
+    ap.add_argument("--overlap", default="auto", choices=["auto", "on", "off", "pipeline", "pipeline-inorder"],
+                    help="N > 1 (thip_solver_set_overlap): off = collectives in order on the launch stream; on = on the "
+                         "solver's side stream under the local-row work; pipeline = column-split pipeline (the all-reduce of "
+                         "a column half under the next half-launch); auto = time off / on / pipeline on the real communicator "
+                         "during the warm-up and keep the fastest")
     ap.add_argument("--path", default="fused", choices=["fused", "trait"],
                     help="fused: the device-resident loop (the product's hot path).  trait: the compiled trait-level host "
                          "(examples/trait_host.cpp over include/totsu_f32hip.hpp): Solver::solve call by call through the "
@@ -501,26 +503,30 @@ def run(a):
             dist.barrier()
         torch.cuda.synchronize()
 
-    overlap_pick = None
+    overlap_pick, overlap_times = None, None
+    OVM = {"off": 0, "on": 1, "pipeline": 2, "pipeline-inorder": 3}
     if hook is not None and a.collective != "gloo":
         if a.overlap == "auto":
-            # untimed: 3 x 20 iterations each way (max over ranks), keep the faster -- like the GEMV plan autotune
+            # untimed: 3 x 20 iterations per mode (max over ranks), keep the fastest -- like the GEMV plan autotune
             best = {}
-            for mode in (0, 1, 0, 1, 0, 1):
-                lib.thip_solver_set_overlap(fs.h, mode)
+            cand = ("off", "on", "pipeline")
+            for mode in cand * 3:
+                lib.thip_solver_set_overlap(fs.h, OVM[mode])
                 barrier()
                 t0 = time.perf_counter()
                 fs.run(20, poll_every=20)
                 barrier()
                 best[mode] = min(best.get(mode, 1e30), time.perf_counter() - t0)
-            tt = torch.tensor([best[0], best[1]], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([best[c] for c in cand], dtype=torch.float64, device="cuda")
             if use_dist:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            overlap_pick = "on" if float(tt[1]) < float(tt[0]) else "off"
-            a.warmup_extra = 120
+            tl = [float(v) for v in tt]
+            overlap_pick = cand[tl.index(min(tl))]
+            overlap_times = {c: 1e3 * v / 20 for c, v in zip(cand, tl)}          # ms per iteration, as timed
+            a.warmup_extra = 20 * 3 * len(cand)
         else:
             overlap_pick = a.overlap
-        lib.thip_solver_set_overlap(fs.h, 1 if overlap_pick == "on" else 0)
+        lib.thip_solver_set_overlap(fs.h, OVM[overlap_pick])
     fs.run(a.warmup, poll_every=max(a.warmup, 1))
     barrier()
     lib.thip_prof_enable(1)
@@ -546,9 +552,11 @@ def run(a):
         rccl_ranks = cnt.value
         assert rccl_ranks == world, (rccl_ranks, world)
     passes, bytes_per_pass = fs.passes()
+    ovi = fs.overlap_info()
+    lpp = ovi["launches_per_pass"]         # 2 when the column-split pipeline runs: a pass is two half-launches
     iters_per_s = a.steps / elapsed
     avg_ms = tot_ms.value / max(nl.value, 1)
-    achieved = bytes_per_pass / (avg_ms * 1e-3) / 1e9 if nl.value else 0.0
+    achieved = bytes_per_pass / lpp / (avg_ms * 1e-3) / 1e9 if nl.value else 0.0
     m_total = inst.m_total
     b_iter = 24.0 * m_total * n                              # 6 GEMVs x 4 m n bytes
     roofline = {
@@ -561,7 +569,8 @@ def run(a):
         "traffic": None,
         "traffic_source": None,
         "timer": "hip_events on the launch stream around every dual_gemv_k launch of the timed region (thip_prof_*)",
-        "bytes_per_launch": bytes_per_pass,
+        "bytes_per_launch": bytes_per_pass / lpp,
+        "launches_per_pass": lpp,
         "avg_launch_ms": avg_ms,
         "launches_timed": nl.value,
         "passes_over_A_per_iter": passes,
@@ -606,6 +615,7 @@ def run(a):
         "state_arith": a.state,
         "config": {"workload": wl, "schedule": a.schedule, "passes_over_A_per_iter": passes,
                    "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll, "overlap": overlap_pick,
+                   "overlap_mode_run": ovi["mode"], "overlap_split_col": ovi["split_col"], "overlap_autotune_ms_per_iter": overlap_times,
                    "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan(), "a_storage": a.a_storage},
         "roofline": roofline,
         # north_star: "same primal/dual objective as the f64 CPU reference within 1e-4 relative".  The f64 oracle runs the
@@ -644,7 +654,7 @@ def run(a):
         t0 = time.perf_counter()
         fs2 = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
                             a.schedule, allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"),
-                            overlap=(overlap_pick == "on") if overlap_pick is not None else None)
+                            overlap=overlap_pick)
         r2 = run_to_end(fs2)
         barrier()
         phase1 = None

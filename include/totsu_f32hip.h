@@ -7,7 +7,12 @@
  * Conventions
  *   - every `float *` / `const float *` is a DEVICE pointer unless the name starts with `host_`;
  *   - every call enqueues on the context stream (thip_set_stream) and returns without
- *     synchronising, except the ones that return a host scalar (marked SYNC);
+ *     synchronising, except the ones that return a host scalar (marked SYNC).  This holds as stated by DEFAULT and
+ *     always while a caller-provided stream is installed.  A host that drives everything through this API may opt into
+ *     deferred execution of small calls with thip_set_lazy_gemv(1) (see there): those calls are then enqueued at the
+ *     latest when the next non-deferred entry point -- including thip_get_stream / thip_sync -- is entered, so call
+ *     order is still what every thip_* caller observes, but work the HOST enqueues by itself on the stream must be
+ *     preceded by thip_get_stream();
  *   - return value: 0 = ok, otherwise a hipError_t (or THIP_E_* below); thip_last_error() gives text.
  *     The reference backends assert on library status (f32cuda.rs:38 etc.): a binding should
  *     `assert_eq!(rc, 0)`;
@@ -41,7 +46,7 @@ int  thip_init(int device);                        /* cuda_mgr.rs:30-60 */
 int  thip_shutdown(void);
 int  thip_device_count(int *host_count);
 int  thip_set_stream(void *hip_stream);            /* NULL = the context's own stream */
-void *thip_get_stream(void);
+void *thip_get_stream(void);                       /* runs what is deferred first; NULL = that failed (thip_last_error) */
 int  thip_sync(void);                              /* SYNC */
 const char *thip_last_error(void);
 const char *thip_version(void);
@@ -75,14 +80,19 @@ int thip_transform_di(size_t n, float alpha, const float *d, const float *x,
  * linalg_ex.rs:23 (cublasSgemv, f32cuda.rs:144-171) */
 int thip_transform_ge(int transpose, size_t n_row, size_t n_col, float alpha, const float *mat,
                       const float *x, float beta, float *y);
-/* Small calls are DEFERRED and batched: thip_transform_ge on matrices <= 64 MB, thip_scale / thip_add on vectors <= 1024
- * long.  A composite operator issues them per block (ProbSOCPOpA / ProbSOCPOpB, socp.rs:77-130,194-246: 5000 per product
- * at BASELINE configs[2]); the library records them and runs the record -- one grouped launch per kind of product plus
- * one finishing launch -- as soon as ANY other entry point is called or a new call would read or overwrite a pending
- * result, so call order is still what every caller observes.  Contributions to the same y are summed in a fixed order of
- * their own (last-bit differences from sequential accumulation).  thip_set_lazy_gemv(0) (or THIP_LAZY_GEMV=0) restores
- * one launch per call. */
+/* OPT-IN deferred, batched execution of small calls (off by default; off while a caller stream is installed with
+ * thip_set_stream): thip_transform_ge on matrices <= 64 MB, thip_scale / thip_add on vectors <= 1024 long and the
+ * single-cone projections thip_proj_soc / _rotsoc / _rpos / _zero are RECORDED instead of launched.  A composite operator
+ * issues them per block (ProbSOCPOpA / ProbSOCPOpB, socp.rs:77-130,194-246: 5000 per product at BASELINE configs[2];
+ * ProbSOCPCone::proj, socp.rs:296-313: 1000 per projection); the library runs the record -- one grouped launch per kind
+ * of product plus one finishing launch, one launch for a run of projections -- as soon as ANY other entry point is
+ * called or a new call would read or overwrite a pending result, so call order is still what every caller of this API
+ * observes.  Contributions to the same y are summed in a fixed order of their own (last-bit differences from sequential
+ * accumulation).  Errors of a deferred call surface at the entry point that runs the record.  The trait-level hosts
+ * (include/totsu_f32hip.hpp Solver, totsu_amd.Solver, the Rust crate's init()) switch it on for their own calls;
+ * THIP_LAZY_GEMV=1 switches it on from the environment. */
 int thip_set_lazy_gemv(int on);
+int thip_get_lazy_gemv(int *host_on);
 int thip_lazy_gemv_stats(int64_t *host_deferred, int64_t *host_flushes);
 /* y = alpha * S x + beta * y, S symmetric, packed upper by columns.  linalg_ex.rs:37 (cublasSspmv, f32cuda.rs:174-187) */
 int thip_transform_sp(size_t n, float alpha, const float *mat, const float *x, float beta, float *y);
@@ -179,6 +189,9 @@ typedef struct thip_solver thip_solver;
  *   THIP_STATE_PLAIN: x + inc in plain f32, the reference's literal arithmetic. */
 enum { THIP_STATE_COMPENSATED = 0, THIP_STATE_PLAIN = 1 };
 
+/* ABI 3 (thip_version): thip_param grew by state_arith + reserved in round 2 (32 -> 40 bytes): callers built against the
+ * 32-byte struct must be rebuilt.  Its zero value selects THIP_STATE_COMPENSATED, i.e. the DEFAULT fused loop does not
+ * perform the reference's literal f32 iterate additions (solver.rs:542,560); set THIP_STATE_PLAIN for those. */
 typedef struct thip_param {           /* solver.rs:13-41 */
     int64_t max_iter;                 /* < 0: None */
     float   eps_acc, eps_inf, eps_zero;
@@ -238,15 +251,32 @@ int thip_solver_set_csr(thip_solver *s, size_t nnz,
                         const int64_t *dev_rowptr, const int32_t *dev_colidx, const float *dev_vals,
                         const int64_t *dev_t_rowptr, const int32_t *dev_t_colidx, const float *dev_t_vals);
 int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
-/* Row-sharded runs: on != 0 runs each stage's all-reduce on a side HIP stream of the solver (event in / event out)
- * while the launch stream goes on with the stage's work on the LOCAL rows (the x_y / x_s update and the cone
- * projections in the x-stage, the v update in the y-stage), which needs no collective; the x_x / u / tau / kappa
- * updates wait for it.  The hook then receives the side stream.  Results are bitwise those of the in-order run.
- * Off by default: it costs two more launches and two cross-stream event hand-offs per stage (+27 us per iteration
- * measured at world size 1), so it pays only where the collective's latency exceeds that -- time both (bench.py
- * --overlap auto does).  May be switched between thip_solver_run calls.  A hook that ignores its stream argument
- * stays correct (and un-overlapped). */
-int thip_solver_set_overlap(thip_solver *s, int on);
+/* Row-sharded runs: where the all-reduce of a stage's A^T y runs relative to the other work (solver.rs:146 vs 149,
+ * 122 vs 125 are the independences used).  May be switched between thip_solver_run calls.
+ *   THIP_OVERLAP_OFF (0, default)  in order on the launch stream;
+ *   THIP_OVERLAP_LOCAL_ROWS (1)    on a side HIP stream of the solver (event in / event out) while the launch stream goes
+ *       on with the stage's work on the LOCAL rows (the x_y / x_s update and the cone projections in the x-stage, the v
+ *       update in the y-stage); the x_x / u / tau / kappa updates wait for it.  Results are bitwise those of mode 0.
+ *       Hides ~10 us of work and costs two launches + two event hand-offs per stage (+27 us at world size 1);
+ *   THIP_OVERLAP_COLUMN_PIPELINE (2)  carried schedule, dense A: every stage's products run as two launches over the
+ *       column halves [0, n1) and [n1, n) (n1 on a boundary of the GEMV plan's column chunks), and the all-reduce of a
+ *       half's A^T y travels on the side stream under the NEXT half-launch, which only needs the entries of the other
+ *       half; the sharded block partials ride with the second half; the termination test of iteration k is enqueued
+ *       after the first half-launch of iteration k + 1 (which writes scratch only).  Every collective has a whole
+ *       half-pass over the local A to complete in.  Costs six more launches per iteration;
+ *   THIP_OVERLAP_COLUMN_INORDER (3)   the kernels of mode 2 with the collectives in order on the launch stream: the
+ *       bitwise reference of mode 2 (same arithmetic, no concurrency).
+ * Modes 2 / 3 fall back to 1 / 0 where the pipeline does not apply (thip_solver_overlap_info tells).  In modes 1 and 2
+ * the hook receives the side stream; a hook that ignores its stream argument stays correct (and un-overlapped). */
+enum { THIP_OVERLAP_OFF = 0, THIP_OVERLAP_LOCAL_ROWS = 1, THIP_OVERLAP_COLUMN_PIPELINE = 2, THIP_OVERLAP_COLUMN_INORDER = 3 };
+int thip_solver_set_overlap(thip_solver *s, int mode);
+/* the mode the next thip_solver_run will actually use, GEMV launches per pass over A (2 when column-split) and the split
+ * column n1 (0 = none) */
+int thip_solver_overlap_info(thip_solver *s, int *host_mode, int *host_launches_per_pass, size_t *host_split_col);
+/* TEST HOOK: installs a stand-in "collective" that does no arithmetic (the sum over ONE rank) and only takes time: a
+ * device spin of latency_us microseconds on the stream the hook is given.  Lets a 1-GPU box measure what each overlap
+ * mode hides of a collective's latency (tests/test_gpu_sharded.py). */
+int thip_test_spin_allreduce(thip_solver *s, int latency_us);
 /* Storage of the dense A the iteration streams: THIP_A_F32 (default: prob->mat_a as given), or THIP_A_BF16 /
  * THIP_A_F16 (a library-owned 16-bit copy, made on the first request; f16 is column-scaled and rounds 8x finer than
  * bf16: half the bytes per pass, the problem solved is the one with the ROUNDED matrix).  Before thip_solver_init the preconditioners are computed from the stored form; between

@@ -161,6 +161,16 @@ struct SolverParam {                                                            
 };
 enum class SolverError { Ok = 0, Unbounded, Infeasible, ExcessIter, InvalidOp, WorkShortage, ConeFailure };   // solver_error.rs:3-17
 
+// The trait-level loop issues one C-ABI call per reference call; it opts into the library's deferred, batched execution
+// of the small ones (thip_set_lazy_gemv) for the duration of a solve and restores the caller's setting afterwards.
+struct LazyCalls {
+    int prev = 0;
+    LazyCalls() { chk(thip_get_lazy_gemv(&prev)); chk(thip_set_lazy_gemv(1)); }
+    ~LazyCalls() { thip_set_lazy_gemv(prev); }
+    LazyCalls(const LazyCalls &) = delete;
+    LazyCalls &operator=(const LazyCalls &) = delete;
+};
+
 class Solver {
 public:
     SolverParam par;
@@ -175,6 +185,7 @@ public:
         if (c.size() != std::make_pair(n, (size_t)1) || b.size() != std::make_pair(m, (size_t)1)) return SolverError::InvalidOp;
         if (query_worklen(m, n) > work.n) return SolverError::WorkShortage;
         const size_t N = n + 2 * m + 1, M = n + m + 1;
+        LazyCalls lazy_scope;
         DeviceVec one(1);
         // calc_norms, solver.rs:460-481 (fr_norm of a single column)
         const float norm_b = fr_norm(b, one.slice(), work.sub(0, m));

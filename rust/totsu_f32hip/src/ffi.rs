@@ -71,6 +71,7 @@ extern "C" {
     pub fn thip_copy_block(transposed: c_int, n_row: usize, n_col: usize, sign: f32, src: *const f32, dst: *mut f32,
                            ld_dst: usize) -> c_int;
     pub fn thip_set_lazy_gemv(on: c_int) -> c_int;
+    pub fn thip_get_lazy_gemv(host_on: *mut c_int) -> c_int;
     pub fn thip_lazy_gemv_stats(host_deferred: *mut i64, host_flushes: *mut i64) -> c_int;
     pub fn thip_proj_zero(dual_cone: c_int, n: usize, x: *mut f32) -> c_int;
     pub fn thip_proj_rpos(n: usize, x: *mut f32) -> c_int;
@@ -81,7 +82,10 @@ extern "C" {
     pub fn thip_solver_create(prob: *const thip_problem, par: *const thip_param, schedule: c_int,
                               out: *mut *mut thip_solver) -> c_int;
     pub fn thip_solver_set_allreduce(s: *mut thip_solver, f: thip_allreduce_fn, ctx: *mut c_void) -> c_int;
-    pub fn thip_solver_set_overlap(s: *mut thip_solver, on: c_int) -> c_int;
+    pub fn thip_solver_set_overlap(s: *mut thip_solver, mode: c_int) -> c_int;
+    pub fn thip_solver_overlap_info(s: *mut thip_solver, host_mode: *mut c_int, host_launches_per_pass: *mut c_int,
+                                    host_split_col: *mut usize) -> c_int;
+    pub fn thip_test_spin_allreduce(s: *mut thip_solver, latency_us: c_int) -> c_int;
     pub fn thip_solver_init(s: *mut thip_solver) -> c_int;
     pub fn thip_solver_run(s: *mut thip_solver, max_steps: i64, poll_every: i64, host_status: *mut thip_status) -> c_int;
     pub fn thip_solver_solution(s: *mut thip_solver, host_x: *mut f32, host_y: *mut f32) -> c_int;

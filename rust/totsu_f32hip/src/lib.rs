@@ -24,4 +24,10 @@ pub use cones::{HipConePSD, HipConeRPos, HipConeSOC};
 pub use prob::{FusedSolver, HipProbLP, HipProbSOCP, HipSolver};
 
 /// Selects the GPU (cuda_mgr.rs:30-60 hard-codes device 0; any device here).  Call once per thread before use.
-pub fn init(device: i32) { ffi::chk(unsafe { ffi::thip_init(device) }); }
+/// The crate drives the library through this API only and never installs a stream of its own, so it opts into the
+/// deferred, batched execution of small calls (`thip_set_lazy_gemv`, off by default in the library): the per-block loops
+/// of `ProbSOCPOpA/OpB` and `ProbSOCPCone::proj` then run as a handful of launches.
+pub fn init(device: i32) {
+    ffi::chk(unsafe { ffi::thip_init(device) });
+    ffi::chk(unsafe { ffi::thip_set_lazy_gemv(1) });
+}

@@ -290,6 +290,15 @@ def test_soc_batched_moreau_decomposition_at_configs2_layout(L, rot):
 import ctypes as C      # noqa: E402
 
 
+@pytest.fixture(autouse=True)
+def _lazy_off_after_each_test():
+    # deferred execution is OPT-IN (thip_set_lazy_gemv): the tests below switch it on for themselves; the library's
+    # default (off) is restored whatever happens
+    yield
+    from totsu_amd._lib import lib
+    lib.thip_set_lazy_gemv(0)
+
+
 def _dev(L, a):
     return L.Sl.new_mut(np.ascontiguousarray(a, dtype=np.float32).copy())
 
@@ -361,7 +370,6 @@ def test_grouped_block_products_match_numpy(L, lazy):
         assert d1.value - d0.value == 6 * len(nis) + 2 and f1.value - f0.value == 3
     else:
         assert d1.value == d0.value
-    lib.thip_set_lazy_gemv(1)
     for s in dG + dc + dh + [dx, dy, dyn, ds]:
         s.drop()
 
@@ -495,10 +503,56 @@ def test_deferred_execution_fuzz_against_eager(L, seed):
         return out
 
     eager, lazy = run(0), run(1)
-    lib.thip_set_lazy_gemv(1)
     for a, b in zip(eager, lazy):
         assert np.all(np.isfinite(a)) == np.all(np.isfinite(b))
         sc = max(1.0, float(np.abs(a[np.isfinite(a)]).max()) if np.isfinite(a).any() else 1.0)
         assert np.allclose(a, b, rtol=2e-4, atol=2e-4 * sc, equal_nan=True), np.nanmax(np.abs(a - b)) / sc
     for d in dm:
         d.drop()
+
+
+def test_deferred_execution_is_opt_in_and_suspended_on_a_caller_stream(L):
+    """the header's ordering contract: by default, and always while a caller-provided stream is installed, every call has
+    been ENQUEUED when it returns (a caller interleaving its own work on the stream must see it ordered)"""
+    from totsu_amd._lib import lib
+    on = C.c_int(-1)
+    lib.thip_get_lazy_gemv(C.byref(on))
+    assert on.value == 0                                   # the library's default
+    k = 24
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((k, k)).astype(np.float32)
+    dA, dx, dy = _dev(L, np.asfortranarray(A).ravel(order="F")), _dev(L, np.ones(k, np.float32)), _dev(L, np.zeros(k, np.float32))
+    d0, f0, d1, f1 = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    lib.thip_lazy_gemv_stats(C.byref(d0), C.byref(f0))
+    lib.thip_transform_ge(0, k, k, 1.0, dA.dev(), dx.dev(), 0.0, dy.dev())
+    lib.thip_lazy_gemv_stats(C.byref(d1), C.byref(f1))
+    assert d1.value == d0.value                            # not deferred: off by default
+    # opted in, but with a caller stream installed: still not deferred, and the caller's own copy on that stream,
+    # enqueued right behind the call, sees the product
+    hip = C.CDLL("libamdhip64.so")
+    stream = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(stream), 1) == 0
+    lib.thip_sync()
+    lib.thip_set_lazy_gemv(1)
+    lib.thip_set_stream(stream)
+    lib.thip_transform_ge(0, k, k, 2.0, dA.dev(), dx.dev(), 0.0, dy.dev())
+    lib.thip_lazy_gemv_stats(C.byref(d1), C.byref(f1))
+    assert d1.value == d0.value
+    host = np.zeros(k, np.float32)
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    assert hip.hipMemcpyAsync(host.ctypes.data, dy.dev(), 4 * k, 2, stream) == 0
+    assert hip.hipStreamSynchronize(stream) == 0
+    assert np.allclose(host, 2.0 * A.sum(axis=1), rtol=1e-5, atol=1e-5)
+    lib.thip_set_stream(None)
+    # back on the library's own stream the opt-in takes effect, and thip_get_stream runs the record before handing it out
+    lib.thip_transform_ge(0, k, k, 3.0, dA.dev(), dx.dev(), 0.0, dy.dev())
+    lib.thip_lazy_gemv_stats(C.byref(d1), C.byref(f1))
+    assert d1.value == d0.value + 1
+    own = lib.thip_get_stream()
+    assert own
+    assert hip.hipMemcpyAsync(host.ctypes.data, dy.dev(), 4 * k, 2, C.c_void_p(own)) == 0
+    assert hip.hipStreamSynchronize(C.c_void_p(own)) == 0
+    assert np.allclose(host, 3.0 * A.sum(axis=1), rtol=1e-5, atol=1e-5)
+    hip.hipStreamDestroy(stream)
+    for s_ in (dA, dx, dy):
+        s_.drop()

@@ -291,3 +291,166 @@ def test_overlapped_allreduce_is_bitwise_the_in_order_run(T, schedule):
         assert np.array_equal(xa, xb) and np.array_equal(ya, yb)
         assert ra.cri == rb.cri
     socp.drop()
+
+
+# ---- column-split pipeline (thip_solver_set_overlap modes 2 / 3) ------------------------------------------------------
+
+def _pipeline_socp(T, n, cones, seed):
+    f, Gs, hs, cs, d = random_socp(n, cones, seed=seed)
+    return T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(f.reshape(-1, 1)),
+                      [_mb(T, T.MatType.General(g.shape[0], n)).set_array(g) for g in Gs],
+                      [_mb(T, T.MatType.General(len(v), 1)).set_array(v.reshape(-1, 1)) for v in hs],
+                      [_mb(T, T.MatType.General(n, 1)).set_array(v.reshape(-1, 1)) for v in cs], d,
+                      _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+
+
+@pytest.mark.parametrize("n,cones", [(36, [7, 20, 33, 4]), (700, [40, 3, 250, 99, 0, 130])])
+def test_column_pipeline_is_bitwise_its_in_order_form(T, n, cones):
+    # mode 2 (all-reduce of a column half under the next half-launch, termination test one half-launch late) against
+    # mode 3 (the same kernels, collectives in order, no skew): same arithmetic, so the iterates after 300 iterations
+    # must be equal bit for bit; and against mode 0 (one launch per stage) to f32 round-off
+    socp = _pipeline_socp(T, n, cones, 11)
+    parts = _split_rows(socp.dense(), T, 2)
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    a = _run_sharded(T, parts, p, "carried", max_steps=300, overlap=3)
+    b = _run_sharded(T, parts, p, "carried", max_steps=300, overlap=2)
+    c = _run_sharded(T, parts, p, "carried", max_steps=300, overlap=0)
+    for (ra, _, _, (xa, ya)), (rb, _, _, (xb, yb)), (rc, _, _, (xc, yc)) in zip(a, b, c):
+        assert ra.iters == rb.iters == rc.iters == 300
+        assert np.array_equal(xa, xb) and np.array_equal(ya, yb)
+        assert ra.cri == rb.cri
+        assert np.abs(xa - xc).max() <= 2e-4 * max(np.abs(xc).max(), 1e-6)
+        assert np.abs(ya - yc).max() <= 2e-4 * max(np.abs(yc).max(), 1e-6)
+    socp.drop()
+
+
+def test_column_pipeline_stops_at_the_iteration_the_in_order_run_stops_at(T):
+    # the termination test of iteration k is enqueued after the first half-launch of iteration k + 1: the answer must
+    # still be the iterate of stopping at exactly iteration k -- same iteration count, bitwise the same x, y as mode 3,
+    # whatever the polling period; and the converged answer agrees with the unsharded solve and the oracle
+    socp = _pipeline_socp(T, 40, [9, 30, 0, 5, 64, 12], 5)
+    dense = socp.dense()
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 200_000, 1e-4
+    parts = _split_rows(dense, T, 3)
+    a = _run_sharded(T, parts, p, "carried", overlap=3)
+    b = _run_sharded(T, parts, p, "carried", overlap=2)
+    for (ra, xa, ya, _), (rb, xb, yb, _) in zip(a, b):
+        assert ra.state == rb.state == 0 and ra.iters == rb.iters
+        assert np.array_equal(xa, xb) and np.array_equal(ya, yb)
+    fs = T.FusedSolver.from_dense(dense, p, "carried")
+    x1, y1 = fs.solve()
+    r1 = fs.status()
+    fs.destroy()
+    (rb0, xb0, yb0, _), (rb1, _, yb1, _) = b
+    assert abs(rb0.iters - r1.iters) <= max(2, 0.01 * r1.iters)
+    assert np.allclose(xb0, x1, rtol=2e-3, atol=2e-4)
+    assert np.allclose(np.concatenate([yb0, yb1]), y1, rtol=2e-3, atol=2e-4)
+    ro = O.solve_matop_cones(O.param(max_iter=200000, eps_acc=1e-4), dense.vec_c, dense.mat_a, dense.vec_b,
+                             dense.seg_type, dense.seg_len)
+    pobj = float(dense.vec_c.astype(np.float64) @ ro.x)
+    assert abs(float(dense.vec_c.astype(np.float64) @ xb0) - pobj) <= 1e-3 * (1 + abs(pobj))
+    # max_iter inside the run: ExcessIter at the same iteration in both forms
+    p2 = T.SolverParam()
+    p2.max_iter, p2.eps_acc = 37, 0.0
+    a = _run_sharded(T, parts, p2, "carried", overlap=3)
+    b = _run_sharded(T, parts, p2, "carried", overlap=2)
+    for (ra, xa, ya, _), (rb, xb, yb, _) in zip(a, b):
+        assert ra.state == rb.state == 3 and ra.iters == rb.iters == 36
+        assert np.array_equal(xa, xb) and np.array_equal(ya, yb)
+    socp.drop()
+
+
+def test_column_pipeline_falls_back_where_it_does_not_apply(T):
+    # modes 2 / 3 need a collective, a dense A and the carried schedule; elsewhere the library says which mode runs
+    socp = _pipeline_socp(T, 36, [7, 20, 33, 4], 3)
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    d = socp.dense()
+    fs = T.FusedSolver(d.n, d.m, d.mat_a, d.vec_b, d.vec_c, d.seg_type, d.seg_len, p, "carried", allreduce=("spin", 0),
+                       overlap=2)
+    info = fs.overlap_info()
+    assert info["mode"] == 2 and info["launches_per_pass"] == 2 and 0 < info["split_col"] < d.n
+    fs.run(20)
+    fs.destroy()
+    fs = T.FusedSolver(d.n, d.m, d.mat_a, d.vec_b, d.vec_c, d.seg_type, d.seg_len, p, "fused", allreduce=("spin", 0),
+                       overlap=2)
+    assert fs.overlap_info() == {"mode": 1, "launches_per_pass": 1, "split_col": 0}
+    fs.run(20)
+    fs.destroy()
+    fs = T.FusedSolver(d.n, d.m, d.mat_a, d.vec_b, d.vec_c, d.seg_type, d.seg_len, p, "carried")
+    fs.set_overlap(3)
+    assert fs.overlap_info()["mode"] == 0        # no collective installed
+    fs.destroy()
+    socp.drop()
+
+
+def test_column_pipeline_hides_an_injected_collective_latency(T):
+    # The per-GPU work of BASELINE configs[2] at N = 8: a 12 500 x 50 000 row shard (2.5 GB).  The "collective" is a
+    # device spin of L microseconds on the stream the hook is given (thip_test_spin_allreduce: the sum over one rank).
+    # In order (mode 0) an iteration grows by 2 L (two collectives per iteration of the carried schedule); with the
+    # column-split pipeline (mode 2) every collective has a half-pass over the shard (~0.19 ms) to hide in.
+    import json
+    import os
+    import time
+    from totsu_amd import synth
+    from totsu_amd._lib import lib
+    inst = synth.SocpInstance(50_000, 1000, 99, seed=0, first_cones=125)
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    K = 300
+
+    def rate(fs):
+        fs.run(40, poll_every=40)
+        best = 1e30
+        for _ in range(3):
+            lib.thip_sync()
+            t0 = time.perf_counter()
+            fs.run(K, poll_every=K)
+            lib.thip_sync()
+            best = min(best, (time.perf_counter() - t0) / K)
+        return best * 1e6          # us per iteration
+
+    fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried",
+                       allreduce=("spin", 0), overlap=0)
+    t = {}
+    plans = {}
+    for mode in (0, 1, 3, 2):
+        fs.set_overlap(mode)
+        for L in (0, 30, 60):
+            fs.set_spin_latency(L)
+            t[mode, L] = rate(fs)
+        plans[mode] = fs.gemv_plan()
+    info = fs.overlap_info()
+    assert info["mode"] == 2 and info["launches_per_pass"] == 2
+    # bitwise: the pipeline against its in-order form, from the same fresh start
+    its = {}
+    for mode in (3, 2):
+        fs.set_overlap(mode)
+        fs.set_spin_latency(40)
+        fs.reinit()
+        fs.run(25, poll_every=7)
+        its[mode] = fs.iterate()
+    fs.destroy()
+    inst.free()
+    rec = {"what": "us per iteration of the carried schedule on a 12 500 x 50 000 row shard (BASELINE configs[2] at N = 8) with "
+                   "a stand-in collective of L us (device spin on the stream the hook is given); overlap modes 0 in order, "
+                   "1 local rows under the collective, 3 column-split in order, 2 column-split pipeline",
+           "us_per_iteration": {"mode%d_L%d" % k: round(v, 1) for k, v in t.items()},
+           "gemv_plan": {str(k): v for k, v in plans.items()}, "split_col": info["split_col"]}
+    print(json.dumps(rec))
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                           "pipeline_latency_injection.json"), "w") as f:
+        json.dump(rec, f)
+    assert np.array_equal(its[2][0], its[3][0]) and np.array_equal(its[2][1], its[3][1])
+    # in order: + 2 L (allow 25 % slack for launch jitter), split or not
+    assert t[0, 60] - t[0, 0] >= 1.5 * 60, t
+    assert t[0, 30] - t[0, 0] >= 1.5 * 30, t
+    assert t[3, 60] - t[3, 0] >= 1.5 * 60, t
+    # pipelined: the latency disappears under the half-launches
+    assert t[2, 60] - t[2, 0] <= 10.0, t
+    assert t[2, 30] - t[2, 0] <= 10.0, t
+    # and it pays: at L = 60 the pipeline beats every other form
+    assert t[2, 60] < min(t[0, 60], t[1, 60], t[3, 60]), t

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "thip_transform_ge": (_i, [_i, _sz, _sz, _f, _vp, _vp, _f, _vp]),
     "thip_transform_sp": (_i, [_sz, _f, _vp, _vp, _f, _vp]),
     "thip_set_lazy_gemv": (_i, [_i]),
+    "thip_get_lazy_gemv": (_i, [C.POINTER(_i)]),
     "thip_lazy_gemv_stats": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "thip_to_bf16": (_i, [_sz, _sz, _vp, _vp, _sz]),
     "thip_to_f16": (_i, [_sz, _sz, _vp, _vp, _sz, _vp]),
@@ -107,6 +108,8 @@ PROTOTYPES = {
     "thip_solver_set_csr": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thip_solver_set_allreduce": (_i, [_vp, ALLREDUCE_FN, _vp]),
     "thip_solver_set_overlap": (_i, [_vp, _i]),
+    "thip_solver_overlap_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz)]),
+    "thip_test_spin_allreduce": (_i, [_vp, _i]),
     "thip_solver_set_a_storage": (_i, [_vp, _i]),
     "thip_solver_set_a_bf16": (_i, [_vp, _vp, _sz]),
     "thip_solver_set_a_f16": (_i, [_vp, _vp, _sz, _vp]),
@@ -187,6 +190,22 @@ def init(device=None):
         device = int(os.environ.get("LOCAL_RANK", "0"))
     lib.thip_init(int(device))
     _inited = True
+
+
+class lazy_calls:
+    """with lazy_calls(): the trait-level hosts' opt-in to deferred, batched small calls (thip_set_lazy_gemv) for the
+    duration of their own call sequence; the previous setting is restored on exit"""
+
+    def __enter__(self):
+        prev = C.c_int(0)
+        lib.thip_get_lazy_gemv(C.byref(prev))
+        self.prev = prev.value
+        lib.thip_set_lazy_gemv(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib.thip_set_lazy_gemv(self.prev)
+        return False
 
 
 def ensure_init():

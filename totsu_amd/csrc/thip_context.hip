@@ -53,7 +53,7 @@ using namespace thip;
 extern "C" {
 
 const char *thip_last_error(void) { return g_err; }
-const char *thip_version(void) { return "totsu_f32hip 0.1 (gfx950)"; }
+const char *thip_version(void) { return "totsu_f32hip 0.3 (gfx950; ABI 3: thip_param is 40 bytes)"; }
 
 int thip_device_count(int *host_count)
 {
@@ -122,7 +122,9 @@ int thip_set_stream(void *hip_stream)
 
 void *thip_get_stream(void)
 {
-    if (ctx().inited && lazy_pending()) lazy_flush();      // the caller may enqueue its own work behind ours
+    // the caller may enqueue its own work behind ours: what has been deferred is launched first; if that fails the
+    // stream is NOT handed out (NULL; thip_last_error() has the reason)
+    if (ctx().inited && lazy_pending() && lazy_flush() != 0) return nullptr;
     return (void *)ctx().stream;
 }
 

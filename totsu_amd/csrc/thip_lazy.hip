@@ -66,7 +66,7 @@ struct Queue {
     size_t n_members = 0;
     uintptr_t xlo = ~(uintptr_t)0, xhi = 0, ylo = ~(uintptr_t)0, yhi = 0;
     std::mutex mu;
-    bool enabled = true, env_read = false;
+    bool enabled = false, env_read = false;     // OFF unless a host asks for it (thip_set_lazy_gemv) or THIP_LAZY_GEMV=1
     char *dev = nullptr; size_t dev_bytes = 0;             // partial sums and tables
     // pinned staging of the tables: two halves, an event each ("the upload out of this half has finished")
     char *pin[2] = { nullptr, nullptr }; size_t pin_bytes[2] = { 0, 0 }; hipEvent_t pin_ev[2] = { nullptr, nullptr };
@@ -321,7 +321,9 @@ bool lazy_on()
         if (e) Q.enabled = atoi(e) != 0;
         Q.env_read = true;
     }
-    return Q.enabled;
+    // a caller that installed its own stream (thip_set_stream) may interleave its own work with ours on it: every call
+    // must then have been ENQUEUED when it returns, so nothing is deferred while a foreign stream is installed
+    return Q.enabled && ctx().stream == ctx().own_stream;
 }
 
 }  // namespace
@@ -368,8 +370,8 @@ int lazy_push_scale(size_t n, float alpha, float *x, int *deferred)
 {
     std::lock_guard<std::mutex> lock(Q.mu);
     *deferred = 0;
+    if (alpha == 1.0f) { *deferred = 1; return 0; }          // x <- 1 x: nothing to do, nothing to order (any length)
     if (!lazy_on() || n > LAZY_MAX_VEC || n == 0) return flush_locked();
-    if (alpha == 1.0f) { *deferred = 1; return 0; }          // x <- 1 x: nothing to record
     Member m{};
     m.kind = K_SCALE;
     return push_locked(x, n, alpha, m, deferred);
@@ -395,6 +397,15 @@ int thip_set_lazy_gemv(int on)
     std::lock_guard<std::mutex> lock(Q.mu);
     Q.enabled = on != 0;
     Q.env_read = true;
+    return 0;
+}
+
+int thip_get_lazy_gemv(int *host_on)
+{
+    if (!host_on) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    std::lock_guard<std::mutex> lock(Q.mu);
+    (void)lazy_on();                 // reads THIP_LAZY_GEMV once
+    *host_on = Q.enabled ? 1 : 0;
     return 0;
 }
 

@@ -95,9 +95,11 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
                                              int crit, const float *__restrict__ xs, const float *__restrict__ xy,
                                              const float *__restrict__ b, float eps_zero,
                                              float *__restrict__ part_rep, float *__restrict__ part_sh,
-                                             const DevStatus *st)
+                                             const DevStatus *st, int do_m)
 {
     if (st->stop != 0) return;
+    // do_m == 0 (column-split runs, first half): the n-part only -- g over the given column range and its q0 partial;
+    // the m-part and q1 .. q3 belong to the launch that follows the last column range
     // 256 threads = 64 elements x 4 partial-index lanes: the sum over the ~100 partials of one element is split
     // four ways (4x the loads in flight), combined through LDS, and lane 0 of each element does the epilogue
     __shared__ float sh[16];
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
         }
         __syncthreads();
     }
+    if (do_m)
     for (size_t i0 = blockIdx.x * (size_t)64; i0 < (size_t)m; i0 += gstride) {
         const size_t i = i0 + e;
         double sd = 0.0;
@@ -145,8 +148,11 @@ __global__ __launch_bounds__(BLK) void post_k(int n, int m,
         }
         __syncthreads();
     }
-    q0 = block_sum(q0, sh); q1 = block_sum(q1, sh);
-    if (threadIdx.x == 0) { part_rep[blockIdx.x] = q0; part_sh[gridDim.x + blockIdx.x] = q1; }
+    q0 = block_sum(q0, sh);
+    if (threadIdx.x == 0) part_rep[blockIdx.x] = q0;
+    if (!do_m) return;
+    q1 = block_sum(q1, sh);
+    if (threadIdx.x == 0) part_sh[gridDim.x + blockIdx.x] = q1;
     if (crit) {
         q2 = block_sum(q2, sh); q3 = block_sum(q3, sh);
         if (threadIdx.x == 0) { part_sh[2 * gridDim.x + blockIdx.x] = q2; part_sh[3 * gridDim.x + blockIdx.x] = q3; }
@@ -193,20 +199,22 @@ __global__ __launch_bounds__(BLK) void xupdate_k(int n, int m, const float *__re
                                                 const unsigned char *__restrict__ cls,
                                                 float *__restrict__ xx, float *__restrict__ xy, float *__restrict__ xs,
                                                 float *__restrict__ rxx, float *__restrict__ rxy, float *__restrict__ rxs,
-                                                DevStatus *st, const float *ps_c, const float *ps_b, int np,
-                                                int do_n, int do_m,
+                                                DevStatus *st, const float *ps_c, int np_c, const float *ps_b, int np_b,
+                                                int do_n, int do_m, int do_tau,
                                                 float *__restrict__ kx, float *__restrict__ ky, float *__restrict__ ks)
 {
     if (st->stop != 0) return;
+    // do_tau: the tau update (with do_n in one launch; column-split runs give the x_x rows as two ranges -- n and the
+    // n-pointers then describe a range -- and update tau with the second)
     // kx / ky / ks != NULL: compensated (Kahan) accumulation of the iterate -- see comp_add
     // do_n: the x_x rows and tau (need the all-reduced gT and b.v); do_m: the x_y / x_s rows (local).  Both in one
     // launch, or the m-part first while the all-reduce is in flight.
     // block 0 sums post_k's block partials of c.u (ps_c) and b.v (ps_b: all-reduced block partials when sharded)
     float dc = 0.0f, db = 0.0f;
-    if (do_n && blockIdx.x == 0) {
+    if (do_tau && blockIdx.x == 0) {
         __shared__ double shd[16];
-        dc = block_sum_of_partials(ps_c, np, shd);
-        db = block_sum_of_partials(ps_b, np, shd);
+        dc = block_sum_of_partials(ps_c, np_c, shd);
+        db = block_sum_of_partials(ps_b, np_b, shd);
     }
     const float kappa = st->kappa;
     const size_t gstride = (size_t)gridDim.x * BLK;
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(BLK) void xupdate_k(int n, int m, const float *__re
         rxy[i] = (k < 2) ? oy - 2.0f * ny : oy;
         rxs[i] = (k < 2) ? os - 2.0f * ns : os;
     }
-    if (do_n && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (do_tau && blockIdx.x == 0 && threadIdx.x == 0) {
         // every other thread only reads st->kappa / st->stop; tau is written by this thread alone
         const float old = st->tau;
         float t = old + st->t_tau * (-dc - db);
@@ -266,18 +274,21 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
                                               const float *__restrict__ rxs, const float *__restrict__ Su,
                                               const float *__restrict__ Sv, float *__restrict__ u, float *__restrict__ v,
                                               const float *__restrict__ xx, float eps_zero, float *__restrict__ part,
-                                              DevStatus *st, const float *ps_c, const float *ps_b, int np,
-                                              int do_n, int do_m,
+                                              DevStatus *st, const float *ps_c, int np_c, const float *ps_b, int np_b,
+                                              int do_n, int do_m, int do_kappa, int pbase, int pstride,
                                               float *__restrict__ ku, float *__restrict__ kv)
 {
     if (st->stop != 0) return;
+    // do_kappa: the kappa update (with do_n in one launch; column-split runs give the u rows as two ranges and update
+    // kappa with the second).  The criteria partials of this launch go to part[pbase + block] (||d||^2) and
+    // part[pstride + pbase + block] (c.x_x): one launch pbase = 0, pstride = gridDim.x
     // do_n: the u rows, kappa and the n-part of the criteria (need the all-reduced products); do_m: the v rows (local)
     __shared__ float sh[16];
     float dc = 0.0f, db = 0.0f;      // c.rx_x and b.rx_y: block partials of post_k summed here by block 0
-    if (doy && do_n && blockIdx.x == 0) {
+    if (doy && do_kappa && blockIdx.x == 0) {
         __shared__ double shd[16];
-        dc = block_sum_of_partials(ps_c, np, shd);
-        db = block_sum_of_partials(ps_b, np, shd);
+        dc = block_sum_of_partials(ps_c, np_c, shd);
+        db = block_sum_of_partials(ps_b, np_b, shd);
     }
     const float rtau = st->r_tau;
     const float tau = st->tau;
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
             else h2 = h2in[i];
             v[i] = comp_add(v[i], Sv[i] * (h2 + rxs[i] - b[i] * rtau), kv, i);
         }
-        if (do_n && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (do_kappa && blockIdx.x == 0 && threadIdx.x == 0) {
             const float k = st->kappa + st->s_kappa * (dc + db);
             st->kappa = fminf(k, 0.0f);       // solver.rs:566-567
         }
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
     if (docrit && do_n) {
         dd = block_sum(dd, sh);
         cx = block_sum(cx, sh);
-        if (threadIdx.x == 0) { part[blockIdx.x] = dd; part[gridDim.x + blockIdx.x] = cx; }
+        if (threadIdx.x == 0) { part[pbase + blockIdx.x] = dd; part[pstride + pbase + blockIdx.x] = cx; }
     }
 }
 
@@ -472,6 +483,14 @@ __global__ void precond_k(int n, int m, const float *__restrict__ colabs, const 
     }
 }
 
+// thip_test_spin_allreduce: a stand-in collective that only takes time -- one thread spinning on the constant-rate
+// device clock for `ticks`, on whatever stream the hook is given
+__global__ void spin_k(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -486,10 +505,17 @@ struct thip_solver {
 
     thip_allreduce_fn allreduce = nullptr;
     void *allreduce_ctx = nullptr;
-    // overlap: the stage's all-reduce runs on `side` (event in / event out) under the stage's local-row work
-    bool overlap = false;
+    // overlap (thip_solver_set_overlap): 0 in order on the launch stream; 1 the stage's all-reduce on `side` (event in /
+    // event out) under the stage's local-row work; 2 column-split pipeline (one_iteration_split); 3 the kernels of 2
+    // with the collectives in order (its bitwise reference)
+    int overlap = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipEvent_t sev_in[4] = { nullptr, nullptr, nullptr, nullptr }, sev_out[4] = { nullptr, nullptr, nullptr, nullptr };
+    size_t n1 = 0;                // split column of modes 2 / 3 (a multiple of the GEMV plan's columns per chunk); 0: no split
+    bool tail_pending = false;    // mode 2: the last column half of the y update + the termination test of the previous
+                                  // iteration are still to be enqueued (they wait for its last all-reduce)
+    long long spin_ticks = 0;     // thip_test_spin_allreduce
 
     // optional sparse A (CSR of A and of A^T)
     bool sparse = false; size_t nnz = 0;
@@ -528,16 +554,28 @@ struct thip_solver {
     int a_kind = THIP_A_F32; uint16_t *A16 = nullptr; size_t ld16 = 0; bool A16_owned = false; int a16_kind = 0;
     float *inv_s = nullptr; bool inv_s_owned = false;
     GemvHint hint16{0, 0}; bool tuned16 = false; float tuned16_ms = 0.0f;
-    // f32 with m % 4 != 0 (e.g. the k = 500 SDP: m = 125 250): a library-owned copy with the leading dimension padded to a
-    // multiple of 4 gives the 16-byte-load kernel instead of the scalar one (made by thip_solver_init for A < 4 GB)
+    // the column-split form (overlap modes 2 / 3) has its own tuned plans: a half-launch has half the workgroups of the
+    // whole-matrix launch, so the best tiling differs (the 12 500 x 50 000 shard: ~1k tall tiles unsplit)
+    bool split_plan = false;      // the next run streams A as two column-half launches per pass
+    GemvHint hint_sp{0, 0}; bool tuned_sp = false; float tuned_sp_ms = 0.0f;
+    GemvHint hint16_sp{0, 0}; bool tuned16_sp = false; float tuned16_sp_ms = 0.0f;
+    // f32 with m % 16 != 0 (e.g. the k = 500 SDP: m = 125 250; a 12 500-row shard): a library-owned copy with the leading
+    // dimension padded to a multiple of 16 floats, made by ensure_apad() when an f32 pass is about to run and the copy
+    // fits a third of the free HBM
     float *Apad = nullptr; size_t ldpad = 0;
+    int lda_pad = -1;             // thip_solver_set_lda_pad: -1 = default (16 floats, or THIP_LDA_PAD), 0 = never copy
+    int autotune = -1;            // thip_solver_set_gemv_autotune: -1 = default (on, or THIP_GEMV_AUTOTUNE), 0 / 1
     bool is16() const { return a_kind != THIP_A_F32; }
     const void *amat() const { return is16() ? (const void *)A16 : (Apad ? (const void *)Apad : (const void *)A); }
     size_t alda() const { return is16() ? ld16 : (Apad ? ldpad : m); }
     // rows m .. alda() - 1 of the matrix in use are zeros written by this library (its padded f32 copy, or a 16-bit copy it made)
     bool apadz() const { return is16() ? A16_owned : Apad != nullptr; }
     const float *ainv() const { return a_kind == THIP_A_F16 ? inv_s : nullptr; }
-    const GemvHint *ahint() const { return is16() ? (tuned16 ? &hint16 : nullptr) : (tuned ? &hint : nullptr); }
+    const GemvHint *ahint() const
+    {
+        if (split_plan) return is16() ? (tuned16_sp ? &hint16_sp : nullptr) : (tuned_sp ? &hint_sp : nullptr);
+        return is16() ? (tuned16 ? &hint16 : nullptr) : (tuned ? &hint : nullptr);
+    }
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
     bool inited = false;
@@ -601,7 +639,7 @@ int do_allreduce(thip_solver *s, float *buf, size_t count)
 int allreduce_begin(thip_solver *s, float *buf, size_t count)
 {
     if (!s->allreduce) return 0;
-    if (!s->overlap) return do_allreduce(s, buf, count);
+    if (!(s->overlap == 1 || s->overlap == 2)) return do_allreduce(s, buf, count);
     hipStream_t st = ctx().stream;
     THIP_TRY(hipEventRecord(s->ev_in, st));
     THIP_TRY(hipStreamWaitEvent(s->side, s->ev_in, 0));
@@ -612,7 +650,7 @@ int allreduce_begin(thip_solver *s, float *buf, size_t count)
 }
 int allreduce_end(thip_solver *s)
 {
-    if (!s->allreduce || !s->overlap) return 0;
+    if (!s->allreduce || !(s->overlap == 1 || s->overlap == 2)) return 0;
     THIP_TRY(hipStreamWaitEvent(ctx().stream, s->ev_out, 0));
     return 0;
 }
@@ -715,21 +753,21 @@ int one_iteration(thip_solver *s)
     auto shp = [&](float *nvec) { return local ? part : nvec + s->n; };
     const size_t arcount = s->n + TAIL;
     float *const part_y = s->part + 4 * PG;          // ycrit_k's own partials (read by status_k)
-    const bool split = !local && s->overlap;         // m-part under the all-reduce, n-part after it
+    const bool split = !local && (s->overlap == 1 || s->overlap == 2);   // m-part under the all-reduce, n-part after it
     float *const kx = s->comp() ? s->kx : nullptr, *const ky = s->comp() ? s->ky : nullptr;
     float *const ks = s->comp() ? s->ks : nullptr, *const ku = s->comp() ? s->ku : nullptr;
     float *const kv = s->comp() ? s->kv : nullptr;
 
     auto xupdate = [&](int do_n, int do_m) {
         hipLaunchKernelGGL(xupdate_k, dim3(g), dim3(BLK), 0, st, n, m, s->g1, s->h1, s->c, s->b, s->v, s->Tx, s->Ty, s->Ts,
-                           s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dst, part, shp(s->g1) + gq, (int)gq,
-                           do_n, do_m, kx, ky, ks);
+                           s->cls, s->xx, s->xy, s->xs, s->rxx, s->rxy, s->rxs, s->dst, part, (int)gq, shp(s->g1) + gq, (int)gq,
+                           do_n, do_m, do_n, kx, ky, ks);
     };
     // ---- stage X: x update (solver.rs:538-555) ----------------------------------------------------
     THIP_RC(products(s, s->u, s->v, &gp, s->h1, s->g1));
     hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g1, gp.partN, gp.nN,
                        gp.strideN, s->h1, s->c, s->u, s->b, s->v, 0, (const float *)nullptr, (const float *)nullptr,
-                       (const float *)nullptr, ez, part, shp(s->g1), s->dst);
+                       (const float *)nullptr, ez, part, shp(s->g1), s->dst, 1);
     THIP_RC(allreduce_begin(s, s->g1, arcount));
     if (split) {
         xupdate(0, 1);
@@ -747,12 +785,12 @@ int one_iteration(thip_solver *s)
         THIP_RC(products(s, s->rxx, s->rxy, &gp, s->h2, s->g2));
         hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g2, gp.partN, gp.nN,
                            gp.strideN, s->h2, s->c, s->rxx, s->b, s->rxy, 0, (const float *)nullptr,
-                           (const float *)nullptr, (const float *)nullptr, ez, part, shp(s->g2), s->dst);
+                           (const float *)nullptr, (const float *)nullptr, ez, part, shp(s->g2), s->dst, 1);
         auto yupdate = [&](int do_n, int do_m) {
             hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, 1, 0, 0, (const float *)nullptr,
                                (const float *)nullptr, (float *)nullptr, (float *)nullptr, s->g2, s->h2, s->c, s->b, s->rxs,
-                               s->Su, s->Sv, s->u, s->v, s->xx, ez, part_y, s->dst, part, shp(s->g2) + gq, (int)gq,
-                               do_n, do_m, ku, kv);
+                               s->Su, s->Sv, s->u, s->v, s->xx, ez, part_y, s->dst, part, (int)gq, shp(s->g2) + gq, (int)gq,
+                               do_n, do_m, do_n, 0, (int)g, ku, kv);
         };
         THIP_RC(allreduce_begin(s, s->g2, arcount));
         if (split) { yupdate(0, 1); THIP_RC(allreduce_end(s)); yupdate(1, 0); }
@@ -764,11 +802,11 @@ int one_iteration(thip_solver *s)
     // block partials: q0 = c.rx_x, q1 = b.rx_y (carried), q2 = ||p||^2, q3 = b.x_y
     hipLaunchKernelGGL(post_k, dim3(gq), dim3(BLK), 0, st, n, m, gp.partT, gp.nT, gp.strideT, s->g3, gp.partN, gp.nN,
                        gp.strideN, s->h3, carried ? s->c : (const float *)nullptr, s->rxx,
-                       carried ? s->b : (const float *)nullptr, s->rxy, 1, s->xs, s->xy, s->b, ez, part, shp(s->g3), s->dst);
+                       carried ? s->b : (const float *)nullptr, s->rxy, 1, s->xs, s->xy, s->b, ez, part, shp(s->g3), s->dst, 1);
     auto ycrit = [&](int do_n, int do_m) {
         hipLaunchKernelGGL(ycrit_k, dim3(g), dim3(BLK), 0, st, n, m, carried ? 1 : 0, 1, 1, s->g3, s->h3, s->gP, s->hP,
                            (const float *)nullptr, (const float *)nullptr, s->c, s->b, s->rxs, s->Su, s->Sv, s->u, s->v, s->xx,
-                           ez, part_y, s->dst, part, shp(s->g3) + gq, (int)gq, do_n, do_m, ku, kv);
+                           ez, part_y, s->dst, part, (int)gq, shp(s->g3) + gq, (int)gq, do_n, do_m, do_n, 0, (int)g, ku, kv);
     };
     THIP_RC(allreduce_begin(s, s->g3, arcount));
     if (split && carried) { ycrit(0, 1); THIP_RC(allreduce_end(s)); ycrit(1, 0); }
@@ -779,15 +817,195 @@ int one_iteration(thip_solver *s)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Column-split pipeline for row-sharded runs (thip_solver_set_overlap(s, 2); carried schedule, dense A).
+//
+// A stage's products only need, column range by column range, the all-reduced entries of the n-vector they multiply
+// (solver.rs:146 vs 149, 122 vs 125: the N product of columns [a, b) reads x[a .. b) only).  So every stage runs as two
+// launches over the column halves H1 = [0, n1) and H2 = [n1, n), and the all-reduce of a half's A^T y travels on the
+// side stream while the NEXT half-launch streams its part of A:
+//
+//   X.1  gemv(H1; u, v)  post -> g1[H1]                         AR(g1[H1])   ---------.
+//        [tail of the previous iteration: wait AR(g3[H2]) ; u[H2], kappa, criteria ; termination test]
+//   X.2  gemv(H2; u, v)  post -> g1[H2], h1, b.v partials       AR(g1[H2] + tail) ----|--.
+//        wait AR(g1[H1]) <----------------------------------------------------------'  |
+//        x_x[H1], x_y, x_s, block cones                                                 |
+//   C.1  gemv(H1; x_x, x_y)  post -> g3[H1]                     AR(g3[H1])   ---------. |
+//        wait AR(g1[H2]) <------------------------------------------------------------|-'
+//        x_x[H2], tau                                                                  |
+//   C.2  gemv(H2; x_x, x_y)  post -> g3[H2], h3, criteria sums  AR(g3[H2] + tail) ----|--.  (consumed by the tail above)
+//        wait AR(g3[H1]) <------------------------------------------------------------'
+//        u[H1], v
+//
+// Every collective has a whole half-launch (0.19 ms on a 1/8 shard of BASELINE configs[2]) to complete in.  The sharded
+// block partials ride with the second half.  The termination test of iteration k is enqueued after the first
+// half-launch of iteration k + 1; that launch and its reduction only write scratch (partial sums, g1[H1]), so the
+// iterate is still exactly the one of stopping at iteration k.  The two half-launches use the tiling of the whole
+// matrix and leave their partial sums where one launch would (dual_gemv_partials_cols), so h = A x is bit for bit the
+// unsplit product.  Mode 3 enqueues the same kernels with the collectives in order and no skew: the iterates of modes
+// 2 and 3 are bitwise equal (tests/test_gpu_sharded.py).
+// ---------------------------------------------------------------------------------------------------
+size_t split_column(const thip_solver *s)
+{
+    if (s->sparse || s->m == 0 || s->n == 0) return 0;
+    int chunks = 0;
+    const int cpc = dual_gemv_cols_per_chunk(s->m, s->n, s->amat(), s->alda(), s->ahint(), s->a_kind, &chunks);
+    if (chunks < 2) return 0;
+    return (size_t)(chunks / 2) * (size_t)cpc;
+}
+
+bool split_active(const thip_solver *s)
+{
+    return s->split_plan && s->n1 > 0 && s->n1 < s->n;
+}
+
+int autotune_gemv(thip_solver *s);
+
+// decides the form of the next run: column-split (its own tuned plan, its split column) or one launch per pass
+int prepare_split(thip_solver *s)
+{
+    s->split_plan = s->overlap >= 2 && s->allreduce != nullptr && !s->sparse && s->schedule == THIP_SCHED_CARRIED
+                    && s->m > 0 && s->n > 0;
+    s->n1 = 0;
+    if (s->inited) THIP_RC(autotune_gemv(s));        // once per stored form and launch form (a no-op afterwards)
+    if (!s->split_plan) return 0;
+    s->n1 = split_column(s);
+    if (s->n1 == 0 || s->n1 >= s->n) { s->split_plan = false; s->n1 = 0; }
+    return 0;
+}
+
+int ar_begin(thip_solver *s, int slot, float *buf, size_t count)
+{
+    if (s->overlap != 2) return do_allreduce(s, buf, count);
+    hipStream_t st = ctx().stream;
+    THIP_TRY(hipEventRecord(s->sev_in[slot], st));
+    THIP_TRY(hipStreamWaitEvent(s->side, s->sev_in[slot], 0));
+    const int rc = s->allreduce(s->allreduce_ctx, buf, count, (void *)s->side);
+    if (rc != 0) return fail(rc, "all-reduce callback failed", __FILE__, __LINE__);
+    THIP_TRY(hipEventRecord(s->sev_out[slot], s->side));
+    return 0;
+}
+
+int ar_wait(thip_solver *s, int slot)
+{
+    if (s->overlap != 2) return 0;
+    THIP_TRY(hipStreamWaitEvent(ctx().stream, s->sev_out[slot], 0));
+    return 0;
+}
+
+int products_cols(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp, size_t col0, size_t col1)
+{
+    hipStream_t st = ctx().stream;
+    prof_begin(st);
+    THIP_RC(dual_gemv_partials_cols(st, s->m, s->n, s->amat(), s->alda(), xn, xt, true, true, s->gemv_scr, s->gemv_scr_n, gp,
+                                    &s->dst->stop, s->ahint(), s->a_kind, s->ainv(), s->apadz(), col0, col1));
+    prof_end(st);
+    return 0;
+}
+
+struct SplitCtx {
+    thip_solver *s; hipStream_t st; int m; unsigned g; size_t n1, n2;
+    float *partX, *partC, *part_y, *kx, *ky, *ks, *ku, *kv; float ez;
+};
+
+SplitCtx split_ctx(thip_solver *s)
+{
+    SplitCtx c;
+    c.s = s; c.st = ctx().stream; c.m = (int)s->m; c.g = egrid(s->n > s->m ? s->n : s->m);
+    c.n1 = s->n1; c.n2 = s->n - s->n1;
+    c.partX = s->part; c.partC = s->part + 2 * NPS; c.part_y = s->part + 4 * PG;
+    const bool k = s->comp();
+    c.kx = k ? s->kx : nullptr; c.ky = k ? s->ky : nullptr; c.ks = k ? s->ks : nullptr;
+    c.ku = k ? s->ku : nullptr; c.kv = k ? s->kv : nullptr;
+    c.ez = s->par.eps_zero;
+    return c;
+}
+
+// y update of one column range of u (+ the v rows, + kappa) and that range's share of the criteria sums
+void split_ycrit(const SplitCtx &c, int half, int do_m, int do_kappa)
+{
+    thip_solver *s = c.s;
+    const size_t c0 = half ? c.n1 : 0, len = half ? c.n2 : c.n1;
+    hipLaunchKernelGGL(ycrit_k, dim3(c.g), dim3(BLK), 0, c.st, (int)len, c.m, 1, 1, 1, s->g3 + c0, s->h3, s->gP + c0, s->hP,
+                       (const float *)nullptr, (const float *)nullptr, s->c + c0, s->b, s->rxs, s->Su + c0, s->Sv, s->u + c0,
+                       s->v, s->xx + c0, c.ez, c.part_y, s->dst, c.partC, (int)(2 * NPS), s->g3 + s->n + NPS, (int)NPS,
+                       1, do_m, do_kappa, half * (int)c.g, 2 * (int)c.g, c.ku ? c.ku + c0 : (float *)nullptr, c.kv);
+}
+
+// what iteration k leaves for after its last all-reduce: u[H2], kappa, the H2 share of the criteria, the termination test
+int split_tail(thip_solver *s)
+{
+    const SplitCtx c = split_ctx(s);
+    THIP_RC(ar_wait(s, 3));
+    split_ycrit(c, 1, 0, 1);
+    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, c.st, 2 * (int)c.g, c.part_y, s->par.eps_acc, s->par.eps_inf, c.ez,
+                       (long long)s->par.max_iter, s->dst, s->g3 + s->n + 2 * NPS, s->g3 + s->n + 3 * NPS, (int)NPS);
+    THIP_LAUNCH_CHECK();
+    s->tail_pending = false;
+    return 0;
+}
+
+int one_iteration_split(thip_solver *s)
+{
+    const SplitCtx c = split_ctx(s);
+    hipStream_t st = c.st;
+    const int m = c.m;
+    const size_t n = s->n, n1 = c.n1, n2 = c.n2;
+    GemvPartials gp;
+    // second reduction stage of one column range (+ the m-part and the sharded sums with the last range)
+    auto post = [&](float *gvec, float *hvec, int half, const float *dn_b, const float *dm_b, int crit, float *prep) {
+        const size_t c0 = half ? n1 : 0, len = half ? n2 : n1;
+        hipLaunchKernelGGL(post_k, dim3(NPS), dim3(BLK), 0, st, (int)len, m, gp.partT + c0, gp.nT, gp.strideT, gvec + c0,
+                           gp.partN, gp.nN, gp.strideN, hvec, s->c + c0, dn_b + c0, s->b, dm_b, crit, s->xs, s->xy, s->b,
+                           c.ez, prep + (size_t)half * NPS, gvec + n, s->dst, half);
+    };
+    auto xupd = [&](int half, int do_m, int do_tau) {
+        const size_t c0 = half ? n1 : 0, len = half ? n2 : n1;
+        hipLaunchKernelGGL(xupdate_k, dim3(c.g), dim3(BLK), 0, st, (int)len, m, s->g1 + c0, s->h1, s->c + c0, s->b, s->v,
+                           s->Tx + c0, s->Ty, s->Ts, s->cls, s->xx + c0, s->xy, s->xs, s->rxx + c0, s->rxy, s->rxs, s->dst,
+                           c.partX, (int)(2 * NPS), s->g1 + n + NPS, (int)NPS, 1, do_m, do_tau,
+                           c.kx ? c.kx + c0 : (float *)nullptr, c.ky, c.ks);
+    };
+
+    // ---- stage X, first half ----
+    THIP_RC(products_cols(s, s->u, s->v, &gp, 0, n1));
+    post(s->g1, s->h1, 0, s->u, s->v, 0, c.partX);
+    THIP_RC(ar_begin(s, 0, s->g1, n1));
+    if (s->tail_pending) THIP_RC(split_tail(s));           // the previous iteration ends here
+    // ---- stage X, second half ----
+    THIP_RC(products_cols(s, s->u, s->v, &gp, n1, n));
+    post(s->g1, s->h1, 1, s->u, s->v, 0, c.partX);
+    THIP_RC(ar_begin(s, 1, s->g1 + n1, n2 + TAIL));
+    THIP_RC(ar_wait(s, 0));
+    xupd(0, 1, 0);
+    THIP_RC(project_blocks(s));
+    // ---- stage C, first half ----
+    THIP_RC(products_cols(s, s->xx, s->xy, &gp, 0, n1));
+    post(s->g3, s->h3, 0, s->rxx, s->rxy, 0, c.partC);
+    THIP_RC(ar_begin(s, 2, s->g3, n1));
+    THIP_RC(ar_wait(s, 1));
+    xupd(1, 0, 1);
+    // ---- stage C, second half ----
+    THIP_RC(products_cols(s, s->xx, s->xy, &gp, n1, n));
+    post(s->g3, s->h3, 1, s->rxx, s->rxy, 1, c.partC);
+    THIP_RC(ar_begin(s, 3, s->g3 + n1, n2 + TAIL));
+    THIP_RC(ar_wait(s, 2));
+    split_ycrit(c, 0, 1, 0);
+    THIP_LAUNCH_CHECK();
+    s->tail_pending = true;
+    if (s->overlap != 2) THIP_RC(split_tail(s));           // in order: no skew
+    return 0;
+}
+
 // Times the candidate tilings of the dual GEMV on THIS matrix (two launches each, the second one timed with HIP
 // events) and keeps the fastest: a handful of passes over A, once per solve.  THIP_GEMV_AUTOTUNE=0 disables it.
 int autotune_gemv(thip_solver *s)
 {
     const char *env = getenv("THIP_GEMV_AUTOTUNE");
-    if ((env && atoi(env) == 0) || getenv("THIP_GEMV_NJ") || getenv("THIP_GEMV_BLOCKS")) return 0;
+    if (s->autotune == 0 || (s->autotune < 0 && env && atoi(env) == 0) || getenv("THIP_GEMV_NJ") || getenv("THIP_GEMV_BLOCKS")) return 0;
     if (s->sparse || s->m * s->n < (size_t)1 << 22) return 0;   // sparse, or tiny: nothing to tune
-    const bool b16 = s->is16();
-    if (b16 ? s->tuned16 : s->tuned) return 0;
+    const bool b16 = s->is16(), sp = s->split_plan;
+    if (sp ? (b16 ? s->tuned16_sp : s->tuned_sp) : (b16 ? s->tuned16 : s->tuned)) return 0;
     hipStream_t st = ctx().stream;
     hipEvent_t e0, e1;
     THIP_TRY(hipEventCreate(&e0));
@@ -797,16 +1015,30 @@ int autotune_gemv(thip_solver *s)
     float best = 1e30f;
     GemvPartials gp;
     GemvHint pick{0, 0};
+    // one pass in the form the iteration will use: one launch, or (split) two launches over the column halves of the
+    // candidate's own chunking
+    auto one_pass = [&](const GemvHint *h) -> int {
+        if (!sp)
+            return dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
+                                      s->gemv_scr_n, &gp, nullptr, h, s->a_kind, s->ainv(), s->apadz());
+        int chunks = 0;
+        const int cpc = dual_gemv_cols_per_chunk(s->m, s->n, s->amat(), s->alda(), h, s->a_kind, &chunks);
+        const size_t n1 = chunks >= 2 ? (size_t)(chunks / 2) * (size_t)cpc : s->n;
+        THIP_RC(dual_gemv_partials_cols(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, s->gemv_scr, s->gemv_scr_n,
+                                        &gp, nullptr, h, s->a_kind, s->ainv(), s->apadz(), 0, n1));
+        if (n1 < s->n)
+            THIP_RC(dual_gemv_partials_cols(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, s->gemv_scr,
+                                            s->gemv_scr_n, &gp, nullptr, h, s->a_kind, s->ainv(), s->apadz(), n1, s->n));
+        return 0;
+    };
     for (int w = 0; w < 3; ++w)         // clocks and caches settle before anything is timed
-        THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
-                                   s->gemv_scr_n, &gp, nullptr, nullptr, s->a_kind, s->ainv(), s->apadz()));
+        THIP_RC(one_pass(nullptr));
     // inputs: the iterate if the loop is already running (storage switch), else zeros -- timing does not depend on them
     for (int i = 0; i < nc; ++i) {
         float ms = 1e30f;
         for (int rep = 0; rep < 5; ++rep) {
             THIP_TRY(hipEventRecord(e0, st));
-            THIP_RC(dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
-                                       s->gemv_scr_n, &gp, nullptr, &c[i], s->a_kind, s->ainv(), s->apadz()));
+            THIP_RC(one_pass(&c[i]));
             // the second reduction stage is part of the price of a plan (finer grids leave more partials to post_k):
             // time it too, into g2 / h2, which every schedule rewrites before reading
             THIP_RC(finalize_partials(st, s->m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, s->h2, nullptr));
@@ -819,8 +1051,13 @@ int autotune_gemv(thip_solver *s)
         }
         if (ms < best) { best = ms; pick = c[i]; }
     }
-    if (b16) { s->hint16 = pick; s->tuned16 = true; s->tuned16_ms = best; }
-    else     { s->hint = pick; s->tuned = true; s->tuned_ms = best; }
+    if (sp) {
+        if (b16) { s->hint16_sp = pick; s->tuned16_sp = true; s->tuned16_sp_ms = best; }
+        else     { s->hint_sp = pick; s->tuned_sp = true; s->tuned_sp_ms = best; }
+    } else {
+        if (b16) { s->hint16 = pick; s->tuned16 = true; s->tuned16_ms = best; }
+        else     { s->hint = pick; s->tuned = true; s->tuned_ms = best; }
+    }
     THIP_TRY(hipEventDestroy(e0));
     THIP_TRY(hipEventDestroy(e1));
     return 0;
@@ -842,6 +1079,45 @@ int rebuild_carried(thip_solver *s)
         THIP_RC(finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, 1.0f, 0.0f, s->gP, nullptr));
     }
     THIP_RC(do_allreduce(s, s->gP, s->n));
+    return 0;
+}
+
+// The f32 passes stream a library-owned copy of A whose leading dimension is padded to a multiple of 16 floats (64 bytes)
+// when m is not one already: aligned columns (measured on row shards of the 50 000-column SOCP: columns of 50 000 B,
+// m = 12 500, 6.32 -> 6.79 TB/s; of 100 000 B 6.3 -> 6.7 TB/s; a 128-byte pitch gains nothing more) and a partial last
+// row tile that may run the unguarded kernel body.  Made only when an f32 pass is about to run (never
+// while the solve streams a 16-bit copy) and when it leaves two thirds of the free HBM untouched (a 40 GB shard of
+// BASELINE configs[4] on a 288 GB part: yes); refreshed by every thip_solver_init, so a caller that rewrites mat_a in
+// place between solves is seen.  THIP_LDA_PAD = the multiple in floats (default 16; 0 = never copy); the API form is
+// thip_solver_set_lda_pad.
+int ensure_apad(thip_solver *s, bool refresh)
+{
+    if (s->sparse || !s->A || s->m == 0 || s->n == 0) return 0;
+    hipStream_t st = ctx().stream;
+    const size_t m = s->m, n = s->n;
+    size_t padto = 16;
+    if (s->lda_pad >= 0) padto = (size_t)s->lda_pad;
+    else if (getenv("THIP_LDA_PAD")) padto = (size_t)atoi(getenv("THIP_LDA_PAD"));
+    if (padto == 0 || m % padto == 0) {
+        if (s->Apad) { THIP_TRY(hipStreamSynchronize(st)); THIP_TRY(hipFree(s->Apad)); s->Apad = nullptr; s->ldpad = 0; s->tuned = s->tuned_sp = false; }
+        return 0;
+    }
+    const size_t ld = (m + padto - 1) / padto * padto;
+    if (s->Apad && s->ldpad != ld) { THIP_TRY(hipStreamSynchronize(st)); THIP_TRY(hipFree(s->Apad)); s->Apad = nullptr; s->tuned = s->tuned_sp = false; }
+    bool fresh = false;
+    if (!s->Apad) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        if (ld * n * sizeof(float) >= free_b / 3) return 0;
+        s->ldpad = ld;
+        THIP_TRY(hipMalloc((void **)&s->Apad, ld * n * sizeof(float)));
+        THIP_TRY(hipMemsetAsync(s->Apad, 0, ld * n * sizeof(float), st));
+        fresh = true;
+        s->tuned = s->tuned_sp = false;             // the plans were timed on the other pitch
+    }
+    if (fresh || refresh)
+        THIP_TRY(hipMemcpy2DAsync(s->Apad, ld * sizeof(float), s->A, m * sizeof(float), m * sizeof(float), n,
+                                  hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -972,7 +1248,7 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
     s->kx = take(pn); s->ku = take(pn); s->ky = take(pm); s->ks = take(pm); s->kv = take(pm);
     s->kahan_n = 2 * pn + 3 * pm;
 
-    THIP_TRY(hipMalloc((void **)&s->part, (4 * PG + 2 * EG) * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&s->part, (4 * PG + 4 * EG) * sizeof(float)));
     // the dense GEMV partial-sum scratch (~ m n / 256 floats) is allocated by thip_solver_init, and only for a dense A
     // (thip_solver_set_csr comes between create and init: a sparse 1e6 x 1e6 operator must not pay 15 GB for it)
     THIP_TRY(hipMalloc((void **)&s->dst, sizeof(DevStatus)));
@@ -1018,13 +1294,18 @@ int thip_solver_set_overlap(thip_solver *s, int on)
 {
     THIP_NEED_INIT();
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (on < 0 || on > 3) return fail(THIP_E_INVALID, "overlap mode is 0 .. 3", __FILE__, __LINE__);
     if (on && !s->side) {
         THIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
         THIP_TRY(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
         THIP_TRY(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
+        for (int k = 0; k < 4; ++k) {
+            THIP_TRY(hipEventCreateWithFlags(&s->sev_in[k], hipEventDisableTiming));
+            THIP_TRY(hipEventCreateWithFlags(&s->sev_out[k], hipEventDisableTiming));
+        }
     }
-    if (!on && s->side && ctx().inited) THIP_TRY(hipStreamSynchronize(s->side));
-    s->overlap = on != 0;
+    if (s->side && ctx().inited) THIP_TRY(hipStreamSynchronize(s->side));
+    s->overlap = on;
     return 0;
 }
 
@@ -1041,23 +1322,7 @@ int thip_solver_init(thip_solver *s)
     s->carried_stale = false;
     s->hst->state = THIP_ST_RUNNING;
     THIP_RC(ensure_gemv_scratch(s));
-    // THIP_LDA_PAD = floats the padded leading dimension is a multiple of (default 16 = 64 bytes; 0 = never copy).
-    // Measured on row shards of the 50 000-column SOCP: columns of 50 000 B (m = 12 500) 6.32 -> 6.79 TB/s and of
-    // 100 000 B (m = 25 000) 6.3 -> 6.7 TB/s once padded; columns of 200 000 B (m = 50 000: a multiple of 64 B but not
-    // of 128) gain nothing from a 128-byte pitch -- so 64 bytes is the pitch that matters
-    const size_t padto = getenv("THIP_LDA_PAD") ? (size_t)atoi(getenv("THIP_LDA_PAD")) : 16;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-    // the copy doubles the footprint of A: made when it leaves two thirds of the free HBM untouched (a 40 GB shard of
-    // BASELINE configs[4] on a 288 GB part: yes)
-    if (!s->sparse && s->A && !s->Apad && padto > 0 && m % padto != 0 && n > 0
-        && ((m + padto) * n * sizeof(float)) < free_b / 3) {
-        s->ldpad = (m + padto - 1) / padto * padto;
-        THIP_TRY(hipMalloc((void **)&s->Apad, s->ldpad * n * sizeof(float)));
-        THIP_TRY(hipMemsetAsync(s->Apad, 0, s->ldpad * n * sizeof(float), st));
-        THIP_TRY(hipMemcpy2DAsync(s->Apad, s->ldpad * sizeof(float), s->A, m * sizeof(float), m * sizeof(float), n,
-                                  hipMemcpyDeviceToDevice, st));
-    }
+    if (!s->is16()) THIP_RC(ensure_apad(s, true));      // a fresh solve re-reads the caller's A (it may have changed in place)
     // init_vecs (solver.rs:483-494): x = 0, y = 0, tau = 1
     THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
     hipLaunchKernelGGL(init_status_k, dim3(1), dim3(1), 0, st, s->dst, 0.0f);
@@ -1093,6 +1358,7 @@ int thip_solver_init(thip_solver *s)
     THIP_TRY(hipMemsetAsync(s->g1, 0, (n + TAIL) * sizeof(float), st));
     THIP_TRY(hipMemsetAsync(s->h1, 0, (m ? m : 1) * sizeof(float), st));
     THIP_LAUNCH_CHECK();
+    s->split_plan = false;           // the one-launch form here; the column-split form is tuned by the first run that uses it
     THIP_RC(autotune_gemv(s));
     s->inited = true;
     return 0;
@@ -1106,10 +1372,13 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
     int64_t done = 0;
     THIP_RC(poll(s, host_status));
     if (s->carried_stale && s->hst->state == THIP_ST_RUNNING) THIP_RC(rebuild_carried(s));
+    THIP_RC(prepare_split(s));
+    const bool split = split_active(s);
     while (s->hst->state == THIP_ST_RUNNING && (max_steps < 0 || done < max_steps)) {
         int64_t batch = poll_every;
         if (max_steps >= 0 && done + batch > max_steps) batch = max_steps - done;
-        for (int64_t k = 0; k < batch; ++k) THIP_RC(one_iteration(s));
+        for (int64_t k = 0; k < batch; ++k) THIP_RC(split ? one_iteration_split(s) : one_iteration(s));
+        if (s->tail_pending) THIP_RC(split_tail(s));       // drain the pipeline before the host looks
         done += batch;
         THIP_RC(poll(s, host_status));
     }
@@ -1225,10 +1494,11 @@ int thip_solver_set_a_storage(thip_solver *s, int a_kind)
             THIP_RC(to_bf16(st, s->m, s->n, s->A, s->A16, s->ld16));
         }
         s->a16_kind = a_kind;
-        s->tuned16 = false;
+        s->tuned16 = s->tuned16_sp = false;
     }
     const bool changed = s->a_kind != a_kind;
     s->a_kind = a_kind;
+    if (s->inited && a_kind == THIP_A_F32) THIP_RC(ensure_apad(s, false));      // first f32 pass of this solve
     if (s->inited) {
         THIP_RC(autotune_gemv(s));      // a switch inside a running solve: tune the other kernel once
         if (changed) s->carried_stale = true;      // rebuilt by the next thip_solver_run (after thip_solver_resume)
@@ -1271,9 +1541,58 @@ int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_byte
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
     if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : 2);
+    // the algorithmic bytes of a pass (4 m n, or 2 m n for a 16-bit A); the padding rows of a library-owned
+    // copy (at most 15 per column) are zeros that the kernel never loads
     if (host_bytes_per_pass) *host_bytes_per_pass = s->sparse ? 2 * s->nnz * (sizeof(float) + sizeof(int32_t))
                                                               : s->m * s->n * (s->is16() ? 2 : sizeof(float));
     return 0;
+}
+
+int thip_solver_set_gemv_autotune(thip_solver *s, int on)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    s->autotune = on != 0;
+    if (!on) { s->tuned = s->tuned16 = s->tuned_sp = s->tuned16_sp = false; }        // back to the shape heuristic: the plan no longer depends on timings
+    return 0;
+}
+
+int thip_solver_set_lda_pad(thip_solver *s, int floats)
+{
+    if (!s || floats < 0) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
+    if (s->inited) return fail(THIP_E_INVALID, "thip_solver_set_lda_pad must precede thip_solver_init", __FILE__, __LINE__);
+    s->lda_pad = floats;
+    return 0;
+}
+
+int thip_solver_overlap_info(thip_solver *s, int *host_mode, int *host_launches_per_pass, size_t *host_split_col)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    THIP_RC(prepare_split(s));
+    const bool split = split_active(s);
+    // what the next thip_solver_run will do: modes 2 / 3 fall back to 1 / 0 where the pipeline does not apply (no
+    // collective installed, sparse A, a schedule other than carried, fewer than two column chunks)
+    if (host_mode) *host_mode = split ? s->overlap : (s->overlap == 2 ? 1 : (s->overlap == 3 ? 0 : s->overlap));
+    if (host_launches_per_pass) *host_launches_per_pass = split ? 2 : 1;
+    if (host_split_col) *host_split_col = split ? s->n1 : 0;
+    return 0;
+}
+
+static int spin_allreduce(void *c, float *, size_t, void *stream)
+{
+    const thip_solver *s = static_cast<const thip_solver *>(c);
+    if (s->spin_ticks > 0) hipLaunchKernelGGL(spin_k, dim3(1), dim3(1), 0, (hipStream_t)stream, s->spin_ticks);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+int thip_test_spin_allreduce(thip_solver *s, int latency_us)
+{
+    THIP_NEED_INIT();
+    if (!s || latency_us < 0) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
+    int khz = 0;
+    THIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx().device));
+    if (khz <= 0) khz = 100000;
+    s->spin_ticks = (long long)latency_us * khz / 1000;
+    return thip_solver_set_allreduce(s, spin_allreduce, s);
 }
 
 int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, float *host_ms)
@@ -1282,7 +1601,7 @@ int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, 
     const GemvHint *h = s->ahint();
     if (host_nj) *host_nj = h ? h->nj : 0;
     if (host_blocks) *host_blocks = h ? h->target_blocks : 0;
-    if (host_ms) *host_ms = s->is16() ? s->tuned16_ms : s->tuned_ms;
+    if (host_ms) *host_ms = s->split_plan ? (s->is16() ? s->tuned16_sp_ms : s->tuned_sp_ms) : (s->is16() ? s->tuned16_ms : s->tuned_ms);
     return 0;
 }
 
@@ -1317,6 +1636,7 @@ int thip_solver_destroy(thip_solver *s)
     if (s->side) { hipStreamSynchronize(s->side); hipStreamDestroy(s->side); }
     if (s->ev_in) hipEventDestroy(s->ev_in);
     if (s->ev_out) hipEventDestroy(s->ev_out);
+    for (int k = 0; k < 4; ++k) { if (s->sev_in[k]) hipEventDestroy(s->sev_in[k]); if (s->sev_out[k]) hipEventDestroy(s->sev_out[k]); }
     hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
     for (auto &g : s->psd_groups) hipFree(g.dev_offs);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);

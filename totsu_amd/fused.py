@@ -163,12 +163,16 @@ class FusedSolver:
         self._cb = None
         if allreduce == "rccl":
             lib.thip_solver_use_rccl(self.h)            # native RCCL on the library's stream (thip_comm_init first)
-        elif allreduce is not None:
+        elif allreduce is not None and not (allreduce == "spin" or (isinstance(allreduce, tuple) and allreduce[0] == "spin")):
             self._cb = _lib.ALLREDUCE_FN(allreduce)
             lib.thip_solver_set_allreduce(self.h, self._cb, None)
+        elif allreduce == "spin" or (isinstance(allreduce, tuple) and allreduce[0] == "spin"):
+            # test hook: a stand-in collective that only takes time (thip_test_spin_allreduce), ("spin", microseconds)
+            lib.thip_test_spin_allreduce(self.h, int(allreduce[1]) if isinstance(allreduce, tuple) else 0)
         if overlap is not None and allreduce is not None:
-            # all-reduce on the solver's side stream under the local-row work (default: on for native RCCL)
-            lib.thip_solver_set_overlap(self.h, 1 if overlap else 0)
+            # OFF by default (the library's default).  True / 1: all-reduce on the solver's side stream under the
+            # local-row work; 2 / "pipeline": column-split pipeline; 3 / "pipeline-inorder": its in-order reference
+            self.set_overlap(overlap)
         self.a_storage = "f32"
         if self._a16 is not None:
             if self._a16.kind == "f16":
@@ -179,6 +183,23 @@ class FusedSolver:
         elif a_storage != "f32":
             self.set_a_storage(a_storage)
         lib.thip_solver_init(self.h)
+
+    OVERLAP = {False: 0, True: 1, 0: 0, 1: 1, 2: 2, 3: 3, "off": 0, "on": 1, "local-rows": 1, "pipeline": 2,
+               "pipeline-inorder": 3}
+
+    def set_overlap(self, mode):
+        """thip_solver_set_overlap: 0 / "off", 1 / "on" (local-row work under the collective), 2 / "pipeline"
+        (column-split pipeline), 3 / "pipeline-inorder" (bitwise reference of 2); allowed between run() calls"""
+        lib.thip_solver_set_overlap(self.h, self.OVERLAP[mode])
+
+    def overlap_info(self):
+        mode, lpp, col = C.c_int(), C.c_int(), C.c_size_t()
+        lib.thip_solver_overlap_info(self.h, C.byref(mode), C.byref(lpp), C.byref(col))
+        return {"mode": mode.value, "launches_per_pass": lpp.value, "split_col": col.value}
+
+    def set_spin_latency(self, us):
+        """test hook (thip_test_spin_allreduce): the stand-in collective's latency in microseconds"""
+        lib.thip_test_spin_allreduce(self.h, int(us))
 
     def reinit(self):
         """thip_solver_init again: a fresh solve of the same problem (x = 0, tau = 1)"""

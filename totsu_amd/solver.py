@@ -175,7 +175,13 @@ class Solver:
         core = _SolverCore(L, self.param, _SelfDualEmbed(L, op_c, op_a, op_b), cone, self.trace)
         w = L.Sl.new_mut(work)
         try:
-            err = core.solve(w)
+            if getattr(L, "name", "") == "F32HIP":
+                # one C-ABI call per reference call: opt into the library's deferred, batched small calls for this solve
+                from ._lib import lazy_calls
+                with lazy_calls():
+                    err = core.solve(w)
+            else:
+                err = core.solve(w)
         finally:
             w.drop()                 # the host `work` is up to date again (f32cuda_slice.rs:203-207)
         self.iters = core.iters
