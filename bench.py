@@ -48,8 +48,10 @@ def parse():
                     help="skip the f64 re-evaluation of the time-to-eps answer (objective_gate.this_run; ~5 s of host f64 at "
                          "the full size, outside every timed region)")
     ap.add_argument("--force-collective", action="store_true", help="install the all-reduce hook even at N = 1")
-    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch", "gloo"],
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "torch", "gloo", "oneshot"],
                     help="rccl: native RCCL call on the library's stream; torch: torch.distributed.all_reduce hook; "
+                         "oneshot: the library's one-launch all-reduce over peer-mapped buffers (hipIpc*; every rank reads its "
+                         "N - 1 peers directly -- for the latency-bound <= 2 MB messages; also works with ranks sharing a GPU); "
                          "gloo: all-reduce staged through the host (lets several ranks share ONE GPU: plumbing tests)")
     ap.add_argument("--to-eps", type=float, default=None,
                     help="also solve to this eps_acc and report time-to-eps (default: 1e-3 for the socp workload at its "
@@ -394,20 +396,22 @@ def run(a):
         sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s): WORLD_SIZE wins\n" % (a.gpus, world))
     n_dev = max(torch.cuda.device_count(), 1)
     shared_gpu = world > n_dev
-    if shared_gpu and a.collective != "gloo":
+    if shared_gpu and a.collective not in ("gloo", "oneshot"):
         # RCCL refuses two ranks on one device: the ranks share the GPU(s) and the all-reduce is staged through the host
         if rank == 0:
             sys.stderr.write("bench.py: %d ranks on %d GPU(s): --collective %s -> gloo (staged through host memory; "
                              "plumbing mode, not a performance configuration)\n" % (world, n_dev, a.collective))
         a.collective = "gloo"
-    if a.collective == "gloo":
+    # the process group (bootstrap, host-side reductions, barriers): RCCL needs one device per rank
+    pg_gloo = a.collective == "gloo" or shared_gpu
+    if pg_gloo:
         local_rank = local_rank % n_dev      # ranks may share a GPU
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_collective
     if use_dist and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if a.collective == "gloo":
+        if pg_gloo:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -421,7 +425,7 @@ def run(a):
         if not use_dist:
             return v
         t = torch.from_numpy(np.ascontiguousarray(v).copy())
-        if a.collective != "gloo":
+        if not pg_gloo:
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
         return t.cpu().numpy()
@@ -457,8 +461,22 @@ def run(a):
             and a.a_storage == "f32":
         a.to_eps = 1e-3
     hook, coll = None, "none"
+    dev_pg = "cpu" if pg_gloo else "cuda"
     if use_dist and a.collective == "gloo":
         hook, coll = GlooAllreduce(torch, dist, lib), "gloo through host memory (plumbing test mode)"
+    elif use_dist and a.collective == "oneshot":
+        # slots for the longest message of the loop (n + the 1024 block partials), handles exchanged through the group
+        import ctypes as C
+        hb = (C.c_uint8 * 64)()
+        lib.thip_oneshot_init(rank, world, n + 2048, hb)
+        mine = torch.frombuffer(bytearray(bytes(hb)), dtype=torch.uint8).to(dev_pg)
+        allh = [torch.zeros(64, dtype=torch.uint8, device=dev_pg) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in allh)
+        lib.thip_oneshot_connect((C.c_uint8 * (64 * world)).from_buffer_copy(blob))
+        dist.barrier()
+        hook, coll = "oneshot", ("one-shot all-reduce over peer-mapped buffers (hipIpc), %d rank(s)%s"
+                                 % (world, " sharing %d GPU(s)" % n_dev if shared_gpu else ""))
     elif use_dist:
         if a.collective == "rccl":
             # every rank takes part in every collective below, whatever fails locally, so that no rank is left waiting
@@ -517,7 +535,7 @@ def run(a):
                 fs.run(20, poll_every=20)
                 barrier()
                 best[mode] = min(best.get(mode, 1e30), time.perf_counter() - t0)
-            tt = torch.tensor([best[c] for c in cand], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([best[c] for c in cand], dtype=torch.float64, device=dev_pg)
             if use_dist:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tl = [float(v) for v in tt]
@@ -539,7 +557,7 @@ def run(a):
     lib.thip_prof_read(C.byref(nl), C.byref(tot_ms))
     lib.thip_prof_enable(0)
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if a.collective == "gloo" else "cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev_pg)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert r.state == _lib.ST_RUNNING and r.iters == a.warmup + a.steps + getattr(a, "warmup_extra", 0), (r.state, r.iters)
@@ -643,7 +661,7 @@ def run(a):
                 # every rank sees the same elapsed-time decision (rank 0's clock)
                 over = time.perf_counter() - t0 > a.to_eps_budget
                 if use_dist:
-                    tt = torch.tensor([1 if over else 0], dtype=torch.int32, device="cpu" if a.collective == "gloo" else "cuda")
+                    tt = torch.tensor([1 if over else 0], dtype=torch.int32, device=dev_pg)
                     dist.broadcast(tt, src=0)
                     over = bool(int(tt.item()))
                 if over:
@@ -717,6 +735,13 @@ def run(a):
     if hook == "rccl":
         from totsu_amd.fused import comm_destroy
         comm_destroy()
+    if hook == "oneshot":
+        err = C.c_int(0)
+        lib.thip_oneshot_error(C.byref(err))
+        assert err.value == 0, "one-shot all-reduce timed out waiting for a peer"
+        if use_dist:
+            dist.barrier()               # nobody unmaps while a peer may still be reading
+        lib.thip_oneshot_destroy()
     def cleanup():
         if use_dist:
             dist.barrier()

@@ -243,6 +243,24 @@ int thip_comm_count(int *host_ranks);                    /* ranks of the live co
 int thip_comm_destroy(void);
 int thip_solver_use_rccl(thip_solver *s);                /* before thip_solver_init */
 
+/* One-shot all-reduce over peer-mapped buffers (third transport behind thip_solver_set_allreduce), for the latency-bound
+ * messages of the loop (n + 1024 floats: 204 KB at BASELINE configs[2]): every rank publishes its contribution in a slot
+ * the peers have mapped (hipIpcGetMemHandle / hipIpcOpenMemHandle), reads its N - 1 peers directly -- one xGMI link
+ * each -- and sums in rank order (identical bits on every rank); ONE launch per call, a 4-byte flag handshake per
+ * chunk of 2048 floats, no trailing barrier (slots alternate by call parity).  Up to 16 ranks, messages up to 2 MB;
+ * works between processes sharing one GPU as well (that is how a 1-GPU box tests it).
+ *   every rank: thip_oneshot_init(rank, world, max_floats, handle)    -> its 64-byte IPC handle
+ *   the launcher all-gathers the handles (rank order)                  -> thip_oneshot_connect(handles[world * 64])
+ *   thip_solver_use_oneshot(s) before thip_solver_init; thip_oneshot_destroy() after a barrier at the end.
+ * A rank that waits more than ~4 s for a peer gives up and raises an error word instead of hanging the GPU:
+ * thip_oneshot_error (SYNC) reads it.  The collective runs on whatever stream the overlap mode hands it. */
+int thip_oneshot_init(int rank, int world, size_t max_floats, uint8_t *host_handle64);
+int thip_oneshot_connect(const uint8_t *host_handles);
+int thip_oneshot_allreduce(float *dev_buf, size_t n);    /* in-place float sum over the ranks, on the context stream */
+int thip_oneshot_error(int *host_err);                   /* SYNC */
+int thip_oneshot_destroy(void);
+int thip_solver_use_oneshot(thip_solver *s);             /* before thip_solver_init */
+
 int thip_solver_create(const thip_problem *prob, const thip_param *par, int schedule, thip_solver **out);
 /* Sparse A for the fused loop (before thip_solver_init; prob->mat_a may then be NULL): CSR of A (m x n) and CSR of
  * A^T (n x m), int64 row pointers / int32 column indices / f32 values, all on the device.  Each stage then costs one
@@ -270,6 +288,15 @@ int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
  * the hook receives the side stream; a hook that ignores its stream argument stays correct (and un-overlapped). */
 enum { THIP_OVERLAP_OFF = 0, THIP_OVERLAP_LOCAL_ROWS = 1, THIP_OVERLAP_COLUMN_PIPELINE = 2, THIP_OVERLAP_COLUMN_INORDER = 3 };
 int thip_solver_set_overlap(thip_solver *s, int mode);
+/* GEMV plan autotune of this solver (thip_solver_init times nine tilings on the actual matrix and keeps the fastest).
+ * For a given plan every result is bitwise reproducible run to run; two solves that autotune to different plans agree
+ * to f32 round-off only.  on = 0: the shape heuristic, whatever the timings -- bit-reproducible across runs and hosts.
+ * Before thip_solver_init (or between runs: takes effect at the next init / storage switch). */
+int thip_solver_set_gemv_autotune(thip_solver *s, int on);
+/* Leading-dimension padding of the library-owned f32 copy of A (made when m is not a multiple of `floats`, default 16 =
+ * 64 bytes, and the copy fits a third of the free HBM): 0 = never copy (stream the caller's matrix as
+ * it is).  Before thip_solver_init. */
+int thip_solver_set_lda_pad(thip_solver *s, int floats);
 /* the mode the next thip_solver_run will actually use, GEMV launches per pass over A (2 when column-split) and the split
  * column n1 (0 = none) */
 int thip_solver_overlap_info(thip_solver *s, int *host_mode, int *host_launches_per_pass, size_t *host_split_col);

@@ -135,6 +135,14 @@ extern "C" {
     pub fn thip_comm_count(host_ranks: *mut c_int) -> c_int;
     pub fn thip_comm_destroy() -> c_int;
     pub fn thip_solver_use_rccl(s: *mut thip_solver) -> c_int;
+    pub fn thip_oneshot_init(rank: c_int, world: c_int, max_floats: usize, host_handle64: *mut u8) -> c_int;
+    pub fn thip_oneshot_connect(host_handles: *const u8) -> c_int;
+    pub fn thip_oneshot_allreduce(dev_buf: *mut f32, n: usize) -> c_int;
+    pub fn thip_oneshot_error(host_err: *mut c_int) -> c_int;
+    pub fn thip_oneshot_destroy() -> c_int;
+    pub fn thip_solver_use_oneshot(s: *mut thip_solver) -> c_int;
+    pub fn thip_solver_set_gemv_autotune(s: *mut thip_solver, on: c_int) -> c_int;
+    pub fn thip_solver_set_lda_pad(s: *mut thip_solver, floats: c_int) -> c_int;
 
     pub fn thip_gen_vector(out: *mut f32, n: usize, seed: u64, stream: u64, idx0: u64, kind: c_int, scale: f32, shift: f32) -> c_int;
     pub fn thip_gen_matrix(out: *mut f32, n_row: usize, n_col: usize, lda: usize, seed: u64, stream: u64, row0: u64,

@@ -454,3 +454,60 @@ def test_column_pipeline_hides_an_injected_collective_latency(T):
     assert t[2, 30] - t[2, 0] <= 10.0, t
     # and it pays: at L = 60 the pipeline beats every other form
     assert t[2, 60] < min(t[0, 60], t[1, 60], t[3, 60]), t
+
+
+# ---- one-shot all-reduce over peer-mapped buffers (thip_oneshot_*) --------------------------------------------------
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_oneshot_allreduce_between_processes_sharing_the_gpu(world):
+    # hipIpc* works between processes on the SAME device, so a 1-GPU box can run the real protocol: N processes, the
+    # handshake flags, the alternating slots, sums in rank order -- checked bit for bit by every rank (tests/oneshot_worker.py)
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29590 + world),
+                        os.path.join(root, "tests", "oneshot_worker.py")], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "ONESHOT_OK world=%d" % world in r.stdout
+
+
+def test_bench_oneshot_transport_is_bitwise_the_gloo_staged_run():
+    # two ranks sharing the GPU, the solver's own collectives through the one-shot transport: a + b == b + a in f32, so
+    # the run must reproduce the gloo-staged one EXACTLY -- same iteration count, same objective digits (the per-rank
+    # matrix is below the GEMV autotune threshold, so both runs use the same tiling)
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "2", "--size", "2000", "--cones", "40", "--steps", "5", "--warmup", "1", "--no-cpu", "--no-gate",
+              "--to-eps", "1e-3", "--overlap", "off"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = {}
+    for coll in ("gloo", "oneshot"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--collective", coll] + common,
+                           capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, lines
+        out[coll] = json.loads(lines[0])
+    g, o = out["gloo"], out["oneshot"]
+    assert o["n_gpus"] == 2 and "one-shot" in o["config"]["collective"]
+    assert g["time_to_eps"]["state"] == o["time_to_eps"]["state"] == 0
+    assert g["time_to_eps"]["iterations"] == o["time_to_eps"]["iterations"]
+    assert g["time_to_eps"]["primal_obj"] == o["time_to_eps"]["primal_obj"]
+    assert g["time_to_eps"]["dual_obj"] == o["time_to_eps"]["dual_obj"]
+    assert g["time_to_eps"]["cri"] == o["time_to_eps"]["cri"]
+    # and with the column-split pipeline on top (collectives on the side stream, four per iteration)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--collective", "oneshot"] + common[:-1] + ["pipeline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    p = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert p["config"]["overlap_mode_run"] == 2
+    assert p["time_to_eps"]["state"] == 0
+    assert abs(p["time_to_eps"]["iterations"] - o["time_to_eps"]["iterations"]) <= max(3, 0.01 * o["time_to_eps"]["iterations"])
+    assert abs(p["time_to_eps"]["primal_obj"] - o["time_to_eps"]["primal_obj"]) <= 1e-4 * (1 + abs(o["time_to_eps"]["primal_obj"]))

@@ -642,6 +642,68 @@ def test_two_solves_of_the_same_problem_are_bitwise_identical(T, schedule):
     inst.free()
 
 
+def test_bitwise_reproducible_with_the_autotune_switched_off_through_the_api(T):
+    # at sizes where thip_solver_init times GEMV plans, two solves may pick different plans (timings) and then agree to
+    # f32 round-off only; thip_solver_set_gemv_autotune(s, 0) (FusedSolver(gemv_autotune=False)) pins the shape
+    # heuristic: same bits run to run, no environment variable involved
+    from totsu_amd import synth
+    inst = synth.SocpInstance(3000, 30, 99, seed=3)          # 3000 x 3000 = 9e6 entries: above the autotune threshold
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    out = []
+    for rep in range(2):
+        fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried",
+                           gemv_autotune=False)
+        assert fs.gemv_plan()["target_workgroups"] == 0      # no timed plan: the heuristic
+        fs.run(200, poll_every=50)
+        out.append(fs.iterate())
+        fs.destroy()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried")
+    assert fs.gemv_plan()["target_workgroups"] > 0           # default: autotuned
+    fs.run(200, poll_every=50)
+    x, y = fs.iterate()
+    fs.destroy()
+    assert np.abs(x - out[0][0]).max() <= 1e-4 * np.abs(x).max()
+    inst.free()
+
+
+def test_lda_pad_switch_through_the_api(T):
+    # m = 12 x 101 = 1212 rows (not a multiple of 16): by default the f32 passes stream a padded library-owned copy;
+    # thip_solver_set_lda_pad(s, 0) streams the caller's matrix as it is.  Same iterates to round-off either way, and a
+    # re-init after the caller rewrote A in place must see the new matrix (the copy was never refreshed)
+    from totsu_amd import synth
+    from totsu_amd._lib import lib
+    inst = synth.SocpInstance(4000, 12, 100, seed=5)
+    assert inst.m % 16 != 0
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    its = []
+    for pad in (None, 0):
+        fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried",
+                           lda_pad=pad)
+        fs.run(50, poll_every=50)
+        its.append(fs.iterate())
+        if pad is None:
+            # rewrite A in place (scale by 2) and start again: the solve must be the one of the NEW matrix
+            lib.thip_scale(inst.m * inst.n, 2.0, inst.mat_a.ptr)
+            fs.reinit()
+            fs.run(50, poll_every=50)
+            new_pad = fs.iterate()
+            fs.destroy()
+            fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p,
+                               "carried", lda_pad=0)
+            fs.run(50, poll_every=50)
+            new_nopad = fs.iterate()
+            lib.thip_scale(inst.m * inst.n, 0.5, inst.mat_a.ptr)
+            assert np.abs(new_pad[0] - new_nopad[0]).max() <= 1e-4 * np.abs(new_nopad[0]).max()
+            assert np.abs(new_pad[0] - its[0][0]).max() > 1e-3 * np.abs(its[0][0]).max()     # it really is another problem
+        fs.destroy()
+    assert np.abs(its[0][0] - its[1][0]).max() <= 1e-4 * np.abs(its[1][0]).max()
+    assert np.abs(its[0][1] - its[1][1]).max() <= 1e-4 * np.abs(its[1][1]).max()
+    inst.free()
+
+
 # ---- the reference's QP / QCQP examples as parity cases (constructions in tests/problems.py) ------------------
 
 def test_svm_qp_example_gpu_vs_oracle(T):

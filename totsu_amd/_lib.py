@@ -104,6 +104,14 @@ PROTOTYPES = {
     "thip_comm_count": (_i, [C.POINTER(_i)]),
     "thip_comm_destroy": (_i, []),
     "thip_solver_use_rccl": (_i, [_vp]),
+    "thip_oneshot_init": (_i, [_i, _i, _sz, C.POINTER(C.c_uint8)]),
+    "thip_oneshot_connect": (_i, [C.POINTER(C.c_uint8)]),
+    "thip_oneshot_allreduce": (_i, [_vp, _sz]),
+    "thip_oneshot_error": (_i, [C.POINTER(_i)]),
+    "thip_oneshot_destroy": (_i, []),
+    "thip_solver_use_oneshot": (_i, [_vp]),
+    "thip_solver_set_gemv_autotune": (_i, [_vp, _i]),
+    "thip_solver_set_lda_pad": (_i, [_vp, _i]),
     "thip_solver_create": (_i, [C.POINTER(Problem), C.POINTER(Param), _i, C.POINTER(_vp)]),
     "thip_solver_set_csr": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thip_solver_set_allreduce": (_i, [_vp, ALLREDUCE_FN, _vp]),

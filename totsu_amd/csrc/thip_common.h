@@ -155,10 +155,11 @@ struct GemvPartials {
     const float *partN; int nN; size_t strideN;   // outN[r] = sum_{k<nN} partN[k*strideN + r]
     const float *partT; int nT; size_t strideT;   // outT[c] = sum_{k<nT} partT[k*strideT + c]
 };
-// descriptor of one matrix of a grouped launch: column-major nr x nc, lda = nr; x = the input vector (nc long for N,
-// nr long for T); part = where the partial sums go; cpc = columns per chunk
-struct GroupDesc { const float *A; const float *x; float *part; int nr, nc, cpc, pad; };
-int grouped_gemv(hipStream_t st, const GroupDesc *dev_tab, int n_desc, int max_tiles, int max_chunks, bool transposed);
+// descriptor of one matrix of a grouped launch: column-major nr x nc, lda = nr; xn (nc long) / xt (nr long) = the input
+// vectors of the N / T product; partN / partT = where their partial sums go; cpc = columns per chunk
+struct GroupDesc { const float *A; const float *xn; const float *xt; float *partN; float *partT; int nr, nc, cpc, pad; };
+// mode 0: N products, 1: T products, 2: both products of every descriptor from one read of its matrix
+int grouped_gemv(hipStream_t st, const GroupDesc *dev_tab, int n_desc, int max_tiles, int max_chunks, int mode);
 struct GemvHint { int nj; int target_blocks; };        // tiling override: row groups per lane, grid size
 const GemvHint *gemv_candidates(int *count);           // plans worth timing on a given matrix
 int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,

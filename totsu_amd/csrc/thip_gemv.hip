@@ -360,7 +360,9 @@ __global__ __launch_bounds__(BLK) void dual_gemv_k(const E *__restrict__ A, size
 // flight instead of 16).  Partial sums: N -> part[chunk * nr + r]; T -> part[tile * nc + c] (8 columns reduced across
 // the wave by the transpose-reduce butterfly, staged in LDS, stored coalesced).
 constexpr int GROWS = 128;      // rows per wave tile
-template <bool DO_T>
+// DO_N && DO_T: both products of the SAME block from one read of it (the N and T calls of one stage of the loop land in
+// the same record: SelfDualEmbed::op / trans_op issue a.trans_op and a.op back to back, solver.rs:122-125,146-149)
+template <bool DO_N, bool DO_T>
 __global__ __launch_bounds__(BLK) void grouped_gemv_k(const GroupDesc *__restrict__ tab)
 {
     const GroupDesc d = tab[blockIdx.z];
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(BLK) void grouped_gemv_k(const GroupDesc *__restric
     const float *__restrict__ A = d.A;
     const size_t lda = (size_t)d.nr;
     float xt0 = 0.0f, xt1 = 0.0f, acc0 = 0.0f, acc1 = 0.0f;
-    if constexpr (DO_T) { xt0 = ok0 ? d.x[r0] : 0.0f; xt1 = ok1 ? d.x[r1] : 0.0f; }
+    if constexpr (DO_T) { xt0 = ok0 ? d.xt[r0] : 0.0f; xt1 = ok1 ? d.xt[r1] : 0.0f; }
     float *lw = ldsT + wave * (DO_T ? MAXCW : 1);
     int c = c0;
     for (; c + 8 <= c1; c += 8) {
@@ -385,10 +387,11 @@ __global__ __launch_bounds__(BLK) void grouped_gemv_k(const GroupDesc *__restric
             a0[u] = ok0 ? __builtin_nontemporal_load(col + r0) : 0.0f;
             a1[u] = ok1 ? __builtin_nontemporal_load(col + r1) : 0.0f;
         }
-        if constexpr (!DO_T) {
+        if constexpr (DO_N) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const float xs = d.x[c + u]; acc0 = fmaf(a0[u], xs, acc0); acc1 = fmaf(a1[u], xs, acc1); }
-        } else {
+            for (int u = 0; u < 8; ++u) { const float xs = d.xn[c + u]; acc0 = fmaf(a0[u], xs, acc0); acc1 = fmaf(a1[u], xs, acc1); }
+        }
+        if constexpr (DO_T) {
             float p[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) p[u] = fmaf(a0[u], xt0, a1[u] * xt1);
@@ -399,18 +402,19 @@ __global__ __launch_bounds__(BLK) void grouped_gemv_k(const GroupDesc *__restric
     for (; c < c1; ++c) {
         const float *col = A + (size_t)c * lda;
         const float a0 = ok0 ? col[r0] : 0.0f, a1 = ok1 ? col[r1] : 0.0f;
-        if constexpr (!DO_T) { const float xs = d.x[c]; acc0 = fmaf(a0, xs, acc0); acc1 = fmaf(a1, xs, acc1); }
-        else { const float r = wave_sum(fmaf(a0, xt0, a1 * xt1)); if (lane == 0) lw[c - c0] = r; }
+        if constexpr (DO_N) { const float xs = d.xn[c]; acc0 = fmaf(a0, xs, acc0); acc1 = fmaf(a1, xs, acc1); }
+        if constexpr (DO_T) { const float r = wave_sum(fmaf(a0, xt0, a1 * xt1)); if (lane == 0) lw[c - c0] = r; }
     }
-    if constexpr (!DO_T) {
-        float *dst = d.part + (size_t)chunk * d.nr;
+    if constexpr (DO_N) {
+        float *dst = d.partN + (size_t)chunk * d.nr;
         if (ok0) dst[r0] = acc0;
         if (ok1) dst[r1] = acc1;
-    } else {
+    }
+    if constexpr (DO_T) {
         // this wave's LDS writes are visible to itself after the wait (no cross-wave sharing)
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        float *dst = d.part + (size_t)tile * d.nc + c0;
+        float *dst = d.partT + (size_t)tile * d.nc + c0;
         for (int t = lane; t < c1 - c0; t += 64) dst[t] = lw[t];
     }
 }
@@ -742,12 +746,13 @@ int dual_gemv_cols_per_chunk(size_t n_row, size_t n_col, const void *mat, size_t
     return p.cols_per_chunk;
 }
 
-int grouped_gemv(hipStream_t st, const GroupDesc *dev_tab, int n_desc, int max_tiles, int max_chunks, bool transposed)
+int grouped_gemv(hipStream_t st, const GroupDesc *dev_tab, int n_desc, int max_tiles, int max_chunks, int mode)
 {
     if (n_desc <= 0) return 0;
     dim3 g(max_tiles, max_chunks, n_desc);
-    if (transposed) hipLaunchKernelGGL(grouped_gemv_k<true>, g, dim3(BLK), 0, st, dev_tab);
-    else            hipLaunchKernelGGL(grouped_gemv_k<false>, g, dim3(BLK), 0, st, dev_tab);
+    if (mode == 2)      hipLaunchKernelGGL((grouped_gemv_k<true, true>), g, dim3(BLK), 0, st, dev_tab);
+    else if (mode == 1) hipLaunchKernelGGL((grouped_gemv_k<false, true>), g, dim3(BLK), 0, st, dev_tab);
+    else                hipLaunchKernelGGL((grouped_gemv_k<true, false>), g, dim3(BLK), 0, st, dev_tab);
     THIP_LAUNCH_CHECK();
     return 0;
 }

@@ -119,7 +119,7 @@ class FusedResult:
 
 class FusedSolver:
     def __init__(self, n, m, mat_a, vec_b, vec_c, seg_type, seg_len, param=None, schedule="fused",
-                 vec_b_rowabs=None, allreduce=None, a_storage="f32", overlap=None):
+                 vec_b_rowabs=None, allreduce=None, a_storage="f32", overlap=None, gemv_autotune=None, lda_pad=None):
         """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded).
         a_storage: "f32" (the matrix as given), "bf16" or "f16" (a rounded 16-bit copy streamed at half the bytes; f16
         is column-scaled and rounds 8x finer; see set_a_storage / include/totsu_f32hip.h).
@@ -163,7 +163,9 @@ class FusedSolver:
         self._cb = None
         if allreduce == "rccl":
             lib.thip_solver_use_rccl(self.h)            # native RCCL on the library's stream (thip_comm_init first)
-        elif allreduce is not None and not (allreduce == "spin" or (isinstance(allreduce, tuple) and allreduce[0] == "spin")):
+        elif allreduce == "oneshot":
+            lib.thip_solver_use_oneshot(self.h)         # one-launch all-reduce over peer-mapped buffers (thip_oneshot_*)
+        elif allreduce is not None and allreduce != "oneshot" and not (allreduce == "spin" or (isinstance(allreduce, tuple) and allreduce[0] == "spin")):
             self._cb = _lib.ALLREDUCE_FN(allreduce)
             lib.thip_solver_set_allreduce(self.h, self._cb, None)
         elif allreduce == "spin" or (isinstance(allreduce, tuple) and allreduce[0] == "spin"):
@@ -173,6 +175,10 @@ class FusedSolver:
             # OFF by default (the library's default).  True / 1: all-reduce on the solver's side stream under the
             # local-row work; 2 / "pipeline": column-split pipeline; 3 / "pipeline-inorder": its in-order reference
             self.set_overlap(overlap)
+        if gemv_autotune is not None:
+            lib.thip_solver_set_gemv_autotune(self.h, 1 if gemv_autotune else 0)     # False: bit-reproducible across runs
+        if lda_pad is not None:
+            lib.thip_solver_set_lda_pad(self.h, int(lda_pad))
         self.a_storage = "f32"
         if self._a16 is not None:
             if self._a16.kind == "f16":
@@ -219,9 +225,9 @@ class FusedSolver:
         self.a_storage = kind
 
     @staticmethod
-    def from_dense(d, param=None, schedule="fused", a_storage="f32"):
+    def from_dense(d, param=None, schedule="fused", a_storage="f32", **kw):
         return FusedSolver(d.n, d.m, d.mat_a, d.vec_b, d.vec_c, d.seg_type, d.seg_len, param, schedule,
-                           d.vec_b_rowabs, a_storage=a_storage)
+                           d.vec_b_rowabs, a_storage=a_storage, **kw)
 
     def _dev(self, a, n):
         if isinstance(a, DeviceBuffer):
