@@ -94,6 +94,9 @@ int thip_transform_ge(int transpose, size_t n_row, size_t n_col, float alpha, co
 int thip_set_lazy_gemv(int on);
 int thip_get_lazy_gemv(int *host_on);
 int thip_lazy_gemv_stats(int64_t *host_deferred, int64_t *host_flushes);
+/* a flushed segment is kept as a plan (call list, device tables, launch geometry); the loop repeats its call sequence
+ * every iteration, so the next pass re-uses the plan (hit) instead of analysing and building again (miss) */
+int thip_lazy_plan_stats(int64_t *host_hits, int64_t *host_misses);
 /* y = alpha * S x + beta * y, S symmetric, packed upper by columns.  linalg_ex.rs:37 (cublasSspmv, f32cuda.rs:174-187) */
 int thip_transform_sp(size_t n, float alpha, const float *mat, const float *x, float beta, float *y);
 /* Reduced-precision STORAGE of a dense operator (not part of the reference's trait surface):

@@ -556,3 +556,136 @@ def test_deferred_execution_is_opt_in_and_suspended_on_a_caller_stream(L):
     hip.hipStreamDestroy(stream)
     for s_ in (dA, dx, dy):
         s_.drop()
+
+
+def _plan_stats(lib):
+    h, m = C.c_int64(), C.c_int64()
+    lib.thip_lazy_plan_stats(C.byref(h), C.byref(m))
+    return h.value, m.value
+
+
+def test_repeated_call_sequence_replays_its_plans_with_new_factors(L):
+    """The loop repeats its call sequence every iteration: the second pass must hit the plans of the first (no analysis, no
+    table build) -- also when alpha / beta differ from pass to pass (criteria_conv passes 1 / tau, solver.rs:594-597) and
+    when the data changed -- and give what one launch per call gives.  An N and a T product of the same block in one
+    segment share one read of it (pairing); a run of projections on disjoint slices is one launch."""
+    from totsu_amd._lib import lib
+    rng = np.random.default_rng(21)
+    n, nis = 300, [5, 99, 1, 64, 130, 7]
+    m = sum(1 + k for k in nis)
+    G = [rng.standard_normal((k, n)).astype(np.float32) for k in nis]
+    cv = [rng.standard_normal(n).astype(np.float32) for _ in nis]
+    dG = [_dev(L, np.asfortranarray(g).ravel(order="F")) for g in G]
+    dc = [_dev(L, v) for v in cv]
+
+    def one_pass(alpha, beta, x, y, xt, yt, proj):
+        # ProbSOCPOpA::op then ::trans_op (socp.rs:77-130) on the same blocks, then the cones of ProbSOCPCone::proj
+        off = 0
+        for i, k in enumerate(nis):
+            lib.thip_transform_ge(1, n, 1, -alpha, dc[i].dev(), x.dev(), beta, y.dev() + 4 * off)
+            lib.thip_transform_ge(0, k, n, -alpha, dG[i].dev(), x.dev(), beta, y.dev() + 4 * (off + 1))
+            off += 1 + k
+        lib.thip_scale(n, beta, yt.dev())
+        off = 0
+        for i, k in enumerate(nis):
+            lib.thip_transform_ge(0, n, 1, -alpha, dc[i].dev(), xt.dev() + 4 * off, 1.0, yt.dev())
+            lib.thip_transform_ge(1, k, n, -alpha, dG[i].dev(), xt.dev() + 4 * (off + 1), 1.0, yt.dev())
+            off += 1 + k
+        off = 0
+        for k in nis:
+            lib.thip_proj_soc(1 + k, proj.dev() + 4 * off)
+            off += 1 + k
+
+    def run(lazy, passes):
+        lib.thip_set_lazy_gemv(lazy)
+        x = _dev(L, np.zeros(n, np.float32))
+        y = _dev(L, np.zeros(m, np.float32))
+        xt = _dev(L, np.zeros(m, np.float32))
+        yt = _dev(L, np.zeros(n, np.float32))
+        pj = _dev(L, np.zeros(m, np.float32))
+        outs = []
+        for p_, (alpha, beta, seed) in enumerate(passes):
+            r2 = np.random.default_rng(seed)
+            for d, ln in ((x, n), (xt, m), (pj, m), (y, m), (yt, n)):
+                h = r2.standard_normal(ln).astype(np.float32)
+                lib.thip_h2d(d.dev(), h.ctypes.data, ln)
+            one_pass(alpha, beta, x, y, xt, yt, pj)
+            outs.append((y.get_ref().copy(), yt.get_ref().copy(), pj.get_ref().copy()))
+        for d in (x, y, xt, yt, pj):
+            d.drop()
+        return outs
+
+    passes = [(1.0, 0.0, 1), (1.0, 0.0, 2), (0.37, 0.0, 3), (2.5, -0.75, 4), (2.5, -0.75, 5)]
+    eager = run(0, passes)
+    h0, m0 = _plan_stats(lib)
+    lazy = run(1, passes)
+    h1, m1 = _plan_stats(lib)
+    lib.thip_set_lazy_gemv(0)
+    # first pass builds its plans (misses); the later ones replay them -- with new factors in passes 3 and 4
+    assert m1 - m0 >= 2 and h1 - h0 >= 2 * (len(passes) - 2), (h1 - h0, m1 - m0)
+    for (ya, yta, pa), (yb, ytb, pb) in zip(eager, lazy):
+        sc = max(1.0, float(np.abs(ya).max()), float(np.abs(yta).max()))
+        assert np.allclose(ya, yb, rtol=2e-5, atol=2e-5 * sc), np.abs(ya - yb).max() / sc
+        assert np.allclose(yta, ytb, rtol=2e-5, atol=2e-5 * sc), np.abs(yta - ytb).max() / sc
+        assert np.array_equal(pa, pb)            # the projection of a slice does not depend on how it was launched
+    for d in dG + dc:
+        d.drop()
+
+
+def test_deferred_projections_respect_order_and_overlaps(L):
+    """projections join the record: a product that reads a slice pending projection, a projection of a slice a pending
+    product writes, two projections of overlapping slices, kinds that alternate -- all must equal one launch per call"""
+    from totsu_amd._lib import lib
+    rng = np.random.default_rng(33)
+    k = 48
+    A = rng.standard_normal((k, k)).astype(np.float32)
+    dA = _dev(L, np.asfortranarray(A).ravel(order="F"))
+
+    def run(lazy):
+        lib.thip_set_lazy_gemv(lazy)
+        v = _dev(L, np.linspace(-2, 3, 4 * k).astype(np.float32))
+        w = _dev(L, np.zeros(k, np.float32))
+        lib.thip_proj_soc(k, v.dev())                                  # slice 0
+        lib.thip_proj_rotsoc(k, v.dev() + 4 * k)                       # another kind: new run
+        lib.thip_proj_soc(k, v.dev() + 4 * 2 * k)                      # back to SOC
+        lib.thip_proj_soc(k // 2, v.dev() + 4 * (2 * k + 10))          # overlaps the previous slice: must come after it
+        lib.thip_transform_ge(0, k, k, 1.0, dA.dev(), v.dev(), 0.0, w.dev())        # reads a projected slice
+        lib.thip_proj_rpos(k, w.dev())                                 # projects what the product writes
+        lib.thip_transform_ge(1, k, k, 0.5, dA.dev(), w.dev(), 1.0, v.dev() + 4 * 3 * k)
+        lib.thip_proj_zero(0, 7, v.dev() + 4 * 3 * k)
+        lib.thip_proj_zero(1, 7, v.dev() + 4 * (3 * k + 7))            # dual cone: identity
+        out = (v.get_ref().copy(), w.get_ref().copy())
+        v.drop(); w.drop()
+        return out
+
+    (va, wa), (vb, wb) = run(0), run(1)
+    lib.thip_set_lazy_gemv(0)
+    assert np.allclose(va, vb, rtol=1e-5, atol=1e-5) and np.allclose(wa, wb, rtol=1e-5, atol=1e-5)
+    assert np.all(wa >= 0) and np.all(va[3 * k:3 * k + 7] == 0)
+    dA.drop()
+
+
+def test_big_block_pair_shares_one_pass(L):
+    """a block above 64 MB (the single G of a ProbLP, lp.rs:76-98) recorded with both of its products: the flush runs ONE
+    dual GEMV over it for both; results equal the two separate products"""
+    from totsu_amd._lib import lib
+    D = __import__("totsu_amd").DeviceBuffer
+    nr, nc = 6000, 3000                       # 18e6 entries = 72 MB
+    A = D(nr * nc)
+    lib.thip_gen_matrix(A.ptr, nr, nc, nr, 7, 1, 0, 0, nr, 1, 1.0, 0.0)
+    x, xt = D(nc), D(nr)
+    lib.thip_gen_vector(x.ptr, nc, 7, 2, 0, 1, 1.0, 0.0)
+    lib.thip_gen_vector(xt.ptr, nr, 7, 3, 0, 1, 1.0, 0.0)
+    res = {}
+    for lazy in (0, 1):
+        lib.thip_set_lazy_gemv(lazy)
+        y, yt = D(nr, zero=True), D(nc, zero=True)
+        lib.thip_transform_ge(1, nr, nc, -1.0, A.ptr, xt.ptr, 0.0, yt.ptr)
+        lib.thip_transform_ge(0, nr, nc, 2.0, A.ptr, x.ptr, 0.0, y.ptr)
+        res[lazy] = (y.to_host(), yt.to_host())
+        y.free(); yt.free()
+    lib.thip_set_lazy_gemv(0)
+    for a, b in zip(res[0], res[1]):
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-4 * np.abs(a).max())
+    for d in (A, x, xt):
+        d.free()

@@ -25,6 +25,9 @@ struct Ctx {
     int         *never_stop = nullptr;  // a device int that stays 0: the stop flag of launches outside a solver loop
 };
 
+// *host_out = *dev_src, in stream order (SYNC)
+int  fetch_scalar(const float *dev_src, float *host_out);
+
 Ctx &ctx();
 // deferred small GEMVs (thip_lazy.hip)
 bool lazy_pending();
@@ -33,6 +36,7 @@ int  lazy_push(int transpose, size_t n_row, size_t n_col, float alpha, const flo
                float *y, int *deferred);
 int  lazy_push_scale(size_t n, float alpha, float *x, int *deferred);
 int  lazy_push_add(size_t n, float alpha, const float *x, float *y, int *deferred);
+int  lazy_push_proj(int kind, size_t n, float *x, int *deferred);      // single-cone projections (THIP_CONE_*)
 void lazy_release();      // frees the queue's device memory (thip_shutdown)
 int  fail(int code, const char *what, const char *file, int line);
 int  need_init();
@@ -175,6 +179,8 @@ int dual_gemv_partials_cols(hipStream_t st, size_t n_row, size_t n_col, const vo
                             size_t col0, size_t col1);
 int dual_gemv_cols_per_chunk(size_t n_row, size_t n_col, const void *mat, size_t lda, const GemvHint *hint, int a_kind,
                              int *chunks);
+int dual_gemv_partials_geometry(size_t n_row, size_t n_col, const void *mat, size_t lda, bool do_n, bool do_t,
+                                float *scratch_base, GemvPartials *out);
 size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col);
 // y[i] = alpha * sum_k part[k*stride + i] + beta * y[i]
 int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float alpha, float beta,

@@ -167,17 +167,26 @@ int group_min_batched(hipStream_t st, float *t, const int64_t *dev_begs, const i
 
 extern "C" {
 
+// The single-cone projections join the deferred record when a host has opted in (thip_set_lazy_gemv): consecutive
+// projections of one kind on disjoint slices -- the per-cone loop of ProbSOCPCone::proj, socp.rs:296-313 -- run as one
+// launch (thip_lazy.hip).
 int thip_proj_zero(int dual_cone, size_t n, float *x)
 {
-    THIP_NEED_INIT();
-    if (dual_cone || n == 0) return 0;
+    THIP_NEED_INIT_NOFLUSH();
+    if (dual_cone || n == 0) return 0;               // cone_zero.rs:38-44: the dual cone is everything
+    int deferred = 0;
+    THIP_RC(lazy_push_proj(THIP_CONE_ZERO, n, x, &deferred));
+    if (deferred) return 0;
     return thip_scale(n, 0.0f, x);
 }
 
 int thip_proj_rpos(size_t n, float *x)
 {
-    THIP_NEED_INIT();
+    THIP_NEED_INIT_NOFLUSH();
     if (n == 0) return 0;
+    int deferred = 0;
+    THIP_RC(lazy_push_proj(THIP_CONE_RPOS, n, x, &deferred));
+    if (deferred) return 0;
     hipLaunchKernelGGL(rpos_k, dim3(grid_for(n, BLK, 2048)), dim3(BLK), 0, ctx().stream, n, x);
     THIP_LAUNCH_CHECK();
     return 0;
@@ -185,8 +194,11 @@ int thip_proj_rpos(size_t n, float *x)
 
 static int soc_single(size_t n, float *x, int rotated)
 {
-    THIP_NEED_INIT();
+    THIP_NEED_INIT_NOFLUSH();
     if (n == 0) return 0;
+    int deferred = 0;
+    THIP_RC(lazy_push_proj(rotated ? THIP_CONE_ROTSOC : THIP_CONE_SOC, n, x, &deferred));
+    if (deferred) return 0;
     if (n > 2048)
         hipLaunchKernelGGL(soc_k<true>, dim3(1), dim3(BLK), 0, ctx().stream, x, (float *)nullptr, (float *)nullptr,
                            (float *)nullptr, (const int64_t *)nullptr, (const int64_t *)nullptr, (int64_t)1, rotated,

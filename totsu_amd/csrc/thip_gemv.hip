@@ -736,6 +736,19 @@ int dual_gemv_partials_cols(hipStream_t st, size_t n_row, size_t n_col, const vo
     return 0;
 }
 
+// where dual_gemv_partials (f32, default plan) will leave its partial sums for this shape, without launching anything
+int dual_gemv_partials_geometry(size_t n_row, size_t n_col, const void *mat, size_t lda, bool do_n, bool do_t,
+                                float *scratch_base, GemvPartials *out)
+{
+    const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (lda % 4 == 0);
+    const Plan p = make_plan(n_row, n_col, vec_ok ? 4 : 1, nullptr);
+    const size_t needN = do_n ? (size_t)p.chunks * p.strideN : 0;
+    float *partN = scratch_base, *partT = scratch_base + needN;
+    out->partN = do_n ? partN : nullptr; out->nN = do_n ? p.chunks : 0; out->strideN = p.strideN;
+    out->partT = do_t ? partT : nullptr; out->nT = do_t ? p.tiles : 0;  out->strideT = p.strideT;
+    return 0;
+}
+
 int dual_gemv_cols_per_chunk(size_t n_row, size_t n_col, const void *mat, size_t lda, const GemvHint *hint, int a_kind,
                              int *chunks)
 {

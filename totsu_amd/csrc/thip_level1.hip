@@ -147,11 +147,7 @@ int reduce_to_dev(hipStream_t st, int op, size_t n, const float *x, const float 
 
 static int host_scalar(float *host_out)
 {
-    Ctx &c = ctx();
-    THIP_TRY(hipMemcpyAsync(c.pinned, c.dev_scalar, sizeof(float), hipMemcpyDeviceToHost, c.stream));
-    THIP_TRY(hipStreamSynchronize(c.stream));
-    *host_out = c.pinned[0];
-    return 0;
+    return fetch_scalar(ctx().dev_scalar, host_out);
 }
 
 extern "C" {
