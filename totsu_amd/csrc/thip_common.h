@@ -171,12 +171,14 @@ int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *m
                        float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
                        const GemvHint *hint = nullptr, int a_kind = 0, const float *inv_s = nullptr,
                        bool pad_zero = false);     // pad_zero: rows n_row .. lda - 1 of mat are zeros (the library's own copy)
-// columns [col0, col1) only, partial sums left where the whole-matrix launch leaves them (thip_gemv.hip)
+// the product over columns [col0, col1) as a launch of its own, partial sums left where a consumer of the whole product
+// expects them (thip_gemv.hip)
 int dual_gemv_partials_cols(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
                             const float *xn, const float *xt, bool do_n, bool do_t,
                             float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
                             const GemvHint *hint, int a_kind, const float *inv_s, bool pad_zero,
-                            size_t col0, size_t col1);
+                            size_t col0, size_t col1, int chunk_row0, int max_chunk_rows, int *chunks_used);
+int dual_gemv_chunk_rows(size_t n_row, size_t cols, bool vec_ok, int a_kind, const GemvHint *hint, int *tiles);
 int dual_gemv_cols_per_chunk(size_t n_row, size_t n_col, const void *mat, size_t lda, const GemvHint *hint, int a_kind,
                              int *chunks);
 int dual_gemv_partials_geometry(size_t n_row, size_t n_col, const void *mat, size_t lda, bool do_n, bool do_t,

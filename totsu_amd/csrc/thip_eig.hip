@@ -35,6 +35,15 @@ constexpr int POLAR_SMALL_MIN_N = 1; // orders 1 .. 64: the polar chain inside o
 constexpr int MAX_SWEEPS = 18;
 
 __host__ __device__ inline size_t np_of(size_t n) { return (n + 63) / 64 * 64; }
+// row pitch of the ld x ld operands of the polar chain.  A power-of-two pitch (2 KB at ld = 512) looked 6 % slower than
+// 544 or 576 floats in the one-tile probe of round 2 (tools/gemm_phases.hip); built in round 3 and measured in the
+// production chain (32 x 64 blocks, dwordx2 loads of operand b): pads of 0 .. 160 floats all give 0.350-0.355 ms per k = 500
+// projection and 1270-1286 iter/s on the SDP -- neutral, so the default stays 0.  THIP_PSD_PITCH_PAD = floats (experiments).
+inline size_t pitch_of(size_t ld)
+{
+    static const size_t pad = getenv("THIP_PSD_PITCH_PAD") ? (size_t)atoi(getenv("THIP_PSD_PITCH_PAD")) : 0;
+    return (ld == 256 || ld == 512) ? ld + pad : ld;
+}
 
 // round-robin (circle method) pairing on n_even players: step in [0, n_even-1), k in [0, n_even/2)
 __device__ __forceinline__ void rr_pair(int n_even, int step, int k, int &p, int &q)
@@ -79,8 +88,9 @@ __device__ __forceinline__ int rotate_pair(float *G, float *V, int ld, int n, in
 // Batched launches (blockIdx.z = item): item z works on packed + z * ps and on work pointers + z * ws.
 __global__ void unpack_k(int n, int ld, const float *__restrict__ packed, int has_scale, float scale,
                          float *__restrict__ G, float *__restrict__ V, float *__restrict__ part,
-                         const int *__restrict__ stop, size_t ws = 0, ptrdiff_t ps = 0)
+                         const int *__restrict__ stop, size_t ws = 0, ptrdiff_t ps = 0, int pitch = 0)
 {
+    if (pitch == 0) pitch = ld;
     if (stop != nullptr && *stop != 0) return;
     packed += (ptrdiff_t)blockIdx.z * ps; G += blockIdx.z * ws; part += blockIdx.z * ws;
     if (V) V += blockIdx.z * ws;
@@ -96,8 +106,8 @@ __global__ void unpack_k(int n, int ld, const float *__restrict__ packed, int ha
             if (r == c && has_scale) v *= scale;
             acc += (double)v * (double)v;
         }
-        G[i] = v;
-        if (V) V[i] = (r == c && r < n) ? 1.0f : 0.0f;
+        G[(size_t)c * pitch + r] = v;
+        if (V) V[(size_t)c * pitch + r] = (r == c && r < n) ? 1.0f : 0.0f;
     }
     // the block's 2-norm, not its sum of squares: representable in f32 whenever the entries are (the squares of a
     // block of 1e-25s are not, and a norm of 0 for a nonzero matrix makes the projection return M / 2)
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(GNW * 64) void gemm_k(int n, int ld, float alpha, c
 template <bool GEN, int KW, int NW, bool SYM>
 __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha, const float *__restrict__ X,
                                                       const float *__restrict__ Y, float beta, const float *D, float gamma,
-                                                      float *C, const int *__restrict__ stop, size_t ws)
+                                                      float *C, const int *__restrict__ stop, size_t ws, int pitch)
 {
     static_assert(!(GEN && SYM), "the symmetric shortcut is for X Y^T products");
     // the stop flag is fetched now and looked at just before the first store: tested here, every launch of the chain
@@ -402,8 +412,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
     const int i0 = bi * GT, j0 = bj * GT;
     const int kb = wave * KW, h = lane >> 5, li = lane & 31;
     // GEN: X symmetric (b), Y general (a, along k).  !GEN: a(i, k) = X(i, k) = Xmem[k * ld + i], b(k, j) = Y(j, k).
-    const float *pa = GEN ? Y + (size_t)(i0 + li) * ld + kb + 4 * h : X + (size_t)(kb + 4 * h) * ld + i0 + li;
-    const float *pb = (GEN ? X : Y) + (size_t)(kb + 4 * h) * ld + j0 + li;
+    const float *pa = GEN ? Y + (size_t)(i0 + li) * pitch + kb + 4 * h : X + (size_t)(kb + 4 * h) * pitch + i0 + li;
+    const float *pb = (GEN ? X : Y) + (size_t)(kb + 4 * h) * pitch + j0 + li;
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     constexpr int NQ = KW / 8;
     // the loads run DEP slabs of 8 k ahead of the MFMAs: as many as fit in the 64 slots a wave has for loads in flight
@@ -416,10 +426,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
         if constexpr (GEN) av[q] = *reinterpret_cast<const f32x4_t *>(pa + 8 * q);
         else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) av[q][t] = pa[(size_t)(8 * q + t) * ld];
+            for (int t = 0; t < 4; ++t) av[q][t] = pa[(size_t)(8 * q + t) * pitch];
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bv[q][t] = pb[(size_t)(8 * q + t) * ld];
+        for (int t = 0; t < 4; ++t) bv[q][t] = pb[(size_t)(8 * q + t) * pitch];
     };
 #pragma unroll
     for (int q = 0; q < DEP; ++q) load(q);
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
 #pragma unroll
             for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
             v *= alpha;
-            const size_t o = (size_t)ti * ld + tj;
+            const size_t o = (size_t)ti * pitch + tj;
             if (beta != 0.0f) v = fmaf(beta, D[o], v);
             if (ti == tj && ti < n) v += gamma;
             C[o] = v;
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int tjl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);      // row of the mirror tile
-                    C[(size_t)(j0 + tjl) * ld + i0 + (lane & 31)] = tr[lane & 31][tjl];
+                    C[(size_t)(j0 + tjl) * pitch + i0 + (lane & 31)] = tr[lane & 31][tjl];
                 }
             }
         }
@@ -495,7 +505,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
 template <bool GEN, int KW, bool SYM>
 __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, const float *__restrict__ X,
                                                    const float *__restrict__ Y, float beta, const float *D, float gamma,
-                                                   float *C, const int *__restrict__ stop, size_t ws)
+                                                   float *C, const int *__restrict__ stop, size_t ws, int pitch)
 {
     static_assert(!(GEN && SYM), "the symmetric shortcut is for X Y^T products");
     // the stop flag is fetched now and looked at just before the first store: tested here, every launch of the chain
@@ -520,8 +530,8 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = bi * GT, j0 = bj * GT;
     const int kb = wave * KW, h = lane >> 5, li = lane & 31;
-    const float *pa = GEN ? Y + (size_t)(i0 + li) * ld + kb + 4 * h : X + (size_t)(kb + 4 * h) * ld + i0 + li;
-    const float *pb = (GEN ? X : Y) + (size_t)(kb + 4 * h) * ld + j0 + 2 * li;
+    const float *pa = GEN ? Y + (size_t)(i0 + li) * pitch + kb + 4 * h : X + (size_t)(kb + 4 * h) * pitch + i0 + li;
+    const float *pb = (GEN ? X : Y) + (size_t)(kb + 4 * h) * pitch + j0 + 2 * li;
     typedef float f32x4_t __attribute__((ext_vector_type(4)));
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     constexpr int NQ = KW / 8;
@@ -532,10 +542,10 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
         if constexpr (GEN) av[q] = *reinterpret_cast<const f32x4_t *>(pa + 8 * q);
         else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) av[q][t] = pa[(size_t)(8 * q + t) * ld];
+            for (int t = 0; t < 4; ++t) av[q][t] = pa[(size_t)(8 * q + t) * pitch];
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bv[q][t] = *reinterpret_cast<const f32x2_t *>(pb + (size_t)(8 * q + t) * ld);
+        for (int t = 0; t < 4; ++t) bv[q][t] = *reinterpret_cast<const f32x2_t *>(pb + (size_t)(8 * q + t) * pitch);
     };
 #pragma unroll
     for (int q = 0; q < DEP; ++q) load(q);
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
 #pragma unroll
         for (int w = 1; w < NW; ++w) { ve += red[w][0][r][lane]; vo += red[w][1][r][lane]; }
         ve *= alpha; vo *= alpha;
-        const size_t o = (size_t)ti * ld + tj;
+        const size_t o = (size_t)ti * pitch + tj;
         if (beta != 0.0f) {
             const f32x2_t d = *reinterpret_cast<const f32x2_t *>(D + o);
             ve = fmaf(beta, d[0], ve); vo = fmaf(beta, d[1], vo);
@@ -594,7 +604,7 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
 #pragma unroll
         for (int sI = 0; sI < 8; ++sI) {
             const int jj = 16 * wave + 2 * sI + h;
-            if (bj + (jj >> 5) < bi) C[(size_t)(j0 + jj) * ld + i0 + li] = tr[li][jj];
+            if (bj + (jj >> 5) < bi) C[(size_t)(j0 + jj) * pitch + i0 + li] = tr[li][jj];
         }
     }
 }
@@ -618,14 +628,14 @@ __global__ __launch_bounds__(BLK) void scale_by_fro_k(size_t tot, const float *_
 // packed(r,c) = (M + MS)(r,c) / 2 symmetrised, diag / scale
 __global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const float *__restrict__ MS, int has_scale,
                             float scale, float *__restrict__ packed, const int *__restrict__ stop, size_t ws, ptrdiff_t ps,
-                            float *__restrict__ rx, ptrdiff_t rps)
+                            float *__restrict__ rx, ptrdiff_t rps, int pitch)
 {
     if (stop != nullptr && *stop != 0) return;
     M += blockIdx.z * ws; MS += blockIdx.z * ws; packed += (ptrdiff_t)blockIdx.z * ps;
     if (rx != nullptr) rx += (ptrdiff_t)blockIdx.z * rps;       // the fused loop's reflection rx <- rx - 2 x rides along
     const int c = blockIdx.y;
     for (int r = blockIdx.x * BLK + threadIdx.x; r <= c; r += gridDim.x * BLK) {
-        const size_t o1 = (size_t)c * ld + r, o2 = (size_t)r * ld + c;
+        const size_t o1 = (size_t)c * pitch + r, o2 = (size_t)r * pitch + c;
         float v = 0.5f * (M[o1] + 0.5f * (MS[o1] + MS[o2]));
         if (r == c && has_scale) v = v / scale;
         const size_t o = (size_t)c * (c + 1) / 2 + r;
@@ -749,8 +759,9 @@ __global__ __launch_bounds__(256) void polar_small_k(int n, float *__restrict__ 
 static int g_force_kernel = 0;     // thip_test_gemm_chain: 1 = one tile per workgroup, 2 = 32 x 64 blocks, 0 = by tile count
 // gen == false: C = alpha X Y^T + beta D + gamma I (symmetric result); gen == true: C = alpha X Y + ... (X symmetric)
 int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, const float *Y, float beta, const float *D,
-         float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0)
+         float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0, int pitch = 0)
 {
+    if (pitch == 0) pitch = ld;                 // rows of the operands are `pitch` floats apart; ld = the extent of every index
     dim3 g(ld / GT, ld / GT, nb);
     if (stop == nullptr) stop = ctx().never_stop;
     // ld <= 512: gemm_pre_k (loads up front, 4 waves, symmetric results from the lower triangle of tiles), or its
@@ -764,10 +775,10 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
     for (int bi = 0; bi < nt; ++bi) npair += bi / 2 + 1;
 #define THIP_GEMM_PRE4(KW)                                                                                                  \
     do {                                                                                                                    \
-        if (pairs && gen) hipLaunchKernelGGL((gemm_pre2_k<true, KW, false>), dim3(nt, nt / 2, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
-        else if (pairs)   hipLaunchKernelGGL((gemm_pre2_k<false, KW, true>), dim3(npair, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
-        else if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false>), g, dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);  \
-        else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, true>), dim3(nt * (nt + 1) / 2, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws); \
+        if (pairs && gen) hipLaunchKernelGGL((gemm_pre2_k<true, KW, false>), dim3(nt, nt / 2, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch); \
+        else if (pairs)   hipLaunchKernelGGL((gemm_pre2_k<false, KW, true>), dim3(npair, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch); \
+        else if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false>), g, dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch);  \
+        else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, true>), dim3(nt * (nt + 1) / 2, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch); \
     } while (0)
     if (mode >= 2 && ld <= 512) {
         switch (ld / 4) {
@@ -781,6 +792,7 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
         default: THIP_GEMM_PRE4(128); break;
         }
     }
+    else if (pitch != ld) return fail(THIP_E_INVALID, "gemm: a padded pitch needs ld <= 512", __FILE__, __LINE__);
     else if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
     else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
 #undef THIP_GEMM_PRE4
@@ -1115,7 +1127,7 @@ struct Work {
 
 Work carve(float *work, size_t n)
 {
-    const size_t ld = np_of(n), sq = ld * ld;
+    const size_t ld = np_of(n), sq = pitch_of(ld) * ld;
     Work k;
     k.G = work; k.V = k.G + sq; k.S = k.V + sq; k.Y = k.S + sq; k.Z = k.Y + sq;
     k.w = k.Z + sq; k.e = k.w + ld; k.sc = k.e + ld; k.part = k.sc + 16;
@@ -1291,12 +1303,12 @@ int rebuild(hipStream_t st, size_t n, float *packed, int has_scale, float scale,
 int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop,
                   int nb, size_t ws, ptrdiff_t ps, float *rx, ptrdiff_t rps)
 {
-    const int ni = (int)n, ld = (int)np_of(n);
-    const size_t tot = (size_t)ld * ld;
+    const int ni = (int)n, ld = (int)np_of(n), pitch = (int)pitch_of((size_t)ld);
+    const size_t tot = (size_t)pitch * ld;
     const unsigned g = grid_for(tot, BLK, 512);
     float *M = k.G, *S = k.S, *Y = k.Y, *Z = k.Z, *T = k.V;
     hipLaunchKernelGGL(unpack_k, dim3(g, 1, nb), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, M, (float *)nullptr,
-                       k.part, stop, ws, ps);
+                       k.part, stop, ws, ps, pitch);
     hipLaunchKernelGGL(scale_by_fro_k, dim3(g, 1, nb), dim3(BLK), 0, st, tot, M, k.part, (int)g, S, stop, ws);
     // sign(M) = the polar factor of S = M / ||M||_F by the polar iteration S <- p_k(S S^T) S with odd quintics
     // p_k(x) = a x + b x^3 + c x^5.  Three GEMMs per step, the polynomial folded into the second one's epilogue:
@@ -1326,20 +1338,20 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
         if (it == 0) { a = LIFT[0] * 1.7f; b = LIFT[1] * 4.913f; c = LIFT[2] * 14.19857f; }     // p(1.7 x)
         else if (it < 11) { a = LIFT[0]; b = LIFT[1]; c = LIFT[2]; }
         else { a = TAILC[it - 11][0]; b = TAILC[it - 11][1]; c = TAILC[it - 11][2]; }
-        THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop, nb, ws));
-        THIP_RC(gemm(st, false, ni, ld, c, Y, Y, b, Y, a, T, stop, nb, ws));
-        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));
+        THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop, nb, ws, pitch));
+        THIP_RC(gemm(st, false, ni, ld, c, Y, Y, b, Y, a, T, stop, nb, ws, pitch));
+        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws, pitch));
         float *tmp = S; S = Z; Z = tmp;
     }
     // Newton-Schulz x (3 - x^2) / 2:  T = -0.5 S S^T + 1.5 I ;  S <- T S
     {
-        THIP_RC(gemm(st, false, ni, ld, -0.5f, S, S, 0.0f, nullptr, 1.5f, T, stop, nb, ws));
-        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));
+        THIP_RC(gemm(st, false, ni, ld, -0.5f, S, S, 0.0f, nullptr, 1.5f, T, stop, nb, ws, pitch));
+        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws, pitch));
         float *tmp = S; S = Z; Z = tmp;
     }
-    THIP_RC(gemm(st, true, ni, ld, 1.0f, M, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws));      // M sign(M)
+    THIP_RC(gemm(st, true, ni, ld, 1.0f, M, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws, pitch));      // M sign(M)
     dim3 gp((unsigned)((n + BLK - 1) / BLK), (unsigned)n, nb);
-    hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop, ws, ps, rx, rps);
+    hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop, ws, ps, rx, rps, pitch);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1433,7 +1445,7 @@ int thip_test_gemm_chain(int shape, int kernel, int n, int ld, int nb, float alp
 size_t thip_map_eig_worklen(size_t n)
 {
     const size_t ld = np_of(n);
-    return 5 * ld * ld + 2 * ld + 16 + 512 + 64;
+    return 5 * pitch_of(ld) * ld + 2 * ld + 16 + 512 + 64;
 }
 
 int thip_map_eig(size_t n, float *mat, int has_scale, float scale_diag, float eps_zero, float *work, size_t worklen,

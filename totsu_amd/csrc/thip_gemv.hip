@@ -687,17 +687,19 @@ int dual_gemv_partials(hipStream_t st, size_t n_row, size_t n_col, const void *m
     return 0;
 }
 
-// Columns [col0, col1) of the same product, with the tiling of the WHOLE matrix: the launch covers the column chunks
-// of the range only and leaves its partial sums where the whole-matrix launch would have left them (N: chunk rows
-// col0 / cpc .. ; T: columns col0 .. col1 of every tile row), so that two launches over [0, c) and [c, n_col) produce
-// bit for bit the partial sums of one launch over [0, n_col).  col0 must be a multiple of the plan's columns per
-// chunk (dual_gemv_cols_per_chunk).  `out` describes the partial sums of the whole matrix.
+// The product over columns [col0, col1) only, as one launch of its own: the tile height of the plan for (n_row x n_col)
+// under `hint`, its own column chunks starting at col0.  Partial sums go where a consumer of the WHOLE product expects
+// them: N partials into chunk rows chunk_row0 .. of partN (so that the launches over [0, c) and [c, n_col) fill
+// consecutive chunk rows and the consumer sums them all), T partials into columns col0 .. col1 of every tile row.
+// *chunks_used = chunk rows this launch filled.  `out` describes the layout (nN = chunk_row0 + *chunks_used).
+// col0 only needs the alignment of the vector loads (a multiple of 4 floats; 8 for 16-bit storage).
 int dual_gemv_partials_cols(hipStream_t st, size_t n_row, size_t n_col, const void *mat, size_t lda,
                             const float *xn, const float *xt, bool do_n, bool do_t,
                             float *scratch_base, size_t scratch_floats, GemvPartials *out, const int *stop_flag,
                             const GemvHint *hint, int a_kind, const float *inv_s, bool pad_zero,
-                            size_t col0, size_t col1)
+                            size_t col0, size_t col1, int chunk_row0, int max_chunk_rows, int *chunks_used)
 {
+    if (chunks_used) *chunks_used = 0;
     if (n_row == 0 || n_col == 0 || (!do_n && !do_t) || col1 <= col0) {
         out->partN = out->partT = nullptr; out->nN = out->nT = 0; out->strideN = out->strideT = 0;
         return 0;
@@ -705,35 +707,45 @@ int dual_gemv_partials_cols(hipStream_t st, size_t n_row, size_t n_col, const vo
     if (n_row > 0x7fffffffull || n_col > 0x7fffffffull || col1 > n_col) return fail(THIP_E_INVALID, "bad column range", __FILE__, __LINE__);
     const bool bf16 = a_kind == THIP_A_BF16, f16 = a_kind == THIP_A_F16;
     if (f16 && inv_s == nullptr) return fail(THIP_E_INVALID, "f16 storage needs the per-column scales", __FILE__, __LINE__);
-    const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (lda % ((bf16 || f16) ? 8 : 4) == 0);
-    Plan p = make_plan(n_row, n_col, vec_ok ? ((bf16 || f16) ? 8 : 4) : 1, hint);
+    const size_t esz = (bf16 || f16) ? 2 : 4;
+    const char *base = (const char *)mat + col0 * lda * esz;
+    const bool vec_ok = (((uintptr_t)mat & 15u) == 0) && (((uintptr_t)base & 15u) == 0) && (lda % ((bf16 || f16) ? 8 : 4) == 0);
+    // tiling of the range's own shape (its columns decide the chunking); strides are those of the whole matrix
+    Plan p = make_plan(n_row, col1 - col0, vec_ok ? ((bf16 || f16) ? 8 : 4) : 1, hint);
+    p.strideN = round_up(n_row, 4);
+    p.strideT = round_up(n_col, 4);
     {
         static const int clamp_on = getenv("THIP_GEMV_CLAMP") ? atoi(getenv("THIP_GEMV_CLAMP")) : 1;
         const size_t m_up = round_up(n_row, (size_t)p.vw);
         if (clamp_on && p.vw > 1 && (n_row % p.vw == 0 || (pad_zero && lda >= m_up))) p.m_load = (int)m_up;
     }
-    if (col0 % (size_t)p.cols_per_chunk != 0) return fail(THIP_E_INVALID, "column range does not start on a chunk", __FILE__, __LINE__);
-    const size_t needN = do_n ? (size_t)p.chunks * p.strideN : 0;
+    if (chunk_row0 + p.chunks > max_chunk_rows) return fail(THIP_E_WORK, "gemv scratch: too many chunk rows", __FILE__, __LINE__);
+    const size_t needN = do_n ? (size_t)max_chunk_rows * p.strideN : 0;
     const size_t needT = do_t ? (size_t)p.tiles * p.strideT : 0;
     if (needN + needT > scratch_floats) return fail(THIP_E_WORK, "gemv scratch too small", __FILE__, __LINE__);
     float *partN = scratch_base;
     float *partT = scratch_base + needN;
-    out->partN = do_n ? partN : nullptr; out->nN = do_n ? p.chunks : 0; out->strideN = p.strideN;
+    out->partN = do_n ? partN : nullptr; out->nN = do_n ? chunk_row0 + p.chunks : 0; out->strideN = p.strideN;
     out->partT = do_t ? partT : nullptr; out->nT = do_t ? p.tiles : 0;  out->strideT = p.strideT;
-    // the sub-launch: same tiles, the chunks of the range, every pointer advanced to the range's first column
-    Plan q = p;
-    q.chunks = (int)((col1 - col0 + p.cols_per_chunk - 1) / p.cols_per_chunk);
+    if (chunks_used) *chunks_used = p.chunks;
     const int m = (int)n_row, n = (int)(col1 - col0);
-    float *pn = partN + (col0 / p.cols_per_chunk) * p.strideN;
+    float *pn = partN + (size_t)chunk_row0 * p.strideN;
     float *pt = partT + col0;
     const float *xnr = xn ? xn + col0 : nullptr;
-    const size_t esz = (bf16 || f16) ? 2 : 4;
-    const char *base = (const char *)mat + col0 * lda * esz;
-    if (bf16) launch_any(q, st, (const bf16raw *)base, lda, m, n, xnr, xt, do_n, do_t, false, pn, pt, stop_flag);
-    else if (f16) launch_any(q, st, (const f16elt *)base, lda, m, n, xnr, xt, do_n, do_t, false, pn, pt, stop_flag, inv_s + col0);
-    else      launch_any(q, st, (const float *)base, lda, m, n, xnr, xt, do_n, do_t, false, pn, pt, stop_flag);
+    if (bf16) launch_any(p, st, (const bf16raw *)base, lda, m, n, xnr, xt, do_n, do_t, false, pn, pt, stop_flag);
+    else if (f16) launch_any(p, st, (const f16elt *)base, lda, m, n, xnr, xt, do_n, do_t, false, pn, pt, stop_flag, inv_s + col0);
+    else      launch_any(p, st, (const float *)base, lda, m, n, xnr, xt, do_n, do_t, false, pn, pt, stop_flag);
     THIP_LAUNCH_CHECK();
     return 0;
+}
+
+// chunk rows a launch over `cols` columns of an n_row-row matrix will fill under `hint` (and its tile count)
+int dual_gemv_chunk_rows(size_t n_row, size_t cols, bool vec_ok, int a_kind, const GemvHint *hint, int *tiles)
+{
+    const bool h16 = a_kind == THIP_A_BF16 || a_kind == THIP_A_F16;
+    const Plan p = make_plan(n_row, cols, vec_ok ? (h16 ? 8 : 4) : 1, hint);
+    if (tiles) *tiles = p.tiles;
+    return p.chunks;
 }
 
 // where dual_gemv_partials (f32, default plan) will leave its partial sums for this shape, without launching anything

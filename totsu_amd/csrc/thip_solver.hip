@@ -512,7 +512,8 @@ struct thip_solver {
     hipStream_t side = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipEvent_t sev_in[4] = { nullptr, nullptr, nullptr, nullptr }, sev_out[4] = { nullptr, nullptr, nullptr, nullptr };
-    size_t n1 = 0;                // split column of modes 2 / 3 (a multiple of the GEMV plan's columns per chunk); 0: no split
+    size_t n1 = 0;                // split column of modes 2 / 3 (the same on every rank: a function of n); 0: no split
+    int rows1 = 0, rows2 = 0;     // chunk rows of partial sums the two half-launches fill under the plan in use
     bool tail_pending = false;    // mode 2: the last column half of the y update + the termination test of the previous
                                   // iteration are still to be enqueued (they wait for its last all-reduce)
     long long spin_ticks = 0;     // thip_test_spin_allreduce
@@ -840,18 +841,27 @@ int one_iteration(thip_solver *s)
 // Every collective has a whole half-launch (0.19 ms on a 1/8 shard of BASELINE configs[2]) to complete in.  The sharded
 // block partials ride with the second half.  The termination test of iteration k is enqueued after the first
 // half-launch of iteration k + 1; that launch and its reduction only write scratch (partial sums, g1[H1]), so the
-// iterate is still exactly the one of stopping at iteration k.  The two half-launches use the tiling of the whole
-// matrix and leave their partial sums where one launch would (dual_gemv_partials_cols), so h = A x is bit for bit the
-// unsplit product.  Mode 3 enqueues the same kernels with the collectives in order and no skew: the iterates of modes
-// 2 and 3 are bitwise equal (tests/test_gpu_sharded.py).
+// iterate is still exactly the one of stopping at iteration k.  The split column n1 is a function of n alone -- every
+// rank must issue collectives of the same lengths, whatever plan its own autotune picked; each half-launch has its own
+// column chunks and fills consecutive chunk rows of the partial sums (dual_gemv_partials_cols).  Mode 3 enqueues the same
+// kernels with the collectives in order and no skew: the iterates of modes 2 and 3 are bitwise equal
+// (tests/test_gpu_sharded.py).
 // ---------------------------------------------------------------------------------------------------
+// The split column is the SAME on every rank (it sets the lengths of the collectives): a function of n alone, never of a
+// rank's own tuned plan.  A multiple of 8 floats keeps every buffer offset 32-byte aligned.
 size_t split_column(const thip_solver *s)
 {
-    if (s->sparse || s->m == 0 || s->n == 0) return 0;
-    int chunks = 0;
-    const int cpc = dual_gemv_cols_per_chunk(s->m, s->n, s->amat(), s->alda(), s->ahint(), s->a_kind, &chunks);
-    if (chunks < 2) return 0;
-    return (size_t)(chunks / 2) * (size_t)cpc;
+    if (s->sparse || s->m == 0 || s->n < 16) return 0;
+    return (s->n / 2) & ~(size_t)7;
+}
+
+// chunk rows the two half-launches fill under the plan in use
+void split_rows(thip_solver *s)
+{
+    const bool h16 = s->is16();
+    const bool vec_ok = (((uintptr_t)s->amat() & 15u) == 0) && (s->alda() % (h16 ? 8 : 4) == 0);
+    s->rows1 = dual_gemv_chunk_rows(s->m, s->n1, vec_ok, s->a_kind, s->ahint(), nullptr);
+    s->rows2 = dual_gemv_chunk_rows(s->m, s->n - s->n1, vec_ok, s->a_kind, s->ahint(), nullptr);
 }
 
 bool split_active(const thip_solver *s)
@@ -870,7 +880,8 @@ int prepare_split(thip_solver *s)
     if (s->inited) THIP_RC(autotune_gemv(s));        // once per stored form and launch form (a no-op afterwards)
     if (!s->split_plan) return 0;
     s->n1 = split_column(s);
-    if (s->n1 == 0 || s->n1 >= s->n) { s->split_plan = false; s->n1 = 0; }
+    if (s->n1 == 0 || s->n1 >= s->n) { s->split_plan = false; s->n1 = 0; return 0; }
+    split_rows(s);
     return 0;
 }
 
@@ -893,12 +904,13 @@ int ar_wait(thip_solver *s, int slot)
     return 0;
 }
 
-int products_cols(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp, size_t col0, size_t col1)
+int products_cols(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp, int half)
 {
     hipStream_t st = ctx().stream;
     prof_begin(st);
     THIP_RC(dual_gemv_partials_cols(st, s->m, s->n, s->amat(), s->alda(), xn, xt, true, true, s->gemv_scr, s->gemv_scr_n, gp,
-                                    &s->dst->stop, s->ahint(), s->a_kind, s->ainv(), s->apadz(), col0, col1));
+                                    &s->dst->stop, s->ahint(), s->a_kind, s->ainv(), s->apadz(), half ? s->n1 : 0,
+                                    half ? s->n : s->n1, half ? s->rows1 : 0, s->rows1 + s->rows2, nullptr));
     prof_end(st);
     return 0;
 }
@@ -968,25 +980,25 @@ int one_iteration_split(thip_solver *s)
     };
 
     // ---- stage X, first half ----
-    THIP_RC(products_cols(s, s->u, s->v, &gp, 0, n1));
+    THIP_RC(products_cols(s, s->u, s->v, &gp, 0));
     post(s->g1, s->h1, 0, s->u, s->v, 0, c.partX);
     THIP_RC(ar_begin(s, 0, s->g1, n1));
     if (s->tail_pending) THIP_RC(split_tail(s));           // the previous iteration ends here
     // ---- stage X, second half ----
-    THIP_RC(products_cols(s, s->u, s->v, &gp, n1, n));
+    THIP_RC(products_cols(s, s->u, s->v, &gp, 1));
     post(s->g1, s->h1, 1, s->u, s->v, 0, c.partX);
     THIP_RC(ar_begin(s, 1, s->g1 + n1, n2 + TAIL));
     THIP_RC(ar_wait(s, 0));
     xupd(0, 1, 0);
     THIP_RC(project_blocks(s));
     // ---- stage C, first half ----
-    THIP_RC(products_cols(s, s->xx, s->xy, &gp, 0, n1));
+    THIP_RC(products_cols(s, s->xx, s->xy, &gp, 0));
     post(s->g3, s->h3, 0, s->rxx, s->rxy, 0, c.partC);
     THIP_RC(ar_begin(s, 2, s->g3, n1));
     THIP_RC(ar_wait(s, 1));
     xupd(1, 0, 1);
     // ---- stage C, second half ----
-    THIP_RC(products_cols(s, s->xx, s->xy, &gp, n1, n));
+    THIP_RC(products_cols(s, s->xx, s->xy, &gp, 1));
     post(s->g3, s->h3, 1, s->rxx, s->rxy, 1, c.partC);
     THIP_RC(ar_begin(s, 3, s->g3 + n1, n2 + TAIL));
     THIP_RC(ar_wait(s, 2));
@@ -1021,14 +1033,18 @@ int autotune_gemv(thip_solver *s)
         if (!sp)
             return dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
                                       s->gemv_scr_n, &gp, nullptr, h, s->a_kind, s->ainv(), s->apadz());
-        int chunks = 0;
-        const int cpc = dual_gemv_cols_per_chunk(s->m, s->n, s->amat(), s->alda(), h, s->a_kind, &chunks);
-        const size_t n1 = chunks >= 2 ? (size_t)(chunks / 2) * (size_t)cpc : s->n;
+        const bool h16 = s->is16();
+        const bool vec_ok = (((uintptr_t)s->amat() & 15u) == 0) && (s->alda() % (h16 ? 8 : 4) == 0);
+        const size_t n1 = split_column(s);
+        if (n1 == 0 || n1 >= s->n)
+            return dual_gemv_partials(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, false, s->gemv_scr,
+                                      s->gemv_scr_n, &gp, nullptr, h, s->a_kind, s->ainv(), s->apadz());
+        const int r1 = dual_gemv_chunk_rows(s->m, n1, vec_ok, s->a_kind, h, nullptr);
+        const int r2 = dual_gemv_chunk_rows(s->m, s->n - n1, vec_ok, s->a_kind, h, nullptr);
         THIP_RC(dual_gemv_partials_cols(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, s->gemv_scr, s->gemv_scr_n,
-                                        &gp, nullptr, h, s->a_kind, s->ainv(), s->apadz(), 0, n1));
-        if (n1 < s->n)
-            THIP_RC(dual_gemv_partials_cols(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, s->gemv_scr,
-                                            s->gemv_scr_n, &gp, nullptr, h, s->a_kind, s->ainv(), s->apadz(), n1, s->n));
+                                        &gp, nullptr, h, s->a_kind, s->ainv(), s->apadz(), 0, n1, 0, r1 + r2, nullptr));
+        THIP_RC(dual_gemv_partials_cols(st, s->m, s->n, s->amat(), s->alda(), s->u, s->v, true, true, s->gemv_scr, s->gemv_scr_n,
+                                        &gp, nullptr, h, s->a_kind, s->ainv(), s->apadz(), n1, s->n, r1, r1 + r2, nullptr));
         return 0;
     };
     for (int w = 0; w < 3; ++w)         // clocks and caches settle before anything is timed
