@@ -33,6 +33,10 @@ pub const THIP_CONE_PSD: i32 = 4;
 pub const THIP_SCHED_REFERENCE: c_int = 0;
 pub const THIP_SCHED_FUSED: c_int = 1;
 pub const THIP_SCHED_CARRIED: c_int = 2;
+pub const THIP_OVERLAP_OFF: c_int = 0;
+pub const THIP_OVERLAP_LOCAL_ROWS: c_int = 1;
+pub const THIP_OVERLAP_COLUMN_PIPELINE: c_int = 2;
+pub const THIP_OVERLAP_COLUMN_INORDER: c_int = 3;
 
 extern "C" {
     pub fn thip_init(device: c_int) -> c_int;

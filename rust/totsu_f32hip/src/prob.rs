@@ -106,10 +106,15 @@ pub struct HipProblem<'a, C> { pub dense: &'a Dense, pub by_calls: C }
 pub struct FusedSolver { h: *mut thip_solver, n: usize, m: usize }
 impl FusedSolver {
     pub fn new(d: &Dense, par: &SolverParam<f32>, schedule: c_int) -> Self {
+        Self::with_state_arith(d, par, schedule, THIP_STATE_COMPENSATED)
+    }
+    /// `state_arith`: THIP_STATE_COMPENSATED (the library's default: Kahan terms on the iterate updates) or
+    /// THIP_STATE_PLAIN (the reference's literal f32 additions, solver.rs:542,560)
+    pub fn with_state_arith(d: &Dense, par: &SolverParam<f32>, schedule: c_int, state_arith: i32) -> Self {
         let prob = thip_problem { n: d.n, m: d.m, mat_a: d.a, vec_b: d.b, vec_c: d.c, vec_b_rowabs: d.b_rowabs,
                                   n_seg: d.seg_type.len(), host_seg_type: d.seg_type.as_ptr(), host_seg_len: d.seg_len.as_ptr() };
         let p = thip_param { max_iter: par.max_iter.map_or(-1, |v| v as i64), eps_acc: par.eps_acc, eps_inf: par.eps_inf,
-                             eps_zero: par.eps_zero, log_period: 0, state_arith: THIP_STATE_COMPENSATED, reserved: 0 };
+                             eps_zero: par.eps_zero, log_period: 0, state_arith, reserved: 0 };
         let mut h = std::ptr::null_mut();
         chk(unsafe { thip_solver_create(&prob, &p, schedule, &mut h) });
         chk(unsafe { thip_solver_init(h) });
@@ -130,13 +135,15 @@ impl FusedSolver {
 impl Drop for FusedSolver { fn drop(&mut self) { unsafe { thip_solver_destroy(self.h) }; } }
 
 /// `Solver::<F32HIP>` with the dispatch: a `HipProblem` goes to the device-resident loop
-pub struct HipSolver { pub inner: Solver<F32HIP>, pub fused: bool }
+pub struct HipSolver { pub inner: Solver<F32HIP>, pub fused: bool, pub state_arith: i32 }
 impl HipSolver {
-    pub fn new() -> Self { HipSolver { inner: Solver::new(), fused: true } }
+    pub fn new() -> Self { HipSolver { inner: Solver::new(), fused: true, state_arith: THIP_STATE_COMPENSATED } }
+    /// the reference's literal f32 iterate arithmetic instead of the compensated default
+    pub fn plain_state(mut self) -> Self { self.state_arith = THIP_STATE_PLAIN; self }
     pub fn par<P: FnOnce(&mut SolverParam<f32>)>(mut self, f: P) -> Self { f(&mut self.inner.param); self }
     pub fn solve<C>(self, prob: HipProblem<'_, C>) -> Result<(Vec<f32>, Vec<f32>), SolverError>
     where C: FnOnce(&Solver<F32HIP>) -> Result<(&[f32], &[f32]), SolverError> {
-        if self.fused { FusedSolver::new(prob.dense, &self.inner.param, THIP_SCHED_CARRIED).solve() }
+        if self.fused { FusedSolver::with_state_arith(prob.dense, &self.inner.param, THIP_SCHED_CARRIED, self.state_arith).solve() }
         else { (prob.by_calls)(&self.inner).map(|(x, y)| (x.to_vec(), y.to_vec())) }
     }
 }

@@ -23,6 +23,8 @@ struct Ctx {
     hipEvent_t   stage_ev[2] = { nullptr, nullptr };   // "the DMA out of half k has finished"
     int          num_cu = 256;
     int         *never_stop = nullptr;  // a device int that stays 0: the stop flag of launches outside a solver loop
+    float       *eig_pin = nullptr;     // pinned staging of the QL rotation record (thip_eig.hip), grown on demand
+    size_t       eig_pin_floats = 0;
 };
 
 // *host_out = *dev_src, in stream order (SYNC)

@@ -116,6 +116,7 @@ int thip_shutdown(void)
     if (c.never_stop) hipFree(c.never_stop);
     c.never_stop = nullptr;
     if (c.pinned) hipHostFree(c.pinned);
+    if (c.eig_pin) hipHostFree(c.eig_pin);
     if (c.stage) hipHostFree(c.stage);
     for (int k = 0; k < 2; ++k) if (c.stage_ev[k]) hipEventDestroy(c.stage_ev[k]);
     if (c.own_stream) hipStreamDestroy(c.own_stream);

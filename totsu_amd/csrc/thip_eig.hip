@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 using namespace thip;
@@ -655,6 +656,9 @@ __global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const fl
 // same order), Z = T S is the left-multiplied update.
 constexpr int PSN = 64, PSP = 65;
 typedef float ps_mat[PSN][PSP];
+// five operands in LDS: 83 200 bytes static -- more than the 64 KB of older parts.  This library is built for gfx950 only
+// (160 KB of LDS per CU; Makefile: --offload-arch=gfx950), which is what makes the one-workgroup form the default engine.
+static_assert(5 * sizeof(ps_mat) <= 160 * 1024, "polar_small_k keeps five 64 x 65 operands in LDS");
 
 // C = alpha * (FORM 0: A B^T, FORM 1: A B) + beta * D + gamma * I_n on this wave's quadrant; nk = number of MFMA steps
 template <int FORM, int NK>
@@ -1219,13 +1223,18 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
     float *scr = nullptr;
     THIP_RC(scratch(2 * per + 64, &scr));
     // pinned staging for the uploads, one half per device buffer (the same event guards both)
-    static float *pin = nullptr; static size_t pin_floats = 0;
-    if (pin_floats < 2 * per) {
-        if (pin) THIP_TRY(hipHostFree(pin));
-        pin = nullptr; pin_floats = 0;
-        THIP_TRY(hipHostMalloc((void **)&pin, 2 * per * sizeof(float), hipHostMallocDefault));
-        pin_floats = 2 * per;
+    // (context-owned: released by thip_shutdown; one decomposition at a time per context -- the mutex covers the whole
+    // replay, like the reference's one-thread-per-backend contract, linalg_ex.rs / cuda_mgr.rs thread_local state)
+    static std::mutex eig_mu;
+    std::lock_guard<std::mutex> eig_lock(eig_mu);
+    Ctx &cx = ctx();
+    if (cx.eig_pin_floats < 2 * per) {
+        if (cx.eig_pin) THIP_TRY(hipHostFree(cx.eig_pin));
+        cx.eig_pin = nullptr; cx.eig_pin_floats = 0;
+        THIP_TRY(hipHostMalloc((void **)&cx.eig_pin, 2 * per * sizeof(float), hipHostMallocDefault));
+        cx.eig_pin_floats = 2 * per;
     }
+    float *const pin = cx.eig_pin;
     hipEvent_t ev[2] = { nullptr, nullptr };
     int which = 0, rc = 0;
     std::vector<float2> rot;

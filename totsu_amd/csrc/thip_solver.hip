@@ -483,6 +483,24 @@ __global__ void precond_k(int n, int m, const float *__restrict__ colabs, const 
     }
 }
 
+// Cross-stream hand-offs of the column-split pipeline without events: the producer stream runs signal_k after its last
+// kernel (in stream order), the consumer stream runs gate_k, which spins until the flag has reached the value.  A
+// hipEventRecord / hipStreamWaitEvent pair leaves ~13 us of idle stream behind the record on this part (rocprof timeline,
+// DESIGN.md 6.1); a one-thread kernel boundary costs 2-3 us.  Every gate is enqueued (host order) after its signal, so
+// the pair is satisfiable on any queue mapping; a gate gives up after ~2 s and raises err instead of hanging the GPU.
+__global__ void signal_k(unsigned *flag, unsigned val)
+{
+    __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void gate_k(const unsigned *flag, unsigned val, long long timeout_ticks, unsigned *err)
+{
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > timeout_ticks) { atomicExch(err, 1u); break; }
+    }
+}
+
 // thip_test_spin_allreduce: a stand-in collective that only takes time -- one thread spinning on the constant-rate
 // device clock for `ticks`, on whatever stream the hook is given
 __global__ void spin_k(long long ticks)
@@ -517,6 +535,14 @@ struct thip_solver {
     bool tail_pending = false;    // mode 2: the last column half of the y update + the termination test of the previous
                                   // iteration are still to be enqueued (they wait for its last all-reduce)
     long long spin_ticks = 0;     // thip_test_spin_allreduce
+    // hand-offs of mode 2 through device flags instead of events (signal_k / gate_k): [0..3] "producer done", [4..7]
+    // "collective done", [8] error word; values = per-slot call counters.  (Folding the signal into the producer's last
+    // block and the gate into the consumer's entry was built and measured SLOWER, 848 vs 839 us: an agent-scope acquire
+    // in every consumer block invalidates its XCD's L2.)
+    bool use_gates = false;
+    unsigned *gflags = nullptr;
+    unsigned gseq[4] = { 0, 0, 0, 0 };
+    long long gate_ticks = 0;
 
     // optional sparse A (CSR of A and of A^T)
     bool sparse = false; size_t nnz = 0;
@@ -889,6 +915,16 @@ int ar_begin(thip_solver *s, int slot, float *buf, size_t count)
 {
     if (s->overlap != 2) return do_allreduce(s, buf, count);
     hipStream_t st = ctx().stream;
+    if (s->use_gates) {
+        const unsigned v = ++s->gseq[slot];
+        hipLaunchKernelGGL(signal_k, dim3(1), dim3(1), 0, st, s->gflags + slot, v);
+        hipLaunchKernelGGL(gate_k, dim3(1), dim3(1), 0, s->side, s->gflags + slot, v, s->gate_ticks, s->gflags + 8);
+        const int rc = s->allreduce(s->allreduce_ctx, buf, count, (void *)s->side);
+        if (rc != 0) return fail(rc, "all-reduce callback failed", __FILE__, __LINE__);
+        hipLaunchKernelGGL(signal_k, dim3(1), dim3(1), 0, s->side, s->gflags + 4 + slot, v);
+        THIP_LAUNCH_CHECK();
+        return 0;
+    }
     THIP_TRY(hipEventRecord(s->sev_in[slot], st));
     THIP_TRY(hipStreamWaitEvent(s->side, s->sev_in[slot], 0));
     const int rc = s->allreduce(s->allreduce_ctx, buf, count, (void *)s->side);
@@ -900,6 +936,12 @@ int ar_begin(thip_solver *s, int slot, float *buf, size_t count)
 int ar_wait(thip_solver *s, int slot)
 {
     if (s->overlap != 2) return 0;
+    if (s->use_gates) {
+        hipLaunchKernelGGL(gate_k, dim3(1), dim3(1), 0, ctx().stream, s->gflags + 4 + slot, s->gseq[slot], s->gate_ticks,
+                           s->gflags + 8);
+        THIP_LAUNCH_CHECK();
+        return 0;
+    }
     THIP_TRY(hipStreamWaitEvent(ctx().stream, s->sev_out[slot], 0));
     return 0;
 }
@@ -1321,6 +1363,16 @@ int thip_solver_set_overlap(thip_solver *s, int on)
         }
     }
     if (s->side && ctx().inited) THIP_TRY(hipStreamSynchronize(s->side));
+    if (on == 2 && !s->gflags) {
+        // THIP_PIPE_GATES=0: cross-stream events instead of the device-flag hand-offs
+        static const int gates_on = getenv("THIP_PIPE_GATES") ? atoi(getenv("THIP_PIPE_GATES")) : 1;
+        THIP_TRY(hipExtMallocWithFlags((void **)&s->gflags, 16 * sizeof(unsigned), hipDeviceMallocUncached));
+        THIP_TRY(hipMemset(s->gflags, 0, 16 * sizeof(unsigned)));
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx().device) != hipSuccess || khz <= 0) khz = 100000;
+        s->gate_ticks = (long long)khz * 2000ll;
+        s->use_gates = gates_on != 0;
+    }
     s->overlap = on;
     return 0;
 }
@@ -1653,6 +1705,7 @@ int thip_solver_destroy(thip_solver *s)
     if (s->ev_in) hipEventDestroy(s->ev_in);
     if (s->ev_out) hipEventDestroy(s->ev_out);
     for (int k = 0; k < 4; ++k) { if (s->sev_in[k]) hipEventDestroy(s->sev_in[k]); if (s->sev_out[k]) hipEventDestroy(s->sev_out[k]); }
+    if (s->gflags) hipFree(s->gflags);
     hipFree(s->cls); hipFree(s->soc_beg); hipFree(s->soc_end); hipFree(s->rot_beg); hipFree(s->rot_end);
     for (auto &g : s->psd_groups) hipFree(g.dev_offs);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
