@@ -97,6 +97,11 @@ int thip_lazy_gemv_stats(int64_t *host_deferred, int64_t *host_flushes);
 /* a flushed segment is kept as a plan (call list, device tables, launch geometry); the loop repeats its call sequence
  * every iteration, so the next pass re-uses the plan (hit) instead of analysing and building again (miss) */
 int thip_lazy_plan_stats(int64_t *host_hits, int64_t *host_misses);
+/* read-ahead of SYNC scalars (deferred mode only): the thip_get / thip_norm calls of a host loop that asks for the same
+ * addresses every pass -- the reference's ConeSOC::proj, cone_soc.rs:44-47, 2 reads per cone -- are learnt, and on the next
+ * pass the first read fetches all of them with one kernel and one transfer (a fetch); the others are served from the host
+ * copy as long as each request is the predicted one and nothing issued in between writes a range still to be read */
+int thip_lazy_read_stats(int64_t *host_served, int64_t *host_fetches);
 /* y = alpha * S x + beta * y, S symmetric, packed upper by columns.  linalg_ex.rs:37 (cublasSspmv, f32cuda.rs:174-187) */
 int thip_transform_sp(size_t n, float alpha, const float *mat, const float *x, float beta, float *y);
 /* Reduced-precision STORAGE of a dense operator (not part of the reference's trait surface):

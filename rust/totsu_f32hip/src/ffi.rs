@@ -78,6 +78,7 @@ extern "C" {
     pub fn thip_get_lazy_gemv(host_on: *mut c_int) -> c_int;
     pub fn thip_lazy_gemv_stats(host_deferred: *mut i64, host_flushes: *mut i64) -> c_int;
     pub fn thip_lazy_plan_stats(host_hits: *mut i64, host_misses: *mut i64) -> c_int;
+    pub fn thip_lazy_read_stats(host_served: *mut i64, host_fetches: *mut i64) -> c_int;
     pub fn thip_proj_zero(dual_cone: c_int, n: usize, x: *mut f32) -> c_int;
     pub fn thip_proj_rpos(n: usize, x: *mut f32) -> c_int;
     pub fn thip_proj_soc(n: usize, x: *mut f32) -> c_int;

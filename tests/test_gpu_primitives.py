@@ -689,3 +689,63 @@ def test_big_block_pair_shares_one_pass(L):
         assert np.allclose(a, b, rtol=1e-4, atol=1e-4 * np.abs(a).max())
     for d in (A, x, xt):
         d.free()
+
+
+def test_read_ahead_of_the_reference_cone_loop(L):
+    """The reference's ConeSOC::proj, literally (cone_soc.rs:38-65): per cone get(0) + norm(v) on the host, then scale / set.
+    With deferred execution on, the reads of a pass are learnt and the next pass fetches them all at once; results must
+    be those of one blocking read per call -- also when the data changes from pass to pass, when a pass takes another
+    branch, and when a write lands in a range still to be read (the cache must be dropped, not served)."""
+    from totsu_amd._lib import lib
+    rng = np.random.default_rng(77)
+    lens = [5, 100, 100, 33, 1, 64, 100, 7, 100, 100, 12, 100, 100, 100, 50, 100, 100, 3, 100, 100]      # 20 cones
+    total = sum(lens)
+
+    def cone_pass(x, poke=None):
+        off = 0
+        for i, ln in enumerate(lens):
+            s0, hn = C.c_float(), C.c_float()
+            lib.thip_get(x.dev() + 4 * off, 0, C.byref(s0))
+            lib.thip_norm(ln - 1, x.dev() + 4 * (off + 1), C.byref(hn))
+            vs, nv = s0.value, hn.value
+            if nv <= -vs:
+                lib.thip_scale(ln - 1, 0.0, x.dev() + 4 * (off + 1))
+                lib.thip_set(x.dev() + 4 * off, 0, 0.0)
+            elif nv > vs:
+                lib.thip_scale(ln - 1, (1.0 + vs / nv) / 2.0, x.dev() + 4 * (off + 1))
+                lib.thip_set(x.dev() + 4 * off, 0, (nv + vs) / 2.0)
+            if poke is not None and i == poke[0]:
+                # a write into a cone still to be read: the read-ahead must not serve its stale value
+                lib.thip_set(x.dev() + 4 * poke[1], 0, 50.0)
+            off += ln
+        return x.get_ref().copy()
+
+    def run(lazy):
+        lib.thip_set_lazy_gemv(lazy)
+        x = _dev(L, np.zeros(total, np.float32))
+        outs = []
+        for p_ in range(6):
+            h = np.random.default_rng(100 + p_).standard_normal(total).astype(np.float32) * (3.0 if p_ % 2 else 0.3)
+            if p_ == 4:
+                h[0] = 40.0                      # cone 0 inside: another branch than the pass before
+            lib.thip_h2d(x.dev(), h.ctypes.data, total)
+            outs.append(cone_pass(x, poke=(2, sum(lens[:9])) if p_ == 5 else None))
+        x.drop()
+        return outs
+
+    eager = run(0)
+    s0, f0, s1, f1 = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    lib.thip_lazy_read_stats(C.byref(s0), C.byref(f0))
+    lazy = run(1)
+    lib.thip_lazy_read_stats(C.byref(s1), C.byref(f1))
+    lib.thip_set_lazy_gemv(0)
+    for a, b in zip(eager, lazy):
+        assert np.allclose(a, b, rtol=2e-6, atol=2e-6), np.abs(a - b).max()
+    # pass 0 learns (40 blocking reads); passes 1 .. 5 are fetched at once (the poked one falls back part of the way)
+    assert f1.value - f0.value >= 4 and s1.value - s0.value >= 4 * 2 * len(lens), (s1.value - s0.value, f1.value - f0.value)
+    # the SOC projection really happened: every cone ends inside its cone
+    off = 0
+    for ln in lens:
+        blk = lazy[3][off:off + ln]
+        assert np.linalg.norm(blk[1:]) <= blk[0] * (1 + 1e-5) + 1e-6
+        off += ln

@@ -458,7 +458,7 @@ def test_column_pipeline_hides_an_injected_collective_latency(T):
 
 # ---- one-shot all-reduce over peer-mapped buffers (thip_oneshot_*) --------------------------------------------------
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_oneshot_allreduce_between_processes_sharing_the_gpu(world):
     # hipIpc* works between processes on the SAME device, so a 1-GPU box can run the real protocol: N processes, the
     # handshake flags, the alternating slots, sums in rank order -- checked bit for bit by every rank (tests/oneshot_worker.py)

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "thip_get_lazy_gemv": (_i, [C.POINTER(_i)]),
     "thip_lazy_gemv_stats": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "thip_lazy_plan_stats": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "thip_lazy_read_stats": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "thip_to_bf16": (_i, [_sz, _sz, _vp, _vp, _sz]),
     "thip_to_f16": (_i, [_sz, _sz, _vp, _vp, _sz, _vp]),
     "thip_transform_ge_f16": (_i, [_i, _sz, _sz, _f, _vp, _sz, _vp, _vp, _f, _vp]),

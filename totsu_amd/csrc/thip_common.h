@@ -39,6 +39,9 @@ int  lazy_push(int transpose, size_t n_row, size_t n_col, float alpha, const flo
 int  lazy_push_scale(size_t n, float alpha, float *x, int *deferred);
 int  lazy_push_add(size_t n, float alpha, const float *x, float *y, int *deferred);
 int  lazy_push_proj(int kind, size_t n, float *x, int *deferred);      // single-cone projections (THIP_CONE_*)
+int  lazy_push_set(float *x, float value, int *deferred);              // SliceLike::set
+// SYNC scalar reads: *served = 1 and the value when the read-ahead has it; else the record has been run and the caller reads
+int  lazy_read(int is_norm, const float *p, size_t n, float *value, int *served);
 void lazy_release();      // frees the queue's device memory (thip_shutdown)
 int  fail(int code, const char *what, const char *file, int line);
 int  need_init();

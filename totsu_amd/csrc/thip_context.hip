@@ -210,7 +210,11 @@ int thip_d2h(float *host_dst, const float *src, size_t n)
 
 int thip_get(const float *x, size_t idx, float *host_out)
 {
-    THIP_NEED_INIT();
+    THIP_NEED_INIT_NOFLUSH();
+    // with deferred execution on, the reads of a host loop are fetched ahead in one transfer (thip_lazy.hip)
+    int served = 0;
+    THIP_RC(lazy_read(0, x + idx, 1, host_out, &served));
+    if (served) return 0;
     return fetch_scalar(x + idx, host_out);
 }
 
@@ -218,7 +222,10 @@ __global__ void set_kernel(float *x, float v) { x[0] = v; }
 
 int thip_set(float *x, size_t idx, float val)
 {
-    THIP_NEED_INIT();
+    THIP_NEED_INIT_NOFLUSH();
+    int deferred = 0;
+    THIP_RC(lazy_push_set(x + idx, val, &deferred));
+    if (deferred) return 0;
     hipLaunchKernelGGL(set_kernel, dim3(1), dim3(1), 0, ctx().stream, x + idx, val);
     THIP_LAUNCH_CHECK();
     return 0;

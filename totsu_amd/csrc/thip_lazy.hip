@@ -58,8 +58,8 @@ constexpr size_t LAZY_MAX_OPS = 32768;
 constexpr int SHORT_LEN = 2048;                         // groups up to this long are finished by one workgroup each
 constexpr int MAX_PLANS = 16;
 
-enum { K_N = 0, K_T = 1, K_AXPY = 2, K_DOT = 3, K_ADDV = 4, K_SCALE = 5 };
-enum { OP_GE = 0, OP_SCALE = 1, OP_ADD = 2, OP_PROJ = 3 };
+enum { K_N = 0, K_T = 1, K_AXPY = 2, K_DOT = 3, K_ADDV = 4, K_SCALE = 5, K_CONST = 6 };
+enum { OP_GE = 0, OP_SCALE = 1, OP_ADD = 2, OP_PROJ = 3, OP_SET = 4 };
 
 // one API call as issued
 struct Call {
@@ -90,7 +90,7 @@ struct Group {
 
 // device-side tables
 struct DotD { const float *v, *x; float *out; int len; int pad; };
-enum { M_PART = 0, M_AXPY = 1, M_ADDV = 2 };
+enum { M_PART = 0, M_AXPY = 1, M_ADDV = 2, M_CONST = 3 };
 struct FinMember { const float *src; const float *xs; int count; int type; size_t stride; };
 struct FinGroup { float *y; int len; int first, count; };
 struct BigMat { const float *A, *xn, *xt; size_t nr, nc; size_t scr_off, scr_floats; };   // run by dual_gemv_partials at flush
@@ -116,7 +116,33 @@ struct Plan {
     uint64_t last_use = 0;
 };
 
+// ---- read-ahead of the SYNC scalars of a host loop ------------------------------------------------------------------------
+// The reference's ConeSOC::proj reads two host scalars per cone -- SliceLike::get(0) and LinAlg::norm (cone_soc.rs:44-47) --
+// and ProbSOCPCone::proj visits 1000 cones twice per iteration (socp.rs:296-313): 4000 blocking round trips of ~25 us.
+// The reads of a pass are independent of each other (each cone only WRITES its own slice, after its reads), and the loop
+// asks for the same addresses every iteration.  So the sequence of reads of a pass is learnt, and on the next pass the
+// first read fetches ALL of them with one kernel and one transfer; the later ones are served from the host copy -- as
+// long as each request is the predicted one and no call issued in between writes into a range still to be read (checked
+// against every recorded write; any other entry point drops the cache).  The writes between the reads (scale, set) are
+// recorded, so a pass of the reference's literal cone code costs one fetch and one flush.
+enum { RD_GET = 0, RD_NORM = 1 };
+struct ReadReq { int kind; const float *p; size_t n; };
+struct ReadD { const float *p; unsigned n; int kind; };
+struct ReadPlan {
+    std::vector<ReadReq> reqs;
+    std::vector<uintptr_t> suf_lo, suf_hi;      // hull of the ranges of reqs[i ..]
+    char *dev = nullptr;                        // table of ReadD, then the results
+    uint64_t last_use = 0;
+};
+
 struct Queue {
+    // ---- read-ahead
+    std::vector<ReadReq> rd_learn; bool rd_open = false;
+    std::vector<ReadPlan *> rd_plans;
+    ReadPlan *rd_cur = nullptr; size_t rd_pos = 0;
+    std::vector<float> rd_vals;
+    float *rd_pin = nullptr; size_t rd_pin_n = 0;
+    long long rd_served = 0, rd_fetches = 0;
     // ---- the segment being recorded by the analysing path
     std::vector<Group> groups;
     std::unordered_map<const float *, int> target;         // y -> group
@@ -195,6 +221,7 @@ __device__ __forceinline__ double contributions(const FinGroup &g, const FinMemb
             for (; t < m.count; ++t) s0 += (double)p[(size_t)t * m.stride];
             acc += (double)al * ((s0 + s1) + (s2 + s3));
         } else if (m.type == M_AXPY) acc += (double)(al * m.xs[0] * m.src[c]);
+        else if (m.type == M_CONST) acc += (double)al;                    // SliceLike::set: y <- value
         else acc += (double)(al * m.src[c]);
     }
     return acc;
@@ -247,6 +274,18 @@ __global__ __launch_bounds__(BLK) void ewise_table_k(float *__restrict__ base, c
     const int64_t b = begs[blockIdx.x], e = ends[blockIdx.x];
     for (int64_t i = b + (int64_t)blockIdx.y * BLK + threadIdx.x; i < e; i += (int64_t)gridDim.y * BLK)
         base[i] = zero ? 0.0f : fmaxf(base[i], 0.0f);
+}
+
+// all the scalars of a pass in one launch: request i -> out[i] (one workgroup each): x[0], or ||x||_2 with f64 squares
+__global__ __launch_bounds__(BLK) void read_batch_k(const ReadD *__restrict__ tab, float *__restrict__ out)
+{
+    __shared__ double shd[16];
+    const ReadD d = tab[blockIdx.x];
+    if (d.kind == RD_GET) { if (threadIdx.x == 0) out[blockIdx.x] = d.p[0]; return; }
+    double acc = 0.0;
+    for (unsigned i = threadIdx.x; i < d.n; i += BLK) { const double t = (double)d.p[i]; acc += t * t; }
+    acc = block_sum_d(acc, shd);
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)sqrt(acc);
 }
 
 size_t up256(size_t v) { return (v + 255) / 256 * 256; }
@@ -308,7 +347,9 @@ void reset_segment()
 
 void update_pending()
 {
-    Q.pending.store(!Q.calls.empty() || (Q.replaying && Q.pos > 0), std::memory_order_relaxed);
+    // a live read cache / an open learning pass count as pending: ANY other entry point must pass through lazy_flush so
+    // that it drops them (it may write what a cached read stands for)
+    Q.pending.store(!Q.calls.empty() || (Q.replaying && Q.pos > 0) || Q.rd_cur != nullptr || Q.rd_open, std::memory_order_relaxed);
 }
 
 uint64_t mix(uint64_t h, uint64_t v)
@@ -659,6 +700,7 @@ int flush_products()
                 fm.src = dpart + dot_off + iDot; fm.type = M_ADDV;
                 ++iDot;
             } else if (m.kind == K_AXPY) { fm.src = m.A; fm.xs = m.x; fm.type = M_AXPY; }
+            else if (m.kind == K_CONST) { fm.type = M_CONST; }
             else { fm.src = m.x; fm.type = M_ADDV; }                                          // K_ADDV
             if (m.call >= 0 && (size_t)m.call < calls.size()) p->mem_slot[m.call] = (int)mpos;
             hm[mpos++] = fm;
@@ -691,7 +733,7 @@ int flush_segment()
 int push_products(float *y, size_t len, float beta, Member m, Call c, int *deferred)
 {
     if (Q.proj_kind >= 0) { g_why = "a product follows projections"; THIP_RC(flush_segment()); }   // a projection run is pending: it comes first
-    const bool has_in = m.kind != K_SCALE;
+    const bool has_in = m.kind != K_SCALE && m.kind != K_CONST;
     const uintptr_t y0 = (uintptr_t)y, y1 = y0 + len * sizeof(float);
     const uintptr_t x0 = (uintptr_t)m.x, x1 = has_in ? x0 + m.inlen * sizeof(float) : x0;
     const bool has_a = m.kind == K_N || m.kind == K_T || m.kind == K_AXPY || m.kind == K_DOT;
@@ -718,6 +760,7 @@ int push_products(float *y, size_t len, float beta, Member m, Call c, int *defer
                 if ((int)gi != join && overlap(y0, y1, py0, py1)) { must_flush = true; break; }
                 if (war)
                     for (const Member &p : g.mem) {
+                        if (p.kind == K_CONST) continue;
                         const uintptr_t px0 = (uintptr_t)p.x, px1 = px0 + p.inlen * sizeof(float);
                         if (overlap(y0, y1, px0, px1)) { must_flush = true; break; }
                         if (p.kind != K_ADDV) {
@@ -750,7 +793,7 @@ int push_products(float *y, size_t len, float beta, Member m, Call c, int *defer
         c.mem = m.call;
         g.mem.push_back(m);
         Q.n_members += 1;
-        Q.xlo = std::min(Q.xlo, x0); Q.xhi = std::max(Q.xhi, x1);
+        if (has_in) { Q.xlo = std::min(Q.xlo, x0); Q.xhi = std::max(Q.xhi, x1); }
         if (has_a) { Q.xlo = std::min(Q.xlo, a0); Q.xhi = std::max(Q.xhi, a1); }
     }
     Q.calls.push_back(c);
@@ -796,6 +839,7 @@ int push_slow(const Call &c, int *deferred)
         else                { m.kind = tr ? K_T : K_N; m.inlen = tr ? c.nr : c.nc; outlen = tr ? c.nc : c.nr; }
         beta = c.beta;
     } else if (c.op == OP_SCALE) { m.kind = K_SCALE; beta = c.beta; }
+    else if (c.op == OP_SET) { m.kind = K_CONST; m.alpha = c.alpha; beta = 0.0f; outlen = 1; }
     else { m.kind = K_ADDV; m.alpha = c.alpha; m.x = c.x; m.inlen = c.nr; m.nr = m.nc = 0; }
     return push_products(c.y, outlen, beta, m, c, deferred);
 }
@@ -838,9 +882,128 @@ int finish_replay()
     return 0;
 }
 
+// ---- read-ahead ----------------------------------------------------------------------------------------------------------------
+
+void drop_read_cache() { Q.rd_cur = nullptr; Q.rd_pos = 0; }
+
+void free_read_plan(ReadPlan *p) { if (p->dev) hipFree(p->dev); delete p; }
+
+// the learning pass ends: keep what it saw as the plan for the next pass (passes shorter than 16 reads are not worth one)
+void close_read_group()
+{
+    if (!Q.rd_open) return;
+    Q.rd_open = false;
+    if (Q.rd_learn.size() < 16 || Q.rd_learn.size() > 65536) { Q.rd_learn.clear(); return; }
+    for (size_t i = 0; i < Q.rd_plans.size(); ++i) {
+        const ReadReq &f = Q.rd_plans[i]->reqs[0];
+        if (f.kind == Q.rd_learn[0].kind && f.p == Q.rd_learn[0].p && f.n == Q.rd_learn[0].n) {
+            hipStreamSynchronize(ctx().stream);
+            free_read_plan(Q.rd_plans[i]);
+            Q.rd_plans.erase(Q.rd_plans.begin() + i);
+            break;
+        }
+    }
+    if (Q.rd_plans.size() >= 4) {
+        size_t v = 0;
+        for (size_t i = 1; i < Q.rd_plans.size(); ++i) if (Q.rd_plans[i]->last_use < Q.rd_plans[v]->last_use) v = i;
+        hipStreamSynchronize(ctx().stream);
+        free_read_plan(Q.rd_plans[v]);
+        Q.rd_plans.erase(Q.rd_plans.begin() + v);
+    }
+    ReadPlan *p = new ReadPlan();
+    p->reqs.swap(Q.rd_learn);
+    const size_t n = p->reqs.size();
+    p->suf_lo.assign(n + 1, ~(uintptr_t)0); p->suf_hi.assign(n + 1, 0);
+    for (size_t i = n; i-- > 0;) {
+        const uintptr_t a = (uintptr_t)p->reqs[i].p, b = a + p->reqs[i].n * sizeof(float);
+        p->suf_lo[i] = std::min(p->suf_lo[i + 1], a); p->suf_hi[i] = std::max(p->suf_hi[i + 1], b);
+    }
+    const size_t b_tab = up256(n * sizeof(ReadD)), b_out = up256(n * sizeof(float));
+    if (hipMalloc((void **)&p->dev, b_tab + b_out) != hipSuccess) { (void)hipGetLastError(); delete p; return; }
+    std::vector<ReadD> tab(n);
+    for (size_t i = 0; i < n; ++i) tab[i] = ReadD{ p->reqs[i].p, (unsigned)p->reqs[i].n, p->reqs[i].kind };
+    if (hipMemcpy(p->dev, tab.data(), n * sizeof(ReadD), hipMemcpyHostToDevice) != hipSuccess) { free_read_plan(p); return; }
+    Q.rd_plans.push_back(p);
+}
+
+int flush_work();      // runs what is recorded (below)
+
+// a recorded write into [w0, w1): any cached read it could change is dropped
+void reads_vs_write(uintptr_t w0, uintptr_t w1)
+{
+    if (Q.rd_cur == nullptr) return;
+    const ReadPlan *p = Q.rd_cur;
+    if (!overlap(w0, w1, p->suf_lo[Q.rd_pos], p->suf_hi[Q.rd_pos])) return;
+    for (size_t i = Q.rd_pos; i < p->reqs.size(); ++i) {
+        const uintptr_t a = (uintptr_t)p->reqs[i].p;
+        if (overlap(w0, w1, a, a + p->reqs[i].n * sizeof(float))) { drop_read_cache(); return; }
+    }
+}
+
+// thip_get / thip_norm: *served = 1 and the value if the read-ahead has it; else everything recorded has been run and the
+// caller performs the read itself
+int read_request(int kind, const float *p, size_t n, float *value, int *served)
+{
+    *served = 0;
+    if (Q.rd_cur) {
+        const ReadPlan *pl = Q.rd_cur;
+        const ReadReq &r = pl->reqs[Q.rd_pos];
+        if (r.kind == kind && r.p == p && r.n == n) {
+            *value = Q.rd_vals[Q.rd_pos];
+            Q.rd_pos += 1; Q.rd_served += 1;
+            if (Q.rd_pos == pl->reqs.size()) drop_read_cache();
+            *served = 1;
+            update_pending();
+            return 0;
+        }
+        drop_read_cache();                 // not the predicted request
+    }
+    ReadPlan *pl = nullptr;
+    if (!Q.rd_open)
+        for (ReadPlan *q : Q.rd_plans) if (q->reqs[0].kind == kind && q->reqs[0].p == p && q->reqs[0].n == n) { pl = q; break; }
+    THIP_RC(flush_work());                 // the read (ours or the caller's) comes after everything recorded so far
+    if (pl) {
+        hipStream_t st = ctx().stream;
+        const size_t nr = pl->reqs.size();
+        if (Q.rd_pin_n < nr) {
+            if (Q.rd_pin) THIP_TRY(hipHostFree(Q.rd_pin));
+            Q.rd_pin = nullptr; Q.rd_pin_n = 0;
+            THIP_TRY(hipHostMalloc((void **)&Q.rd_pin, (nr + 1024) * sizeof(float), hipHostMallocDefault));
+            Q.rd_pin_n = nr + 1024;
+        }
+        float *dout = reinterpret_cast<float *>(pl->dev + up256(nr * sizeof(ReadD)));
+        hipLaunchKernelGGL(read_batch_k, dim3((unsigned)nr), dim3(BLK), 0, st, reinterpret_cast<const ReadD *>(pl->dev), dout);
+        THIP_LAUNCH_CHECK();
+        THIP_TRY(hipMemcpyAsync(Q.rd_pin, dout, nr * sizeof(float), hipMemcpyDeviceToHost, st));
+        THIP_TRY(hipStreamSynchronize(st));
+        Q.rd_vals.assign(Q.rd_pin, Q.rd_pin + nr);
+        pl->last_use = ++Q.tick;
+        Q.rd_fetches += 1; Q.rd_served += 1;
+        Q.rd_cur = pl; Q.rd_pos = 1;
+        if (nr == 1) drop_read_cache();
+        *value = Q.rd_vals[0];
+        *served = 1;
+        update_pending();
+        return 0;
+    }
+    // uncached: the caller reads; this pass is being learnt
+    if (!Q.rd_open) { Q.rd_learn.clear(); Q.rd_open = true; }
+    Q.rd_learn.push_back(ReadReq{ kind, p, n });
+    update_pending();
+    return 0;
+}
+
+uintptr_t write_len(const Call &c)
+{
+    if (c.op == OP_GE) return (c.transpose ? c.nc : c.nr) * sizeof(float);
+    if (c.op == OP_SET) return sizeof(float);
+    return c.nr * sizeof(float);
+}
+
 int push_call(const Call &c, int *deferred)
 {
     *deferred = 0;
+    if (Q.rd_cur) reads_vs_write((uintptr_t)c.y, (uintptr_t)c.y + write_len(c));
     for (int guard = 0; guard < 4 && Q.replaying; ++guard) {
         Plan *p = Q.pred;
         if (p->generation != Q.generation || !p->replayable) { THIP_RC(abandon_replay()); break; }
@@ -861,7 +1024,17 @@ int push_call(const Call &c, int *deferred)
     return push_slow(c, deferred);
 }
 
+// every entry point that is not a recorded call or a served read: what it does may change what a cached read stands for
 int flush_locked()
+{
+    drop_read_cache();
+    close_read_group();
+    THIP_RC(flush_work());
+    update_pending();
+    return 0;
+}
+
+int flush_work()
 {
     if (Q.replaying && Q.pos > 0) {
         if (Q.pos == Q.pred->calls.size() && Q.pred->generation == Q.generation) return finish_replay();
@@ -901,6 +1074,11 @@ void lazy_release()
     std::lock_guard<std::mutex> lock(Q.mu);
     reset_segment();
     drop_all_plans();
+    drop_read_cache();
+    Q.rd_open = false; Q.rd_learn.clear();
+    for (ReadPlan *p : Q.rd_plans) free_read_plan(p);
+    Q.rd_plans.clear();
+    if (Q.rd_pin) { hipHostFree(Q.rd_pin); Q.rd_pin = nullptr; Q.rd_pin_n = 0; }
     Q.pending.store(false, std::memory_order_relaxed);
     if (Q.part) { hipFree(Q.part); Q.part = nullptr; Q.part_floats = 0; Q.generation += 1; }
     for (int k = 0; k < 2; ++k) {
@@ -943,6 +1121,26 @@ int lazy_push_add(size_t n, float alpha, const float *x, float *y, int *deferred
     return push_call(c, deferred);
 }
 
+// SliceLike::set(idx, value) joins the record (y <- value)
+int lazy_push_set(float *x, float value, int *deferred)
+{
+    std::lock_guard<std::mutex> lock(Q.mu);
+    *deferred = 0;
+    if (!lazy_on()) return flush_locked();
+    Call c{};
+    c.op = OP_SET; c.bclass = 0; c.alpha = value; c.beta = 0.0f; c.nr = 1; c.y = x;
+    return push_call(c, deferred);
+}
+
+// SYNC scalar reads (SliceLike::get, LinAlg::norm): served from the read-ahead when it has them
+int lazy_read(int is_norm, const float *p, size_t n, float *value, int *served)
+{
+    std::lock_guard<std::mutex> lock(Q.mu);
+    *served = 0;
+    if (!lazy_on() || n == 0 || n > 0xffffffffull) return flush_locked();
+    return read_request(is_norm ? RD_NORM : RD_GET, p, n, value, served);
+}
+
 // single-cone projections (thip_proj_soc / _rotsoc / _rpos / _zero on x[0 .. n)): consecutive calls of one kind on
 // disjoint slices become one launch
 int lazy_push_proj(int kind, size_t n, float *x, int *deferred)
@@ -981,6 +1179,13 @@ int thip_lazy_gemv_stats(int64_t *host_deferred, int64_t *host_flushes)
 {
     if (host_deferred) *host_deferred = Q.deferred;
     if (host_flushes) *host_flushes = Q.flushes;
+    return 0;
+}
+
+int thip_lazy_read_stats(int64_t *host_served, int64_t *host_fetches)
+{
+    if (host_served) *host_served = Q.rd_served;
+    if (host_fetches) *host_fetches = Q.rd_fetches;
     return 0;
 }
 
