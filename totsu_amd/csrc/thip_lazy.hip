@@ -56,7 +56,7 @@ constexpr size_t LAZY_MAX_ELEMS = (size_t)16 << 20;     // blocks above 64 MB ta
 constexpr size_t LAZY_MAX_VEC = 1024;                   // scale / add on longer vectors run at once
 constexpr size_t LAZY_MAX_OPS = 32768;
 constexpr int SHORT_LEN = 2048;                         // groups up to this long are finished by one workgroup each
-constexpr int MAX_PLANS = 16;
+constexpr int MAX_PLANS = 64;
 
 enum { K_N = 0, K_T = 1, K_AXPY = 2, K_DOT = 3, K_ADDV = 4, K_SCALE = 5, K_CONST = 6 };
 enum { OP_GE = 0, OP_SCALE = 1, OP_ADD = 2, OP_PROJ = 3, OP_SET = 4 };
@@ -164,6 +164,10 @@ struct Queue {
     std::mutex mu;
     bool enabled = false, env_read = false;     // OFF unless a host asks for it (thip_set_lazy_gemv) or THIP_LAZY_GEMV=1
     float *part = nullptr; size_t part_floats = 0; unsigned generation = 1;      // partial sums (shared by the plans)
+    // the plans' device tables live in one arena, handed out front to back; when it (or the plan list) is full ALL plans
+    // are dropped and the arena starts over -- no allocation per plan (a host loop that never repeats itself, e.g. a
+    // known-answer test driven call by call, would otherwise pay a hipMalloc and a hipFree per flushed segment)
+    char *tab = nullptr; size_t tab_bytes = 0, tab_used = 0;
     // pinned staging of tables / factors: two halves, an event each ("the upload out of this half has finished")
     char *pin[2] = { nullptr, nullptr }; size_t pin_bytes[2] = { 0, 0 }; hipEvent_t pin_ev[2] = { nullptr, nullptr };
     int pin_next = 0;
@@ -290,11 +294,7 @@ __global__ __launch_bounds__(BLK) void read_batch_k(const ReadD *__restrict__ ta
 
 size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
-void free_plan(Plan *p)
-{
-    if (p->dev) hipFree(p->dev);
-    delete p;
-}
+void free_plan(Plan *p) { delete p; }        // its tables live in the arena
 
 void drop_all_plans()
 {
@@ -302,6 +302,27 @@ void drop_all_plans()
     Q.plans.clear();
     Q.pred = Q.last_plan = nullptr;
     Q.replaying = false; Q.pos = 0;
+    Q.tab_used = 0;
+}
+
+// `bytes` of table space for a new plan (256-byte aligned)
+int alloc_tab(size_t bytes, char **out)
+{
+    bytes = (bytes + 255) / 256 * 256;
+    if (Q.tab_used + bytes > Q.tab_bytes || (int)Q.plans.size() >= MAX_PLANS) {
+        // start over: launches still in flight may be reading the old tables
+        THIP_TRY(hipStreamSynchronize(ctx().stream));
+        drop_all_plans();
+        if (bytes > Q.tab_bytes) {
+            if (Q.tab) { THIP_TRY(hipFree(Q.tab)); Q.tab = nullptr; Q.tab_bytes = 0; }
+            const size_t want = std::max<size_t>((size_t)8 << 20, 2 * bytes);
+            THIP_TRY(hipMalloc((void **)&Q.tab, want));
+            Q.tab_bytes = want;
+        }
+    }
+    *out = Q.tab + Q.tab_used;
+    Q.tab_used += bytes;
+    return 0;
 }
 
 // the shared partial-sum buffer; growing it invalidates every plan (their tables hold pointers into it)
@@ -454,21 +475,7 @@ void plan_done(Plan *p)
     Q.replaying = Q.pred != nullptr;
 }
 
-void remember(Plan *p)
-{
-    if ((int)Q.plans.size() >= MAX_PLANS) {
-        size_t victim = 0;
-        for (size_t i = 1; i < Q.plans.size(); ++i) if (Q.plans[i]->last_use < Q.plans[victim]->last_use) victim = i;
-        Plan *v = Q.plans[victim];
-        hipStreamSynchronize(ctx().stream);          // its tables may be in use by launches still in flight
-        for (Plan *q : Q.plans) if (q->next == v) q->next = nullptr;
-        if (Q.last_plan == v) Q.last_plan = nullptr;
-        if (Q.pred == v) { Q.pred = nullptr; Q.replaying = false; }
-        free_plan(v);
-        Q.plans.erase(Q.plans.begin() + victim);
-    }
-    Q.plans.push_back(p);
-}
+void remember(Plan *p) { Q.plans.push_back(p); }       // alloc_tab() has made room
 
 Plan *find_plan(uint64_t key, const std::vector<Call> &calls, int type)
 {
@@ -504,7 +511,7 @@ int flush_projections()
         hipStream_t st = ctx().stream;
         char *host; int half;
         int rc = staging(bytes, &host, &half);
-        if (rc == 0 && hipMalloc((void **)&p->dev, bytes) != hipSuccess) rc = fail(THIP_E_INVALID, "hipMalloc (projection table)", __FILE__, __LINE__);
+        if (rc == 0) rc = alloc_tab(bytes, &p->dev);
         if (rc != 0) { delete p; return rc; }
         p->dev_bytes = bytes;
         int64_t *begs = reinterpret_cast<int64_t *>(host), *ends = begs + calls.size();
@@ -652,7 +659,7 @@ int flush_products()
     const size_t b_tab = p->off_beta + b_be;
     char *host; int half;
     rc = staging(b_tab, &host, &half);
-    if (rc == 0 && hipMalloc((void **)&p->dev, b_tab) != hipSuccess) rc = fail(THIP_E_INVALID, "hipMalloc (lazy tables)", __FILE__, __LINE__);
+    if (rc == 0) rc = alloc_tab(b_tab, &p->dev);
     if (rc != 0) { delete p; return rc; }
     p->dev_bytes = b_tab;
     memset(host, 0, b_tab);
@@ -1081,6 +1088,7 @@ void lazy_release()
     if (Q.rd_pin) { hipHostFree(Q.rd_pin); Q.rd_pin = nullptr; Q.rd_pin_n = 0; }
     Q.pending.store(false, std::memory_order_relaxed);
     if (Q.part) { hipFree(Q.part); Q.part = nullptr; Q.part_floats = 0; Q.generation += 1; }
+    if (Q.tab) { hipFree(Q.tab); Q.tab = nullptr; Q.tab_bytes = 0; Q.tab_used = 0; }
     for (int k = 0; k < 2; ++k) {
         if (Q.pin[k]) { hipHostFree(Q.pin[k]); Q.pin[k] = nullptr; Q.pin_bytes[k] = 0; }
         if (Q.pin_ev[k]) { hipEventDestroy(Q.pin_ev[k]); Q.pin_ev[k] = nullptr; }
