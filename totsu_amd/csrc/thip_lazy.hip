@@ -204,30 +204,60 @@ __global__ __launch_bounds__(DBLK) void dot_k(const DotD *__restrict__ tab)
     if (threadIdx.x == 0) d.out[0] = (float)s;
 }
 
-// contributions of members k0, k0 + kstep, .. of a group to element c.  Partial sums (M_PART) are read four at a time:
-// the sum over the ~100 column-chunk partials of an N product is a latency chain, not a bandwidth problem
+// one member's contribution to element c (alpha applied)
+__device__ __forceinline__ double one_member(const FinMember &m, float al, int c)
+{
+    if (m.type == M_PART) {
+        // partial sums are read four at a time: the sum over the ~100 column-chunk partials of an N product is a
+        // latency chain, not a bandwidth problem
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        const float *p = m.src + c;
+        int t = 0;
+        for (; t + 4 <= m.count; t += 4) {
+            const float a0 = p[(size_t)t * m.stride], a1 = p[(size_t)(t + 1) * m.stride];
+            const float a2 = p[(size_t)(t + 2) * m.stride], a3 = p[(size_t)(t + 3) * m.stride];
+            s0 += (double)a0; s1 += (double)a1; s2 += (double)a2; s3 += (double)a3;
+        }
+        for (; t < m.count; ++t) s0 += (double)p[(size_t)t * m.stride];
+        return (double)al * ((s0 + s1) + (s2 + s3));
+    }
+    if (m.type == M_AXPY) return (double)(al * m.xs[0] * m.src[c]);
+    if (m.type == M_CONST) return (double)al;                     // SliceLike::set: y <- value
+    return (double)(al * m.src[c]);
+}
+
+// contributions of members k0, k0 + kstep, .. of a group to element c.  Eight members at a time: their descriptors
+// (wave-uniform: scalar loads), then their eight data loads, then the sums -- a group with 2000 members (the G_i^T x_i and
+// c_i x_i of ProbSOCPOpA::trans_op) is otherwise 2000 dependent descriptor -> data round trips per element.
 __device__ __forceinline__ double contributions(const FinGroup &g, const FinMember *__restrict__ mem,
                                                 const float *__restrict__ alphas, int c, int k0, int kstep)
 {
+    constexpr int U = 8;
     double acc = 0.0;
-    for (int k = k0; k < g.count; k += kstep) {
-        const FinMember m = mem[g.first + k];
-        const float al = alphas[g.first + k];
-        if (m.type == M_PART) {
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            const float *p = m.src + c;
-            int t = 0;
-            for (; t + 4 <= m.count; t += 4) {
-                const float a0 = p[(size_t)t * m.stride], a1 = p[(size_t)(t + 1) * m.stride];
-                const float a2 = p[(size_t)(t + 2) * m.stride], a3 = p[(size_t)(t + 3) * m.stride];
-                s0 += (double)a0; s1 += (double)a1; s2 += (double)a2; s3 += (double)a3;
-            }
-            for (; t < m.count; ++t) s0 += (double)p[(size_t)t * m.stride];
-            acc += (double)al * ((s0 + s1) + (s2 + s3));
-        } else if (m.type == M_AXPY) acc += (double)(al * m.xs[0] * m.src[c]);
-        else if (m.type == M_CONST) acc += (double)al;                    // SliceLike::set: y <- value
-        else acc += (double)(al * m.src[c]);
+    int k = k0;
+    for (; k + (U - 1) * kstep < g.count; k += U * kstep) {
+        FinMember m[U];
+        float al[U];
+        bool simple = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            m[u] = mem[g.first + k + u * kstep];
+            al[u] = alphas[g.first + k + u * kstep];
+            simple = simple && (m[u].type == M_ADDV || (m[u].type == M_PART && m[u].count == 1) || m[u].type == M_AXPY);
+        }
+        if (simple) {
+            float v[U], x0[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { v[u] = m[u].src[c]; x0[u] = m[u].type == M_AXPY ? m[u].xs[0] : 1.0f; }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                acc += m[u].type == M_PART ? (double)al[u] * (double)v[u] : (double)(al[u] * x0[u] * v[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += one_member(m[u], al[u], c);
+        }
     }
+    for (; k < g.count; k += kstep) acc += one_member(mem[g.first + k], alphas[g.first + k], c);
     return acc;
 }
 
