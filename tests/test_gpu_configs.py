@@ -259,3 +259,46 @@ def test_c3_first_328_cones_at_full_n_iterates_vs_oracle(T, schedule):
         assert np.allclose(fs.status().cri, tr[2:], rtol=5e-3, atol=1e-5), (it, fs.status().cri, tr)
     fs.destroy()
     inst.free()
+
+
+# ---- configs[1] at full size ----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("schedule", ["reference", "carried"])
+def test_c2_full_size_lp_iterates_vs_oracle(T, schedule):
+    """BASELINE configs[1]: the benchmark_lp construction at n = 10 000, m = 20 000 (A 0.8 GB f32 on the GPU, 1.6 GB f64 in
+    the oracle, the device's own entries widened): preconditioner, iterates after iterations 0, 1, 2, 9 and the criteria
+    against the f64 oracle -- the reference's six-GEMV sequence and the 2-pass carried schedule"""
+    import os
+    from totsu_amd import synth
+    inst = synth.LpInstance(10_000, seed=0)
+    n, m = inst.n, inst.m
+    a = inst.mat_a.to_host()[:m * n].astype(np.float64)
+    b, c = inst.vec_b_host.astype(np.float64), inst.vec_c_host.astype(np.float64)
+    iters = [0, 1, 2, 9]
+    k = O.num_threads()
+    O.set_num_threads(max(k, min(64, (os.cpu_count() or 8))))
+    try:
+        ro = O.solve_matop_cones(O.param(max_iter=12, eps_acc=1e-30), c, a, b, [O.CONE_RPOS], [m], snap_iters=iters, trace_cap=16)
+    finally:
+        O.set_num_threads(k)
+    del a
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    fs = T.FusedSolver(n, m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule)
+    t, s = fs.precond()
+    N = n + 2 * m + 1
+    assert np.allclose(t, ro.precond[:N], rtol=5e-5, atol=0), np.abs(t / ro.precond[:N] - 1).max()
+    assert np.allclose(s, ro.precond[N:], rtol=5e-5, atol=0), np.abs(s / ro.precond[N:] - 1).max()
+    done = 0
+    for q, it in enumerate(iters):
+        fs.run(it + 1 - done, poll_every=8)
+        done = it + 1
+        x, y = fs.iterate()
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        sx, sy = max(np.abs(rx).max(), 1e-6), max(np.abs(ry).max(), 1e-6)
+        assert np.abs(x - rx).max() <= 1e-4 * sx, (it, np.abs(x - rx).max() / sx)
+        assert np.abs(y - ry).max() <= 1e-4 * sy, (it, np.abs(y - ry).max() / sy)
+        tr = ro.trace[it]
+        assert np.allclose(fs.status().cri, tr[2:], rtol=5e-3, atol=1e-5), (it, fs.status().cri, tr)
+    fs.destroy()
+    inst.free()
