@@ -135,6 +135,14 @@ int thip_eig_decompose(size_t n, float *mat, int has_scale, float scale_diag, fl
                        float *work, size_t worklen, float *host_w);
 int thip_eig_rebuild(size_t n, float *mat, int has_scale, float scale_diag,
                      float *work, size_t worklen, const float *host_e, const uint8_t *host_keep);
+/* which engine served the last decomposition of order > 32 on this context (dsyevr / syevdx in the reference,
+ * f64lapack.rs:78-108, f32cuda.rs:253-263): *host_engine = 1 host QL + rotation replay, 2 = device multisection + twisted
+ * factorisation (certified), 3 = 2 failed its certificate and 1 took over; *host_polish = Newton-Schulz polish steps
+ * applied; host_cert[0] = ||Z Z^T - I||_F, host_cert[1] = largest relative residual of the tridiagonal stage */
+int thip_eig_engine_info(int *host_engine, int *host_polish, float *host_cert);
+/* test switch: 0 = the library's choice, 1 = the QL engine, 2 = the device engine with its certificate forced to fail
+ * (exercises the hand-over) */
+int thip_test_eig_force(int engine);
 
 /* Sparse operators: y = alpha * A x + beta * y, A in CSR (int64 row pointers, int32 column indices,
  * all on the device); abs_mode != 0 uses |A| and x = 1 (MatOp::absadd_*, matop.rs:98-117).  The transposed product

@@ -68,6 +68,8 @@ extern "C" {
                               work: *mut f32, worklen: usize, host_w: *mut f32) -> c_int;
     pub fn thip_eig_rebuild(n: usize, mat: *mut f32, has_scale: c_int, scale_diag: f32, work: *mut f32,
                             worklen: usize, host_e: *const f32, host_keep: *const u8) -> c_int;
+    pub fn thip_eig_engine_info(host_engine: *mut c_int, host_polish: *mut c_int, host_cert: *mut f32) -> c_int;
+    pub fn thip_test_eig_force(engine: c_int) -> c_int;
 
     pub fn thip_absadd_cols(n_row: usize, n_col: usize, mat: *const f32, tau: *mut f32) -> c_int;
     pub fn thip_absadd_rows(n_row: usize, n_col: usize, mat: *const f32, sigma: *mut f32) -> c_int;

@@ -85,6 +85,8 @@ PROTOTYPES = {
     "thip_map_eig": (_i, [_sz, _vp, _i, _f, _f, _vp, _sz, _i]),
     "thip_eig_decompose": (_i, [_sz, _vp, _i, _f, _f, _vp, _sz, fp]),
     "thip_eig_rebuild": (_i, [_sz, _vp, _i, _f, _vp, _sz, fp, C.POINTER(C.c_uint8)]),
+    "thip_eig_engine_info": (_i, [C.POINTER(_i), C.POINTER(_i), fp]),
+    "thip_test_eig_force": (_i, [_i]),
     "thip_norm_dev": (_i, [_sz, _vp, _vp]),
     "thip_dot_dev": (_i, [_sz, _vp, _vp, _vp]),
     "thip_abssum_dev": (_i, [_sz, _vp, _sz, _vp]),

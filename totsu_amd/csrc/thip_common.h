@@ -219,6 +219,14 @@ int eig_psd_project_small(hipStream_t st, size_t n, float *base, const int64_t *
                           ptrdiff_t rx_stride = 0);
 size_t psd_small_max();
 
+// thip_trieig.hip: eigenvalues (multisection) and eigenvectors (twisted factorisation) of a symmetric tridiagonal matrix
+// on the device, f64 inside; the caller certifies orthogonality / residuals (thip_eig.hip decompose_tridiag)
+size_t tri_eigen_scratch_floats(int n);
+int tri_eigen(hipStream_t st, int n, int ld, const float *d, const float *e, float *w32, float *V0, unsigned *cert_bits,
+              float *scr);
+int tri_orth_partials(hipStream_t st, int n, int ld, const float *P, float *part, int nblocks);
+int tri_map(hipStream_t st, int n, int ld, int map_kind, const float *w, float *e);
+
 // counter-based generator, identical integer function to oracle/totsu_oracle.c:oc_rng_hash
 __host__ __device__ __forceinline__ uint64_t rng_hash(uint64_t seed, uint64_t stream, uint64_t idx)
 {

@@ -1187,11 +1187,9 @@ int launch_rot(hipStream_t st, int n, int ld, float *Z, const float2 *rot, const
     return 0;
 }
 
-// M = Z diag(w) Z^T by Householder tridiagonalisation + QL; eigenvectors -> k.V (columns), eigenvalues -> k.w, and for
-// map_kind 0 / 1 the mapped values -> k.e.  SYNC (d and e visit the host).
-int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_scale, float scale, const Work &k, int map_kind)
+// Q^T M Q = T: d -> k.Y[0 .. ld), e -> k.Y[ld .. 2 ld), tau -> k.Y[2 ld .. 3 ld), reflectors -> k.S (below the diagonal)
+int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_scale, float scale, const Work &k)
 {
-    const int ni = (int)n, ld = (int)np_of(n);
     if (ni > TRI_MAXN) return fail(THIP_E_INVALID, "map_eig: order above 2048", __FILE__, __LINE__);
     const unsigned g = grid_for((size_t)ld * ld, BLK, 512);
     hipLaunchKernelGGL(unpack_k, dim3(g), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, k.G, (float *)nullptr, k.part,
@@ -1209,6 +1207,101 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
     }
     hipLaunchKernelGGL(tri_fin_k, dim3(1), dim3(64), 0, st, ni, ld, k.G, d, e);
     THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// which engine served the last decomposition of order > 32 (thip_eig_engine_info), and the test switch
+int   g_eig_force = 0;          // thip_test_eig_force: 0 = default, 1 = the QL engine, 2 = the device engine with a failing certificate
+int   g_eig_engine = 0;         // 1 = host QL + rotation replay, 2 = multisection + twisted factorisation, 3 = 2 failed its certificate -> 1
+int   g_eig_polish = 0;
+float g_eig_orth = 0.0f, g_eig_resid = 0.0f;
+
+int eig_pin_floats(size_t want, float **out)
+{
+    Ctx &cx = ctx();
+    if (cx.eig_pin_floats < want) {
+        if (cx.eig_pin) THIP_TRY(hipHostFree(cx.eig_pin));
+        cx.eig_pin = nullptr; cx.eig_pin_floats = 0;
+        THIP_TRY(hipHostMalloc((void **)&cx.eig_pin, want * sizeof(float), hipHostMallocDefault));
+        cx.eig_pin_floats = want;
+    }
+    *out = cx.eig_pin;
+    return 0;
+}
+
+// The tridiagonal eigenproblem on the device (thip_trieig.hip), the back-transform Z = Q V0 and the certificate
+// ||Z Z^T - I||_F, max residual -- three products on the matrix cores (this engine's dense contractions).
+//   k.Z <- Q (form_q_k), k.G <- V0 (T's eigenvectors), k.V <- Q V0, k.G <- P = 3/2 I - 1/2 Z Z^T, [k.Z <- P Z -> k.V]
+// k.S (reflectors) and the head of k.Y (d, e, tau) stay intact, so a failed certificate can hand over to the QL engine.
+// SYNC: one read-back of the eigenvalues and the two certificate numbers per measurement.
+int decompose_device(hipStream_t st, size_t n, const Work &k, int map_kind, int *ok)
+{
+    static std::mutex eig_mu;
+    std::lock_guard<std::mutex> eig_lock(eig_mu);
+    *ok = 0;
+    const int ni = (int)n, ld = (int)np_of(n);
+    float *d = k.Y, *e = k.Y + ld, *tau = k.Y + 2 * (size_t)ld, *Vh = k.S;
+    hipLaunchKernelGGL(form_q_k, dim3((unsigned)((ld + 3) / 4)), dim3(BLK), 0, st, ni, ld, Vh, tau, k.Z);
+    float *scr = nullptr;
+    THIP_RC(scratch(tri_eigen_scratch_floats(ni), &scr));
+    unsigned *cert = reinterpret_cast<unsigned *>(k.sc + 4);
+    THIP_RC(tri_eigen(st, ni, ld, d, e, k.w, k.G, cert, scr));
+    if (map_kind >= 0) THIP_RC(tri_map(st, ni, ld, map_kind, k.w, k.e));
+    THIP_RC(gemm(st, true, ni, ld, 1.0f, k.Z, k.G, 0.0f, nullptr, 0.0f, k.V, nullptr));
+    const int nparts = 64;
+    const size_t back = 2 * (size_t)ld + 16 + nparts;          // k.w, k.e, k.sc, k.part are adjacent (carve)
+    float *pin = nullptr;
+    THIP_RC(eig_pin_floats(back, &pin));
+    const float thr = std::fmax(1.5e-7f * (float)ni, 1.0e-5f);
+    g_eig_polish = 0;
+    for (int round = 0;; ++round) {
+        THIP_RC(gemm(st, false, ni, ld, -0.5f, k.V, k.V, 0.0f, nullptr, 1.5f, k.G, nullptr));
+        THIP_RC(tri_orth_partials(st, ni, ld, k.G, k.part, nparts));
+        THIP_TRY(hipMemcpyAsync(pin, k.w, back * sizeof(float), hipMemcpyDeviceToHost, st));
+        THIP_TRY(hipStreamSynchronize(st));
+        double acc = 0.0;
+        for (int i = 0; i < nparts; ++i) acc += (double)pin[2 * (size_t)ld + 16 + i];
+        unsigned bits;
+        memcpy(&bits, pin + 2 * (size_t)ld + 4, sizeof(bits));
+        float resid;
+        memcpy(&resid, &bits, sizeof(resid));
+        const float orth = 2.0f * (float)std::sqrt(acc);
+        g_eig_orth = orth; g_eig_resid = resid;
+        if (g_eig_force == 2 || !(resid <= 1.0e-9f) || !(orth < 0.5f)) return 0;          // -> the QL engine
+        if (orth <= (round == 0 ? thr : 2.0f * thr)) break;
+        if (round == 3) return 0;
+        // Newton-Schulz polish: Z <- (3/2 I - 1/2 Z Z^T) Z, quadratic in ||Z Z^T - I||
+        THIP_RC(gemm(st, true, ni, ld, 1.0f, k.G, k.V, 0.0f, nullptr, 0.0f, k.Z, nullptr));
+        THIP_TRY(hipMemcpyAsync(k.V, k.Z, (size_t)ld * ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+        g_eig_polish = round + 1;
+    }
+    *ok = 1;
+    return 0;
+}
+
+int decompose_ql(hipStream_t st, size_t n, const Work &k, int map_kind);
+
+// M = Z diag(w) Z^T: Householder tridiagonalisation, then T's eigenproblem on the device (certified) or, failing that, by
+// QL on the host; eigenvectors -> k.V (columns), eigenvalues -> k.w, and for map_kind 0 / 1 the mapped values -> k.e.  SYNC.
+int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_scale, float scale, const Work &k, int map_kind)
+{
+    const int ni = (int)n, ld = (int)np_of(n);
+    THIP_RC(tridiagonalise(st, ni, ld, packed, has_scale, scale, k));
+    static const int env_ql = getenv("THIP_EIG_QL") ? atoi(getenv("THIP_EIG_QL")) : 0;
+    if (!env_ql && g_eig_force != 1) {
+        int ok = 0;
+        THIP_RC(decompose_device(st, n, k, map_kind, &ok));
+        g_eig_engine = ok ? 2 : 3;
+        if (ok) return 0;
+    } else g_eig_engine = 1;
+    return decompose_ql(st, n, k, map_kind);
+}
+
+// the QL engine (round 2): d, e visit the host, the rotations are replayed on Q.  SYNC.
+int decompose_ql(hipStream_t st, size_t n, const Work &k, int map_kind)
+{
+    const int ni = (int)n, ld = (int)np_of(n);
+    float *d = k.Y, *tau = k.Y + 2 * (size_t)ld, *Vh = k.S;
     std::vector<float> hde(2 * (size_t)ld);
     THIP_TRY(hipMemcpyAsync(hde.data(), d, 2 * (size_t)ld * sizeof(float), hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(form_q_k, dim3((unsigned)((ld + 3) / 4)), dim3(BLK), 0, st, ni, ld, Vh, tau, k.V);   // runs under the host QL
@@ -1227,14 +1320,9 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
     // replay, like the reference's one-thread-per-backend contract, linalg_ex.rs / cuda_mgr.rs thread_local state)
     static std::mutex eig_mu;
     std::lock_guard<std::mutex> eig_lock(eig_mu);
-    Ctx &cx = ctx();
-    if (cx.eig_pin_floats < 2 * per) {
-        if (cx.eig_pin) THIP_TRY(hipHostFree(cx.eig_pin));
-        cx.eig_pin = nullptr; cx.eig_pin_floats = 0;
-        THIP_TRY(hipHostMalloc((void **)&cx.eig_pin, 2 * per * sizeof(float), hipHostMallocDefault));
-        cx.eig_pin_floats = 2 * per;
-    }
-    float *const pin = cx.eig_pin;
+    float *pin_base = nullptr;
+    THIP_RC(eig_pin_floats(2 * per, &pin_base));
+    float *const pin = pin_base;
     hipEvent_t ev[2] = { nullptr, nullptr };
     int which = 0, rc = 0;
     std::vector<float2> rot;
@@ -1491,6 +1579,23 @@ int thip_eig_rebuild(size_t n, float *mat, int has_scale, float scale_diag, floa
     free(tmp);
     THIP_RC(rc);
     return rebuild(ctx().stream, n, mat, has_scale, scale_diag, k, nullptr);
+}
+
+int thip_eig_engine_info(int *host_engine, int *host_polish, float *host_cert)
+{
+    THIP_NEED_INIT_NOFLUSH();
+    if (host_engine) *host_engine = g_eig_engine;
+    if (host_polish) *host_polish = g_eig_polish;
+    if (host_cert) { host_cert[0] = g_eig_orth; host_cert[1] = g_eig_resid; }
+    return 0;
+}
+
+int thip_test_eig_force(int engine)
+{
+    THIP_NEED_INIT_NOFLUSH();
+    if (engine < 0 || engine > 2) return fail(THIP_E_INVALID, "thip_test_eig_force: 0, 1 or 2", __FILE__, __LINE__);
+    g_eig_force = engine;
+    return 0;
 }
 
 int thip_proj_psd(size_t sn, float *x, float eps_zero, float *work, size_t worklen)
