@@ -18,9 +18,9 @@ lib = _lib.load()
 
 def info():
     e, p = C.c_int(), C.c_int()
-    c = (C.c_float * 2)()
+    c = (C.c_float * 3)()
     lib.thip_eig_engine_info(C.byref(e), C.byref(p), c)
-    return e.value, p.value, c[0], c[1]
+    return e.value, p.value, c[0], c[1], c[2]
 
 
 def run(s, force, reps=3):
@@ -52,7 +52,7 @@ def run(s, force, reps=3):
             s32[r, c] = s32[c, r] = packed[c * (c + 1) // 2 + r]
     w = np.linalg.eigvalsh(s32)
     nrm = max(np.abs(w).max(), 1e-300)
-    return dict(engine=eng[0], polish=eng[1], orth=eng[2], resid=eng[3],
+    return dict(engine=eng[0], polish=eng[1], orth=eng[2], resid=eng[3], tri=eng[4],
                 eig_err=np.abs(np.sort(np.array(seen, dtype=np.float64)) - w).max() / nrm,
                 recon_err=np.abs(got.astype(np.float64) - packed).max() / nrm, ms=1e3 * min(ts))
 
@@ -62,8 +62,8 @@ if __name__ == "__main__":
     for k in ks:
         rng = np.random.default_rng(1)
         for name, a in cases(k, rng):
-            for force in (0, 1):
+            for force in (0, 4, 1):
                 r = run(a, force)
-                print("k=%-4d %-34s %s  engine=%d polish=%d orth=%.1e resid=%.1e eig=%.1e recon=%.1e  %.2f ms" % (
-                    k, name, "forced-QL" if force else "default  ", r["engine"], r["polish"], r["orth"], r["resid"],
+                print("k=%-4d %-34s %s  engine=%d tri=%d polish=%d orth=%.1e resid=%.1e eig=%.1e recon=%.1e  %.2f ms" % (
+                    k, name, {0: "default  ", 4: "persist  ", 1: "forced-QL"}[force], r["engine"], r["tri"], r["polish"], r["orth"], r["resid"],
                     r["eig_err"], r["recon_err"], r["ms"]), flush=True)

@@ -855,40 +855,72 @@ __global__ __launch_bounds__(BLK) void tri_upd_k(int n, int ld, int j, float *__
 // p_{j-1} and v_{j-1}) and the updated column j (-> d_j, the reflector v_j, tau_j, e_j): O(n) work per workgroup against
 // a launch boundary saved per step.  Column c's update is local to the workgroup that owns c, and p_j[c] = column c . v_j
 // by symmetry, so nothing crosses workgroups inside the launch.  Step 0 has no pending update (first != 0).
+// Round 3: everything a workgroup reads from global memory -- p_{j-1}, v_{j-1}, column j and the wave's own column -- is
+// requested at ENTRY, into registers (NQ = ceil(n / 256) resp. ceil(n / 64) values per thread); the kernel used to walk
+// three dependent L2 round trips (p and v -> w; column j -> v_j; own column -> p_j) and is one round trip plus three block
+// reductions now.
+template <int NQ>       // n <= 256 * NQ
 __global__ __launch_bounds__(BLK) void tri_step_k(int n, int ld, int j, int first, float *__restrict__ G, float *__restrict__ Vh,
                                                  const float *__restrict__ p_prev, float *__restrict__ p_out,
                                                  float *__restrict__ d, float *__restrict__ e, float *__restrict__ tau)
 {
-    __shared__ float vp[TRI_MAXN];      // v_{j-1}, indices j .. n-1  (local 0 .. Lp-1)
-    __shared__ float wp[TRI_MAXN];      // w_{j-1}
-    __shared__ float vsh[TRI_MAXN];     // v_j, indices j+1 .. n-1   (local 0 .. L-1)
+    __shared__ float vp[256 * NQ];      // v_{j-1}, indices j .. n-1  (local 0 .. Lp-1)
+    __shared__ float wp[256 * NQ];      // w_{j-1}
+    __shared__ float vsh[256 * NQ];     // v_j, indices j+1 .. n-1   (local 0 .. L-1)
     __shared__ float red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Lp = n - j, L = n - j - 1;
+    // ---- all global reads up front
+    const float *cj = G + (size_t)j * ld + j;
+    float r_v[NQ], r_p[NQ], r_x[NQ], r_a[4 * NQ];
     float tprev = 0.0f;
+    if (!first) tprev = tau[j - 1];
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) {
+        const int i = tid + BLK * m;
+        r_v[m] = (!first && i < Lp) ? Vh[(size_t)(j - 1) * ld + j + i] : 0.0f;
+        r_p[m] = (!first && i < Lp) ? p_prev[i] : 0.0f;
+        r_x[m] = i < Lp ? cj[i] : 0.0f;
+    }
+    const int c = blockIdx.x * 4 + wave;
+    float *col = G + (size_t)(j + 1 + c) * ld + j + 1;
+    if (c < L) {
+#pragma unroll
+        for (int m = 0; m < 4 * NQ; ++m) {
+            const int r = lane + 64 * m;
+            r_a[m] = r < L ? col[r] : 0.0f;
+        }
+    }
+    // ---- w_{j-1}
     if (!first) {
-        tprev = tau[j - 1];
         float acc = 0.0f;
-        for (int i = tid; i < Lp; i += BLK) {
-            const float vi = Vh[(size_t)(j - 1) * ld + j + i], pi = p_prev[i];
-            vp[i] = vi; wp[i] = pi;
-            acc = fmaf(pi, vi, acc);
+#pragma unroll
+        for (int m = 0; m < NQ; ++m) {
+            const int i = tid + BLK * m;
+            if (i < Lp) { vp[i] = r_v[m]; wp[i] = r_p[m]; acc = fmaf(r_p[m], r_v[m], acc); }
         }
         acc = block_sum(acc, red);
         const float kk = -0.5f * tprev * acc;
-        for (int i = tid; i < Lp; i += BLK) wp[i] = fmaf(kk, vp[i], wp[i]);
+#pragma unroll
+        for (int m = 0; m < NQ; ++m) {
+            const int i = tid + BLK * m;
+            if (i < Lp) wp[i] = fmaf(kk, r_v[m], r_p[m]);
+        }
         __syncthreads();
     }
     const bool upd = !first && tprev != 0.0f;
     // column j after the pending update (local row r <-> global row j + r); x = its rows below the diagonal
-    const float *cj = G + (size_t)j * ld + j;
     const float w0 = upd ? wp[0] : 0.0f, v0 = upd ? vp[0] : 0.0f;
     float ss = 0.0f;
-    for (int i = tid; i < Lp; i += BLK) {
-        float x = cj[i];
-        if (upd) x -= vp[i] * w0 + wp[i] * v0;
-        if (i >= 1) { vsh[i - 1] = x; if (i >= 2) ss = fmaf(x, x, ss); }
-        else if (blockIdx.x == 0) d[j] = x;
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) {
+        const int i = tid + BLK * m;
+        if (i < Lp) {
+            float x = r_x[m];
+            if (upd) x -= vp[i] * w0 + wp[i] * v0;
+            if (i >= 1) { vsh[i - 1] = x; if (i >= 2) ss = fmaf(x, x, ss); }
+            else if (blockIdx.x == 0) d[j] = x;
+        }
     }
     ss = block_sum(ss, red);
     __syncthreads();
@@ -908,18 +940,208 @@ __global__ __launch_bounds__(BLK) void tri_step_k(int n, int ld, int j, int firs
         if (tid == 0) { e[j] = beta; tau[j] = t; }
     }
     // own columns: one wave per column c (trailing block of step j: global column j + 1 + c)
-    const int c = blockIdx.x * 4 + wave;
     if (c < L) {
-        float *col = G + (size_t)(j + 1 + c) * ld + j + 1;
         const float wc = upd ? wp[c + 1] : 0.0f, vc = upd ? vp[c + 1] : 0.0f;
         float sacc = 0.0f;
-        for (int r = lane; r < L; r += 64) {
-            float a = col[r];
-            if (upd) { a -= vp[r + 1] * wc + wp[r + 1] * vc; col[r] = a; }
-            sacc = fmaf(a, vsh[r], sacc);
+#pragma unroll
+        for (int m = 0; m < 4 * NQ; ++m) {
+            const int r = lane + 64 * m;
+            if (r < L) {
+                float a = r_a[m];
+                if (upd) { a -= vp[r + 1] * wc + wp[r + 1] * vc; col[r] = a; }
+                sacc = fmaf(a, vsh[r], sacc);
+            }
         }
         sacc = wave_sum(sacc);
         if (lane == 0) p_out[c] = t * sacc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same reduction as ONE persistent launch (round 3).  A launch per reflector costs 4.6 us at k = 500 (the kernel is
+// three dependent L2 round trips and three block reductions; 2.3 ms for 498 of them).  Here W workgroups keep the columns
+// they own (column c belongs to workgroup c mod W) in LDS for the whole reduction, and the only thing that crosses
+// workgroups per reflector is ONE all-gather: the entries of p_j = tau_j A v_j a workgroup formed from its columns, and
+// column j + 1 from its owner -- "stale" by the rank-2 update of step j, which every workgroup applies to its copy itself
+// (it has v_j and forms w_j like everybody else), exactly as tri_step_k does.  Transport: 8-byte {value, tag} granules
+// written with one write-through (sc1) store each and polled with sc1 loads (MI355X_MICROARCH.md, "allgather" row of the
+// price list); tag = step + 1, two buffers alternate by step parity (a workgroup can be at most one step ahead of the
+// slowest: to publish step j + 1 it must have gathered all of step j).  Every spin is bounded: a workgroup that gives up
+// raises *errflag and leaves, the others follow, and the host redoes the reduction with one launch per reflector.
+// ---------------------------------------------------------------------------------------------------
+constexpr int TP_THREADS = 256;
+constexpr int TP_SPIN_MAX = 300000;
+
+__device__ __forceinline__ unsigned long long tp_pack(float v, unsigned tag)
+{
+    return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+// gathers rows [r0, n) of one or two granule arrays into LDS; false if a granule never arrived
+__device__ __forceinline__ bool tp_gather(const unsigned long long *__restrict__ g0, float *__restrict__ dst0,
+                                          const unsigned long long *__restrict__ g1, float *__restrict__ dst1, int r0, int n,
+                                          unsigned tag, unsigned *errflag)
+{
+    const int tid = threadIdx.x;
+    unsigned pend = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int r = r0 + tid + TP_THREADS * m;
+        if (r < n) pend |= (1u << m) | (g1 != nullptr ? (1u << (m + 8)) : 0u);
+    }
+    int spins = 0;
+    bool ok = true;
+    while (pend) {
+        unsigned long long v[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int r = r0 + tid + TP_THREADS * (m & 7);
+            if ((pend >> m) & 1u) v[m] = __hip_atomic_load((m < 8 ? g0 : g1) + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int r = r0 + tid + TP_THREADS * (m & 7);
+            if (((pend >> m) & 1u) && (unsigned)(v[m] >> 32) == tag) {
+                (m < 8 ? dst0 : dst1)[r] = __uint_as_float((unsigned)v[m]);
+                pend &= ~(1u << m);
+            }
+        }
+        if (pend) {
+            ++spins;
+            if (spins > TP_SPIN_MAX || ((spins & 1023) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W, int slots, float *__restrict__ G,
+                                                           float *__restrict__ Vh, float *__restrict__ d, float *__restrict__ e,
+                                                           float *__restrict__ tau, unsigned long long *__restrict__ gran,
+                                                           unsigned *__restrict__ errflag)
+{
+    extern __shared__ float tp_sh[];
+    float *cols = tp_sh;                                  // [slots][n]: column s * W + wg, all rows
+    float *va = cols + (size_t)slots * n, *vb = va + n;   // v_{j-1} and v_j (they swap), indexed by global row, zero above
+    float *wp = vb + n;                                   // w_{j-1}
+    float *ps = wp + n;                                   // p_{j-1} as gathered
+    float *xs = ps + n;                                   // column j
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    for (int sl = 0; sl < slots; ++sl) {
+        const int c = sl * W + wg;
+        if (c < n)
+            for (int r = tid; r < n; r += TP_THREADS) cols[(size_t)sl * n + r] = G[(size_t)c * ld + r];
+    }
+    for (int r = tid; r < n; r += TP_THREADS) { va[r] = 0.0f; vb[r] = 0.0f; wp[r] = 0.0f; xs[r] = G[r]; }
+    __syncthreads();
+    float *vprev = va, *vcur = vb;
+    float tprev = 0.0f;
+    for (int j = 0; j + 2 < n; ++j) {
+        const int par = j & 1;
+        const bool upd = j > 0 && tprev != 0.0f;
+        if (j > 0) {
+            // S1: p_{j-1} (rows >= j) and column j as its owner had it before the update of step j - 1
+            const unsigned long long *gp = gran + (size_t)(par ^ 1) * 2 * n, *gc = gp + n;
+            const bool ok = tp_gather(gp, ps, gc, xs, j, n, (unsigned)j, errflag);
+            if (__syncthreads_or(ok ? 0 : 1)) {
+                if (tid == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            // S2: w_{j-1} = p - (tau / 2)(p . v) v
+            float acc = 0.0f;
+            for (int r = j + tid; r < n; r += TP_THREADS) acc = fmaf(ps[r], vprev[r], acc);
+            acc = block_sum(acc, red);
+            const float kk = -0.5f * tprev * acc;
+            for (int r = j + tid; r < n; r += TP_THREADS) wp[r] = fmaf(kk, vprev[r], ps[r]);
+            __syncthreads();
+        }
+        // column j after the pending update; d_j, the reflector v_j, tau_j, e_j -- every workgroup for itself
+        const float wj = upd ? wp[j] : 0.0f, vj = upd ? vprev[j] : 0.0f;
+        float ss = 0.0f;
+        for (int r = j + tid; r < n; r += TP_THREADS) {
+            float x = xs[r];
+            if (upd) x -= vprev[r] * wj + wp[r] * vj;
+            xs[r] = x;
+            if (r >= j + 2) ss = fmaf(x, x, ss);
+        }
+        ss = block_sum(ss, red);            // (its barriers also publish xs)
+        __syncthreads();
+        const float alpha = xs[j + 1];
+        const float xnorm = sqrtf(ss);
+        float t = 0.0f, beta = alpha, scale = 0.0f;
+        if (xnorm != 0.0f) {
+            beta = -copysignf(hypotf(alpha, xnorm), alpha);
+            t = (beta - alpha) / beta;
+            scale = 1.0f / (alpha - beta);
+        }
+        for (int r = tid; r < n; r += TP_THREADS) {
+            const float v = r <= j ? 0.0f : (r == j + 1 ? 1.0f : xs[r] * scale);
+            vcur[r] = v;
+            if (wg == 0 && r > j) Vh[(size_t)j * ld + r] = v;
+        }
+        if (wg == 0 && tid == 0) { d[j] = xs[j]; e[j] = beta; tau[j] = t; }
+        __syncthreads();
+        // S4: own columns c >= j + 1, rows >= j + 1: the update of step j - 1, then p_j[c] = tau_j column . v_j; one wave per column
+        unsigned long long *gp = gran + (size_t)par * 2 * n, *gc = gp + n;
+        const unsigned tag = (unsigned)(j + 1);
+        for (int sl = wave; sl < slots; sl += TP_THREADS / 64) {
+            const int c = sl * W + wg;
+            if (c < j + 1 || c >= n) continue;
+            float *col = cols + (size_t)sl * n;
+            const float wc = upd ? wp[c] : 0.0f, vc = upd ? vprev[c] : 0.0f;
+            const bool next = c == j + 1;
+            float acc = 0.0f;
+            for (int r0 = j + 1; r0 < n; r0 += 256) {
+                float a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + lane + 64 * u;
+                    a[u] = r < n ? col[r] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + lane + 64 * u;
+                    if (r < n) {
+                        if (upd) { a[u] -= vprev[r] * wc + wp[r] * vc; col[r] = a[u]; }
+                        acc = fmaf(a[u], vcur[r], acc);
+                        if (next) __hip_atomic_store(gc + r, tp_pack(a[u], tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) __hip_atomic_store(gp + c, tp_pack(t * acc, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float *sw = vprev; vprev = vcur; vcur = sw;
+        tprev = t;
+    }
+    // the update of the last reflector on the 2 x 2 tail (tri_fin_k reads it from G)
+    if (n >= 3) {
+        const int j = n - 2;
+        const unsigned long long *gp = gran + (size_t)((j & 1) ^ 1) * 2 * n;
+        const bool ok = tp_gather(gp, ps, nullptr, nullptr, j, n, (unsigned)j, errflag);
+        if (__syncthreads_or(ok ? 0 : 1)) {
+            if (tid == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            const float acc = ps[j] * vprev[j] + ps[j + 1] * vprev[j + 1];
+            const float kk = -0.5f * tprev * acc;
+            wp[j] = fmaf(kk, vprev[j], ps[j]);
+            wp[j + 1] = fmaf(kk, vprev[j + 1], ps[j + 1]);
+        }
+        __syncthreads();
+        if (tid < 4) {
+            const int c = j + (tid >> 1), r = j + (tid & 1);
+            if (c % W == wg) {
+                float a = cols[(size_t)(c / W) * n + r];
+                if (tprev != 0.0f) a -= vprev[r] * wp[c] + wp[r] * vprev[c];
+                G[(size_t)c * ld + r] = a;
+            }
+        }
     }
 }
 
@@ -934,30 +1156,93 @@ __global__ void tri_fin_k(int n, int ld, const float *__restrict__ G, float *__r
     e[n - 1] = 0.0f;
 }
 
-// Z(:, c) = H_0 H_1 .. H_{n-3} e_c, one wave per column (zero padded to ld x ld)
+// Z(:, c) = H_0 H_1 .. H_{n-3} e_c, one wave per column (zero padded to ld x ld), four columns per workgroup.
+// A column is a chain of n - 2 reflector applications (a dot product across the wave, then an update).  Round 2 kept the
+// column in LDS and fetched each reflector from global memory when its turn came: every link of the chain was a string of
+// dependent LDS / L2 round trips (1.1 us per reflector, 0.53 ms at n = 500).  Now the column lives in REGISTERS (lane l
+// holds rows l, l + 64, ..: NQ values), the workgroup streams the reflectors through LDS FQ_G at a time, stored at their
+// global row positions with zeros above (so that the register file and the LDS slot are indexed alike and every read
+// of a link is issued at once), and the next group's loads are in flight while the current group is applied.
+constexpr int FQ_G = 8;              // reflectors per group
+template <int NQ>                    // rows per lane: n <= 64 NQ
 __global__ __launch_bounds__(BLK) void form_q_k(int n, int ld, const float *__restrict__ Vh, const float *__restrict__ tau,
                                                float *__restrict__ Z)
 {
-    __shared__ float qs[4][TRI_MAXN];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NR = 64 * NQ;                 // slot length
+    constexpr int PT = FQ_G * NR / BLK;         // staged elements per thread per group
+    __shared__ float ring[2][FQ_G][NR];
+    __shared__ float taus[NR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x * 4 + wave;
-    if (c >= ld) return;
-    float *q = qs[wave];
-    for (int r = lane; r < n; r += 64) q[r] = (r == c) ? 1.0f : 0.0f;
-    if (c < n) {
-        for (int j = n - 3; j >= 0; --j) {
-            const int L = n - j - 1;
-            if (j + 1 + L <= c) continue;            // never true; kept for clarity
-            const float t = tau[j];
-            if (t == 0.0f) continue;
-            const float *v = Vh + (size_t)j * ld + j + 1;
-            float sacc = 0.0f;
-            for (int r = lane; r < L; r += 64) sacc = fmaf(v[r], q[j + 1 + r], sacc);
-            sacc = wave_sum(sacc) * t;
-            for (int r = lane; r < L; r += 64) q[j + 1 + r] = fmaf(-sacc, v[r], q[j + 1 + r]);
+    float q[NQ];
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) q[m] = (lane + 64 * m == c) ? 1.0f : 0.0f;
+    for (int i = tid; i < NR; i += BLK) taus[i] = i + 2 < n ? tau[i] : 0.0f;
+    const int nref = n - 2;                                    // reflectors j = nref - 1 .. 0; slot u of group g: j = jtop - u
+    const int ngroups = nref > 0 ? (nref + FQ_G - 1) / FQ_G : 0;
+    float nxt[PT];
+    auto fetch = [&](int g) {
+        const int jtop = nref - 1 - g * FQ_G;
+#pragma unroll
+        for (int w = 0; w < PT; ++w) {
+            const int e = tid + w * BLK, u = e / NR, row = e % NR, j = jtop - u;
+            nxt[w] = (j >= 0 && row > j && row < n) ? Vh[(size_t)j * ld + row] : 0.0f;
+        }
+    };
+    auto land = [&](int half) {
+#pragma unroll
+        for (int w = 0; w < PT; ++w) {
+            const int e = tid + w * BLK;
+            (&ring[half][0][0])[e] = nxt[w];
+        }
+    };
+    if (ngroups > 0) { fetch(0); land(0); }
+    __syncthreads();
+    for (int g = 0; g < ngroups; ++g) {
+        const int half = g & 1;
+        const int jtop = nref - 1 - g * FQ_G;
+        const bool more = g + 1 < ngroups;
+        if (more) fetch(g + 1);
+        if (c < n) {
+#pragma unroll
+            for (int u = 0; u < FQ_G; ++u) {
+                const int j = jtop - u;
+                if (j < 0) break;
+                const float t = taus[j];
+                if (t == 0.0f) continue;
+                const int m0 = (j + 1) / 64;                  // chunks below hold only zeros of this reflector
+                float v[NQ];
+#pragma unroll
+                for (int m = 0; m < NQ; ++m) v[m] = m >= m0 ? ring[half][u][lane + 64 * m] : 0.0f;
+                float sacc = 0.0f;
+#pragma unroll
+                for (int m = 0; m < NQ; ++m) sacc = fmaf(v[m], q[m], sacc);
+                sacc = wave_sum(sacc) * t;
+#pragma unroll
+                for (int m = 0; m < NQ; ++m) q[m] = fmaf(-sacc, v[m], q[m]);
+            }
+        }
+        if (more) land(half ^ 1);
+        __syncthreads();
+    }
+    if (c < ld) {
+#pragma unroll
+        for (int m = 0; m < NQ; ++m) {
+            const int r = lane + 64 * m;
+            if (r < ld) Z[(size_t)c * ld + r] = (r < n && c < n) ? q[m] : 0.0f;
         }
     }
-    for (int r = lane; r < ld; r += 64) Z[(size_t)c * ld + r] = (r < n && c < n) ? q[r] : 0.0f;
+}
+
+static int launch_form_q(hipStream_t st, int n, int ld, const float *Vh, const float *tau, float *Z)
+{
+    const dim3 g((unsigned)((ld + 3) / 4)), b(BLK);
+    if (n <= 256) hipLaunchKernelGGL(form_q_k<4>, g, b, 0, st, n, ld, Vh, tau, Z);
+    else if (n <= 512) hipLaunchKernelGGL(form_q_k<8>, g, b, 0, st, n, ld, Vh, tau, Z);
+    else if (n <= 1024) hipLaunchKernelGGL(form_q_k<16>, g, b, 0, st, n, ld, Vh, tau, Z);
+    else hipLaunchKernelGGL(form_q_k<32>, g, b, 0, st, n, ld, Vh, tau, Z);
+    THIP_LAUNCH_CHECK();
+    return 0;
 }
 
 struct RotSweep { int start, count, off, pad; };     // rotations on columns (i, i + 1), i = start, start - 1, ..
@@ -1188,22 +1473,47 @@ int launch_rot(hipStream_t st, int n, int ld, float *Z, const float2 *rot, const
 }
 
 // Q^T M Q = T: d -> k.Y[0 .. ld), e -> k.Y[ld .. 2 ld), tau -> k.Y[2 ld .. 3 ld), reflectors -> k.S (below the diagonal)
-int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_scale, float scale, const Work &k)
+int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_scale, float scale, const Work &k,
+                   bool persist)
 {
     if (ni > TRI_MAXN) return fail(THIP_E_INVALID, "map_eig: order above 2048", __FILE__, __LINE__);
     const unsigned g = grid_for((size_t)ld * ld, BLK, 512);
     hipLaunchKernelGGL(unpack_k, dim3(g), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, k.G, (float *)nullptr, k.part,
                        (const int *)nullptr);
     float *d = k.Y, *e = k.Y + ld, *tau = k.Y + 2 * (size_t)ld, *p = k.Y + 3 * (size_t)ld, *Vh = k.S;
-    float *pbuf[2] = { p, p + ld };            // p_{j-1} is read while p_j is written
-    for (int j = 0; j + 2 < ni; ++j) {
-        const unsigned blocks = (unsigned)((ni - j - 1 + 3) / 4);
-        hipLaunchKernelGGL(tri_step_k, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, j == 0 ? 1 : 0, k.G, Vh, pbuf[(j + 1) & 1],
-                           pbuf[j & 1], d, e, tau);
-    }
-    if (ni >= 3) {              // the last reflector's update of the 2 x 2 tail is still pending
-        const int j = ni - 3;
-        hipLaunchKernelGGL(tri_upd_k, dim3((unsigned)((ni - j - 1 + 3) / 4)), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, pbuf[j & 1], tau);
+    unsigned *errflag = reinterpret_cast<unsigned *>(k.sc + 6);
+    if (persist) {
+        // k.Z is free until the eigenvector stage: 4 n granules of 8 bytes, zeroed (tag 0 is never waited for)
+        const int slots = ni <= 1536 ? 16 : 12, W = (ni + slots - 1) / slots;
+        unsigned long long *gran = reinterpret_cast<unsigned long long *>(k.Z);
+        THIP_TRY(hipMemsetAsync(gran, 0, 4 * (size_t)ni * sizeof(unsigned long long), st));
+        THIP_TRY(hipMemsetAsync(errflag, 0, sizeof(unsigned), st));
+        const size_t lds = ((size_t)slots + 5) * ni * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&tri_persist_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         140 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(tri_persist_k, dim3((unsigned)W), dim3(TP_THREADS), lds, st, ni, ld, W, slots, k.G, Vh, d, e, tau,
+                           gran, errflag);
+    } else {
+        float *pbuf[2] = { p, p + ld };            // p_{j-1} is read while p_j is written
+        for (int j = 0; j + 2 < ni; ++j) {
+            const unsigned blocks = (unsigned)((ni - j - 1 + 3) / 4);
+#define THIP_TRI_STEP(NQ) hipLaunchKernelGGL(tri_step_k<NQ>, dim3(blocks), dim3(BLK), 0, st, ni, ld, j, j == 0 ? 1 : 0, k.G, Vh, \
+                                             pbuf[(j + 1) & 1], pbuf[j & 1], d, e, tau)
+            const int Lp = ni - j;             // the kernel is instantiated by the length that is left, not by n
+            if (Lp <= 256) THIP_TRI_STEP(1);
+            else if (Lp <= 512) THIP_TRI_STEP(2);
+            else if (Lp <= 1024) THIP_TRI_STEP(4);
+            else THIP_TRI_STEP(8);
+#undef THIP_TRI_STEP
+        }
+        if (ni >= 3) {              // the last reflector's update of the 2 x 2 tail is still pending
+            const int j = ni - 3;
+            hipLaunchKernelGGL(tri_upd_k, dim3((unsigned)((ni - j - 1 + 3) / 4)), dim3(BLK), 0, st, ni, ld, j, k.G, Vh, pbuf[j & 1], tau);
+        }
     }
     hipLaunchKernelGGL(tri_fin_k, dim3(1), dim3(64), 0, st, ni, ld, k.G, d, e);
     THIP_LAUNCH_CHECK();
@@ -1214,6 +1524,8 @@ int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_
 int   g_eig_force = 0;          // thip_test_eig_force: 0 = default, 1 = the QL engine, 2 = the device engine with a failing certificate
 int   g_eig_engine = 0;         // 1 = host QL + rotation replay, 2 = multisection + twisted factorisation, 3 = 2 failed its certificate -> 1
 int   g_eig_polish = 0;
+int   g_tri_force = 0;          // thip_test_eig_force bit 2 (value 4): the persistent reduction instead of one launch per reflector
+int   g_tri_persist = 0;        // how the last reduction ran: 1 = persistent launch, 0 = one launch per reflector, -1 = persistent gave up -> 0
 float g_eig_orth = 0.0f, g_eig_resid = 0.0f;
 
 int eig_pin_floats(size_t want, float **out)
@@ -1234,14 +1546,14 @@ int eig_pin_floats(size_t want, float **out)
 //   k.Z <- Q (form_q_k), k.G <- V0 (T's eigenvectors), k.V <- Q V0, k.G <- P = 3/2 I - 1/2 Z Z^T, [k.Z <- P Z -> k.V]
 // k.S (reflectors) and the head of k.Y (d, e, tau) stay intact, so a failed certificate can hand over to the QL engine.
 // SYNC: one read-back of the eigenvalues and the two certificate numbers per measurement.
-int decompose_device(hipStream_t st, size_t n, const Work &k, int map_kind, int *ok)
+int decompose_device(hipStream_t st, size_t n, const Work &k, int map_kind, int *ok, int *tri_failed)
 {
     static std::mutex eig_mu;
     std::lock_guard<std::mutex> eig_lock(eig_mu);
     *ok = 0;
     const int ni = (int)n, ld = (int)np_of(n);
     float *d = k.Y, *e = k.Y + ld, *tau = k.Y + 2 * (size_t)ld, *Vh = k.S;
-    hipLaunchKernelGGL(form_q_k, dim3((unsigned)((ld + 3) / 4)), dim3(BLK), 0, st, ni, ld, Vh, tau, k.Z);
+    THIP_RC(launch_form_q(st, ni, ld, Vh, tau, k.Z));
     float *scr = nullptr;
     THIP_RC(scratch(tri_eigen_scratch_floats(ni), &scr));
     unsigned *cert = reinterpret_cast<unsigned *>(k.sc + 4);
@@ -1267,6 +1579,11 @@ int decompose_device(hipStream_t st, size_t n, const Work &k, int map_kind, int 
         memcpy(&resid, &bits, sizeof(resid));
         const float orth = 2.0f * (float)std::sqrt(acc);
         g_eig_orth = orth; g_eig_resid = resid;
+        if (tri_failed != nullptr && round == 0) {
+            unsigned fl;
+            memcpy(&fl, pin + 2 * (size_t)ld + 6, sizeof(fl));
+            if (fl != 0u) { *tri_failed = 1; return 0; }
+        }
         if (g_eig_force == 2 || !(resid <= 1.0e-9f) || !(orth < 0.5f)) return 0;          // -> the QL engine
         if (orth <= (round == 0 ? thr : 2.0f * thr)) break;
         if (round == 3) return 0;
@@ -1286,15 +1603,30 @@ int decompose_ql(hipStream_t st, size_t n, const Work &k, int map_kind);
 int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_scale, float scale, const Work &k, int map_kind)
 {
     const int ni = (int)n, ld = (int)np_of(n);
-    THIP_RC(tridiagonalise(st, ni, ld, packed, has_scale, scale, k));
     static const int env_ql = getenv("THIP_EIG_QL") ? atoi(getenv("THIP_EIG_QL")) : 0;
-    if (!env_ql && g_eig_force != 1) {
-        int ok = 0;
-        THIP_RC(decompose_device(st, n, k, map_kind, &ok));
-        g_eig_engine = ok ? 2 : 3;
-        if (ok) return 0;
-    } else g_eig_engine = 1;
-    return decompose_ql(st, n, k, map_kind);
+    static const int env_persist = getenv("THIP_TRI_PERSIST") ? atoi(getenv("THIP_TRI_PERSIST")) : 0;       // measured slower than the launches
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool persist = (env_persist != 0 || g_tri_force == 1) && attempt == 0;
+        g_tri_persist = persist ? 1 : 0;
+        THIP_RC(tridiagonalise(st, ni, ld, packed, has_scale, scale, k, persist));
+        int tri_failed = 0;
+        if (!env_ql && g_eig_force != 1) {
+            int ok = 0;
+            THIP_RC(decompose_device(st, n, k, map_kind, &ok, persist ? &tri_failed : nullptr));
+            g_eig_engine = ok ? 2 : 3;
+            if (ok) return 0;
+        } else {
+            g_eig_engine = 1;
+            if (persist) {
+                float f = 0.0f;
+                THIP_RC(fetch_scalar(k.sc + 6, &f));
+                tri_failed = f != 0.0f;
+            }
+        }
+        if (tri_failed) { g_tri_persist = -1; continue; }           // the persistent launch gave up: one launch per reflector
+        return decompose_ql(st, n, k, map_kind);
+    }
+    return fail(THIP_E_NOCONV, "map_eig: tridiagonalisation failed twice", __FILE__, __LINE__);
 }
 
 // the QL engine (round 2): d, e visit the host, the rotations are replayed on Q.  SYNC.
@@ -1304,8 +1636,7 @@ int decompose_ql(hipStream_t st, size_t n, const Work &k, int map_kind)
     float *d = k.Y, *tau = k.Y + 2 * (size_t)ld, *Vh = k.S;
     std::vector<float> hde(2 * (size_t)ld);
     THIP_TRY(hipMemcpyAsync(hde.data(), d, 2 * (size_t)ld * sizeof(float), hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(form_q_k, dim3((unsigned)((ld + 3) / 4)), dim3(BLK), 0, st, ni, ld, Vh, tau, k.V);   // runs under the host QL
-    THIP_LAUNCH_CHECK();
+    THIP_RC(launch_form_q(st, ni, ld, Vh, tau, k.V));      // runs under the host QL
     THIP_TRY(hipStreamSynchronize(st));
     std::vector<double> dd(ni), ee(ni, 0.0);
     for (int i = 0; i < ni; ++i) { dd[i] = hde[i]; if (i + 1 < ni) ee[i] = hde[ld + i]; }
@@ -1586,15 +1917,16 @@ int thip_eig_engine_info(int *host_engine, int *host_polish, float *host_cert)
     THIP_NEED_INIT_NOFLUSH();
     if (host_engine) *host_engine = g_eig_engine;
     if (host_polish) *host_polish = g_eig_polish;
-    if (host_cert) { host_cert[0] = g_eig_orth; host_cert[1] = g_eig_resid; }
+    if (host_cert) { host_cert[0] = g_eig_orth; host_cert[1] = g_eig_resid; host_cert[2] = (float)g_tri_persist; }
     return 0;
 }
 
 int thip_test_eig_force(int engine)
 {
     THIP_NEED_INIT_NOFLUSH();
-    if (engine < 0 || engine > 2) return fail(THIP_E_INVALID, "thip_test_eig_force: 0, 1 or 2", __FILE__, __LINE__);
-    g_eig_force = engine;
+    if (engine < 0 || (engine & 3) > 2 || engine > 6) return fail(THIP_E_INVALID, "thip_test_eig_force: 0, 1 or 2, + 4", __FILE__, __LINE__);
+    g_eig_force = engine & 3;
+    g_tri_force = (engine & 4) ? 1 : 0;
     return 0;
 }
 

@@ -35,6 +35,17 @@ __device__ __forceinline__ double fix_pivot(double x, double piv)
     return x;
 }
 
+// 1 / x: v_rcp_f64 and two Newton steps.  The compiler's IEEE division is ~25 dependent instructions (scaling, fix-ups);
+// the recurrences below are latency chains of one reciprocal per row, and their arguments are normal numbers by
+// construction (|x| >= pivmin), so the plain form is enough -- 6 dependent instructions.
+__device__ __forceinline__ double rcp2(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
 // (d, e) f32 -> f64 copies with negligible couplings set to zero, the unreduced block [lo, hi) of every index, the
 // Gershgorin interval and norm of that block; head[0] = pivmin, head[1] = max |bound|, cert words zeroed.
 __global__ __launch_bounds__(1024) void te_prep_k(int n, const float *__restrict__ d32, const float *__restrict__ e32,
@@ -92,23 +103,58 @@ __global__ __launch_bounds__(1024) void te_prep_k(int n, const float *__restrict
         }
         __syncthreads();
     }
+    // Gershgorin bounds of every block: segmented min / max scans over [lo, i], read back at the block's last row.
+    // (d, e) go out to global memory first; the scans then run in the LDS arrays that held them.
+    double *smin = sd, *smax = se;
+    {
+        double vmin[2], vmax[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 1024;
+            if (i < n) {
+                const double r = (i > 0 ? fabs(se[i - 1]) : 0.0) + fabs(se[i]);      // a cut coupling is 0
+                vmin[u] = sd[i] - r;
+                vmax[u] = sd[i] + r;
+                dd[i] = sd[i];
+                ee[i] = se[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 1024;
+            if (i < n) { smin[i] = vmin[u]; smax[i] = vmax[u]; }
+        }
+        __syncthreads();
+    }
+    for (int off = 1; off < n; off <<= 1) {
+        double a[2], b[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 1024;
+            if (i < n) {
+                a[u] = smin[i]; b[u] = smax[i];
+                if (i - off >= slo[i]) { a[u] = fmin(a[u], smin[i - off]); b[u] = fmax(b[u], smax[i - off]); }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 1024;
+            if (i < n) { smin[i] = a[u]; smax[i] = b[u]; }
+        }
+        __syncthreads();
+    }
     double tmax = 0.0;
     for (int i = tid; i < n; i += 1024) {
         const int lo = slo[i], hi = shi[i];
-        double gl = DBL_MAX, gu = -DBL_MAX;
-        for (int j = lo; j < hi; ++j) {
-            const double r = (j > lo ? fabs(se[j - 1]) : 0.0) + fabs(se[j]);
-            gl = fmin(gl, sd[j] - r);
-            gu = fmax(gu, sd[j] + r);
-        }
+        const double gl = smin[hi - 1], gu = smax[hi - 1];
         const double tn = fmax(fabs(gl), fabs(gu));
         const double margin = 2.1 * tn * TE_EPS * (double)(hi - lo) + 2.1 * pivmin;
         blk[i] = make_int2(lo, hi);
         bnd[3 * (size_t)i + 0] = gl - margin;
         bnd[3 * (size_t)i + 1] = gu + margin;
         bnd[3 * (size_t)i + 2] = tn;
-        dd[i] = sd[i];
-        ee[i] = se[i];
         tmax = fmax(tmax, tn);
     }
     {
@@ -131,15 +177,15 @@ __global__ __launch_bounds__(256) void te_bisect_k(int n, const double *__restri
                                                    float *__restrict__ w32)
 {
     extern __shared__ double te_sh[];
-    double *sd = te_sh, *s2 = te_sh + n;
-    for (int i = threadIdx.x; i < n; i += 256) { sd[i] = dd[i]; const double e = ee[i]; s2[i] = e * e; }
+    double2 *sde = reinterpret_cast<double2 *>(te_sh);            // (d_i, e_{i-1}^2): one 16-byte LDS read per row
+    for (int i = threadIdx.x; i < n; i += 256) { const double e = i > 0 ? ee[i - 1] : 0.0; sde[i] = make_double2(dd[i], e * e); }
     __syncthreads();
     const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= n) return;
     const int2 b = blk[t];
     const int k = t - b.x;
     double l;
-    if (b.y - b.x == 1) l = sd[b.x];
+    if (b.y - b.x == 1) l = sde[b.x].x;
     else {
         const double pivmin = head[0];
         double lo = bnd[3 * (size_t)t], hi = bnd[3 * (size_t)t + 1];
@@ -147,11 +193,13 @@ __global__ __launch_bounds__(256) void te_bisect_k(int n, const double *__restri
             const double w = hi - lo;
             if (w <= 2.0 * TE_EPS * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) break;
             const double sig = lo + w * ((double)(lane + 1) * (1.0 / 65.0));
-            double q = sd[b.x] - sig;
+            double q = sde[b.x].x - sig;
             if (fabs(q) < pivmin) q = -pivmin;
             int cnt = q < 0.0 ? 1 : 0;
+#pragma unroll 4
             for (int i = b.x + 1; i < b.y; ++i) {
-                q = (sd[i] - sig) - s2[i - 1] / q;
+                const double2 de = sde[i];
+                q = fma(-de.y, rcp2(q), de.x - sig);
                 if (fabs(q) < pivmin) q = -pivmin;
                 cnt += q < 0.0 ? 1 : 0;
             }
@@ -167,22 +215,29 @@ __global__ __launch_bounds__(256) void te_bisect_k(int n, const double *__restri
     if (lane == 0) { lam[t] = l; w32[t] = (float)l; }
 }
 
-// one lane per eigenvector.  Dp and Um are n x n doubles, element (row i, vector t) at [i * n + t] (coalesced across
-// the lanes); on return column t of Dp holds the unnormalised vector on rows [lo, hi) of its block (nothing elsewhere),
-// nrm[t] its 2-norm; cert_bits[0] = max over t of |gamma_r| / (||z|| ||T||) as float bits.
-__global__ __launch_bounds__(64) void te_vec_k(int n, const double *__restrict__ dd, const double *__restrict__ ee,
-                                               const int2 *__restrict__ blk, const double *__restrict__ bnd,
-                                               const double *__restrict__ head, const double *__restrict__ lam,
-                                               double *__restrict__ Dp, double *__restrict__ Um, double *__restrict__ nrm,
-                                               unsigned *__restrict__ cert_bits)
+// 64 eigenvectors per workgroup, one LANE per eigenvector in each of two waves: wave 0 runs the forward pivots D+ and the
+// part of z above the twist, wave 1 the backward pivots D- and the part below -- the four recurrences of the twisted
+// factorisation are two pairs of independent chains.  Dp and Dm are n x n doubles, element (row i, vector t) at
+// [i * n + t] (coalesced across the lanes).  On return column t of Dp holds the unnormalised vector on rows [lo, r],
+// column t of Dm on rows (r, hi); twist[t] = r, nrm[t] = its 2-norm; cert_bits[0] = max over t of
+// |gamma_r| / (||z|| ||T||) as float bits.  Loads run 8 rows ahead of the chains (the multipliers L+ = e / D+ and
+// U- = e / D- of the z chains are formed off-chain from them).
+__global__ __launch_bounds__(128) void te_vec_k(int n, const double *__restrict__ dd, const double *__restrict__ ee,
+                                                const int2 *__restrict__ blk, const double *__restrict__ bnd,
+                                                const double *__restrict__ head, const double *__restrict__ lam,
+                                                double *__restrict__ Dp, double *__restrict__ Dm, double *__restrict__ nrm,
+                                                int *__restrict__ twist, unsigned *__restrict__ cert_bits)
 {
     extern __shared__ double te_sh[];
     double *sd = te_sh, *se = te_sh + n;
-    const int lane = threadIdx.x;
-    for (int i = lane; i < n; i += 64) { sd[i] = dd[i]; se[i] = ee[i]; }
+    __shared__ double xbest[2][64], xg[2][64], xss[64];
+    __shared__ int xr[2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < n; i += 128) { sd[i] = dd[i]; se[i] = ee[i]; }
     __syncthreads();
     const int t = blockIdx.x * 64 + lane;
     const bool act = t < n;
+    const int tt = act ? t : n - 1;                  // address of an inactive lane's (discarded) loads
     int lo = n, hi = 0;
     double l = 0.0, piv = 1.0;
     if (act) {
@@ -194,54 +249,106 @@ __global__ __launch_bounds__(64) void te_vec_k(int n, const double *__restrict__
     int wlo = lo, whi = hi;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { wlo = min(wlo, __shfl_xor(wlo, o, 64)); whi = max(whi, __shfl_xor(whi, o, 64)); }
-    // forward pivots D+
-    double D = 0.0, mult = 0.0;
-    for (int i = wlo; i < whi; ++i) {
-        if (act && i >= lo && i < hi) {
-            D = (i == lo) ? sd[i] - l : (sd[i] - l) - mult * se[i - 1];
-            Dp[(size_t)i * n + t] = D;
-            mult = se[i] / fix_pivot(D, piv);
-        }
-    }
-    // backward pivots D-, multipliers U-, gamma and its smallest magnitude
-    double best = DBL_MAX, gbest = 0.0;
-    int r = lo;
-    for (int i = whi - 1; i >= wlo; --i) {
-        if (act && i >= lo && i < hi) {
-            const double a = sd[i] - l;
-            if (i == hi - 1) D = a;
-            else {
-                mult = se[i] / fix_pivot(D, piv);          // D = D-[i + 1]
-                Um[(size_t)i * n + t] = mult;
-                D = a - mult * se[i];
+    if (wave == 0) {
+        // D+[lo] = d - l; D+[i + 1] = (d[i + 1] - l) - e_i^2 / D+[i]
+        double D = 0.0;
+        for (int i = wlo; i < whi; ++i) {
+            if (act && i >= lo && i < hi) {
+                const double e = i > lo ? se[i - 1] : 0.0;
+                D = fma(-e * e, i > lo ? rcp2(fix_pivot(D, piv)) : 0.0, sd[i] - l);
+                Dp[(size_t)i * n + t] = D;
             }
-            const double g = Dp[(size_t)i * n + t] + D - a;
-            const double ag = fabs(g);
-            if (ag < best) { best = ag; gbest = g; r = i; }      // NaN never wins
+        }
+    } else {
+        // D-[hi - 1] = d - l; D-[i] = (d[i] - l) - e_i^2 / D-[i + 1]
+        double D = 0.0;
+        for (int i = whi - 1; i >= wlo; --i) {
+            if (act && i >= lo && i < hi) {
+                const double e = i < hi - 1 ? se[i] : 0.0;
+                D = fma(-e * e, i < hi - 1 ? rcp2(fix_pivot(D, piv)) : 0.0, sd[i] - l);
+                Dm[(size_t)i * n + t] = D;
+            }
         }
     }
-    // z: 1 at the twist, upwards through L+, downwards through U-
-    double z = 1.0, ss = 1.0;
-    if (act && hi > lo) Dp[(size_t)r * n + t] = 1.0;
-    for (int i = whi - 2; i >= wlo; --i) {
-        if (act && i >= lo && i < r) {
-            const double dpi = Dp[(size_t)i * n + t];
-            z = -(se[i] / fix_pivot(dpi, piv)) * z;
-            Dp[(size_t)i * n + t] = z;
-            ss = fma(z, z, ss);
+    __threadfence_block();
+    __syncthreads();
+    // gamma_i = D+[i] + D-[i] - (d_i - l): no chain; the waves take half of the rows each
+    {
+        double best = DBL_MAX, gbest = 0.0;
+        int r = lo;
+        const int mid = (wlo + whi) >> 1;
+        const int i_beg = wave == 0 ? wlo : mid, i_end = wave == 0 ? mid : whi;
+        for (int i0 = i_beg; i0 < i_end; i0 += 8) {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u, i_end - 1);
+                a[u] = __builtin_nontemporal_load(&Dp[(size_t)i * n + tt]);
+                b[u] = __builtin_nontemporal_load(&Dm[(size_t)i * n + tt]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u;
+                if (i < i_end && act && i >= lo && i < hi) {
+                    const double g = a[u] + b[u] - (sd[i] - l);
+                    const double ag = fabs(g);
+                    if (ag < best) { best = ag; gbest = g; r = i; }      // NaN never wins
+                }
+            }
         }
+        xbest[wave][lane] = best; xg[wave][lane] = gbest; xr[wave][lane] = r;
     }
-    z = 1.0;
-    for (int i = wlo; i < whi - 1; ++i) {
-        if (act && i >= r && i < hi - 1) {
-            z = -Um[(size_t)i * n + t] * z;
-            Dp[(size_t)(i + 1) * n + t] = z;
-            ss = fma(z, z, ss);
+    __syncthreads();
+    int r;
+    double gbest;
+    {
+        const bool first = xbest[0][lane] <= xbest[1][lane];
+        r = first ? xr[0][lane] : xr[1][lane];
+        gbest = first ? xg[0][lane] : xg[1][lane];
+    }
+    __syncthreads();
+    double z = 1.0, ss = 0.0;
+    if (wave == 0) {
+        // upwards: z_i = -(e_i / D+[i]) z_{i+1}, i = r - 1 .. lo; z_r = 1 is stored in Dp as well
+        ss = 1.0;
+        if (act && hi > lo) Dp[(size_t)r * n + t] = 1.0;
+        for (int i0 = whi - 2; i0 >= wlo; i0 -= 8) {
+            double dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dv[u] = __builtin_nontemporal_load(&Dp[(size_t)max(i0 - u, wlo) * n + tt]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 - u;
+                if (i >= wlo && act && i >= lo && i < r) {
+                    z = -(se[i] * rcp2(fix_pivot(dv[u], piv))) * z;
+                    Dp[(size_t)i * n + t] = z;
+                    ss = fma(z, z, ss);
+                }
+            }
         }
+    } else {
+        // downwards: z_{i+1} = -(e_i / D-[i + 1]) z_i, i = r .. hi - 2
+        for (int i0 = wlo; i0 < whi - 1; i0 += 8) {
+            double dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dv[u] = __builtin_nontemporal_load(&Dm[(size_t)min(i0 + u + 1, whi - 1) * n + tt]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u;
+                if (i < whi - 1 && act && i >= r && i < hi - 1) {
+                    z = -(se[i] * rcp2(fix_pivot(dv[u], piv))) * z;
+                    Dm[(size_t)(i + 1) * n + t] = z;
+                    ss = fma(z, z, ss);
+                }
+            }
+        }
+        xss[lane] = ss;
     }
-    if (act) {
-        const double nz = sqrt(ss);
+    __syncthreads();
+    if (wave == 0 && act) {
+        const double nz = sqrt(ss + xss[lane]);
         nrm[t] = nz;
+        twist[t] = r;
         const double tn = head[1];
         float res = tn > 0.0 ? (float)(fabs(gbest) / (nz * tn)) : 0.0f;
         if (!(res >= 0.0f) || !(nz > 0.0) || nz > DBL_MAX) res = __builtin_inff();          // NaN / overflow -> fails the certificate
@@ -251,7 +358,8 @@ __global__ __launch_bounds__(64) void te_vec_k(int n, const double *__restrict__
 
 // V0(i, t) = z_t[i] / ||z_t|| on the rows of t's block, 0 elsewhere; column-major ld x ld f32, zero padded.
 // 32 x 32 tiles through LDS: reads run along t, writes along i.
-__global__ __launch_bounds__(256) void te_pack_k(int n, int ld, const double *__restrict__ Dp, const double *__restrict__ nrm,
+__global__ __launch_bounds__(256) void te_pack_k(int n, int ld, const double *__restrict__ Dp, const double *__restrict__ Dm,
+                                                 const double *__restrict__ nrm, const int *__restrict__ twist,
                                                  const int2 *__restrict__ blk, float *__restrict__ V0)
 {
     __shared__ float tile[32][33];
@@ -261,12 +369,13 @@ __global__ __launch_bounds__(256) void te_pack_k(int n, int ld, const double *__
         const int t = t0 + tx;
         int2 b = make_int2(0, 0);
         double inv = 0.0;
-        if (t < n) { b = blk[t]; inv = 1.0 / nrm[t]; }
+        int r = 0;
+        if (t < n) { b = blk[t]; inv = 1.0 / nrm[t]; r = twist[t]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + ty + 8 * u;
             float v = 0.0f;
-            if (t < n && i >= b.x && i < b.y) v = (float)(Dp[(size_t)i * n + t] * inv);
+            if (t < n && i >= b.x && i < b.y) v = (float)((i <= r ? Dp : Dm)[(size_t)i * n + t] * inv);
             tile[ty + 8 * u][tx] = v;
         }
     }
@@ -311,8 +420,8 @@ __global__ void te_map_k(int n, int ld, int map_kind, const float *__restrict__ 
 
 size_t tri_eigen_scratch_floats(int n)
 {
-    // doubles: dd, ee, lam, nrm (n each), bnd (3 n), head (4), Dp and Um (n^2 each); int2 blk (n) = n doubles
-    return 2 * ((size_t)8 * n + 8 + 2 * (size_t)n * n) + 16;
+    // doubles: dd, ee, lam, nrm (n each), bnd (3 n), head (4), Dp and Dm (n^2 each); int2 blk (n) = n doubles; twist (n ints)
+    return 2 * ((size_t)9 * n + 8 + 2 * (size_t)n * n) + 16;
 }
 
 // T = (d, e) -> eigenvalues w32[0 .. n), eigenvectors as the columns of V0 (ld x ld, zero padded); cert_bits[0] receives the
@@ -324,13 +433,15 @@ int tri_eigen(hipStream_t st, int n, int ld, const float *d, const float *e, flo
     double *base = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(scr) + 15) & ~(uintptr_t)15);
     double *dd = base, *ee = dd + n, *lam = ee + n, *nrm = lam + n, *bnd = nrm + n, *head = bnd + 3 * (size_t)n;
     int2 *blk = reinterpret_cast<int2 *>(head + 4);
-    double *Dp = head + 4 + n, *Um = Dp + (size_t)n * n;
+    int *twist = reinterpret_cast<int *>(head + 4 + n);
+    double *Dp = head + 4 + 2 * (size_t)n, *Dm = Dp + (size_t)n * n;
     hipLaunchKernelGGL(te_prep_k, dim3(1), dim3(1024), 0, st, n, d, e, dd, ee, blk, bnd, head, cert_bits);
     const size_t lds = 2 * (size_t)n * sizeof(double);
     hipLaunchKernelGGL(te_bisect_k, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, st, n, dd, ee, blk, bnd, head, lam, w32);
-    hipLaunchKernelGGL(te_vec_k, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, n, dd, ee, blk, bnd, head, lam, Dp, Um,
-                       nrm, cert_bits);
-    hipLaunchKernelGGL(te_pack_k, dim3((unsigned)(ld / 32), (unsigned)(ld / 32)), dim3(256), 0, st, n, ld, Dp, nrm, blk, V0);
+    hipLaunchKernelGGL(te_vec_k, dim3((unsigned)((n + 63) / 64)), dim3(128), lds, st, n, dd, ee, blk, bnd, head, lam, Dp, Dm,
+                       nrm, twist, cert_bits);
+    hipLaunchKernelGGL(te_pack_k, dim3((unsigned)(ld / 32), (unsigned)(ld / 32)), dim3(256), 0, st, n, ld, Dp, Dm, nrm, twist,
+                       blk, V0);
     THIP_LAUNCH_CHECK();
     return 0;
 }
