@@ -139,12 +139,12 @@ int thip_eig_rebuild(size_t n, float *mat, int has_scale, float scale_diag,
  * f64lapack.rs:78-108, f32cuda.rs:253-263): *host_engine = 1 host QL + rotation replay, 2 = device multisection + twisted
  * factorisation (certified), 3 = 2 failed its certificate and 1 took over; *host_polish = Newton-Schulz polish steps
  * applied; host_cert[0] = ||Z Z^T - I||_F, host_cert[1] = largest relative residual of the tridiagonal stage,
- * host_cert[2] = how the Householder reduction ran: 1 one persistent launch, 0 one launch per reflector, -1 the
+ * host_cert[2] = how the Householder reduction ran: 1 / 2 one persistent launch (device / one XCD), 0 one launch per reflector, -1 the
  * persistent launch gave up (a bounded spin ran out) and the launches took over.  host_cert holds 3 floats. */
 int thip_eig_engine_info(int *host_engine, int *host_polish, float *host_cert);
 /* test switch: 0 = the library's choice, 1 = the QL engine, 2 = the device engine with its certificate forced to fail
- * (exercises the hand-over); + 4 = the Householder reduction as ONE persistent launch (granule all-gather per reflector;
- * measured slower than one launch per reflector, which is the default: DESIGN.md 4.5) */
+ * (exercises the hand-over); + 4 = the Householder reduction as ONE persistent launch over the whole device (granule
+ * all-gather per reflector over the fabric), + 8 = the same on the workgroups of one XCD (through its L2); DESIGN.md 4.5 */
 int thip_test_eig_force(int engine);
 
 /* Sparse operators: y = alpha * A x + beta * y, A in CSR (int64 row pointers, int32 column indices,

@@ -25,6 +25,8 @@ struct Ctx {
     int         *never_stop = nullptr;  // a device int that stays 0: the stop flag of launches outside a solver loop
     float       *eig_pin = nullptr;     // pinned staging of the QL rotation record (thip_eig.hip), grown on demand
     size_t       eig_pin_floats = 0;
+    hipStream_t  eig_side = nullptr;    // Q is formed here while the tridiagonal eigenproblem runs on `stream` (thip_eig.hip)
+    hipEvent_t   eig_ev[2] = { nullptr, nullptr };
 };
 
 // *host_out = *dev_src, in stream order (SYNC)
@@ -84,6 +86,22 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// the same sum through the DPP network (row shifts 1, 2, 4, 8, then row_bcast 15 and 31: six VALU operations instead of six
+// LDS-crossbar permutes), result read from lane 63 and broadcast.  The order of the additions differs from wave_sum's
+// butterfly, so a kernel uses one or the other throughout; this one is for the latency chains of the eigen engine.
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+#define THIP_DPP_ADD(ctrl, rows) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rows, 0xf, true))
+    THIP_DPP_ADD(0x111, 0xf);
+    THIP_DPP_ADD(0x112, 0xf);
+    THIP_DPP_ADD(0x114, 0xf);
+    THIP_DPP_ADD(0x118, 0xf);
+    THIP_DPP_ADD(0x142, 0xa);
+    THIP_DPP_ADD(0x143, 0xc);
+#undef THIP_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __device__ __forceinline__ double wave_sum_d(double v)
 {
 #pragma unroll
@@ -109,6 +127,17 @@ __device__ __forceinline__ float block_sum(float v, float *sh)
     float t = (lane < nw) ? sh[lane] : 0.0f;
     t = wave_sum(t);
     return t;
+}
+
+// block_sum on the DPP network (see wave_sum_dpp: another order of additions)
+__device__ __forceinline__ float block_sum_dpp(float v, float *sh)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum_dpp(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return wave_sum_dpp((lane < nw) ? sh[lane] : 0.0f);
 }
 
 __device__ __forceinline__ double block_sum_d(double v, double *sh)

@@ -117,6 +117,8 @@ int thip_shutdown(void)
     c.never_stop = nullptr;
     if (c.pinned) hipHostFree(c.pinned);
     if (c.eig_pin) hipHostFree(c.eig_pin);
+    for (int k = 0; k < 2; ++k) if (c.eig_ev[k]) hipEventDestroy(c.eig_ev[k]);
+    if (c.eig_side) hipStreamDestroy(c.eig_side);
     if (c.stage) hipHostFree(c.stage);
     for (int k = 0; k < 2; ++k) if (c.stage_ev[k]) hipEventDestroy(c.stage_ev[k]);
     if (c.own_stream) hipStreamDestroy(c.own_stream);

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(BLK) void tri_step_k(int n, int ld, int j, int firs
             const int i = tid + BLK * m;
             if (i < Lp) { vp[i] = r_v[m]; wp[i] = r_p[m]; acc = fmaf(r_p[m], r_v[m], acc); }
         }
-        acc = block_sum(acc, red);
+        acc = block_sum_dpp(acc, red);
         const float kk = -0.5f * tprev * acc;
 #pragma unroll
         for (int m = 0; m < NQ; ++m) {
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(BLK) void tri_step_k(int n, int ld, int j, int firs
             else if (blockIdx.x == 0) d[j] = x;
         }
     }
-    ss = block_sum(ss, red);
+    ss = block_sum_dpp(ss, red);
     __syncthreads();
     const float alpha = vsh[0];
     const float xnorm = sqrtf(ss);
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(BLK) void tri_step_k(int n, int ld, int j, int firs
                 sacc = fmaf(a, vsh[r], sacc);
             }
         }
-        sacc = wave_sum(sacc);
+        sacc = wave_sum_dpp(sacc);
         if (lane == 0) p_out[c] = t * sacc;
     }
 }
@@ -1018,19 +1018,39 @@ __device__ __forceinline__ bool tp_gather(const unsigned long long *__restrict__
     return ok;
 }
 
+// XCD_LOCAL: all W workgroups run on ONE XCD (the launch has 8 W + 64 of them; those that find HW_REG_XCC_ID == 0 draw a
+// ticket, the first W tickets are the roles, everybody else leaves at once), so that the granules are exchanged through the
+// L2 they share: plain 8-byte stores (the line stays in that L2) and sc1 loads (served by it), no trip over the fabric.
+template <bool XCD_LOCAL>
+__device__ __forceinline__ void tp_store(unsigned long long *p, unsigned long long v)
+{
+    if constexpr (XCD_LOCAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool XCD_LOCAL>
 __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W, int slots, float *__restrict__ G,
                                                            float *__restrict__ Vh, float *__restrict__ d, float *__restrict__ e,
                                                            float *__restrict__ tau, unsigned long long *__restrict__ gran,
-                                                           unsigned *__restrict__ errflag)
+                                                           unsigned *__restrict__ errflag, unsigned *__restrict__ ticket)
 {
     extern __shared__ float tp_sh[];
+    __shared__ int role;
+    if constexpr (XCD_LOCAL) {
+        if (threadIdx.x == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;        // HW_REG_XCC_ID, bits 3:0
+            role = xcc == 0u ? (int)atomicAdd(ticket, 1u) : -1;
+        }
+        __syncthreads();
+        if (role < 0 || role >= W) return;
+    }
     float *cols = tp_sh;                                  // [slots][n]: column s * W + wg, all rows
     float *va = cols + (size_t)slots * n, *vb = va + n;   // v_{j-1} and v_j (they swap), indexed by global row, zero above
     float *wp = vb + n;                                   // w_{j-1}
     float *ps = wp + n;                                   // p_{j-1} as gathered
     float *xs = ps + n;                                   // column j
     __shared__ float red[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = XCD_LOCAL ? role : (int)blockIdx.x;
     for (int sl = 0; sl < slots; ++sl) {
         const int c = sl * W + wg;
         if (c < n)
@@ -1054,7 +1074,7 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
             // S2: w_{j-1} = p - (tau / 2)(p . v) v
             float acc = 0.0f;
             for (int r = j + tid; r < n; r += TP_THREADS) acc = fmaf(ps[r], vprev[r], acc);
-            acc = block_sum(acc, red);
+            acc = block_sum_dpp(acc, red);
             const float kk = -0.5f * tprev * acc;
             for (int r = j + tid; r < n; r += TP_THREADS) wp[r] = fmaf(kk, vprev[r], ps[r]);
             __syncthreads();
@@ -1068,7 +1088,7 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
             xs[r] = x;
             if (r >= j + 2) ss = fmaf(x, x, ss);
         }
-        ss = block_sum(ss, red);            // (its barriers also publish xs)
+        ss = block_sum_dpp(ss, red);            // (its barriers also publish xs)
         __syncthreads();
         const float alpha = xs[j + 1];
         const float xnorm = sqrtf(ss);
@@ -1108,12 +1128,12 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
                     if (r < n) {
                         if (upd) { a[u] -= vprev[r] * wc + wp[r] * vc; col[r] = a[u]; }
                         acc = fmaf(a[u], vcur[r], acc);
-                        if (next) __hip_atomic_store(gc + r, tp_pack(a[u], tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (next) tp_store<XCD_LOCAL>(gc + r, tp_pack(a[u], tag));
                     }
                 }
             }
-            acc = wave_sum(acc);
-            if (lane == 0) __hip_atomic_store(gp + c, tp_pack(t * acc, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc = wave_sum_dpp(acc);
+            if (lane == 0) tp_store<XCD_LOCAL>(gp + c, tp_pack(t * acc, tag));
         }
         float *sw = vprev; vprev = vcur; vcur = sw;
         tprev = t;
@@ -1217,7 +1237,7 @@ __global__ __launch_bounds__(BLK) void form_q_k(int n, int ld, const float *__re
                 float sacc = 0.0f;
 #pragma unroll
                 for (int m = 0; m < NQ; ++m) sacc = fmaf(v[m], q[m], sacc);
-                sacc = wave_sum(sacc) * t;
+                sacc = wave_sum_dpp(sacc) * t;
 #pragma unroll
                 for (int m = 0; m < NQ; ++m) q[m] = fmaf(-sacc, v[m], q[m]);
             }
@@ -1474,7 +1494,7 @@ int launch_rot(hipStream_t st, int n, int ld, float *Z, const float2 *rot, const
 
 // Q^T M Q = T: d -> k.Y[0 .. ld), e -> k.Y[ld .. 2 ld), tau -> k.Y[2 ld .. 3 ld), reflectors -> k.S (below the diagonal)
 int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_scale, float scale, const Work &k,
-                   bool persist)
+                   int persist)         // 0: one launch per reflector, 1: persistent over the whole device, 2: persistent on one XCD
 {
     if (ni > TRI_MAXN) return fail(THIP_E_INVALID, "map_eig: order above 2048", __FILE__, __LINE__);
     const unsigned g = grid_for((size_t)ld * ld, BLK, 512);
@@ -1483,20 +1503,27 @@ int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_
     float *d = k.Y, *e = k.Y + ld, *tau = k.Y + 2 * (size_t)ld, *p = k.Y + 3 * (size_t)ld, *Vh = k.S;
     unsigned *errflag = reinterpret_cast<unsigned *>(k.sc + 6);
     if (persist) {
-        // k.Z is free until the eigenvector stage: 4 n granules of 8 bytes, zeroed (tag 0 is never waited for)
-        const int slots = ni <= 1536 ? 16 : 12, W = (ni + slots - 1) / slots;
+        // k.Z is free until the eigenvector stage: 4 n granules of 8 bytes, zeroed (tag 0 is never waited for), then the ticket
+        const bool local = persist == 2;
+        const int W = local ? std::min(32, (ni + 3) / 4) : (ni + (ni <= 1536 ? 16 : 12) - 1) / (ni <= 1536 ? 16 : 12);
+        const int slots = local ? (ni + W - 1) / W : (ni <= 1536 ? 16 : 12);
         unsigned long long *gran = reinterpret_cast<unsigned long long *>(k.Z);
-        THIP_TRY(hipMemsetAsync(gran, 0, 4 * (size_t)ni * sizeof(unsigned long long), st));
+        unsigned *ticket = reinterpret_cast<unsigned *>(gran + 4 * (size_t)ni);
+        THIP_TRY(hipMemsetAsync(gran, 0, (4 * (size_t)ni + 1) * sizeof(unsigned long long), st));
         THIP_TRY(hipMemsetAsync(errflag, 0, sizeof(unsigned), st));
         const size_t lds = ((size_t)slots + 5) * ni * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
-            THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&tri_persist_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+            THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&tri_persist_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          140 * 1024));
+            THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&tri_persist_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         156 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(tri_persist_k, dim3((unsigned)W), dim3(TP_THREADS), lds, st, ni, ld, W, slots, k.G, Vh, d, e, tau,
-                           gran, errflag);
+        if (local) hipLaunchKernelGGL(tri_persist_k<true>, dim3((unsigned)(8 * W + 64)), dim3(TP_THREADS), lds, st, ni, ld, W, slots,
+                                      k.G, Vh, d, e, tau, gran, errflag, ticket);
+        else hipLaunchKernelGGL(tri_persist_k<false>, dim3((unsigned)W), dim3(TP_THREADS), lds, st, ni, ld, W, slots, k.G, Vh, d, e,
+                                tau, gran, errflag, ticket);
     } else {
         float *pbuf[2] = { p, p + ld };            // p_{j-1} is read while p_j is written
         for (int j = 0; j + 2 < ni; ++j) {
@@ -1524,7 +1551,7 @@ int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_
 int   g_eig_force = 0;          // thip_test_eig_force: 0 = default, 1 = the QL engine, 2 = the device engine with a failing certificate
 int   g_eig_engine = 0;         // 1 = host QL + rotation replay, 2 = multisection + twisted factorisation, 3 = 2 failed its certificate -> 1
 int   g_eig_polish = 0;
-int   g_tri_force = 0;          // thip_test_eig_force bit 2 (value 4): the persistent reduction instead of one launch per reflector
+int   g_tri_force = 0;          // thip_test_eig_force bits 2-3: 1 (+ 4) the persistent reduction over the whole device, 2 (+ 8) on one XCD
 int   g_tri_persist = 0;        // how the last reduction ran: 1 = persistent launch, 0 = one launch per reflector, -1 = persistent gave up -> 0
 float g_eig_orth = 0.0f, g_eig_resid = 0.0f;
 
@@ -1553,12 +1580,26 @@ int decompose_device(hipStream_t st, size_t n, const Work &k, int map_kind, int 
     *ok = 0;
     const int ni = (int)n, ld = (int)np_of(n);
     float *d = k.Y, *e = k.Y + ld, *tau = k.Y + 2 * (size_t)ld, *Vh = k.S;
-    THIP_RC(launch_form_q(st, ni, ld, Vh, tau, k.Z));
+    // Q is formed on a side stream under the tridiagonal eigenproblem: both need only what the reduction left
+    Ctx &cx = ctx();
+    static const int side_on = getenv("THIP_EIG_SIDE") ? atoi(getenv("THIP_EIG_SIDE")) : 1;
+    const bool side = side_on != 0 && ni >= 128;
+    if (side) {
+        if (cx.eig_side == nullptr) {
+            THIP_TRY(hipStreamCreateWithFlags(&cx.eig_side, hipStreamNonBlocking));
+            for (int b = 0; b < 2; ++b) THIP_TRY(hipEventCreateWithFlags(&cx.eig_ev[b], hipEventDisableTiming));
+        }
+        THIP_TRY(hipEventRecord(cx.eig_ev[0], st));
+        THIP_TRY(hipStreamWaitEvent(cx.eig_side, cx.eig_ev[0], 0));
+        THIP_RC(launch_form_q(cx.eig_side, ni, ld, Vh, tau, k.Z));
+        THIP_TRY(hipEventRecord(cx.eig_ev[1], cx.eig_side));
+    } else THIP_RC(launch_form_q(st, ni, ld, Vh, tau, k.Z));
     float *scr = nullptr;
     THIP_RC(scratch(tri_eigen_scratch_floats(ni), &scr));
     unsigned *cert = reinterpret_cast<unsigned *>(k.sc + 4);
     THIP_RC(tri_eigen(st, ni, ld, d, e, k.w, k.G, cert, scr));
     if (map_kind >= 0) THIP_RC(tri_map(st, ni, ld, map_kind, k.w, k.e));
+    if (side) THIP_TRY(hipStreamWaitEvent(st, cx.eig_ev[1], 0));
     THIP_RC(gemm(st, true, ni, ld, 1.0f, k.Z, k.G, 0.0f, nullptr, 0.0f, k.V, nullptr));
     const int nparts = 64;
     const size_t back = 2 * (size_t)ld + 16 + nparts;          // k.w, k.e, k.sc, k.part are adjacent (carve)
@@ -1605,9 +1646,14 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
     const int ni = (int)n, ld = (int)np_of(n);
     static const int env_ql = getenv("THIP_EIG_QL") ? atoi(getenv("THIP_EIG_QL")) : 0;
     static const int env_persist = getenv("THIP_TRI_PERSIST") ? atoi(getenv("THIP_TRI_PERSIST")) : 0;       // measured slower than the launches
+    static int persist_broken = 0;              // a persistent launch gave up once: do not pay its time-out again
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const bool persist = (env_persist != 0 || g_tri_force == 1) && attempt == 0;
-        g_tri_persist = persist ? 1 : 0;
+        int persist = 0;
+        if (attempt == 0 && !persist_broken) {
+            persist = g_tri_force != 0 ? g_tri_force : env_persist;
+            if (persist == 2 && (ni > 1024 || (((size_t)(ni + 31) / 32) + 5) * ni * sizeof(float) > 150 * 1024)) persist = 0;
+        }
+        g_tri_persist = persist;
         THIP_RC(tridiagonalise(st, ni, ld, packed, has_scale, scale, k, persist));
         int tri_failed = 0;
         if (!env_ql && g_eig_force != 1) {
@@ -1623,7 +1669,7 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
                 tri_failed = f != 0.0f;
             }
         }
-        if (tri_failed) { g_tri_persist = -1; continue; }           // the persistent launch gave up: one launch per reflector
+        if (tri_failed) { g_tri_persist = -1; persist_broken = 1; continue; }           // the persistent launch gave up: one launch per reflector
         return decompose_ql(st, n, k, map_kind);
     }
     return fail(THIP_E_NOCONV, "map_eig: tridiagonalisation failed twice", __FILE__, __LINE__);
@@ -1924,9 +1970,9 @@ int thip_eig_engine_info(int *host_engine, int *host_polish, float *host_cert)
 int thip_test_eig_force(int engine)
 {
     THIP_NEED_INIT_NOFLUSH();
-    if (engine < 0 || (engine & 3) > 2 || engine > 6) return fail(THIP_E_INVALID, "thip_test_eig_force: 0, 1 or 2, + 4", __FILE__, __LINE__);
+    if (engine < 0 || (engine & 3) > 2 || engine > 10) return fail(THIP_E_INVALID, "thip_test_eig_force: 0, 1 or 2, + 4 or + 8", __FILE__, __LINE__);
     g_eig_force = engine & 3;
-    g_tri_force = (engine & 4) ? 1 : 0;
+    g_tri_force = (engine >> 2) & 3;
     return 0;
 }
 
