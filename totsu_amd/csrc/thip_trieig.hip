@@ -189,9 +189,12 @@ __global__ __launch_bounds__(256) void te_bisect_k(int n, const double *__restri
     else {
         const double pivmin = head[0];
         double lo = bnd[3 * (size_t)t], hi = bnd[3 * (size_t)t + 1];
-        for (int round = 0; round < 14; ++round) {
+        // absolute tolerance, relative to the block's norm (dstebz's default abstol = ulp ||T||): T itself is only known to
+        // eps ||T||, and a tolerance relative to |lambda| would spend four more rounds on every eigenvalue near zero
+        const double tol = TE_EPS * bnd[3 * (size_t)t + 2] + 2.0 * pivmin;
+        for (int round = 0; round < 12; ++round) {
             const double w = hi - lo;
-            if (w <= 2.0 * TE_EPS * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) break;
+            if (w <= tol) break;
             const double sig = lo + w * ((double)(lane + 1) * (1.0 / 65.0));
             double q = sde[b.x].x - sig;
             if (fabs(q) < pivmin) q = -pivmin;
@@ -215,12 +218,13 @@ __global__ __launch_bounds__(256) void te_bisect_k(int n, const double *__restri
     if (lane == 0) { lam[t] = l; w32[t] = (float)l; }
 }
 
+constexpr int TE_B = 24;          // rows fetched per batch by te_vec_k's unchained passes (one memory round trip per batch)
 // 64 eigenvectors per workgroup, one LANE per eigenvector in each of two waves: wave 0 runs the forward pivots D+ and the
 // part of z above the twist, wave 1 the backward pivots D- and the part below -- the four recurrences of the twisted
 // factorisation are two pairs of independent chains.  Dp and Dm are n x n doubles, element (row i, vector t) at
 // [i * n + t] (coalesced across the lanes).  On return column t of Dp holds the unnormalised vector on rows [lo, r],
 // column t of Dm on rows (r, hi); twist[t] = r, nrm[t] = its 2-norm; cert_bits[0] = max over t of
-// |gamma_r| / (||z|| ||T||) as float bits.  Loads run 8 rows ahead of the chains (the multipliers L+ = e / D+ and
+// |gamma_r| / (||z|| ||T||) as float bits.  Loads run TE_B rows ahead of the chains (the multipliers L+ = e / D+ and
 // U- = e / D- of the z chains are formed off-chain from them).
 __global__ __launch_bounds__(128) void te_vec_k(int n, const double *__restrict__ dd, const double *__restrict__ ee,
                                                 const int2 *__restrict__ blk, const double *__restrict__ bnd,
@@ -249,24 +253,48 @@ __global__ __launch_bounds__(128) void te_vec_k(int n, const double *__restrict_
     int wlo = lo, whi = hi;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { wlo = min(wlo, __shfl_xor(wlo, o, 64)); whi = max(whi, __shfl_xor(whi, o, 64)); }
+    // (the LDS operands of four rows are read ahead of the chain: a read inside the predicated body would add its latency
+    // to every link)
     if (wave == 0) {
         // D+[lo] = d - l; D+[i + 1] = (d[i + 1] - l) - e_i^2 / D+[i]
         double D = 0.0;
-        for (int i = wlo; i < whi; ++i) {
-            if (act && i >= lo && i < hi) {
-                const double e = i > lo ? se[i - 1] : 0.0;
-                D = fma(-e * e, i > lo ? rcp2(fix_pivot(D, piv)) : 0.0, sd[i] - l);
-                Dp[(size_t)i * n + t] = D;
+        for (int i0 = wlo; i0 < whi; i0 += 4) {
+            double dv[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u, whi - 1);
+                dv[u] = sd[i];
+                ev[u] = i > 0 ? se[i - 1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u;
+                if (i < whi && act && i >= lo && i < hi) {
+                    const double e2 = i > lo ? ev[u] * ev[u] : 0.0;
+                    D = fma(-e2, i > lo ? rcp2(fix_pivot(D, piv)) : 0.0, dv[u] - l);
+                    Dp[(size_t)i * n + t] = D;
+                }
             }
         }
     } else {
         // D-[hi - 1] = d - l; D-[i] = (d[i] - l) - e_i^2 / D-[i + 1]
         double D = 0.0;
-        for (int i = whi - 1; i >= wlo; --i) {
-            if (act && i >= lo && i < hi) {
-                const double e = i < hi - 1 ? se[i] : 0.0;
-                D = fma(-e * e, i < hi - 1 ? rcp2(fix_pivot(D, piv)) : 0.0, sd[i] - l);
-                Dm[(size_t)i * n + t] = D;
+        for (int i0 = whi - 1; i0 >= wlo; i0 -= 4) {
+            double dv[4], ev[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = max(i0 - u, wlo);
+                dv[u] = sd[i];
+                ev[u] = se[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 - u;
+                if (i >= wlo && act && i >= lo && i < hi) {
+                    const double e2 = i < hi - 1 ? ev[u] * ev[u] : 0.0;
+                    D = fma(-e2, i < hi - 1 ? rcp2(fix_pivot(D, piv)) : 0.0, dv[u] - l);
+                    Dm[(size_t)i * n + t] = D;
+                }
             }
         }
     }
@@ -278,19 +306,19 @@ __global__ __launch_bounds__(128) void te_vec_k(int n, const double *__restrict_
         int r = lo;
         const int mid = (wlo + whi) >> 1;
         const int i_beg = wave == 0 ? wlo : mid, i_end = wave == 0 ? mid : whi;
-        for (int i0 = i_beg; i0 < i_end; i0 += 8) {
-            double a[8], b[8];
+        for (int i0 = i_beg; i0 < i_end; i0 += TE_B) {
+            double a[TE_B], b[TE_B];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < TE_B; ++u) {
                 const int i = min(i0 + u, i_end - 1);
-                a[u] = __builtin_nontemporal_load(&Dp[(size_t)i * n + tt]);
+                a[u] = __builtin_nontemporal_load(&Dp[(size_t)i * n + tt]) - sd[i];
                 b[u] = __builtin_nontemporal_load(&Dm[(size_t)i * n + tt]);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < TE_B; ++u) {
                 const int i = i0 + u;
                 if (i < i_end && act && i >= lo && i < hi) {
-                    const double g = a[u] + b[u] - (sd[i] - l);
+                    const double g = a[u] + b[u] + l;
                     const double ag = fabs(g);
                     if (ag < best) { best = ag; gbest = g; r = i; }      // NaN never wins
                 }
@@ -312,15 +340,18 @@ __global__ __launch_bounds__(128) void te_vec_k(int n, const double *__restrict_
         // upwards: z_i = -(e_i / D+[i]) z_{i+1}, i = r - 1 .. lo; z_r = 1 is stored in Dp as well
         ss = 1.0;
         if (act && hi > lo) Dp[(size_t)r * n + t] = 1.0;
-        for (int i0 = whi - 2; i0 >= wlo; i0 -= 8) {
-            double dv[8];
+        for (int i0 = whi - 2; i0 >= wlo; i0 -= TE_B) {
+            double dv[TE_B];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dv[u] = __builtin_nontemporal_load(&Dp[(size_t)max(i0 - u, wlo) * n + tt]);
+            for (int u = 0; u < TE_B; ++u) {
+                const int i = max(i0 - u, wlo);
+                dv[u] = -(se[i] * rcp2(fix_pivot(__builtin_nontemporal_load(&Dp[(size_t)i * n + tt]), piv)));
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < TE_B; ++u) {
                 const int i = i0 - u;
                 if (i >= wlo && act && i >= lo && i < r) {
-                    z = -(se[i] * rcp2(fix_pivot(dv[u], piv))) * z;
+                    z = dv[u] * z;
                     Dp[(size_t)i * n + t] = z;
                     ss = fma(z, z, ss);
                 }
@@ -328,15 +359,18 @@ __global__ __launch_bounds__(128) void te_vec_k(int n, const double *__restrict_
         }
     } else {
         // downwards: z_{i+1} = -(e_i / D-[i + 1]) z_i, i = r .. hi - 2
-        for (int i0 = wlo; i0 < whi - 1; i0 += 8) {
-            double dv[8];
+        for (int i0 = wlo; i0 < whi - 1; i0 += TE_B) {
+            double dv[TE_B];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) dv[u] = __builtin_nontemporal_load(&Dm[(size_t)min(i0 + u + 1, whi - 1) * n + tt]);
+            for (int u = 0; u < TE_B; ++u) {
+                const int i = min(i0 + u, whi - 2);
+                dv[u] = -(se[i] * rcp2(fix_pivot(__builtin_nontemporal_load(&Dm[(size_t)(i + 1) * n + tt]), piv)));
+            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < TE_B; ++u) {
                 const int i = i0 + u;
                 if (i < whi - 1 && act && i >= r && i < hi - 1) {
-                    z = -(se[i] * rcp2(fix_pivot(dv[u], piv))) * z;
+                    z = dv[u] * z;
                     Dm[(size_t)(i + 1) * n + t] = z;
                     ss = fma(z, z, ss);
                 }
