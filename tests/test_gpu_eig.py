@@ -431,9 +431,11 @@ def test_persistent_householder_reduction_matches_the_launches(L, k, mode):
     rng = np.random.default_rng(k + mode)
     b = rng.standard_normal((k, k))
     s = (b + b.T) / 2
-    seen0, got0, packed, info0 = _closure_roundtrip(L, s, force=0)
+    seen0, got0, packed, info0 = _closure_roundtrip(L, s, force=12)          # one launch per reflector
     seen1, got1, _, info1 = _closure_roundtrip(L, s, force=mode)
     assert info0[4] == 0 and info1[4] == mode // 4, (info0, info1)
+    _, _, _, info2 = _closure_roundtrip(L, s)                                 # the library's choice: one XCD up to order 1024
+    assert info2[4] == 2, info2
     assert info1[0] == 2
     nrm = np.abs(seen0).max()
     assert np.abs(np.sort(seen0) - np.sort(seen1)).max() <= 2e-6 * nrm

@@ -62,8 +62,8 @@ if __name__ == "__main__":
     for k in ks:
         rng = np.random.default_rng(1)
         for name, a in cases(k, rng):
-            for force in (0, 4, 8, 1):
+            for force in (0, 12, 4, 8, 1):
                 r = run(a, force)
                 print("k=%-4d %-34s %s  engine=%d tri=%d polish=%d orth=%.1e resid=%.1e eig=%.1e recon=%.1e  %.2f ms" % (
-                    k, name, {0: "default  ", 4: "persist  ", 8: "persistX ", 1: "forced-QL"}[force], r["engine"], r["tri"], r["polish"], r["orth"], r["resid"],
+                    k, name, {0: "default  ", 12: "launches ", 4: "persist  ", 8: "persistX ", 1: "forced-QL"}[force], r["engine"], r["tri"], r["polish"], r["orth"], r["resid"],
                     r["eig_err"], r["recon_err"], r["ms"]), flush=True)

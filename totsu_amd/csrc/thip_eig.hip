@@ -969,8 +969,10 @@ __global__ __launch_bounds__(BLK) void tri_step_k(int n, int ld, int j, int firs
 // slowest: to publish step j + 1 it must have gathered all of step j).  Every spin is bounded: a workgroup that gives up
 // raises *errflag and leaves, the others follow, and the host redoes the reduction with one launch per reflector.
 // ---------------------------------------------------------------------------------------------------
-constexpr int TP_THREADS = 256;
+constexpr int TP_THREADS = 1024;     // 16 waves: one column per wave in the pass over the workgroup's columns (n <= 512)
 constexpr int TP_SPIN_MAX = 300000;
+constexpr unsigned TP_DONE = 0xD0E5u;             // *errflag after a completed persistent reduction
+constexpr int TP_GM = 2048 / TP_THREADS;          // granules of one array a thread may have to fetch (n <= 2048)
 
 __device__ __forceinline__ unsigned long long tp_pack(float v, unsigned tag)
 {
@@ -985,24 +987,24 @@ __device__ __forceinline__ bool tp_gather(const unsigned long long *__restrict__
     const int tid = threadIdx.x;
     unsigned pend = 0;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
+    for (int m = 0; m < TP_GM; ++m) {
         const int r = r0 + tid + TP_THREADS * m;
-        if (r < n) pend |= (1u << m) | (g1 != nullptr ? (1u << (m + 8)) : 0u);
+        if (r < n) pend |= (1u << m) | (g1 != nullptr ? (1u << (m + TP_GM)) : 0u);
     }
     int spins = 0;
     bool ok = true;
     while (pend) {
-        unsigned long long v[16];
+        unsigned long long v[2 * TP_GM];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int r = r0 + tid + TP_THREADS * (m & 7);
-            if ((pend >> m) & 1u) v[m] = __hip_atomic_load((m < 8 ? g0 : g1) + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int m = 0; m < 2 * TP_GM; ++m) {
+            const int r = r0 + tid + TP_THREADS * (m % TP_GM);
+            if ((pend >> m) & 1u) v[m] = __hip_atomic_load((m < TP_GM ? g0 : g1) + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int r = r0 + tid + TP_THREADS * (m & 7);
+        for (int m = 0; m < 2 * TP_GM; ++m) {
+            const int r = r0 + tid + TP_THREADS * (m % TP_GM);
             if (((pend >> m) & 1u) && (unsigned)(v[m] >> 32) == tag) {
-                (m < 8 ? dst0 : dst1)[r] = __uint_as_float((unsigned)v[m]);
+                (m < TP_GM ? dst0 : dst1)[r] = __uint_as_float((unsigned)v[m]);
                 pend &= ~(1u << m);
             }
         }
@@ -1047,50 +1049,119 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
     float *cols = tp_sh;                                  // [slots][n]: column s * W + wg, all rows
     float *va = cols + (size_t)slots * n, *vb = va + n;   // v_{j-1} and v_j (they swap), indexed by global row, zero above
     float *wp = vb + n;                                   // w_{j-1}
-    float *ps = wp + n;                                   // p_{j-1} as gathered
-    float *xs = ps + n;                                   // column j
-    __shared__ float red[16];
+    float *ps = wp + n;                                   // p_{n-3} as gathered for the 2 x 2 tail
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = XCD_LOCAL ? role : (int)blockIdx.x;
     for (int sl = 0; sl < slots; ++sl) {
         const int c = sl * W + wg;
         if (c < n)
             for (int r = tid; r < n; r += TP_THREADS) cols[(size_t)sl * n + r] = G[(size_t)c * ld + r];
     }
-    for (int r = tid; r < n; r += TP_THREADS) { va[r] = 0.0f; vb[r] = 0.0f; wp[r] = 0.0f; xs[r] = G[r]; }
+    for (int r = tid; r < n; r += TP_THREADS) { va[r] = 0.0f; vb[r] = 0.0f; wp[r] = 0.0f; }
     __syncthreads();
     float *vprev = va, *vcur = vb;
     float tprev = 0.0f;
+    // Between two exchanges a thread works on the rows r = tid + 1024 m it owns, in REGISTERS (what it gathered never
+    // visits LDS; only w and v_j do, for the pass over the columns), and a block sum costs ONE barrier: the waves' partial
+    // sums and the two broadcast values of a step (p_{j-1}[j] and x[j + 1]) go through a scratch that alternates between
+    // two copies, so the write of a sum can never overtake the reads of the sum before last.
+    __shared__ float rsh[2][2][20];
+    int phase = 0;
+    auto sum2 = [&](float &a, float &b2, float bc_val, bool bc_mine, float &bc_out) {
+        a = wave_sum_dpp(a); b2 = wave_sum_dpp(b2);
+        if (lane == 0) { rsh[phase][0][wave] = a; rsh[phase][1][wave] = b2; }
+        if (bc_mine) rsh[phase][0][16] = bc_val;
+        __syncthreads();
+        constexpr int nw = TP_THREADS / 64;
+        a = wave_sum_dpp(lane < nw ? rsh[phase][0][lane] : 0.0f);
+        b2 = wave_sum_dpp(lane < nw ? rsh[phase][1][lane] : 0.0f);
+        bc_out = rsh[phase][0][16];
+        phase ^= 1;
+    };
     for (int j = 0; j + 2 < n; ++j) {
         const int par = j & 1;
         const bool upd = j > 0 && tprev != 0.0f;
+        float pr[TP_GM], xr[TP_GM], vpr[TP_GM], wpr[TP_GM];
+        float failed = 0.0f;
         if (j > 0) {
             // S1: p_{j-1} (rows >= j) and column j as its owner had it before the update of step j - 1
             const unsigned long long *gp = gran + (size_t)(par ^ 1) * 2 * n, *gc = gp + n;
-            const bool ok = tp_gather(gp, ps, gc, xs, j, n, (unsigned)j, errflag);
-            if (__syncthreads_or(ok ? 0 : 1)) {
-                if (tid == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
+            unsigned pend = 0;
+#pragma unroll
+            for (int m = 0; m < TP_GM; ++m) {
+                const int r = tid + TP_THREADS * m;
+                pr[m] = 0.0f; xr[m] = 0.0f;
+                if (r >= j && r < n) pend |= (1u << m) | (1u << (m + TP_GM));
             }
-            // S2: w_{j-1} = p - (tau / 2)(p . v) v
-            float acc = 0.0f;
-            for (int r = j + tid; r < n; r += TP_THREADS) acc = fmaf(ps[r], vprev[r], acc);
-            acc = block_sum_dpp(acc, red);
-            const float kk = -0.5f * tprev * acc;
-            for (int r = j + tid; r < n; r += TP_THREADS) wp[r] = fmaf(kk, vprev[r], ps[r]);
-            __syncthreads();
+            int spins = 0;
+            while (pend) {
+                unsigned long long v[2 * TP_GM];
+#pragma unroll
+                for (int m = 0; m < 2 * TP_GM; ++m)
+                    if ((pend >> m) & 1u)
+                        v[m] = __hip_atomic_load((m < TP_GM ? gp : gc) + tid + TP_THREADS * (m % TP_GM), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int m = 0; m < 2 * TP_GM; ++m) {
+                    if (((pend >> m) & 1u) && (unsigned)(v[m] >> 32) == (unsigned)j) {
+                        const float val = __uint_as_float((unsigned)v[m]);
+                        if (m < TP_GM) pr[m] = val; else xr[m - TP_GM] = val;
+                        pend &= ~(1u << m);
+                    }
+                }
+                if (pend) {
+                    ++spins;
+                    if (spins > TP_SPIN_MAX || ((spins & 1023) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        failed = 1.0f;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < TP_GM; ++m) {
+                const int r = tid + TP_THREADS * m;
+                pr[m] = 0.0f;
+                xr[m] = r < n ? G[r] : 0.0f;
+            }
         }
-        // column j after the pending update; d_j, the reflector v_j, tau_j, e_j -- every workgroup for itself
-        const float wj = upd ? wp[j] : 0.0f, vj = upd ? vprev[j] : 0.0f;
-        float ss = 0.0f;
-        for (int r = j + tid; r < n; r += TP_THREADS) {
-            float x = xs[r];
-            if (upd) x -= vprev[r] * wj + wp[r] * vj;
-            xs[r] = x;
-            if (r >= j + 2) ss = fmaf(x, x, ss);
+        // w_{j-1} = p - (tau / 2)(p . v) v; the sum also carries the vote "somebody's granule never came"
+        float acc = 0.0f, pj = 0.0f;
+        bool mine = false;
+#pragma unroll
+        for (int m = 0; m < TP_GM; ++m) {
+            const int r = tid + TP_THREADS * m;
+            vpr[m] = (r >= j && r < n) ? vprev[r] : 0.0f;
+            acc = fmaf(pr[m], vpr[m], acc);
+            if (r == j) { mine = true; pj = pr[m]; }
         }
-        ss = block_sum_dpp(ss, red);            // (its barriers also publish xs)
-        __syncthreads();
-        const float alpha = xs[j + 1];
+        float pj_all;
+        sum2(acc, failed, pj, mine, pj_all);
+        if (failed != 0.0f) {
+            if (tid == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        const float kk = -0.5f * tprev * acc;
+        // column j after the pending update (v_{j-1}[j] = 1); d_j, the reflector v_j, tau_j, e_j -- every workgroup for itself
+        const float wj = upd ? fmaf(kk, 1.0f, pj_all) : 0.0f, vj = upd ? 1.0f : 0.0f;
+        float ss = 0.0f, zero = 0.0f, alpha_mine = 0.0f;
+        mine = false;
+#pragma unroll
+        for (int m = 0; m < TP_GM; ++m) {
+            const int r = tid + TP_THREADS * m;
+            wpr[m] = fmaf(kk, vpr[m], pr[m]);
+            if (r >= j && r < n) {
+                wp[r] = wpr[m];
+                float x = xr[m];
+                if (upd) x -= vpr[m] * wj + wpr[m] * vj;
+                xr[m] = x;
+                if (r >= j + 2) ss = fmaf(x, x, ss);
+                if (r == j + 1) { mine = true; alpha_mine = x; }
+                if (r == j && wg == 0) d[j] = x;
+            }
+        }
+        float alpha;
+        sum2(ss, zero, alpha_mine, mine, alpha);
         const float xnorm = sqrtf(ss);
         float t = 0.0f, beta = alpha, scale = 0.0f;
         if (xnorm != 0.0f) {
@@ -1098,12 +1169,16 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
             t = (beta - alpha) / beta;
             scale = 1.0f / (alpha - beta);
         }
-        for (int r = tid; r < n; r += TP_THREADS) {
-            const float v = r <= j ? 0.0f : (r == j + 1 ? 1.0f : xs[r] * scale);
-            vcur[r] = v;
-            if (wg == 0 && r > j) Vh[(size_t)j * ld + r] = v;
+#pragma unroll
+        for (int m = 0; m < TP_GM; ++m) {
+            const int r = tid + TP_THREADS * m;
+            if (r < n) {
+                const float v = r <= j ? 0.0f : (r == j + 1 ? 1.0f : xr[m] * scale);
+                vcur[r] = v;
+                if (wg == 0 && r > j) Vh[(size_t)j * ld + r] = v;
+            }
         }
-        if (wg == 0 && tid == 0) { d[j] = xs[j]; e[j] = beta; tau[j] = t; }
+        if (wg == 0 && tid == 0) { e[j] = beta; tau[j] = t; }
         __syncthreads();
         // S4: own columns c >= j + 1, rows >= j + 1: the update of step j - 1, then p_j[c] = tau_j column . v_j; one wave per column
         unsigned long long *gp = gran + (size_t)par * 2 * n, *gc = gp + n;
@@ -1163,6 +1238,9 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
             }
         }
     }
+    // workgroup 0 has gathered every p and written every d, e, tau and reflector: the positive "done" (a launch in which
+    // nobody took a role, or one that bailed, leaves 0 or 1 and the host redoes the reduction with launches)
+    if (wg == 0 && tid == 0) atomicCAS(errflag, 0u, TP_DONE);
 }
 
 // the 2 x 2 tail (and the whole of n <= 2)
@@ -1511,7 +1589,7 @@ int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_
         unsigned *ticket = reinterpret_cast<unsigned *>(gran + 4 * (size_t)ni);
         THIP_TRY(hipMemsetAsync(gran, 0, (4 * (size_t)ni + 1) * sizeof(unsigned long long), st));
         THIP_TRY(hipMemsetAsync(errflag, 0, sizeof(unsigned), st));
-        const size_t lds = ((size_t)slots + 5) * ni * sizeof(float);
+        const size_t lds = ((size_t)slots + 4) * ni * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
             THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&tri_persist_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1551,7 +1629,7 @@ int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_
 int   g_eig_force = 0;          // thip_test_eig_force: 0 = default, 1 = the QL engine, 2 = the device engine with a failing certificate
 int   g_eig_engine = 0;         // 1 = host QL + rotation replay, 2 = multisection + twisted factorisation, 3 = 2 failed its certificate -> 1
 int   g_eig_polish = 0;
-int   g_tri_force = 0;          // thip_test_eig_force bits 2-3: 1 (+ 4) the persistent reduction over the whole device, 2 (+ 8) on one XCD
+int   g_tri_force = 0;          // thip_test_eig_force bits 2-3: 1 (+ 4) the persistent reduction over the whole device, 2 (+ 8) on one XCD, 3 (+ 12) launches
 int   g_tri_persist = 0;        // how the last reduction ran: 1 = persistent launch, 0 = one launch per reflector, -1 = persistent gave up -> 0
 float g_eig_orth = 0.0f, g_eig_resid = 0.0f;
 
@@ -1623,7 +1701,7 @@ int decompose_device(hipStream_t st, size_t n, const Work &k, int map_kind, int 
         if (tri_failed != nullptr && round == 0) {
             unsigned fl;
             memcpy(&fl, pin + 2 * (size_t)ld + 6, sizeof(fl));
-            if (fl != 0u) { *tri_failed = 1; return 0; }
+            if (fl != TP_DONE) { *tri_failed = 1; return 0; }
         }
         if (g_eig_force == 2 || !(resid <= 1.0e-9f) || !(orth < 0.5f)) return 0;          // -> the QL engine
         if (orth <= (round == 0 ? thr : 2.0f * thr)) break;
@@ -1645,12 +1723,12 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
 {
     const int ni = (int)n, ld = (int)np_of(n);
     static const int env_ql = getenv("THIP_EIG_QL") ? atoi(getenv("THIP_EIG_QL")) : 0;
-    static const int env_persist = getenv("THIP_TRI_PERSIST") ? atoi(getenv("THIP_TRI_PERSIST")) : 0;       // measured slower than the launches
+    static const int env_persist = getenv("THIP_TRI_PERSIST") ? atoi(getenv("THIP_TRI_PERSIST")) : 2;       // 0 launches, 1 whole device, 2 one XCD (orders <= 1024)
     static int persist_broken = 0;              // a persistent launch gave up once: do not pay its time-out again
     for (int attempt = 0; attempt < 2; ++attempt) {
         int persist = 0;
         if (attempt == 0 && !persist_broken) {
-            persist = g_tri_force != 0 ? g_tri_force : env_persist;
+            persist = g_tri_force != 0 ? (g_tri_force == 3 ? 0 : g_tri_force) : env_persist;
             if (persist == 2 && (ni > 1024 || (((size_t)(ni + 31) / 32) + 5) * ni * sizeof(float) > 150 * 1024)) persist = 0;
         }
         g_tri_persist = persist;
@@ -1666,7 +1744,9 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
             if (persist) {
                 float f = 0.0f;
                 THIP_RC(fetch_scalar(k.sc + 6, &f));
-                tri_failed = f != 0.0f;
+                unsigned fl;
+                memcpy(&fl, &f, sizeof(fl));
+                tri_failed = fl != TP_DONE;
             }
         }
         if (tri_failed) { g_tri_persist = -1; persist_broken = 1; continue; }           // the persistent launch gave up: one launch per reflector
@@ -1970,7 +2050,7 @@ int thip_eig_engine_info(int *host_engine, int *host_polish, float *host_cert)
 int thip_test_eig_force(int engine)
 {
     THIP_NEED_INIT_NOFLUSH();
-    if (engine < 0 || (engine & 3) > 2 || engine > 10) return fail(THIP_E_INVALID, "thip_test_eig_force: 0, 1 or 2, + 4 or + 8", __FILE__, __LINE__);
+    if (engine < 0 || (engine & 3) > 2 || engine > 14) return fail(THIP_E_INVALID, "thip_test_eig_force: 0, 1 or 2, + 4, + 8 or + 12", __FILE__, __LINE__);
     g_eig_force = engine & 3;
     g_tri_force = (engine >> 2) & 3;
     return 0;
