@@ -1034,7 +1034,8 @@ template <bool XCD_LOCAL>
 __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W, int slots, float *__restrict__ G,
                                                            float *__restrict__ Vh, float *__restrict__ d, float *__restrict__ e,
                                                            float *__restrict__ tau, unsigned long long *__restrict__ gran,
-                                                           unsigned *__restrict__ errflag, unsigned *__restrict__ ticket)
+                                                           unsigned *__restrict__ errflag, unsigned *__restrict__ ticket,
+                                                           unsigned long long *__restrict__ stamps)
 {
     extern __shared__ float tp_sh[];
     __shared__ int role;
@@ -1077,6 +1078,12 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
         bc_out = rsh[phase][0][16];
         phase ^= 1;
     };
+#ifdef THIP_TP_PROFILE
+    unsigned long long tacc[5] = { 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memrealtime();
+#define TP_STAMP(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tacc[i] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define TP_STAMP(i) do { } while (0)
+#endif
     for (int j = 0; j + 2 < n; ++j) {
         const int par = j & 1;
         const bool upd = j > 0 && tprev != 0.0f;
@@ -1125,6 +1132,7 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
                 xr[m] = r < n ? G[r] : 0.0f;
             }
         }
+        TP_STAMP(0);
         // w_{j-1} = p - (tau / 2)(p . v) v; the sum also carries the vote "somebody's granule never came"
         float acc = 0.0f, pj = 0.0f;
         bool mine = false;
@@ -1137,6 +1145,7 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
         }
         float pj_all;
         sum2(acc, failed, pj, mine, pj_all);
+        TP_STAMP(1);
         if (failed != 0.0f) {
             if (tid == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
@@ -1162,6 +1171,7 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
         }
         float alpha;
         sum2(ss, zero, alpha_mine, mine, alpha);
+        TP_STAMP(2);
         const float xnorm = sqrtf(ss);
         float t = 0.0f, beta = alpha, scale = 0.0f;
         if (xnorm != 0.0f) {
@@ -1180,6 +1190,7 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
         }
         if (wg == 0 && tid == 0) { e[j] = beta; tau[j] = t; }
         __syncthreads();
+        TP_STAMP(3);
         // S4: own columns c >= j + 1, rows >= j + 1: the update of step j - 1, then p_j[c] = tau_j column . v_j; one wave per column
         unsigned long long *gp = gran + (size_t)par * 2 * n, *gc = gp + n;
         const unsigned tag = (unsigned)(j + 1);
@@ -1212,7 +1223,11 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
         }
         float *sw = vprev; vprev = vcur; vcur = sw;
         tprev = t;
+        TP_STAMP(4);
     }
+#ifdef THIP_TP_PROFILE
+    if (wg == 0 && tid == 0) for (int i = 0; i < 5; ++i) stamps[i] = tacc[i];
+#endif
     // the update of the last reflector on the 2 x 2 tail (tri_fin_k reads it from G)
     if (n >= 3) {
         const int j = n - 2;
@@ -1587,6 +1602,7 @@ int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_
         const int slots = local ? (ni + W - 1) / W : (ni <= 1536 ? 16 : 12);
         unsigned long long *gran = reinterpret_cast<unsigned long long *>(k.Z);
         unsigned *ticket = reinterpret_cast<unsigned *>(gran + 4 * (size_t)ni);
+        unsigned long long *stamps = reinterpret_cast<unsigned long long *>(k.part + 128);      // -DTHIP_TP_PROFILE: phase times of workgroup 0
         THIP_TRY(hipMemsetAsync(gran, 0, (4 * (size_t)ni + 1) * sizeof(unsigned long long), st));
         THIP_TRY(hipMemsetAsync(errflag, 0, sizeof(unsigned), st));
         const size_t lds = ((size_t)slots + 4) * ni * sizeof(float);
@@ -1599,9 +1615,9 @@ int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_
             attr_set = true;
         }
         if (local) hipLaunchKernelGGL(tri_persist_k<true>, dim3((unsigned)(8 * W + 64)), dim3(TP_THREADS), lds, st, ni, ld, W, slots,
-                                      k.G, Vh, d, e, tau, gran, errflag, ticket);
+                                      k.G, Vh, d, e, tau, gran, errflag, ticket, stamps);
         else hipLaunchKernelGGL(tri_persist_k<false>, dim3((unsigned)W), dim3(TP_THREADS), lds, st, ni, ld, W, slots, k.G, Vh, d, e,
-                                tau, gran, errflag, ticket);
+                                tau, gran, errflag, ticket, stamps);
     } else {
         float *pbuf[2] = { p, p + ld };            // p_{j-1} is read while p_j is written
         for (int j = 0; j + 2 < ni; ++j) {
