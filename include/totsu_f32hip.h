@@ -145,7 +145,9 @@ int thip_eig_engine_info(int *host_engine, int *host_polish, float *host_cert);
 /* test switch: 0 = the library's choice, 1 = the QL engine, 2 = the device engine with its certificate forced to fail
  * (exercises the hand-over); + 4 = the Householder reduction as ONE persistent launch over the whole device (granule
  * all-gather per reflector over the fabric), + 8 = the same on the workgroups of one XCD (through its L2: the default up
- * to order 1024), + 12 = one launch per reflector (the default above); DESIGN.md 4.5 */
+ * to order 1024), + 12 = one launch per reflector (the default above); + 16 = the one-XCD launch is started with a role
+ * missing, so that its bounded spins run out (the time-out path: the launches must take over).  Every call also forgets
+ * that a persistent launch ever gave up.  DESIGN.md 4.5 */
 int thip_test_eig_force(int engine);
 
 /* Sparse operators: y = alpha * A x + beta * y, A in CSR (int64 row pointers, int32 column indices,

@@ -440,3 +440,27 @@ def test_persistent_householder_reduction_matches_the_launches(L, k, mode):
     nrm = np.abs(seen0).max()
     assert np.abs(np.sort(seen0) - np.sort(seen1)).max() <= 2e-6 * nrm
     assert np.abs(got1.astype(np.float64) - packed).max() <= 4e-6 * nrm
+
+
+def test_persistent_reduction_that_times_out_is_redone_with_launches(L):
+    """the persistent Householder reduction is the default, so its failure path must work: started with a role missing
+    (test switch + 16) every workgroup runs into its spin bound (a fraction of a second, no hang), the flag is raised, the
+    host redoes the reduction with one launch per reflector (info -1) and stops using the persistent form until told
+    otherwise; the answer is the usual one"""
+    import time
+    from totsu_amd._lib import lib
+    k = 300
+    rng = np.random.default_rng(7)
+    b = rng.standard_normal((k, k))
+    s = (b + b.T) / 2
+    t0 = time.perf_counter()
+    seen, got, packed, info = _closure_roundtrip(L, s, force=8 + 16)
+    dt = time.perf_counter() - t0
+    assert info[4] == -1 and info[0] == 2, info
+    assert dt < 5.0, dt
+    w = np.linalg.eigvalsh(s.astype(np.float32).astype(np.float64))
+    assert np.abs(np.sort(seen) - w).max() <= 2e-6 * np.abs(w).max()
+    assert np.abs(got.astype(np.float64) - packed).max() <= 4e-6 * np.abs(w).max()
+    # (_closure_roundtrip reset the switch: the next call is served by the persistent form again)
+    _, _, _, info = _closure_roundtrip(L, s)
+    assert info[4] == 2, info

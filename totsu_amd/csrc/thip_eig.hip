@@ -1585,6 +1585,16 @@ int launch_rot(hipStream_t st, int n, int ld, float *Z, const float2 *rot, const
     return 0;
 }
 
+// which engine served the last decomposition of order > 32 (thip_eig_engine_info), and the test switch
+int   g_eig_force = 0;          // thip_test_eig_force: 0 = default, 1 = the QL engine, 2 = the device engine with a failing certificate
+int   g_eig_engine = 0;         // 1 = host QL + rotation replay, 2 = multisection + twisted factorisation, 3 = 2 failed its certificate -> 1
+int   g_eig_polish = 0;
+int   g_tri_force = 0;          // thip_test_eig_force bits 2-3: 1 (+ 4) the persistent reduction over the whole device, 2 (+ 8) on one XCD, 3 (+ 12) launches
+int   g_tri_sabotage = 0;       // thip_test_eig_force + 16: the one-XCD persistent launch is started with a role missing (time-out path)
+int   g_persist_broken = 0;     // a persistent launch gave up once: do not pay its time-out again (thip_test_eig_force resets it)
+int   g_tri_persist = 0;        // how the last reduction ran: 1 = persistent launch, 0 = one launch per reflector, -1 = persistent gave up -> 0
+float g_eig_orth = 0.0f, g_eig_resid = 0.0f;
+
 // Q^T M Q = T: d -> k.Y[0 .. ld), e -> k.Y[ld .. 2 ld), tau -> k.Y[2 ld .. 3 ld), reflectors -> k.S (below the diagonal)
 int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_scale, float scale, const Work &k,
                    int persist)         // 0: one launch per reflector, 1: persistent over the whole device, 2: persistent on one XCD
@@ -1604,6 +1614,10 @@ int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_
         unsigned *ticket = reinterpret_cast<unsigned *>(gran + 4 * (size_t)ni);
         unsigned long long *stamps = reinterpret_cast<unsigned long long *>(k.part + 128);      // -DTHIP_TP_PROFILE: phase times of workgroup 0
         THIP_TRY(hipMemsetAsync(gran, 0, (4 * (size_t)ni + 1) * sizeof(unsigned long long), st));
+        if (g_tri_sabotage && local) {           // test: role 0 is never taken, so every workgroup runs into its spin bound
+            const unsigned one = 1u;
+            THIP_TRY(hipMemcpyAsync(ticket, &one, sizeof(one), hipMemcpyHostToDevice, st));
+        }
         THIP_TRY(hipMemsetAsync(errflag, 0, sizeof(unsigned), st));
         const size_t lds = ((size_t)slots + 4) * ni * sizeof(float);
         static bool attr_set = false;
@@ -1640,14 +1654,6 @@ int tridiagonalise(hipStream_t st, int ni, int ld, const float *packed, int has_
     THIP_LAUNCH_CHECK();
     return 0;
 }
-
-// which engine served the last decomposition of order > 32 (thip_eig_engine_info), and the test switch
-int   g_eig_force = 0;          // thip_test_eig_force: 0 = default, 1 = the QL engine, 2 = the device engine with a failing certificate
-int   g_eig_engine = 0;         // 1 = host QL + rotation replay, 2 = multisection + twisted factorisation, 3 = 2 failed its certificate -> 1
-int   g_eig_polish = 0;
-int   g_tri_force = 0;          // thip_test_eig_force bits 2-3: 1 (+ 4) the persistent reduction over the whole device, 2 (+ 8) on one XCD, 3 (+ 12) launches
-int   g_tri_persist = 0;        // how the last reduction ran: 1 = persistent launch, 0 = one launch per reflector, -1 = persistent gave up -> 0
-float g_eig_orth = 0.0f, g_eig_resid = 0.0f;
 
 int eig_pin_floats(size_t want, float **out)
 {
@@ -1740,14 +1746,13 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
     const int ni = (int)n, ld = (int)np_of(n);
     static const int env_ql = getenv("THIP_EIG_QL") ? atoi(getenv("THIP_EIG_QL")) : 0;
     static const int env_persist = getenv("THIP_TRI_PERSIST") ? atoi(getenv("THIP_TRI_PERSIST")) : 2;       // 0 launches, 1 whole device, 2 one XCD (orders <= 1024)
-    static int persist_broken = 0;              // a persistent launch gave up once: do not pay its time-out again
     for (int attempt = 0; attempt < 2; ++attempt) {
         int persist = 0;
-        if (attempt == 0 && !persist_broken) {
+        if (attempt == 0 && !g_persist_broken) {
             persist = g_tri_force != 0 ? (g_tri_force == 3 ? 0 : g_tri_force) : env_persist;
             if (persist == 2 && (ni > 1024 || (((size_t)(ni + 31) / 32) + 5) * ni * sizeof(float) > 150 * 1024)) persist = 0;
         }
-        g_tri_persist = persist;
+        g_tri_persist = attempt == 0 ? persist : -1;
         THIP_RC(tridiagonalise(st, ni, ld, packed, has_scale, scale, k, persist));
         int tri_failed = 0;
         if (!env_ql && g_eig_force != 1) {
@@ -1765,7 +1770,7 @@ int decompose_tridiag(hipStream_t st, size_t n, const float *packed, int has_sca
                 tri_failed = fl != TP_DONE;
             }
         }
-        if (tri_failed) { g_tri_persist = -1; persist_broken = 1; continue; }           // the persistent launch gave up: one launch per reflector
+        if (tri_failed) { g_persist_broken = 1; continue; }           // the persistent launch gave up: one launch per reflector
         return decompose_ql(st, n, k, map_kind);
     }
     return fail(THIP_E_NOCONV, "map_eig: tridiagonalisation failed twice", __FILE__, __LINE__);
@@ -2066,9 +2071,11 @@ int thip_eig_engine_info(int *host_engine, int *host_polish, float *host_cert)
 int thip_test_eig_force(int engine)
 {
     THIP_NEED_INIT_NOFLUSH();
-    if (engine < 0 || (engine & 3) > 2 || engine > 14) return fail(THIP_E_INVALID, "thip_test_eig_force: 0, 1 or 2, + 4, + 8 or + 12", __FILE__, __LINE__);
+    if (engine < 0 || (engine & 3) > 2 || engine > 31) return fail(THIP_E_INVALID, "thip_test_eig_force: 0, 1 or 2, + 4, + 8 or + 12, + 16", __FILE__, __LINE__);
     g_eig_force = engine & 3;
     g_tri_force = (engine >> 2) & 3;
+    g_tri_sabotage = (engine >> 4) & 1;
+    g_persist_broken = 0;
     return 0;
 }
 
