@@ -261,28 +261,96 @@ __device__ __forceinline__ double contributions(const FinGroup &g, const FinMemb
     return acc;
 }
 
+// the same for E elements c0, c0 + 64, .. of one thread: a member's descriptor (a 32-byte scalar-path load per wave) is
+// read once for E data loads.  A group of 2000 members is 72 KB of descriptors and factors per wave; with one element per
+// thread the 12 500 waves of a 50 000-long output pulled 900 MB through the scalar caches (fin_k<true>: 0.34 ms for 200 MB
+// of data, whatever the number of member lanes).
+template <int E>
+__device__ __forceinline__ void contributions_multi(const FinGroup &g, const FinMember *__restrict__ mem,
+                                                    const float *__restrict__ alphas, int c0, int k0, int kstep, double *acc)
+{
+    constexpr int U = 8;
+    int k = k0;
+    for (; k + (U - 1) * kstep < g.count; k += U * kstep) {
+        FinMember m[U];
+        float al[U];
+        bool simple = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            m[u] = mem[g.first + k + u * kstep];
+            al[u] = alphas[g.first + k + u * kstep];
+            simple = simple && (m[u].type == M_ADDV || (m[u].type == M_PART && m[u].count == 1) || m[u].type == M_AXPY);
+        }
+        if (simple) {
+            float v[U][E], x0[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x0[u] = m[u].type == M_AXPY ? m[u].xs[0] : 1.0f;
+#pragma unroll
+                for (int i = 0; i < E; ++i) v[u][i] = c0 + 64 * i < g.len ? m[u].src[c0 + 64 * i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < E; ++i)
+                    acc[i] += m[u].type == M_PART ? (double)al[u] * (double)v[u][i] : (double)(al[u] * x0[u] * v[u][i]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < E; ++i)
+                    if (c0 + 64 * i < g.len) acc[i] += one_member(m[u], al[u], c0 + 64 * i);
+        }
+    }
+    for (; k < g.count; k += kstep) {
+        const FinMember m = mem[g.first + k];
+        const float al = alphas[g.first + k];
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            if (c0 + 64 * i < g.len) acc[i] += one_member(m, al, c0 + 64 * i);
+    }
+}
+
 // y[c] = beta y[c] + sum of the group's contributions.
-// LONG: grid (len / 64, groups): 64 elements x 4 member lanes per workgroup -- a group with thousands of members (the
-// 1000 G_i^T x_i + 1000 c_i x_i of ProbSOCPOpA::trans_op, socp.rs:104-130) is summed four members at a time per element
+// LONG: grid (len / 64, groups): 64 elements x 16 member lanes per workgroup -- a group with thousands of members (the
+// 1000 G_i^T x_i + 1000 c_i x_i of ProbSOCPOpA::trans_op, socp.rs:104-130) is summed eight members at a time per lane
 // and combined through LDS.  Else one workgroup per group (the 2000 short outputs of ProbSOCPOpA::op).
-template <bool LONG>
-__global__ __launch_bounds__(BLK) void fin_k(const FinGroup *__restrict__ groups, const FinMember *__restrict__ mem,
+constexpr int FIN_E = 4;              // measured: 1 -> 0.34 ms, 4 -> 0.14 ms, 8 -> 0.35 ms (too few waves)
+template <bool LONG, int FIN_LONG_LANES>          // member lanes of the LONG form: 64 elements x 16 (4) lanes = 1024 (256) threads
+__global__ __launch_bounds__(LONG ? 64 * FIN_LONG_LANES : BLK) void fin_k(const FinGroup *__restrict__ groups, const FinMember *__restrict__ mem,
                                              const float *__restrict__ alphas, const float *__restrict__ betas)
 {
     const int gi = LONG ? blockIdx.y : blockIdx.x;
     const FinGroup g = groups[gi];
     const float beta = betas[gi];
     if (LONG) {
-        __shared__ double comb[3][64];
+        // round 3: 16 member lanes instead of 4 -- a group of 2000 members was 62 dependent descriptor -> data round trips per
+        // thread (0.34 ms for the 200 MB of T partials of a pass over the SOCP blocks: 590 GB/s); now 16
+        constexpr int E = FIN_E;             // elements per thread: c0 + 64 i; a workgroup covers 64 E consecutive elements
+        __shared__ double comb[FIN_LONG_LANES - 1][E][64];
         const int e = threadIdx.x & 63, kq = threadIdx.x >> 6;
-        const int c = blockIdx.x * 64 + e;
-        double a = 0.0;
-        if (c < g.len) a = contributions(g, mem, alphas, c, kq, 4);
-        if (kq > 0) comb[kq - 1][e] = a;
+        const int c0 = blockIdx.x * (64 * E) + e;
+        double a[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) a[i] = 0.0;
+        if (c0 < g.len) contributions_multi<E>(g, mem, alphas, c0, kq, FIN_LONG_LANES, a);
+        if (kq > 0) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) comb[kq - 1][i][e] = a[i];
+        }
         __syncthreads();
-        if (kq == 0 && c < g.len) {
-            const float v = (float)((a + comb[0][e]) + (comb[1][e] + comb[2][e]));
-            g.y[c] = beta == 0.0f ? v : fmaf(beta, g.y[c], v);
+        if (kq == 0) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int c = c0 + 64 * i;
+                if (c < g.len) {
+                    double sacc = a[i];
+#pragma unroll
+                    for (int q = 0; q < FIN_LONG_LANES - 1; ++q) sacc += comb[q][i][e];
+                    const float v = (float)sacc;
+                    g.y[c] = beta == 0.0f ? v : fmaf(beta, g.y[c], v);
+                }
+            }
         }
     } else if (g.len <= 4 && g.count > 32) {
         // a few numbers with MANY contributions (ProbSOCPOpB::trans_op, socp.rs:219-246: 1000 d_i x_i + 1000 h_i . x_i
@@ -452,8 +520,10 @@ int launch_plan(Plan *p)
     const FinMember *dm = reinterpret_cast<const FinMember *>(p->dev + p->off_mem);
     const float *da = reinterpret_cast<const float *>(p->dev + p->off_alpha);
     const float *db = reinterpret_cast<const float *>(p->dev + p->off_beta);
-    if (p->nLong) hipLaunchKernelGGL(fin_k<true>, dim3((p->maxlen + 63) / 64, (unsigned)p->nLong), dim3(BLK), 0, st, dg, dm, da, db);
-    if (p->nShort) hipLaunchKernelGGL(fin_k<false>, dim3((unsigned)p->nShort), dim3(BLK), 0, st, dg + p->nLong, dm, da, db + p->nLong);
+    static const int fin_lanes = getenv("THIP_FIN_LANES") ? atoi(getenv("THIP_FIN_LANES")) : 16;
+    if (p->nLong && fin_lanes == 4) hipLaunchKernelGGL((fin_k<true, 4>), dim3((p->maxlen + 64 * FIN_E - 1) / (64 * FIN_E), (unsigned)p->nLong), dim3(256), 0, st, dg, dm, da, db);
+    else if (p->nLong) hipLaunchKernelGGL((fin_k<true, 16>), dim3((p->maxlen + 64 * FIN_E - 1) / (64 * FIN_E), (unsigned)p->nLong), dim3(1024), 0, st, dg, dm, da, db);
+    if (p->nShort) hipLaunchKernelGGL((fin_k<false, 4>), dim3((unsigned)p->nShort), dim3(BLK), 0, st, dg + p->nLong, dm, da, db + p->nLong);
     THIP_LAUNCH_CHECK();
     return 0;
 }
