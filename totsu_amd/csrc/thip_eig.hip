@@ -1063,19 +1063,20 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
     float tprev = 0.0f;
     // Between two exchanges a thread works on the rows r = tid + 1024 m it owns, in REGISTERS (what it gathered never
     // visits LDS; only w and v_j do, for the pass over the columns), and a block sum costs ONE barrier: the waves' partial
-    // sums and the two broadcast values of a step (p_{j-1}[j] and x[j + 1]) go through a scratch that alternates between
-    // two copies, so the write of a sum can never overtake the reads of the sum before last.
-    __shared__ float rsh[2][2][20];
+    // sums and the broadcast value of a sum (p_{j-1}[j], then x[j + 1]) go through a scratch that alternates between two
+    // copies, so the write of a sum can never overtake the reads of the sum before last.
+    __shared__ float rsh[2][20];
+    __shared__ int bail;                    // a thread whose granule never came says so here, ahead of the step's first barrier
+    if (tid == 0) bail = 0;
     int phase = 0;
-    auto sum2 = [&](float &a, float &b2, float bc_val, bool bc_mine, float &bc_out) {
-        a = wave_sum_dpp(a); b2 = wave_sum_dpp(b2);
-        if (lane == 0) { rsh[phase][0][wave] = a; rsh[phase][1][wave] = b2; }
-        if (bc_mine) rsh[phase][0][16] = bc_val;
+    auto sum1 = [&](float &a, float bc_val, bool bc_mine, float &bc_out) {
+        a = wave_sum_dpp(a);
+        if (lane == 0) rsh[phase][wave] = a;
+        if (bc_mine) rsh[phase][16] = bc_val;
         __syncthreads();
         constexpr int nw = TP_THREADS / 64;
-        a = wave_sum_dpp(lane < nw ? rsh[phase][0][lane] : 0.0f);
-        b2 = wave_sum_dpp(lane < nw ? rsh[phase][1][lane] : 0.0f);
-        bc_out = rsh[phase][0][16];
+        a = wave_sum_dpp(lane < nw ? rsh[phase][lane] : 0.0f);
+        bc_out = rsh[phase][16];
         phase ^= 1;
     };
 #ifdef THIP_TP_PROFILE
@@ -1088,7 +1089,7 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
         const int par = j & 1;
         const bool upd = j > 0 && tprev != 0.0f;
         float pr[TP_GM], xr[TP_GM], vpr[TP_GM], wpr[TP_GM];
-        float failed = 0.0f;
+        bool failed = false;
         if (j > 0) {
             // S1: p_{j-1} (rows >= j) and column j as its owner had it before the update of step j - 1
             const unsigned long long *gp = gran + (size_t)(par ^ 1) * 2 * n, *gc = gp + n;
@@ -1118,12 +1119,12 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
                 if (pend) {
                     ++spins;
                     if (spins > TP_SPIN_MAX || ((spins & 1023) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                        failed = 1.0f;
+                        failed = true;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(1);
                 }
             }
+            if (failed) bail = 1;
         } else {
 #pragma unroll
             for (int m = 0; m < TP_GM; ++m) {
@@ -1133,7 +1134,7 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
             }
         }
         TP_STAMP(0);
-        // w_{j-1} = p - (tau / 2)(p . v) v; the sum also carries the vote "somebody's granule never came"
+        // w_{j-1} = p - (tau / 2)(p . v) v
         float acc = 0.0f, pj = 0.0f;
         bool mine = false;
 #pragma unroll
@@ -1144,16 +1145,16 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
             if (r == j) { mine = true; pj = pr[m]; }
         }
         float pj_all;
-        sum2(acc, failed, pj, mine, pj_all);
+        sum1(acc, pj, mine, pj_all);
         TP_STAMP(1);
-        if (failed != 0.0f) {
+        if (bail != 0) {
             if (tid == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         const float kk = -0.5f * tprev * acc;
         // column j after the pending update (v_{j-1}[j] = 1); d_j, the reflector v_j, tau_j, e_j -- every workgroup for itself
         const float wj = upd ? fmaf(kk, 1.0f, pj_all) : 0.0f, vj = upd ? 1.0f : 0.0f;
-        float ss = 0.0f, zero = 0.0f, alpha_mine = 0.0f;
+        float ss = 0.0f, alpha_mine = 0.0f;
         mine = false;
 #pragma unroll
         for (int m = 0; m < TP_GM; ++m) {
@@ -1170,14 +1171,15 @@ __global__ __launch_bounds__(TP_THREADS) void tri_persist_k(int n, int ld, int W
             }
         }
         float alpha;
-        sum2(ss, zero, alpha_mine, mine, alpha);
+        sum1(ss, alpha_mine, mine, alpha);
         TP_STAMP(2);
-        const float xnorm = sqrtf(ss);
+        // beta = -sign(alpha) sqrt(alpha^2 + ss): ss IS the sum of squares already, so hypot's overflow care buys nothing here;
+        // the two quotients through v_rcp_f32 (1 ulp): these scalars sit on the critical path of every reflector
         float t = 0.0f, beta = alpha, scale = 0.0f;
-        if (xnorm != 0.0f) {
-            beta = -copysignf(hypotf(alpha, xnorm), alpha);
-            t = (beta - alpha) / beta;
-            scale = 1.0f / (alpha - beta);
+        if (ss != 0.0f) {
+            beta = -copysignf(sqrtf(fmaf(alpha, alpha, ss)), alpha);
+            t = (beta - alpha) * __builtin_amdgcn_rcpf(beta);
+            scale = __builtin_amdgcn_rcpf(alpha - beta);
         }
 #pragma unroll
         for (int m = 0; m < TP_GM; ++m) {
