@@ -6,8 +6,9 @@
 // device: 4.5 ms of a scalar chain at k = 500 that nothing parallel can shorten.  This file replaces the chain by two
 // embarrassingly parallel stages in f64 (T carries the f32 round-off of the reduction, ~1e-7 ||T||; f64 makes every
 // cluster of that noise a set of well separated eigenvalues):
-//   1. te_bisect_k: eigenvalue k of its unreduced block by Sturm-count MULTIsection -- one wave per eigenvalue, 64
-//      shifts per round (6 bits), <= 10 rounds for 53 bits; the count recurrence is dstebz's (monotone, pivmin guarded);
+//   1. te_bisect_k: eigenvalue k of its unreduced block by Sturm-count MULTIsection -- 64 shifts per round (6 bits),
+//      9 rounds to ulp ||T||; the count is the inertia of the twisted factorisation, formed from both ends by two waves
+//      (dstebz's pivmin-guarded recurrence, half the chain each);
 //   2. te_vec_k: ONE eigenvector per eigenvalue from the twisted factorisation of T - lambda I (the dlar1v step of
 //      MRRR without the representation tree): forward and backward pivots, the twist index r = argmin |gamma_r|,
 //      z from the two multiplier chains; one LANE per eigenvector, lanes in lockstep over the rows.
@@ -170,52 +171,100 @@ __global__ __launch_bounds__(1024) void te_prep_k(int n, const float *__restrict
     if (tid == 0) { head[0] = pivmin; head[1] = tmax; cert_bits[0] = 0u; cert_bits[1] = 0u; }
 }
 
-// one wave per eigenvalue: index t is eigenvalue number t - lo of its block [lo, hi)
-__global__ __launch_bounds__(256) void te_bisect_k(int n, const double *__restrict__ dd, const double *__restrict__ ee,
+// TWO waves per eigenvalue (index t is eigenvalue number t - lo of its block [lo, hi)): the number of eigenvalues below a
+// shift is the inertia of T - sigma I, and the twisted factorisation gives it from BOTH ends at once -- the negative pivots
+// D+ of rows [lo, mid), the negative pivots D- of rows (mid, hi), and the sign of gamma_mid = (d_mid - sigma) - e^2/D+ -
+// e^2/D- (Sylvester: the factorisation is a congruence).  The forward and the backward recurrences are independent chains
+// of half the length; the waves exchange (count, e^2 / last pivot) through LDS once per round.  Four eigenvalues (eight
+// waves) per workgroup; a round is two barriers, whether an eigenvalue has converged or not.
+__global__ __launch_bounds__(512) void te_bisect_k(int n, const double *__restrict__ dd, const double *__restrict__ ee,
                                                    const int2 *__restrict__ blk, const double *__restrict__ bnd,
                                                    const double *__restrict__ head, double *__restrict__ lam,
                                                    float *__restrict__ w32)
 {
     extern __shared__ double te_sh[];
     double2 *sde = reinterpret_cast<double2 *>(te_sh);            // (d_i, e_{i-1}^2): one 16-byte LDS read per row
-    for (int i = threadIdx.x; i < n; i += 256) { const double e = i > 0 ? ee[i - 1] : 0.0; sde[i] = make_double2(dd[i], e * e); }
+    __shared__ double xterm[4][64];
+    __shared__ int xcnt[4][64];
+    __shared__ double xlohi[4][2];
+    __shared__ int xdone[4];
+    for (int i = threadIdx.x; i < n; i += 512) { const double e = i > 0 ? ee[i - 1] : 0.0; sde[i] = make_double2(dd[i], e * e); }
     __syncthreads();
-    const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= n) return;
-    const int2 b = blk[t];
-    const int k = t - b.x;
-    double l;
-    if (b.y - b.x == 1) l = sde[b.x].x;
-    else {
-        const double pivmin = head[0];
-        double lo = bnd[3 * (size_t)t], hi = bnd[3 * (size_t)t + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q4 = wave >> 1, dir = wave & 1;
+    const int t = blockIdx.x * 4 + q4;
+    const bool live = t < n;
+    int2 b = make_int2(0, 1);
+    if (live) b = blk[t];
+    const int k = t - b.x, m = b.y - b.x, mid = b.x + m / 2;
+    const double pivmin = head[0];
+    double lo = 0.0, hi = 0.0, tol = 0.0;
+    bool done = !live || m == 1;
+    if (live && m > 1) {
+        lo = bnd[3 * (size_t)t]; hi = bnd[3 * (size_t)t + 1];
         // absolute tolerance, relative to the block's norm (dstebz's default abstol = ulp ||T||): T itself is only known to
         // eps ||T||, and a tolerance relative to |lambda| would spend four more rounds on every eigenvalue near zero
-        const double tol = TE_EPS * bnd[3 * (size_t)t + 2] + 2.0 * pivmin;
-        for (int round = 0; round < 12; ++round) {
-            const double w = hi - lo;
-            if (w <= tol) break;
-            const double sig = lo + w * ((double)(lane + 1) * (1.0 / 65.0));
-            double q = sde[b.x].x - sig;
-            if (fabs(q) < pivmin) q = -pivmin;
-            int cnt = q < 0.0 ? 1 : 0;
-#pragma unroll 4
-            for (int i = b.x + 1; i < b.y; ++i) {
-                const double2 de = sde[i];
-                q = fma(-de.y, rcp2(q), de.x - sig);
-                if (fabs(q) < pivmin) q = -pivmin;
-                cnt += q < 0.0 ? 1 : 0;
-            }
-            const unsigned long long mask = __ballot(cnt <= k);          // lanes whose shift is still a lower bound
-            const int idx = (mask == ~0ull) ? 64 : __ffsll((long long)~mask) - 1;
-            const double below = __shfl(sig, idx > 0 ? idx - 1 : 0, 64);
-            const double above = __shfl(sig, idx < 64 ? idx : 63, 64);
-            if (idx > 0) lo = below;
-            if (idx < 64) hi = above;
-        }
-        l = 0.5 * (lo + hi);
+        tol = TE_EPS * bnd[3 * (size_t)t + 2] + 2.0 * pivmin;
     }
-    if (lane == 0) { lam[t] = l; w32[t] = (float)l; }
+    for (int round = 0; round < 13; ++round) {
+        const double w = hi - lo;
+        if (!done && w <= tol) done = true;
+        const double sig = lo + w * ((double)(lane + 1) * (1.0 / 65.0));
+        int cnt = 0;
+        double term = 0.0;
+        if (!done) {
+            if (dir == 0) {
+                // rows b.x .. mid - 1 (at least one): D+ and its negative pivots; term = e_{mid-1}^2 / D+[mid - 1]
+                double q = sde[b.x].x - sig;
+                if (fabs(q) < pivmin) q = -pivmin;
+                cnt = q < 0.0 ? 1 : 0;
+#pragma unroll 4
+                for (int i = b.x + 1; i < mid; ++i) {
+                    const double2 de = sde[i];
+                    q = fma(-de.y, rcp2(q), de.x - sig);
+                    if (fabs(q) < pivmin) q = -pivmin;
+                    cnt += q < 0.0 ? 1 : 0;
+                }
+                term = sde[mid].y * rcp2(q);
+            } else if (mid + 1 < b.y) {
+                // rows b.y - 1 .. mid + 1: D- and its negative pivots; term = e_mid^2 / D-[mid + 1]
+                double q = sde[b.y - 1].x - sig;
+                if (fabs(q) < pivmin) q = -pivmin;
+                cnt = q < 0.0 ? 1 : 0;
+#pragma unroll 4
+                for (int i = b.y - 2; i > mid; --i) {
+                    const double e2 = sde[i + 1].y;
+                    q = fma(-e2, rcp2(q), sde[i].x - sig);
+                    if (fabs(q) < pivmin) q = -pivmin;
+                    cnt += q < 0.0 ? 1 : 0;
+                }
+                term = sde[mid + 1].y * rcp2(q);
+            }
+            if (dir == 1) { xterm[q4][lane] = term; xcnt[q4][lane] = cnt; }
+        }
+        __syncthreads();
+        if (dir == 0) {
+            if (!done) {
+                double g = (sde[mid].x - sig) - term - xterm[q4][lane];
+                if (fabs(g) < pivmin) g = -pivmin;
+                cnt += xcnt[q4][lane] + (g < 0.0 ? 1 : 0);
+                const unsigned long long mask = __ballot(cnt <= k);          // lanes whose shift is still a lower bound
+                const int idx = (mask == ~0ull) ? 64 : __ffsll((long long)~mask) - 1;
+                const double below = __shfl(sig, idx > 0 ? idx - 1 : 0, 64);
+                const double above = __shfl(sig, idx < 64 ? idx : 63, 64);
+                if (idx > 0) lo = below;
+                if (idx < 64) hi = above;
+            }
+            if (lane == 0) { xlohi[q4][0] = lo; xlohi[q4][1] = hi; xdone[q4] = done ? 1 : 0; }
+        }
+        __syncthreads();
+        lo = xlohi[q4][0]; hi = xlohi[q4][1];
+        done = xdone[q4] != 0;
+        // (all four eigenvalues done: the remaining rounds are two barriers each; not worth a vote)
+    }
+    if (live && dir == 0 && lane == 0) {
+        const double l = m == 1 ? sde[b.x].x : 0.5 * (lo + hi);
+        lam[t] = l; w32[t] = (float)l;
+    }
 }
 
 constexpr int TE_B = 24;          // rows fetched per batch by te_vec_k's unchained passes (one memory round trip per batch)
@@ -471,7 +520,7 @@ int tri_eigen(hipStream_t st, int n, int ld, const float *d, const float *e, flo
     double *Dp = head + 4 + 2 * (size_t)n, *Dm = Dp + (size_t)n * n;
     hipLaunchKernelGGL(te_prep_k, dim3(1), dim3(1024), 0, st, n, d, e, dd, ee, blk, bnd, head, cert_bits);
     const size_t lds = 2 * (size_t)n * sizeof(double);
-    hipLaunchKernelGGL(te_bisect_k, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, st, n, dd, ee, blk, bnd, head, lam, w32);
+    hipLaunchKernelGGL(te_bisect_k, dim3((unsigned)((n + 3) / 4)), dim3(512), lds, st, n, dd, ee, blk, bnd, head, lam, w32);
     hipLaunchKernelGGL(te_vec_k, dim3((unsigned)((n + 63) / 64)), dim3(128), lds, st, n, dd, ee, blk, bnd, head, lam, Dp, Dm,
                        nrm, twist, cert_bits);
     hipLaunchKernelGGL(te_pack_k, dim3((unsigned)(ld / 32), (unsigned)(ld / 32)), dim3(256), 0, st, n, ld, Dp, Dm, nrm, twist,
