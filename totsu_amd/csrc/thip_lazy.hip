@@ -104,6 +104,7 @@ struct Plan {
     char *dev = nullptr; size_t dev_bytes = 0;
     // products
     int nN = 0, nT = 0, nD = 0, nDot = 0, nLong = 0, nShort = 0, maxlen = 0;
+    int long_members = 0;                    // most members of a long group (picks the form of fin_k<true>)
     int maxt[3] = { 0, 0, 0 }, maxc[3] = { 0, 0, 0 };
     size_t off_dot = 0, off_grp = 0, off_mem = 0, off_alpha = 0, off_beta = 0;
     size_t n_members = 0, n_groups = 0;
@@ -208,11 +209,18 @@ __global__ __launch_bounds__(DBLK) void dot_k(const DotD *__restrict__ tab)
 __device__ __forceinline__ double one_member(const FinMember &m, float al, int c)
 {
     if (m.type == M_PART) {
-        // partial sums are read four at a time: the sum over the ~100 column-chunk partials of an N product is a
-        // latency chain, not a bandwidth problem
+        // partial sums are read SIXTEEN at a time: the sum over the ~100 column-chunk partials of an N product is a
+        // latency chain, not a bandwidth problem (four at a time: 40 us for the 14 MB of an LP's block, of which 30 are waits)
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         const float *p = m.src + c;
         int t = 0;
+        for (; t + 16 <= m.count; t += 16) {
+            float a[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u] = p[(size_t)(t + u) * m.stride];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { s0 += (double)a[u]; s1 += (double)a[u + 1]; s2 += (double)a[u + 2]; s3 += (double)a[u + 3]; }
+        }
         for (; t + 4 <= m.count; t += 4) {
             const float a0 = p[(size_t)t * m.stride], a1 = p[(size_t)(t + 1) * m.stride];
             const float a2 = p[(size_t)(t + 2) * m.stride], a3 = p[(size_t)(t + 3) * m.stride];
@@ -315,8 +323,10 @@ __device__ __forceinline__ void contributions_multi(const FinGroup &g, const Fin
 // LONG: grid (len / 64, groups): 64 elements x 16 member lanes per workgroup -- a group with thousands of members (the
 // 1000 G_i^T x_i + 1000 c_i x_i of ProbSOCPOpA::trans_op, socp.rs:104-130) is summed eight members at a time per lane
 // and combined through LDS.  Else one workgroup per group (the 2000 short outputs of ProbSOCPOpA::op).
-constexpr int FIN_E = 4;              // measured: 1 -> 0.34 ms, 4 -> 0.14 ms, 8 -> 0.35 ms (too few waves)
-template <bool LONG, int FIN_LONG_LANES>          // member lanes of the LONG form: 64 elements x 16 (4) lanes = 1024 (256) threads
+// FIN_E elements per thread of the LONG form.  Thousands of members (the SOCP's T partials): 4 x 16 lanes -- measured
+// 1 -> 0.34 ms, 4 -> 0.14 ms, 8 -> 0.35 ms (too few waves).  A handful of members with many partial slabs each (the one big
+// block of an LP): the elements are the only parallelism, so one element per thread and 4 lanes (4 x 16 there: 40 -> 61 us).
+template <bool LONG, int FIN_LONG_LANES, int FIN_E = 1>          // member lanes of the LONG form: 64 elements x 16 (4) lanes = 1024 (256) threads
 __global__ __launch_bounds__(LONG ? 64 * FIN_LONG_LANES : BLK) void fin_k(const FinGroup *__restrict__ groups, const FinMember *__restrict__ mem,
                                              const float *__restrict__ alphas, const float *__restrict__ betas)
 {
@@ -520,9 +530,10 @@ int launch_plan(Plan *p)
     const FinMember *dm = reinterpret_cast<const FinMember *>(p->dev + p->off_mem);
     const float *da = reinterpret_cast<const float *>(p->dev + p->off_alpha);
     const float *db = reinterpret_cast<const float *>(p->dev + p->off_beta);
-    static const int fin_lanes = getenv("THIP_FIN_LANES") ? atoi(getenv("THIP_FIN_LANES")) : 16;
-    if (p->nLong && fin_lanes == 4) hipLaunchKernelGGL((fin_k<true, 4>), dim3((p->maxlen + 64 * FIN_E - 1) / (64 * FIN_E), (unsigned)p->nLong), dim3(256), 0, st, dg, dm, da, db);
-    else if (p->nLong) hipLaunchKernelGGL((fin_k<true, 16>), dim3((p->maxlen + 64 * FIN_E - 1) / (64 * FIN_E), (unsigned)p->nLong), dim3(1024), 0, st, dg, dm, da, db);
+    if (p->nLong && p->long_members < 256)
+        hipLaunchKernelGGL((fin_k<true, 4, 1>), dim3((p->maxlen + 63) / 64, (unsigned)p->nLong), dim3(256), 0, st, dg, dm, da, db);
+    else if (p->nLong)
+        hipLaunchKernelGGL((fin_k<true, 16, 4>), dim3((p->maxlen + 255) / 256, (unsigned)p->nLong), dim3(1024), 0, st, dg, dm, da, db);
     if (p->nShort) hipLaunchKernelGGL((fin_k<false, 4>), dim3((unsigned)p->nShort), dim3(BLK), 0, st, dg + p->nLong, dm, da, db + p->nLong);
     THIP_LAUNCH_CHECK();
     return 0;
@@ -775,7 +786,7 @@ int flush_products()
         const int gi = order[oi];
         const Group &g = groups[gi];
         p->grp_slot[gi] = (int)oi;
-        if ((int)g.len > SHORT_LEN) p->maxlen = std::max(p->maxlen, (int)g.len);
+        if ((int)g.len > SHORT_LEN) { p->maxlen = std::max(p->maxlen, (int)g.len); p->long_members = std::max(p->long_members, (int)g.mem.size()); }
         hg[oi] = FinGroup{ g.y, (int)g.len, (int)mpos, (int)g.mem.size() };
         for (size_t mi = 0; mi < g.mem.size(); ++mi) {
             const Member &m = g.mem[mi];
