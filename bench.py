@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--k", type=int, default=500, help="PSD order of the sdp workload")
     ap.add_argument("--n", "--size", dest="n", type=int, default=None, help="number of variables (use --size under torchrun: --n is an ambiguous prefix there)")
     ap.add_argument("--cones", type=int, default=1000)
-    ap.add_argument("--schedule", default="carried", choices=["reference", "fused", "carried"])
+    ap.add_argument("--schedule", default="sweep", choices=["reference", "fused", "carried", "sweep"],
+                    help="sweep = one pass over A per iteration (one GPU, dense f32 A); where it cannot run the library "
+                         "executes the carried schedule (2 passes) and the line says so")
     ap.add_argument("--a-storage", default="f32", choices=["f32", "bf16", "f16", "mixed", "mixed-bf16"],
                     help="stored form of A streamed by the iteration (default f32 = the reference's data). bf16: a rounded copy, "
                          "half the bytes per pass, f32 accumulation -- solves the ROUNDED problem, not the headline metric. "
@@ -579,7 +581,8 @@ def run(a):
     b_iter = 24.0 * m_total * n                              # 6 GEMVs x 4 m n bytes
     roofline = {
         "bound": "hbm",
-        "kernel": "dual_gemv_k (one pass over the local A: y_N = A x_N and y_T = A^T x_T)",
+        "kernel": ("sweep_k (one pass over A per iteration: per column both dots, the x_x / u updates and both axpys)"
+                   if passes == 1 else "dual_gemv_k (one pass over the local A: y_N = A x_N and y_T = A^T x_T)"),
         "achieved": achieved,                                # physical bytes of one pass / avg launch duration
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
@@ -600,7 +603,7 @@ def run(a):
     if os.path.exists(prof) and a.a_storage in ("f32", "bf16", "f16"):
         try:
             tr = json.load(open(prof))
-            key = "%s_n%d_m%d_%s%s" % (a.workload, n, inst.m, a.schedule, "" if a.a_storage == "f32" else "_" + a.a_storage)
+            key = "%s_n%d_m%d_%s%s" % (a.workload, n, inst.m, fs.schedule_in_use(), "" if a.a_storage == "f32" else "_" + a.a_storage)
             if key in tr:
                 roofline["traffic"] = tr[key]["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = ("stored PMC run (profiles/hbm_traffic.json: %s), not a counter of this run"
@@ -631,7 +634,7 @@ def run(a):
         "data": "synthetic (counter-based generator on device, seed 0; 'normal' entries are Irwin-Hall(4) sums scaled to "
                 "unit variance, not exact Gaussians)",
         "state_arith": a.state,
-        "config": {"workload": wl, "schedule": a.schedule, "passes_over_A_per_iter": passes,
+        "config": {"workload": wl, "schedule": fs.schedule_in_use(), "schedule_asked": a.schedule, "passes_over_A_per_iter": passes,
                    "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll, "overlap": overlap_pick,
                    "overlap_mode_run": ovi["mode"], "overlap_split_col": ovi["split_col"], "overlap_autotune_ms_per_iter": overlap_times,
                    "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan(), "a_storage": a.a_storage},

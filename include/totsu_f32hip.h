@@ -228,7 +228,9 @@ enum { THIP_ST_RUNNING = -1,
 
 enum { THIP_SCHED_REFERENCE = 0,   /* 6 single GEMVs per iteration, the reference's op sequence (solver.rs:122-597) */
        THIP_SCHED_FUSED     = 1,   /* 3 passes over A: N and T products of one stage share a tile read */
-       THIP_SCHED_CARRIED   = 2 }; /* 2 passes: K*rx obtained by linearity from the criteria products */
+       THIP_SCHED_CARRIED   = 2,   /* 2 passes: K*rx obtained by linearity from the criteria products */
+       THIP_SCHED_SWEEP     = 3 }; /* 1 pass: per column, both dots, the x_x / u updates and both axpys while the column is in
+                                    * registers (thip_sweep.hip; dense f32 A on one GPU, else the carried schedule runs) */
 
 typedef struct thip_problem {
     size_t n, m;                      /* A is m x n (local rows if sharded) */
@@ -359,6 +361,30 @@ int thip_solver_precond(thip_solver *s, float *host_dp_tau, float *host_dp_sigma
 int thip_solver_destroy(thip_solver *s);
 /* physical passes over A per iteration of the schedule in use, and bytes one pass reads */
 int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_bytes_per_pass);
+/* the schedule the next thip_solver_run will execute: the one given to thip_solver_create, or THIP_SCHED_CARRIED when
+ * THIP_SCHED_SWEEP was asked for and the one-pass kernel cannot take this problem (sharded rows, sparse or 16-bit A,
+ * m or lda not a multiple of 4, fewer than 40 column panels per group, a device that is not 8 XCDs x 32 CUs, a failed
+ * placement census) */
+int thip_solver_schedule_in_use(thip_solver *s, int *host_schedule);
+/* THIP_SCHED_SWEEP is used for matrices of at least this many bytes (default 32 MiB: below that an iteration is a handful
+ * of launches whatever the schedule); 0 = whenever the kernel can take the shape.  Before thip_solver_init. */
+int thip_solver_set_sweep_min_bytes(thip_solver *s, size_t bytes);
+
+/* test entry point of the one-pass kernel (thip_sweep.hip): one sweep over the m x n matrix A (device, column-major),
+ *   gT = A^T v ; g3 = A^T xy ; u <- u + Su o (-(gP - 2 g3) - c rtau) unless `first` ; gP <- g3 ;
+ *   xx_out = xx_in + Tx o (gT + c kappa) ; hN = A u ; h3 = A xx_out            (Kahan terms ku / kx_* may be NULL)
+ * `reps` launches are timed with HIP events (reps > 1 only with first != 0, which is idempotent); host_info[0] = the
+ * kernel's error word (0 = ok), [1] = members per group, [2] = groups, [3] = panels per group */
+typedef struct thip_sweep_test {
+    size_t m, n, lda;
+    const float *mat_a, *v, *xy, *c, *su, *tx;
+    float *u, *ku;
+    const float *xx_in, *kx_in;
+    float *xx_out, *kx_out, *gp, *hn, *h3;
+    float kappa, rtau;
+    int32_t first, reps;
+} thip_sweep_test;
+int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *host_info);
 
 /* test entry point for the matrix-core GEMM of the PSD projection chain: C = alpha * A * B + beta * D + gamma * I_n
  * with A symmetric and B arbitrary, all ld x ld column-major, ld a multiple of 64, zero padded beyond n */

@@ -22,6 +22,16 @@ pub struct thip_status {
     pub tau: f32, pub kappa: f32, pub norm_b: f32, pub norm_c: f32,
 }
 
+#[repr(C)]
+pub struct thip_sweep_test {
+    pub m: usize, pub n: usize, pub lda: usize,
+    pub mat_a: *const f32, pub v: *const f32, pub xy: *const f32, pub c: *const f32, pub su: *const f32, pub tx: *const f32,
+    pub u: *mut f32, pub ku: *mut f32,
+    pub xx_in: *const f32, pub kx_in: *const f32,
+    pub xx_out: *mut f32, pub kx_out: *mut f32, pub gp: *mut f32, pub hn: *mut f32, pub h3: *mut f32,
+    pub kappa: f32, pub rtau: f32, pub first: i32, pub reps: i32,
+}
+
 pub enum thip_solver {}
 pub type thip_allreduce_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, dev_buf: *mut f32, n: usize, stream: *mut c_void) -> c_int>;
 
@@ -33,6 +43,7 @@ pub const THIP_CONE_PSD: i32 = 4;
 pub const THIP_SCHED_REFERENCE: c_int = 0;
 pub const THIP_SCHED_FUSED: c_int = 1;
 pub const THIP_SCHED_CARRIED: c_int = 2;
+pub const THIP_SCHED_SWEEP: c_int = 3;
 pub const THIP_OVERLAP_OFF: c_int = 0;
 pub const THIP_OVERLAP_LOCAL_ROWS: c_int = 1;
 pub const THIP_OVERLAP_COLUMN_PIPELINE: c_int = 2;
@@ -135,6 +146,9 @@ extern "C" {
     pub fn thip_solver_iterate(s: *mut thip_solver, host_x: *mut f32, host_y: *mut f32) -> c_int;
     pub fn thip_solver_precond(s: *mut thip_solver, host_dp_tau: *mut f32, host_dp_sigma: *mut f32) -> c_int;
     pub fn thip_solver_passes(s: *const thip_solver, host_passes: *mut c_int, host_bytes_per_pass: *mut usize) -> c_int;
+    pub fn thip_solver_schedule_in_use(s: *mut thip_solver, host_schedule: *mut c_int) -> c_int;
+    pub fn thip_solver_set_sweep_min_bytes(s: *mut thip_solver, bytes: usize) -> c_int;
+    pub fn thip_test_sweep(t: *const thip_sweep_test, host_ms: *mut f32, host_info: *mut c_int) -> c_int;
     pub fn thip_solver_gemv_plan(s: *const thip_solver, host_nj: *mut c_int, host_blocks: *mut c_int, host_ms: *mut f32) -> c_int;
 
     pub fn thip_comm_unique_id(host_id128: *mut u8) -> c_int;

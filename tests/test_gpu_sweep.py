@@ -1,0 +1,275 @@
+"""GPU parity tests of the one-pass schedule (THIP_SCHED_SWEEP, totsu_amd/csrc/thip_sweep.hip): the kernel alone against
+numpy f64, the schedule's iterates against the CPU oracle and against the carried schedule (same recurrences,
+solver.rs:525-570, evaluated in a skewed order), termination at the same iteration with the same answer, restart from a
+stopped iterate, the fall-back to the carried schedule where the kernel cannot take the problem."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from problems import benchmark_lp, random_sdp, random_socp
+from test_gpu_solver import _mb, _oracle_snaps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import totsu_amd
+    from totsu_amd import _lib
+    _lib.init()
+    return totsu_amd
+
+
+def _sweep_case(m, n, first, comp, seed, lda=None):
+    from totsu_amd import _lib
+    from totsu_amd.fused import DeviceBuffer
+    lib = _lib.lib
+    rng = np.random.default_rng(seed)
+    lda = lda or m
+    A = (rng.standard_normal((n, lda)) / np.sqrt(n)).astype(np.float32)        # row j = column j of the m x n matrix
+    v, xy = rng.standard_normal(m).astype(np.float32), rng.standard_normal(m).astype(np.float32)
+    c = rng.standard_normal(n).astype(np.float32)
+    su, tx = (rng.random(n) + 0.5).astype(np.float32), (rng.random(n) + 0.5).astype(np.float32)
+    u, xx, gp = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+    ku = (1e-7 * rng.standard_normal(n)).astype(np.float32)
+    kx = (1e-7 * rng.standard_normal(n)).astype(np.float32)
+    kappa, rtau = -0.37, 0.81
+    bufs = {k: DeviceBuffer.from_host(a) for k, a in dict(A=A.ravel(), v=v, xy=xy, c=c, su=su, tx=tx, u=u, xx=xx, gp=gp,
+                                                          ku=ku, kx=kx).items()}
+    outs = {k: DeviceBuffer(sz, zero=True) for k, sz in dict(xx_out=n, kx_out=n, hn=m, h3=m).items()}
+    t = _lib.SweepTest()
+    t.m, t.n, t.lda = m, n, lda
+    t.mat_a, t.v, t.xy, t.c, t.su, t.tx = (bufs[k].ptr for k in ("A", "v", "xy", "c", "su", "tx"))
+    t.u, t.ku = bufs["u"].ptr, (bufs["ku"].ptr if comp else None)
+    t.xx_in, t.kx_in = bufs["xx"].ptr, (bufs["kx"].ptr if comp else None)
+    t.xx_out, t.kx_out = outs["xx_out"].ptr, (outs["kx_out"].ptr if comp else None)
+    t.gp, t.hn, t.h3 = bufs["gp"].ptr, outs["hn"].ptr, outs["h3"].ptr
+    t.kappa, t.rtau, t.first, t.reps = kappa, rtau, int(first), 1
+    ms = (C.c_float * 2)()
+    info = (C.c_int * 4)()
+    lib.thip_test_sweep(C.byref(t), ms, info)
+    assert info[0] == 0, "the kernel raised its error word: %d" % info[0]
+    Ad = A[:, :m].astype(np.float64)
+    gT, g3 = Ad @ v.astype(np.float64), Ad @ xy.astype(np.float64)
+    k_u = ku.astype(np.float64) if comp else 0.0
+    k_x = kx.astype(np.float64) if comp else 0.0
+    u_ref = u.astype(np.float64) if first else u + (su * (-(gp - 2 * g3) - c * rtau) - k_u)
+    x_ref = xx + (tx * (gT + c * kappa) - k_x)
+    got = {"u": bufs["u"].to_host(), "x": outs["xx_out"].to_host(), "gp": bufs["gp"].to_host(),
+           "hn": outs["hn"].to_host(), "h3": outs["h3"].to_host()}
+    ref = {"u": u_ref, "x": x_ref, "gp": g3, "hn": Ad.T @ u_ref, "h3": Ad.T @ x_ref}
+    for k in ref:
+        err = np.abs(got[k] - ref[k]).max() / (np.abs(ref[k]).max() + 1e-30)
+        assert err < 5e-6, (m, n, first, comp, k, err)
+    if comp:
+        # the Kahan term carries what the f32 sum dropped: (x + inc) - stored = -k (to f32 round-off of k itself)
+        kxo = outs["kx_out"].to_host().astype(np.float64)
+        assert np.abs((got["x"].astype(np.float64) - kxo) - x_ref).max() <= 1e-6 * np.abs(x_ref).max()
+    for b in list(bufs.values()) + list(outs.values()):
+        b.free()
+    return info[1], info[2], info[3]
+
+
+@pytest.mark.parametrize("m,n", [(4096, 30000), (20000, 10000), (3584, 24000), (100000, 3000), (12500, 8000), (1000, 25000),
+                                 (240, 120), (96, 83)])
+def test_sweep_kernel_vs_numpy(T, m, n):
+    """every group size (1 .. 32 workgroups per column), one and two 16-byte slots per thread, partial last panels,
+    groups without columns, with and without the u update / the Kahan terms"""
+    for first in (0, 1):
+        for comp in (0, 1):
+            _sweep_case(m, n, first, comp, seed=m + 3 * n + first + 2 * comp)
+
+
+def test_sweep_kernel_padded_leading_dimension(T):
+    _sweep_case(2000, 5000, 0, 1, seed=5, lda=2048)
+
+
+def _check_sweep_iterates(T, dense, iters, tols):
+    ro = _oracle_snaps(dense, iters)
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    fs = T.FusedSolver.from_dense(dense, p, "sweep", sweep_min_bytes=0)
+    assert fs.schedule_in_use() == "sweep"
+    assert fs.passes()[0] == 1
+    fc = T.FusedSolver.from_dense(dense, p, "carried")
+    N = dense.n + 2 * dense.m + 1
+    done = 0
+    for q, (it, tol) in enumerate(zip(iters, tols)):
+        fs.run(it + 1 - done, poll_every=64)
+        fc.run(it + 1 - done, poll_every=64)
+        done = it + 1
+        x, y = fs.iterate()
+        xc, yc = fc.iterate()
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        sx, sy = max(np.abs(rx).max(), 1e-6), max(np.abs(ry).max(), 1e-6)
+        assert np.abs(x - rx).max() <= tol * sx, (it, np.abs(x - rx).max() / sx)
+        assert np.abs(y - ry).max() <= tol * sy, (it, np.abs(y - ry).max() / sy)
+        # and the carried schedule's iterate (same arithmetic but the order of the sums in the products)
+        assert np.abs(x - xc).max() <= tol * sx and np.abs(y - yc).max() <= tol * sy
+        st = fs.status()
+        assert st.iters == it + 1
+        assert np.allclose(st.cri, ro.trace[it][2:], rtol=max(50 * tol, 1e-3), atol=1e-5), (it, st.cri, ro.trace[it])
+    fs.destroy()
+    fc.destroy()
+
+
+def _lp(T, sz, seed):
+    c, G, h = benchmark_lp(sz, seed=seed)
+    return T.ProbLP(_mb(T, T.MatType.General(sz, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(2 * sz, sz)).set_array(G),
+                    _mb(T, T.MatType.General(2 * sz, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, sz)),
+                    _mb(T, T.MatType.General(0, 1))), (c, G, h)
+
+
+def test_sweep_iterates_lp(T):
+    lp, _ = _lp(T, 120, 1)
+    _check_sweep_iterates(T, lp.dense(), [0, 1, 2, 9, 99], [2e-5, 2e-5, 2e-5, 1e-4, 2e-3])
+
+
+def _socp(T, n, cones, seed):
+    f, Gs, hs, cs, d = random_socp(n, cones, seed=seed)
+    return T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(f.reshape(-1, 1)),
+                      [_mb(T, T.MatType.General(G.shape[0], n)).set_array(G) for G in Gs],
+                      [_mb(T, T.MatType.General(len(h_), 1)).set_array(h_.reshape(-1, 1)) for h_ in hs],
+                      [_mb(T, T.MatType.General(n, 1)).set_array(c_.reshape(-1, 1)) for c_ in cs], d,
+                      _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
+
+
+def test_sweep_iterates_socp(T):
+    # m = sum of (1 + n_i) = 164 rows: a multiple of 4
+    socp = _socp(T, 100, [5, 1, 0, 17, 99, 3, 32], seed=2)
+    assert socp.dense().m % 4 == 0
+    _check_sweep_iterates(T, socp.dense(), [0, 1, 2, 9, 99], [2e-5, 2e-5, 2e-5, 1e-4, 2e-3])
+
+
+def test_sweep_iterates_socp_rows_not_a_multiple_of_4(T):
+    # m = 130: the library's padded copy of A (zero rows behind row m) lets the kernel take it.  (An instance whose d_i are
+    # all positive: _oracle_snaps hands b to the oracle as a MatOp, whose absadd_rows is |b|, while ProbSOCPOpB adds the
+    # signed d_i, socp.rs:271 -- the dense description carries the latter in vec_b_rowabs.)
+    socp = _socp(T, 96, [7, 20, 1, 33, 64], seed=4)
+    assert socp.dense().m % 4 != 0
+    _check_sweep_iterates(T, socp.dense(), [0, 1, 9, 49], [2e-5, 2e-5, 1e-4, 1e-3])
+
+
+def test_sweep_iterates_sdp(T):
+    # one PSD cone of order 12 (78 rows) and n = 90 columns: block-cone projection between the sweeps
+    n, k = 90, 12
+    c, syms = random_sdp(n, k, seed=4)
+    sdp = T.ProbSDP(_mb(T, T.MatType.General(n, 1)).set_array(c.reshape(-1, 1)),
+                    [_mb(T, T.MatType.SymPack(k)).set_array(s_) for s_ in syms],
+                    _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)), 1e-12)
+    _check_sweep_iterates(T, sdp.dense(), [0, 1, 9, 49], [3e-5, 3e-5, 2e-4, 2e-3])
+
+
+def test_sweep_terminates_where_the_carried_schedule_does(T):
+    lp, (c, G, h) = _lp(T, 150, 7)
+    d = lp.dense()
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 200_000, 1e-4
+    res = {}
+    for sched in ("carried", "sweep"):
+        fs = T.FusedSolver.from_dense(d, p, sched, sweep_min_bytes=0)
+        assert fs.schedule_in_use() == sched
+        x, y = fs.solve(poll_every=37)
+        st = fs.status()
+        res[sched] = (x, y, st.iters, st.state)
+        fs.destroy()
+    xs, ys, its, sts = res["sweep"]
+    xc, yc, itc, stc = res["carried"]
+    assert sts == stc == 0
+    assert abs(its - itc) <= max(3, itc // 200), (its, itc)
+    pobj = float(c.astype(np.float64) @ xc)
+    assert abs(float(c.astype(np.float64) @ xs) - pobj) <= 2e-4 * (1 + abs(pobj))
+    assert np.abs(xs - xc).max() <= 2e-3 * max(np.abs(xc).max(), 1.0)
+    ro = O.solve_lp(O.param(max_iter=200000, eps_acc=1e-4), c, G, h, np.zeros((0, 150)), [])
+    assert ro.status == O.OK
+    assert abs(float(c.astype(np.float64) @ xs) - float(c.astype(np.float64) @ ro.x)) <= 1e-3 * (1 + abs(pobj))
+
+
+def test_sweep_stop_at_max_iter_returns_that_iterate_and_resumes(T):
+    """ExcessIter at iteration K: the answer is iterate K (the x_x buffer the test recorded, not the one the next sweep
+    already wrote), and a resumed run goes on exactly as an uninterrupted one"""
+    lp, _ = _lp(T, 128, 11)
+    d = lp.dense()
+    K = 57
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    ref = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0)
+    ref.run(K, poll_every=K)
+    xr, yr = ref.iterate()
+    ref.run(40, poll_every=13)
+    xr2, yr2 = ref.iterate()
+    ref.destroy()
+    p2 = T.SolverParam()
+    p2.eps_acc, p2.max_iter = 1e-30, K
+    fs = T.FusedSolver.from_dense(d, p2, "sweep", sweep_min_bytes=0)
+    r = fs.run(-1, poll_every=100)              # the device stops by itself in the middle of a batch
+    assert r.state == 3 and r.iters == K - 1
+    tau = fs.status().tau
+    x, y = fs.iterate()
+    n, m = d.n, d.m
+    # ExcessIter with tau > eps_zero: x_x and x_y come back scaled by 1 / tau (solver.rs:397-400)
+    assert np.allclose(x[:n] * tau, xr[:n], rtol=1e-6, atol=1e-7)
+    assert np.allclose(x[n:n + m] * tau, xr[n:n + m], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(x[n + m:], xr[n + m:]) and np.array_equal(y, yr)
+    p3 = T.SolverParam()
+    p3.eps_acc, p3.max_iter = 1e-30, None
+    fs.resume(p3)
+    fs.run(40, poll_every=40)
+    x2, y2 = fs.iterate()
+    assert np.allclose(x2, xr2, rtol=2e-6, atol=1e-7) and np.allclose(y2, yr2, rtol=2e-6, atol=1e-7)
+    fs.destroy()
+
+
+def test_sweep_is_reproducible_and_independent_of_the_polling_period(T):
+    socp = _socp(T, 120, [15, 40, 3, 66], seed=9)
+    d = socp.dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    outs = []
+    for poll in (200, 7, 200):
+        fs = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0)
+        fs.run(200, poll_every=poll)
+        outs.append(fs.iterate())
+        fs.destroy()
+    for x, y in outs[1:]:
+        assert np.array_equal(x, outs[0][0]) and np.array_equal(y, outs[0][1])
+
+
+def test_sweep_falls_back_to_carried(T):
+    # too few columns for the kernel, and (default threshold) too small a matrix
+    lp, _ = _lp(T, 40, 1)
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    fs = T.FusedSolver.from_dense(lp.dense(), p, "sweep", sweep_min_bytes=0)
+    assert fs.schedule_in_use() == "carried" and fs.passes()[0] == 2
+    fc = T.FusedSolver.from_dense(lp.dense(), p, "carried")
+    fs.run(50, poll_every=50)
+    fc.run(50, poll_every=50)
+    assert all(np.array_equal(a, b) for a, b in zip(fs.iterate(), fc.iterate()))
+    fs.destroy()
+    fc.destroy()
+    lp2, _ = _lp(T, 120, 1)
+    f2 = T.FusedSolver.from_dense(lp2.dense(), p, "sweep")
+    assert f2.schedule_in_use() == "carried"
+    f2.destroy()
+
+
+def test_sweep_at_a_size_where_it_is_the_default(T):
+    """SOCP n = 4000, 80 cones of 1 + 99 rows (m = 8000, 128 MB): objective of the sweep and of the carried run agree"""
+    from totsu_amd import synth
+    inst = synth.SocpInstance(4000, 80, 99, seed=0)
+    p = T.SolverParam()
+    p.eps_acc, p.max_iter = 1e-3, 400_000
+    res = {}
+    for sched in ("carried", "sweep"):
+        fs = T.FusedSolver(4000, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, sched)
+        assert fs.schedule_in_use() == sched
+        x, y = fs.solve(poll_every=500)
+        res[sched] = (x, fs.status().iters)
+        fs.destroy()
+    c = inst.vec_c.to_host().astype(np.float64)
+    pc, ps = float(c @ res["carried"][0]), float(c @ res["sweep"][0])
+    assert abs(pc - ps) <= 1e-4 * (1 + abs(pc)), (pc, ps)
+    assert abs(res["sweep"][1] - res["carried"][1]) <= max(5, res["carried"][1] // 100)

@@ -13,7 +13,7 @@ E_INVALID, E_NOTINIT, E_NOGPU, E_WORK, E_NOCONV = 10001, 10002, 10003, 10004, 10
 
 ST_RUNNING, ST_OK, ST_UNBOUNDED, ST_INFEASIBLE, ST_EXCESS_ITER, ST_INVALID_OP, ST_WORK_SHORTAGE, ST_CONE_FAILURE = \
     -1, 0, 1, 2, 3, 4, 5, 6
-SCHED_REFERENCE, SCHED_FUSED, SCHED_CARRIED = 0, 1, 2
+SCHED_REFERENCE, SCHED_FUSED, SCHED_CARRIED, SCHED_SWEEP = 0, 1, 2, 3
 STATE_COMPENSATED, STATE_PLAIN = 0, 1
 CONE_ZERO, CONE_RPOS, CONE_SOC, CONE_ROTSOC, CONE_PSD = 0, 1, 2, 3, 4
 
@@ -40,6 +40,13 @@ class Problem(C.Structure):
 class Status(C.Structure):
     _fields_ = [("state", C.c_int32), ("iter", C.c_int64), ("kind", C.c_int32), ("cri", C.c_float * 3),
                 ("tau", C.c_float), ("kappa", C.c_float), ("norm_b", C.c_float), ("norm_c", C.c_float)]
+
+
+class SweepTest(C.Structure):
+    _fields_ = [("m", C.c_size_t), ("n", C.c_size_t), ("lda", C.c_size_t)] + \
+               [(k, C.c_void_p) for k in ("mat_a", "v", "xy", "c", "su", "tx", "u", "ku", "xx_in", "kx_in", "xx_out",
+                                          "kx_out", "gp", "hn", "h3")] + \
+               [("kappa", C.c_float), ("rtau", C.c_float), ("first", C.c_int32), ("reps", C.c_int32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -135,6 +142,9 @@ PROTOTYPES = {
     "thip_solver_precond": (_i, [_vp, _vp, _vp]),
     "thip_solver_destroy": (_i, [_vp]),
     "thip_solver_passes": (_i, [_vp, C.POINTER(_i), C.POINTER(_sz)]),
+    "thip_solver_schedule_in_use": (_i, [_vp, C.POINTER(_i)]),
+    "thip_solver_set_sweep_min_bytes": (_i, [_vp, _sz]),
+    "thip_test_sweep": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
     "thip_test_gemm_sym": (_i, [_i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_test_gemm_chain": (_i, [_i, _i, _i, _i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_solver_gemv_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),

@@ -222,6 +222,30 @@ size_t dual_gemv_scratch_floats(size_t n_row, size_t n_col);
 int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_t stride, float alpha, float beta,
                       float *y, const int *stop);
 
+// thip_sweep.hip: one pass over A per iteration (THIP_SCHED_SWEEP)
+struct SweepGeom { int G, ngroups, rows_per_member, cols_per_group, nslot, npan, w, variant, m_eff; size_t mpad; };
+struct SweepArgs {
+    const float *A; size_t lda; int m, n;
+    int G, rows_per_member, cols_per_group;
+    const float *v, *xy;                    // the m-vectors every column is multiplied with
+    const float *c, *Su, *Tx;               // per column
+    float *u, *ku;                          // updated in place (ku == NULL: plain additions)
+    const float *xx_in, *kx_in;             // x_x_k (and its Kahan term) ...
+    float *xx_out, *kx_out;                 // ... x_x_{k+1}
+    float *gP;                              // A^T x_y of the previous sweep in, of this one out
+    float *partH; size_t mpad;              // [group][2][mpad]: the groups' shares of A u_k and A x_x_{k+1}
+    unsigned long long *gran;               // [group][SW_RING][G][2 W] granules
+    unsigned *census;                       // [0..7] workgroups per XCD, [8] total, [9] error word
+    unsigned seq, tagbase;
+    int first;                              // 1: u is current (a (re)start): no u update
+    int dbg;                                // experiments (THIP_SWEEP_DBG): 1 no polling, 2 no wave reduction of the dots
+    const int *stop; const float *kappa_p, *rtau_p;
+};
+int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g);
+size_t sweep_gran_words(const SweepGeom &g);
+int sweep_census_dry_run(hipStream_t st, unsigned *census, unsigned seq);
+int sweep_launch(hipStream_t st, const SweepGeom &g, const SweepArgs &a);
+
 void prof_release();      // destroys the HIP events of thip_prof_* (thip_shutdown)
 
 int reduce_to_dev(hipStream_t st, int op, size_t n, const float *x, const float *y, size_t incx, float *dev_out);

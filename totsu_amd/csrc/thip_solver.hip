@@ -41,7 +41,7 @@ struct DevStatus {
     int       stop;              // != 0: every kernel returns at entry
     int       state;             // THIP_ST_*
     int       kind;
-    int       pad;
+    int       xbuf;              // sweep schedule: which of the two x_x buffers holds the iterate the device stopped at
     long long iter;              // index of the iteration being / last executed
     float     cri[3];
     float     tau, kappa;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
 // ps_pp / ps_by: post_k's block partials of ||p||^2 and b.x_y (all-reduced block partials when sharded).
 __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict__ part,
                                                float eps_acc, float eps_inf, float eps_zero, long long max_iter,
-                                               DevStatus *st, const float *ps_pp, const float *ps_by, int npsum)
+                                               DevStatus *st, const float *ps_pp, const float *ps_by, int npsum, int xbuf)
 {
     if (st->stop != 0) return;
     __shared__ double shd[16];
@@ -377,7 +377,138 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
         else if (excess_iter) state = THIP_ST_EXCESS_ITER;
     }
     if (state == THIP_ST_RUNNING) st->iter = i + 1;
-    else { st->state = state; st->stop = 1; }     // one block, last kernel of the iteration: later launches are no-ops
+    else { st->state = state; st->xbuf = xbuf; st->stop = 1; }     // one block, last kernel of the iteration: later launches are no-ops
+}
+
+// ---------------------------------------------------------------------------------------------------
+// THIP_SCHED_SWEEP: the O(n + m) work between two sweeps over A (thip_sweep.hip).  Step k (k >= 1) is
+//   sw_xm_k   tau_k ; x_y_k, x_s_k from hN = A u_{k-1} (the groups' shares summed here), element-wise cones, rx
+//   [block cones]
+//   sw_vm_k   v_k from h2 = hP - 2 h3 (h3 = A x_x_k, carried form) ; partial sums of b.v_k, b.rx_y, ||p_k||^2, b.x_y_k
+//   sw_scal_k kappa_k
+//   SWEEP     u_k, x_x_{k+1}, gP = A^T x_y_k, the shares of A u_k and A x_x_{k+1}
+//   sw_post_k partial sums over n: ||d_k||^2, c.x_x_k, c.u_k, c.rx_x_k
+//   status_k  the termination test of iterate k (solver.rs:381-451)
+// The arithmetic of every update is xupdate_k's / ycrit_k's / post_k's.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, const float *__restrict__ partH,
+                                              float *__restrict__ h3, const float *__restrict__ b,
+                                              const float *__restrict__ v, const float *__restrict__ Ty,
+                                              const float *__restrict__ Ts, const unsigned char *__restrict__ cls,
+                                              float *__restrict__ xy, float *__restrict__ xs, float *__restrict__ rxy,
+                                              float *__restrict__ rxs, DevStatus *st, const float *ps_cu, int np_n,
+                                              const float *ps_bv, int np_m, float *__restrict__ ky, float *__restrict__ ks)
+{
+    if (st->stop != 0) return;
+    float dc = 0.0f, db = 0.0f;
+    if (blockIdx.x == 0) {
+        __shared__ double shd[16];
+        dc = block_sum_of_partials(ps_cu, np_n, shd);
+        db = block_sum_of_partials(ps_bv, np_m, shd);
+    }
+    const float kappa = st->kappa;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
+        float hN = 0.0f, hx = 0.0f;
+        for (int g = 0; g < ngroups; ++g) {
+            hN += partH[((size_t)g * 2 + 0) * mpad + i];
+            hx += partH[((size_t)g * 2 + 1) * mpad + i];
+        }
+        h3[i] = hx;
+        const unsigned char k = cls[i];
+        const float oy = xy[i], os = xs[i];
+        float ny = comp_add(oy, Ty[i] * (b[i] * kappa - hN), ky, i);
+        float ns = comp_add(os, Ts[i] * v[i], ks, i);
+        if (k == 1) { ny = fmaxf(ny, 0.0f); ns = fmaxf(ns, 0.0f); }
+        else if (k == 0) { ns = 0.0f; }
+        xy[i] = ny;
+        xs[i] = ns;
+        rxy[i] = (k < 2) ? oy - 2.0f * ny : oy;
+        rxs[i] = (k < 2) ? os - 2.0f * ns : os;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float old = st->tau;
+        float t = old + st->t_tau * (-dc - db);
+        t = fmaxf(t, 0.0f);
+        st->tau = t;
+        st->r_tau = old - 2.0f * t;
+    }
+}
+
+// part: [0] b.v_k, [1] b.rx_y, [2] ||p_k||^2, [3] b.x_y_k, gridDim.x block partials each
+__global__ __launch_bounds__(BLK) void sw_vm_k(int m, const float *__restrict__ h3, float *__restrict__ hP,
+                                              const float *__restrict__ b, const float *__restrict__ rxs,
+                                              const float *__restrict__ rxy, const float *__restrict__ Sv,
+                                              float *__restrict__ v, float *__restrict__ kv, const float *__restrict__ xs,
+                                              const float *__restrict__ xy, float eps_zero, const DevStatus *st,
+                                              float *__restrict__ part)
+{
+    if (st->stop != 0) return;
+    __shared__ float sh[16];
+    const float rtau = st->r_tau, tau = st->tau;
+    const bool conv = tau > eps_zero;
+    const float rt = conv ? 1.0f / tau : 1.0f;
+    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
+        const float nw = h3[i], bi = b[i];
+        const float h2 = hP[i] - 2.0f * nw;
+        hP[i] = nw;
+        const float vn = comp_add(v[i], Sv[i] * (h2 + rxs[i] - bi * rtau), kv, i);
+        v[i] = vn;
+        q0 = fmaf(bi, vn, q0);
+        q1 = fmaf(bi, rxy[i], q1);
+        float p;
+        if (conv) { p = xs[i] * rt - bi; p = fmaf(rt, nw, p); }
+        else p = xs[i] + nw;
+        q2 = fmaf(p, p, q2);
+        q3 = fmaf(bi, xy[i], q3);
+    }
+    q0 = block_sum(q0, sh); q1 = block_sum(q1, sh); q2 = block_sum(q2, sh); q3 = block_sum(q3, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = q0; part[gridDim.x + blockIdx.x] = q1;
+        part[2 * gridDim.x + blockIdx.x] = q2; part[3 * gridDim.x + blockIdx.x] = q3;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void sw_scal_k(DevStatus *st, const float *ps_crx, int np_n, const float *ps_brx, int np_m)
+{
+    if (st->stop != 0) return;
+    __shared__ double shd[16];
+    const float dc = block_sum_of_partials(ps_crx, np_n, shd);
+    const float db = block_sum_of_partials(ps_brx, np_m, shd);
+    if (threadIdx.x == 0) {
+        const float k = st->kappa + st->s_kappa * (dc + db);
+        st->kappa = fminf(k, 0.0f);       // solver.rs:566-567
+    }
+}
+
+// part: [0] ||d_k||^2, [1] c.x_x_k (the layout status_k reads), [2] c.u_k, [3] c.rx_x_k, gridDim.x block partials each
+__global__ __launch_bounds__(BLK) void sw_post_k(int n, const float *__restrict__ c, const float *__restrict__ xcur,
+                                                const float *__restrict__ xnxt, const float *__restrict__ u,
+                                                const float *__restrict__ gP, float eps_zero, const DevStatus *st,
+                                                float *__restrict__ part)
+{
+    if (st->stop != 0) return;
+    __shared__ float sh[16];
+    const float tau = st->tau;
+    const bool conv = tau > eps_zero;
+    const float rt = conv ? 1.0f / tau : 1.0f;
+    float dd = 0.0f, cx = 0.0f, cu = 0.0f, crx = 0.0f;
+    const size_t gstride = (size_t)gridDim.x * BLK;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
+        const float ci = c[i], xo = xcur[i];
+        const float d = conv ? fmaf(rt, gP[i], ci) : gP[i];
+        dd = fmaf(d, d, dd);
+        cx = fmaf(ci, xo, cx);
+        cu = fmaf(ci, u[i], cu);
+        crx = fmaf(ci, xo - 2.0f * xnxt[i], crx);
+    }
+    dd = block_sum(dd, sh); cx = block_sum(cx, sh); cu = block_sum(cu, sh); crx = block_sum(crx, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = dd; part[gridDim.x + blockIdx.x] = cx;
+        part[2 * gridDim.x + blockIdx.x] = cu; part[3 * gridDim.x + blockIdx.x] = crx;
+    }
 }
 
 // solver.rs:397-400: on Converged / ExcessIter in the tau > eps_zero branch, x_x and x_y are scaled by 1/tau.  Launched
@@ -571,6 +702,7 @@ struct thip_solver {
     // par.state_arith == THIP_STATE_COMPENSATED, NULL (plain f32 additions) otherwise
     float *kx = nullptr, *ky = nullptr, *ks = nullptr, *ku = nullptr, *kv = nullptr;
     bool comp() const { return par.state_arith == THIP_STATE_COMPENSATED; }
+    bool carried_like() const { return schedule == THIP_SCHED_CARRIED || schedule == THIP_SCHED_SWEEP; }
     size_t kahan_n = 0;                              // kx .. kv are contiguous: kahan_n floats from kx
     float *part = nullptr;                           // block partials (4 * EG)
     float *dotc = nullptr;                           // local scalars: [0] c.u, [1] c.rx_x, [2..3] dd,cx
@@ -603,6 +735,17 @@ struct thip_solver {
         if (split_plan) return is16() ? (tuned16_sp ? &hint16_sp : nullptr) : (tuned_sp ? &hint_sp : nullptr);
         return is16() ? (tuned16 ? &hint16 : nullptr) : (tuned ? &hint : nullptr);
     }
+    // THIP_SCHED_SWEEP (thip_sweep.hip): the second x_x buffer (x_x_{k+1} is formed while x_x_k is still the iterate), its
+    // Kahan term, the groups' shares of the N products, the granule ring, the census words, block partials
+    float *xx2 = nullptr, *kx2 = nullptr, *xx_home = nullptr, *kx_home = nullptr;
+    int xbuf = 0;                 // which of the two buffers s->xx points at (0: the arena's own)
+    SweepGeom sgeom{};
+    int sweep_state = 0;          // 0 not examined, 1 usable, -1 not usable for this problem / device
+    bool sw_first = true;         // the next sweep step starts from a consistent iterate (no u update, no test)
+    float *sw_partH = nullptr; unsigned long long *sw_gran = nullptr; unsigned *sw_census = nullptr;
+    float *sw_part = nullptr;     // 8 * EG block partials
+    unsigned sw_seq = 0, sw_tag = 0;
+    size_t sweep_min_bytes = (size_t)32 << 20;      // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
     bool inited = false;
@@ -769,7 +912,7 @@ int one_iteration(thip_solver *s)
     const int n = (int)s->n, m = (int)s->m;
     const unsigned g = egrid(s->n > s->m ? s->n : s->m);
     float *const part = s->part;
-    const bool carried = s->schedule == THIP_SCHED_CARRIED;
+    const bool carried = s->carried_like();
     const float ez = s->par.eps_zero;
     GemvPartials gp;
     // post_k leaves its sums as block partials: q0 (over the replicated n-vectors) in `part`, q1..q3 (over the local
@@ -839,7 +982,7 @@ int one_iteration(thip_solver *s)
     if (split && carried) { ycrit(0, 1); THIP_RC(allreduce_end(s)); ycrit(1, 0); }
     else                  { THIP_RC(allreduce_end(s)); ycrit(1, 1); }
     hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part_y, s->par.eps_acc, s->par.eps_inf,
-                       ez, (long long)s->par.max_iter, s->dst, shp(s->g3) + 2 * gq, shp(s->g3) + 3 * gq, (int)gq);
+                       ez, (long long)s->par.max_iter, s->dst, shp(s->g3) + 2 * gq, shp(s->g3) + 3 * gq, (int)gq, 0);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -900,7 +1043,7 @@ int autotune_gemv(thip_solver *s);
 // decides the form of the next run: column-split (its own tuned plan, its split column) or one launch per pass
 int prepare_split(thip_solver *s)
 {
-    s->split_plan = s->overlap >= 2 && s->allreduce != nullptr && !s->sparse && s->schedule == THIP_SCHED_CARRIED
+    s->split_plan = s->overlap >= 2 && s->allreduce != nullptr && !s->sparse && s->carried_like()
                     && s->m > 0 && s->n > 0;
     s->n1 = 0;
     if (s->inited) THIP_RC(autotune_gemv(s));        // once per stored form and launch form (a no-op afterwards)
@@ -993,7 +1136,7 @@ int split_tail(thip_solver *s)
     THIP_RC(ar_wait(s, 3));
     split_ycrit(c, 1, 0, 1);
     hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, c.st, 2 * (int)c.g, c.part_y, s->par.eps_acc, s->par.eps_inf, c.ez,
-                       (long long)s->par.max_iter, s->dst, s->g3 + s->n + 2 * NPS, s->g3 + s->n + 3 * NPS, (int)NPS);
+                       (long long)s->par.max_iter, s->dst, s->g3 + s->n + 2 * NPS, s->g3 + s->n + 3 * NPS, (int)NPS, 0);
     THIP_LAUNCH_CHECK();
     s->tail_pending = false;
     return 0;
@@ -1128,7 +1271,7 @@ int autotune_gemv(thip_solver *s)
 int rebuild_carried(thip_solver *s)
 {
     s->carried_stale = false;
-    if (s->schedule != THIP_SCHED_CARRIED || s->m == 0 || s->n == 0) return 0;
+    if (!s->carried_like() || s->m == 0 || s->n == 0) return 0;
     hipStream_t st = ctx().stream;
     GemvPartials gp;
     THIP_RC(products(s, s->xx, s->xy, &gp, s->hP, s->gP));
@@ -1137,6 +1280,122 @@ int rebuild_carried(thip_solver *s)
         THIP_RC(finalize_partials(st, s->n, gp.partT, gp.nT, gp.strideT, 1.0f, 0.0f, s->gP, nullptr));
     }
     THIP_RC(do_allreduce(s, s->gP, s->n));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// THIP_SCHED_SWEEP on the host
+// ---------------------------------------------------------------------------------------------------
+// Can the next run use the one-pass kernel?  Dense f32 A on one GPU in a shape sweep_plan() takes, on a device whose
+// placement census came out as 8 x 32 in a dry run.  Examined once per (re)initialisation.
+int sweep_prepare(thip_solver *s)
+{
+    if (s->schedule != THIP_SCHED_SWEEP) return 0;
+    if (s->allreduce != nullptr || s->sparse || s->is16() || s->m == 0 || s->n == 0) return 0;      // not now (may change)
+    if (s->sweep_state != 0) return 0;
+    s->sweep_state = -1;
+    static const int env_off = getenv("THIP_SWEEP_OFF") ? atoi(getenv("THIP_SWEEP_OFF")) : 0;
+    if (env_off) return 0;
+    size_t m_eff = s->m;
+    // a library-owned padded copy has zero rows behind row m, and every m-vector of the arena has zeros behind entry m
+    if (m_eff % 4 != 0 && s->Apad != nullptr && s->ldpad >= (m_eff + 3) / 4 * 4) m_eff = (m_eff + 3) / 4 * 4;
+    if (s->m * s->n * sizeof(float) < s->sweep_min_bytes) return 0;
+    SweepGeom g;
+    if (sweep_plan(m_eff, s->n, s->alda(), s->amat(), &g) != 0) return 0;
+    hipStream_t st = ctx().stream;
+    if (!s->sw_census) {
+        THIP_TRY(hipMalloc((void **)&s->sw_census, 64 * sizeof(unsigned)));
+        THIP_TRY(hipMalloc((void **)&s->sw_part, 8 * EG * sizeof(float)));
+    }
+    THIP_TRY(hipMemsetAsync(s->sw_census, 0, 64 * sizeof(unsigned), st));
+    s->sw_seq = 0;
+    THIP_RC(sweep_census_dry_run(st, s->sw_census, s->sw_seq++));
+    unsigned hc[10];
+    THIP_TRY(hipMemcpyAsync(hc, s->sw_census, sizeof(hc), hipMemcpyDeviceToHost, st));
+    THIP_TRY(hipStreamSynchronize(st));
+    if (hc[9] != 0u) return 0;                      // not 32 workgroups per XCD: the carried schedule runs
+    if (s->sw_partH) { THIP_TRY(hipFree(s->sw_partH)); s->sw_partH = nullptr; }
+    if (s->sw_gran) { THIP_TRY(hipFree(s->sw_gran)); s->sw_gran = nullptr; }
+    THIP_TRY(hipMalloc((void **)&s->sw_partH, (size_t)g.ngroups * 2 * g.mpad * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&s->sw_gran, sweep_gran_words(g) * sizeof(unsigned long long)));
+    THIP_TRY(hipMemsetAsync(s->sw_partH, 0, (size_t)g.ngroups * 2 * g.mpad * sizeof(float), st));
+    THIP_TRY(hipMemsetAsync(s->sw_gran, 0, sweep_gran_words(g) * sizeof(unsigned long long), st));
+    s->sgeom = g;
+    s->sgeom.m_eff = (int)m_eff;
+    s->sweep_state = 1;
+    return 0;
+}
+
+bool sweep_active(const thip_solver *s)
+{
+    return s->schedule == THIP_SCHED_SWEEP && s->sweep_state == 1 && s->allreduce == nullptr && !s->sparse && !s->is16();
+}
+
+int sweep_pass(thip_solver *s, int first)
+{
+    hipStream_t st = ctx().stream;
+    const SweepGeom &g = s->sgeom;
+    SweepArgs a;
+    a.A = reinterpret_cast<const float *>(s->amat()); a.lda = s->alda(); a.m = g.m_eff; a.n = (int)s->n;
+    a.G = g.G; a.rows_per_member = g.rows_per_member; a.cols_per_group = g.cols_per_group;
+    a.v = s->v; a.xy = s->xy; a.c = s->c; a.Su = s->Su; a.Tx = s->Tx;
+    a.u = s->u; a.ku = s->comp() ? s->ku : nullptr;
+    const bool b0 = s->xbuf == 0;        // s->xx is the arena's own buffer
+    a.xx_in = s->xx; a.xx_out = b0 ? s->xx2 : s->xx_home;
+    a.kx_in = s->comp() ? s->kx : nullptr; a.kx_out = s->comp() ? (b0 ? s->kx2 : s->kx_home) : nullptr;
+    a.gP = s->gP;
+    a.partH = s->sw_partH; a.mpad = g.mpad; a.gran = s->sw_gran; a.census = s->sw_census;
+    a.seq = s->sw_seq++; a.tagbase = s->sw_tag; s->sw_tag += (unsigned)g.npan + 1u;
+    a.first = first; a.dbg = 0;
+    a.stop = &s->dst->stop; a.kappa_p = &s->dst->kappa; a.rtau_p = &s->dst->r_tau;
+    prof_begin(st);
+    THIP_RC(sweep_launch(st, g, a));
+    prof_end(st);
+    return 0;
+}
+
+void sweep_swap(thip_solver *s)
+{
+    const bool b0 = s->xbuf == 0;
+    s->xx = b0 ? s->xx2 : s->xx_home;
+    s->kx = b0 ? s->kx2 : s->kx_home;
+    s->xbuf ^= 1;
+}
+
+// the x_x buffer that is NOT the iterate: x_x_{k+1} after a sweep
+float *sweep_next(thip_solver *s) { return s->xbuf == 0 ? s->xx2 : s->xx_home; }
+
+int one_iteration_sweep(thip_solver *s)
+{
+    hipStream_t st = ctx().stream;
+    const int n = (int)s->n, m = (int)s->m;
+    const unsigned gn = egrid(s->n), gm = egrid(s->m);
+    const float ez = s->par.eps_zero;
+    float *const pn = s->sw_part;                 // [0] ||d||^2 [1] c.x_x [2] c.u [3] c.rx_x, gn partials each
+    float *const pm = s->sw_part + 4 * EG;        // [0] b.v [1] b.rx_y [2] ||p||^2 [3] b.x_y, gm partials each
+    float *const ky = s->comp() ? s->ky : nullptr, *const ks = s->comp() ? s->ks : nullptr;
+    float *const kv = s->comp() ? s->kv : nullptr;
+    auto post = [&]() {
+        hipLaunchKernelGGL(sw_post_k, dim3(gn), dim3(BLK), 0, st, n, s->c, s->xx, sweep_next(s), s->u, s->gP, ez, s->dst, pn);
+    };
+    if (s->sw_first) {
+        // from a consistent iterate (x_0, or wherever a run stopped): u is current, so the sweep leaves it alone
+        THIP_RC(sweep_pass(s, 1));
+        post();
+        s->sw_first = false;
+    }
+    hipLaunchKernelGGL(sw_xm_k, dim3(gm), dim3(BLK), 0, st, m, s->sgeom.ngroups, s->sgeom.mpad, s->sw_partH, s->h3, s->b, s->v,
+                       s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs, s->dst, pn + 2 * gn, (int)gn, pm, (int)gm, ky, ks);
+    THIP_RC(project_blocks(s));
+    hipLaunchKernelGGL(sw_vm_k, dim3(gm), dim3(BLK), 0, st, m, s->h3, s->hP, s->b, s->rxs, s->rxy, s->Sv, s->v, kv, s->xs,
+                       s->xy, ez, s->dst, pm);
+    hipLaunchKernelGGL(sw_scal_k, dim3(1), dim3(BLK), 0, st, s->dst, pn + 3 * gn, (int)gn, pm + gm, (int)gm);
+    sweep_swap(s);                                // x_x_k (formed by the previous sweep) is now the iterate
+    THIP_RC(sweep_pass(s, 0));
+    post();
+    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)gn, pn, s->par.eps_acc, s->par.eps_inf, ez,
+                       (long long)s->par.max_iter, s->dst, pm + 2 * gm, pm + 3 * gm, (int)gm, s->xbuf);
+    THIP_LAUNCH_CHECK();
     return 0;
 }
 
@@ -1184,6 +1443,12 @@ int poll(thip_solver *s, thip_status *out)
     hipStream_t st = ctx().stream;
     THIP_TRY(hipMemcpyAsync(s->hst, s->dst, sizeof(DevStatus), hipMemcpyDeviceToHost, st));
     THIP_TRY(hipStreamSynchronize(st));
+    if (s->hst->state != THIP_ST_RUNNING && s->schedule == THIP_SCHED_SWEEP) {
+        // the device stopped at an iterate of its own choosing: the host kept swapping the two x_x buffers for the
+        // launches that then returned at entry -- point s->xx at the buffer the termination test recorded
+        if (s->sweep_state == 1 && !s->sw_first && s->hst->xbuf != s->xbuf) sweep_swap(s);
+        s->sw_first = true;
+    }
     if (s->hst->state != THIP_ST_RUNNING && !s->finalized) {
         // the device has stopped by itself: apply the final 1/tau scaling once (solver.rs:397-400)
         hipLaunchKernelGGL(finalize_k, dim3(egrid(s->n > s->m ? s->n : s->m)), dim3(BLK), 0, st, (int)s->n, (int)s->m,
@@ -1208,7 +1473,7 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
 {
     THIP_NEED_INIT();
     if (!prob || !par || !out) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
-    if (schedule < 0 || schedule > 2) return fail(THIP_E_INVALID, "bad schedule", __FILE__, __LINE__);
+    if (schedule < 0 || schedule > THIP_SCHED_SWEEP) return fail(THIP_E_INVALID, "bad schedule", __FILE__, __LINE__);
     int64_t tot = 0;
     for (size_t i = 0; i < prob->n_seg; ++i) {
         if (prob->host_seg_len[i] < 0 || prob->host_seg_type[i] < 0 || prob->host_seg_type[i] > THIP_CONE_PSD)
@@ -1291,20 +1556,21 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
     const size_t pn = pad64(n + TAIL), pm = pad64(m + 1);
     if (par->state_arith != THIP_STATE_COMPENSATED && par->state_arith != THIP_STATE_PLAIN)
         return fail(THIP_E_INVALID, "bad thip_param.state_arith", __FILE__, __LINE__);
-    const size_t total = 9 * pn /* xx u Tx Su rxx g1 g2 g3 gP */ + 13 * pm + 64 + 2 * pn + 3 * pm /* Kahan terms */;
+    const size_t total = 10 * pn /* xx u Tx Su rxx g1 g2 g3 gP xx2 */ + 13 * pm + 64 + 3 * pn + 3 * pm /* Kahan terms */;
     THIP_TRY(hipMalloc((void **)&s->arena, total * sizeof(float)));
     THIP_TRY(hipMemsetAsync(s->arena, 0, total * sizeof(float), st));
     s->arena_n = total;
     float *p = s->arena;
     auto take = [&](size_t k) { float *r = p; p += k; return r; };
     s->xx = take(pn); s->u = take(pn); s->Tx = take(pn); s->Su = take(pn); s->rxx = take(pn);
-    s->g1 = take(pn); s->g2 = take(pn); s->g3 = take(pn); s->gP = take(pn);
+    s->g1 = take(pn); s->g2 = take(pn); s->g3 = take(pn); s->gP = take(pn); s->xx2 = take(pn);
     s->xy = take(pm); s->xs = take(pm); s->v = take(pm); s->Ty = take(pm); s->Ts = take(pm); s->Sv = take(pm);
     s->rxy = take(pm); s->rxs = take(pm); s->h1 = take(pm); s->h2 = take(pm); s->h3 = take(pm); s->hP = take(pm);
     (void)take(pm);
     s->dotc = take(64);
-    s->kx = take(pn); s->ku = take(pn); s->ky = take(pm); s->ks = take(pm); s->kv = take(pm);
-    s->kahan_n = 2 * pn + 3 * pm;
+    s->kx = take(pn); s->ku = take(pn); s->ky = take(pm); s->ks = take(pm); s->kv = take(pm); s->kx2 = take(pn);
+    s->kahan_n = 3 * pn + 3 * pm;
+    s->xx_home = s->xx; s->kx_home = s->kx;
 
     THIP_TRY(hipMalloc((void **)&s->part, (4 * PG + 4 * EG) * sizeof(float)));
     // the dense GEMV partial-sum scratch (~ m n / 256 floats) is allocated by thip_solver_init, and only for a dense A
@@ -1391,6 +1657,10 @@ int thip_solver_init(thip_solver *s)
     s->hst->state = THIP_ST_RUNNING;
     THIP_RC(ensure_gemv_scratch(s));
     if (!s->is16()) THIP_RC(ensure_apad(s, true));      // a fresh solve re-reads the caller's A (it may have changed in place)
+    s->xx = s->xx_home; s->kx = s->kx_home; s->xbuf = 0;
+    s->sw_first = true; s->sweep_state = 0;
+    THIP_RC(sweep_prepare(s));
+    if (s->sw_part) THIP_TRY(hipMemsetAsync(s->sw_part, 0, 8 * EG * sizeof(float), st));
     // init_vecs (solver.rs:483-494): x = 0, y = 0, tau = 1
     THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
     hipLaunchKernelGGL(init_status_k, dim3(1), dim3(1), 0, st, s->dst, 0.0f);
@@ -1442,10 +1712,19 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
     if (s->carried_stale && s->hst->state == THIP_ST_RUNNING) THIP_RC(rebuild_carried(s));
     THIP_RC(prepare_split(s));
     const bool split = split_active(s);
+    THIP_RC(sweep_prepare(s));
+    const bool sweep = sweep_active(s);
+    if (!sweep) s->sw_first = true;         // whatever runs instead leaves a consistent iterate and gP / hP of it
     while (s->hst->state == THIP_ST_RUNNING && (max_steps < 0 || done < max_steps)) {
         int64_t batch = poll_every;
         if (max_steps >= 0 && done + batch > max_steps) batch = max_steps - done;
-        for (int64_t k = 0; k < batch; ++k) THIP_RC(split ? one_iteration_split(s) : one_iteration(s));
+        for (int64_t k = 0; k < batch; ++k) THIP_RC(sweep ? one_iteration_sweep(s) : (split ? one_iteration_split(s) : one_iteration(s)));
+        if (sweep) {
+            unsigned err = 0;
+            THIP_TRY(hipMemcpyAsync(&err, s->sw_census + 9, sizeof(err), hipMemcpyDeviceToHost, ctx().stream));
+            THIP_TRY(hipStreamSynchronize(ctx().stream));
+            if (err != 0u) return fail(THIP_E_INVALID, "the one-pass kernel gave up (placement changed or a spin ran out)", __FILE__, __LINE__);
+        }
         if (s->tail_pending) THIP_RC(split_tail(s));       // drain the pipeline before the host looks
         done += batch;
         THIP_RC(poll(s, host_status));
@@ -1581,7 +1860,7 @@ int thip_solver_set_param(thip_solver *s, const thip_param *par)
         return fail(THIP_E_INVALID, "bad thip_param.state_arith", __FILE__, __LINE__);
     // compensation switched on inside a solve starts from clean Kahan terms
     if (s->par.state_arith != par->state_arith && par->state_arith == THIP_STATE_COMPENSATED && s->kx && ctx().inited)
-        THIP_TRY(hipMemsetAsync(s->kx, 0, s->kahan_n * sizeof(float), ctx().stream));
+        THIP_TRY(hipMemsetAsync(s->kx_home, 0, s->kahan_n * sizeof(float), ctx().stream));
     s->par = *par;
     return 0;
 }
@@ -1608,11 +1887,28 @@ int thip_solver_resume(thip_solver *s)
 int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_bytes_per_pass)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
-    if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : 2);
+    if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : (sweep_active(s) ? 1 : 2));
     // the algorithmic bytes of a pass (4 m n, or 2 m n for a 16-bit A); the padding rows of a library-owned
     // copy (at most 15 per column) are zeros that the kernel never loads
     if (host_bytes_per_pass) *host_bytes_per_pass = s->sparse ? 2 * s->nnz * (sizeof(float) + sizeof(int32_t))
                                                               : s->m * s->n * (s->is16() ? 2 : sizeof(float));
+    return 0;
+}
+
+int thip_solver_schedule_in_use(thip_solver *s, int *host_schedule)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    THIP_NEED_INIT();
+    if (s->inited) THIP_RC(sweep_prepare(s));
+    if (host_schedule) *host_schedule = (s->schedule == THIP_SCHED_SWEEP && !sweep_active(s)) ? THIP_SCHED_CARRIED : s->schedule;
+    return 0;
+}
+
+int thip_solver_set_sweep_min_bytes(thip_solver *s, size_t bytes)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    s->sweep_min_bytes = bytes;
+    s->sweep_state = 0;
     return 0;
 }
 
@@ -1710,6 +2006,7 @@ int thip_solver_destroy(thip_solver *s)
     for (auto &g : s->psd_groups) hipFree(g.dev_offs);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
     hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->Apad); if (s->A16_owned) hipFree(s->A16); if (s->inv_s_owned) hipFree(s->inv_s);
+    hipFree(s->sw_partH); hipFree(s->sw_gran); hipFree(s->sw_census); hipFree(s->sw_part);
     if (s->hst) hipHostFree(s->hst);
     delete s;
     return 0;

@@ -10,7 +10,8 @@ from . import _lib
 from ._lib import lib
 from .solver import SolverError, SolverParam
 
-SCHEDULES = {"reference": _lib.SCHED_REFERENCE, "fused": _lib.SCHED_FUSED, "carried": _lib.SCHED_CARRIED}
+SCHEDULES = {"reference": _lib.SCHED_REFERENCE, "fused": _lib.SCHED_FUSED, "carried": _lib.SCHED_CARRIED,
+             "sweep": _lib.SCHED_SWEEP}
 
 
 class DeviceBuffer:
@@ -119,7 +120,8 @@ class FusedResult:
 
 class FusedSolver:
     def __init__(self, n, m, mat_a, vec_b, vec_c, seg_type, seg_len, param=None, schedule="fused",
-                 vec_b_rowabs=None, allreduce=None, a_storage="f32", overlap=None, gemv_autotune=None, lda_pad=None):
+                 vec_b_rowabs=None, allreduce=None, a_storage="f32", overlap=None, gemv_autotune=None, lda_pad=None,
+                 sweep_min_bytes=None):
         """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded).
         a_storage: "f32" (the matrix as given), "bf16" or "f16" (a rounded 16-bit copy streamed at half the bytes; f16
         is column-scaled and rounds 8x finer; see set_a_storage / include/totsu_f32hip.h).
@@ -179,6 +181,8 @@ class FusedSolver:
             lib.thip_solver_set_gemv_autotune(self.h, 1 if gemv_autotune else 0)     # False: bit-reproducible across runs
         if lda_pad is not None:
             lib.thip_solver_set_lda_pad(self.h, int(lda_pad))
+        if sweep_min_bytes is not None:
+            lib.thip_solver_set_sweep_min_bytes(self.h, int(sweep_min_bytes))   # 0: "sweep" whenever the kernel takes the shape
         self.a_storage = "f32"
         if self._a16 is not None:
             if self._a16.kind == "f16":
@@ -270,6 +274,16 @@ class FusedSolver:
         nj, bl, ms = C.c_int(), C.c_int(), C.c_float()
         lib.thip_solver_gemv_plan(self.h, C.byref(nj), C.byref(bl), C.byref(ms))
         return {"rows_groups_per_lane": nj.value, "target_workgroups": bl.value, "autotune_ms": ms.value}
+
+    def schedule_in_use(self):
+        """the schedule the next run executes: "sweep" falls back to "carried" when the one-pass kernel cannot take the
+        problem (thip_solver_schedule_in_use)"""
+        v = C.c_int()
+        lib.thip_solver_schedule_in_use(self.h, C.byref(v))
+        return {v_: k for k, v_ in SCHEDULES.items()}[v.value]
+
+    def set_sweep_min_bytes(self, nbytes):
+        lib.thip_solver_set_sweep_min_bytes(self.h, int(nbytes))
 
     def passes(self):
         p, b = C.c_int(), C.c_size_t()
