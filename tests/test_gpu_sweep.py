@@ -239,7 +239,7 @@ def test_sweep_is_reproducible_and_independent_of_the_polling_period(T):
 
 def test_sweep_falls_back_to_carried(T):
     # too few columns for the kernel, and (default threshold) too small a matrix
-    lp, _ = _lp(T, 40, 1)
+    lp, _ = _lp(T, 24, 1)
     p = T.SolverParam()
     p.eps_acc = 1e-30
     fs = T.FusedSolver.from_dense(lp.dense(), p, "sweep", sweep_min_bytes=0)

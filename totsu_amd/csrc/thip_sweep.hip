@@ -45,7 +45,8 @@ constexpr int SW_CT = SW_CW * 64;          // streaming threads
 constexpr int SW_RING = 32;                // granule slots per group (> 2 (LAGL - DLAG) - 1: see the header of sweep_k)
 constexpr int SW_CR = 16;                  // slots of the per-column LDS ring (> LAGL - DLAG)
 constexpr int SW_SPIN_MAX = 2000000;
-constexpr int SW_MAXROWS = SW_CT * 4 * 2;  // rows a member can own (two 16-byte slots per streaming thread)
+constexpr int SW_MAXSLOT = 7;               // 16-byte slots of a column per streaming thread, at most
+constexpr int SW_MAXROWS = SW_CT * 4 * SW_MAXSLOT;  // rows a member can own
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -93,8 +94,14 @@ __device__ __forceinline__ void sw_halve(float *v, int lane)
 template <int K>
 __device__ __forceinline__ float sw_reduce(float *v, int lane)
 {
-    static_assert(K == 4 || K == 8, "2 or 4 columns per panel");
-    if constexpr (K == 8) {
+    static_assert(K == 2 || K == 4 || K == 8, "1, 2 or 4 columns per panel");
+    if constexpr (K == 2) {
+        sw_halve<2, 32>(v, lane);
+        float r = v[0];
+        r += __shfl_xor(r, 16, 64); r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 4, 64);
+        r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
+        return r;
+    } else if constexpr (K == 8) {
         sw_halve<8, 32>(v, lane); sw_halve<4, 16>(v, lane); sw_halve<2, 8>(v, lane);
         float r = v[0];
         r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
@@ -498,13 +505,21 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 namespace thip {
 
 namespace {
-// (W, LAGL, DLAG, LS) of the kernel variants; THIP_SWEEP_VARIANT picks one (experiments), default 0
-struct SwVariant { int w, lagl, dlag, ls; };
-const SwVariant g_variants[4] = { { 2, 8, 3, 5 }, { 2, 8, 3, 0 }, { 2, 8, 3, 3 }, { 2, 6, 3, 5 } };
+// Kernel classes: (columns per panel W, 16-byte slots per thread NSLOT, load lead LAGL, dot lead DLAG, LDS panels LS).  What a
+// class fixes is the BYTES a workgroup stages per panel, W x rows x 4: the ring's depth in time is (bytes staged) / (the
+// workgroup's share of the HBM stream) whatever the shape, so fewer members per group (more rows each, one column per
+// panel) buy longer intervals for the service wave and fewer workgroups that can hold a group up.
+struct SwClass { int w, nslot_max; };
+const SwClass g_classes[3] = { { 2, 2 }, { 1, 4 }, { 1, 7 } };
+int sweep_class()
+{
+    static const int v = getenv("THIP_SWEEP_CLASS") ? atoi(getenv("THIP_SWEEP_CLASS")) : 2;
+    return v >= 0 && v < 3 ? v : 0;
+}
 int sweep_variant()
 {
     static const int v = getenv("THIP_SWEEP_VARIANT") ? atoi(getenv("THIP_SWEEP_VARIANT")) : 0;
-    return v >= 0 && v < 4 ? v : 0;
+    return v >= 0 && v < 2 ? v : 0;
 }
 }  // namespace
 
@@ -514,12 +529,18 @@ int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g)
     if (m == 0 || n == 0 || m % 4 != 0 || lda % 4 != 0 || ((uintptr_t)mat & 15u) != 0) return 1;
     if (m > (size_t)SW_MAXROWS * 32 || n > ((size_t)1 << 30)) return 1;
     if (ctx().num_cu != 256) return 1;
-    const int variant = sweep_variant();
-    const int W = g_variants[variant].w;
-    int G = 1;
-    while (G < 32 && ((m + G - 1) / G + 3) / 4 * 4 > (size_t)SW_MAXROWS) G *= 2;
-    const size_t rpm = ((m + G - 1) / G + 3) / 4 * 4;
-    if (rpm > (size_t)SW_MAXROWS) return 1;
+    int cls = sweep_class();
+    int G = 32;
+    size_t rpm = 0;
+    for (; cls < 3; ++cls) {
+        const size_t cap = (size_t)SW_CT * 4 * g_classes[cls].nslot_max;
+        G = 1;
+        while (G < 32 && ((m + G - 1) / G + 3) / 4 * 4 > cap) G *= 2;
+        rpm = ((m + G - 1) / G + 3) / 4 * 4;
+        if (rpm <= cap) break;
+    }
+    if (cls == 3) return 1;
+    const int W = g_classes[cls].w;
     const int ngroups = 256 / G;
     // at least 40 panels per group that has columns at all (the ring's fill and drain); with few columns some groups idle
     size_t cpg = (n + ngroups - 1) / ngroups;
@@ -527,9 +548,10 @@ int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g)
     cpg = (cpg + W - 1) / W * W;
     if (n < (size_t)40 * W) return 1;
     g->G = G; g->ngroups = ngroups; g->rows_per_member = (int)rpm; g->cols_per_group = (int)cpg;
-    g->nslot = rpm > (size_t)SW_CT * 4 ? 2 : 1;
+    const int need = (int)((rpm + (size_t)SW_CT * 4 - 1) / ((size_t)SW_CT * 4));
+    g->nslot = cls == 0 ? (need <= 1 ? 1 : 2) : (cls == 1 ? 4 : 7);
     g->mpad = (m + 63) / 64 * 64;
-    g->w = W; g->variant = variant;
+    g->w = W; g->variant = sweep_variant();
     g->npan = (int)(cpg / W);
     return 0;
 }
@@ -560,20 +582,12 @@ static int sweep_go(hipStream_t st, const SweepArgs &a)
 
 int sweep_launch(hipStream_t st, const SweepGeom &g, const SweepArgs &a)
 {
-    if (g.nslot == 2) {
-        switch (g.variant) {
-        case 1: return sweep_go<2, 2, 8, 3, 0>(st, a);
-        case 2: return sweep_go<2, 2, 8, 3, 3>(st, a);
-        case 3: return sweep_go<2, 2, 6, 3, 5>(st, a);
-        default: return sweep_go<2, 2, 8, 3, 5>(st, a);
-        }
+    if (g.w == 2) {
+        if (g.nslot == 2) return g.variant == 1 ? sweep_go<2, 2, 8, 3, 0>(st, a) : sweep_go<2, 2, 8, 3, 5>(st, a);
+        return g.variant == 1 ? sweep_go<1, 2, 8, 3, 0>(st, a) : sweep_go<1, 2, 8, 3, 5>(st, a);
     }
-    switch (g.variant) {
-    case 1: return sweep_go<1, 2, 8, 3, 0>(st, a);
-    case 2: return sweep_go<1, 2, 8, 3, 3>(st, a);
-    case 3: return sweep_go<1, 2, 6, 3, 5>(st, a);
-    default: return sweep_go<1, 2, 8, 3, 5>(st, a);
-    }
+    if (g.nslot == 4) return g.variant == 1 ? sweep_go<4, 1, 8, 3, 3>(st, a) : sweep_go<4, 1, 8, 3, 5>(st, a);
+    return g.variant == 1 ? sweep_go<7, 1, 3, 1, 2>(st, a) : sweep_go<7, 1, 2, 1, 3>(st, a);
 }
 
 }  // namespace thip
