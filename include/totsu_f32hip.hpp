@@ -288,7 +288,7 @@ class FusedSolver {
 public:
     // a, b, c: device slices (A column-major m x n); seg_type: THIP_CONE_*, seg_len: rows of each segment
     FusedSolver(size_t n, size_t m, Slice a, Slice b, Slice c, const std::vector<int32_t> &seg_type,
-                const std::vector<int64_t> &seg_len, const SolverParam &par, int schedule = THIP_SCHED_CARRIED)
+                const std::vector<int64_t> &seg_len, const SolverParam &par, int schedule = THIP_SCHED_SWEEP)
         : n_(n), m_(m), seg_type_(seg_type), seg_len_(seg_len)
     {
         thip_problem prob{};

@@ -536,7 +536,7 @@ inline SolverError solve(Solver &s, Problem &pr, SolveInfo *info = nullptr, bool
         p.max_iter = s.par.max_iter; p.eps_acc = s.par.eps_acc; p.eps_inf = s.par.eps_inf; p.eps_zero = s.par.eps_zero;
         p.state_arith = s.par.state_arith;
         thip_solver *h = nullptr;
-        chk(thip_solver_create(&prob, &p, THIP_SCHED_CARRIED, &h));
+        chk(thip_solver_create(&prob, &p, THIP_SCHED_SWEEP, &h));      // falls back to the carried schedule by itself
         thip_status st{};
         int rc = thip_solver_init(h);
         if (rc == 0) rc = thip_solver_run(h, max_steps, 64, &st);

@@ -52,7 +52,10 @@ def pmc(fetch_db, write_db, key):
         for name, calls, val, dur in cur.execute(q, (label,)):
             short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             print("%-6d %-16.1f %-12.1f %s" % (calls, val, dur / 1e3, short))
-            if short.startswith("dual_gemv_k<") and ", true, true, false" in short \
+            if key.endswith("_sweep"):
+                if "sweep_k<" in short:
+                    out.setdefault(label, val)
+            elif short.startswith("dual_gemv_k<") and ", true, true, false" in short \
                     and ("unsigned short" in short) == key.endswith("_bf16"):                # DO_N, DO_T, !ABS; storage type
                 out.setdefault(label, val)      # rows are ordered by total traffic: keep the dominant plan
         print()
@@ -61,7 +64,7 @@ def pmc(fetch_db, write_db, key):
         wr = out.get("WRITE_SIZE", 0.0) * 1024.0
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hbm_traffic.json")
         d = json.load(open(path)) if os.path.exists(path) else {}
-        d[key] = {"kernel": "dual_gemv_k<DO_N, DO_T>", "fetch_size_KiB_raw": out["FETCH_SIZE"],
+        d[key] = {"kernel": "sweep_k" if key.endswith("_sweep") else "dual_gemv_k<DO_N, DO_T>", "fetch_size_KiB_raw": out["FETCH_SIZE"],
                   "write_size_KiB_raw": out.get("WRITE_SIZE"), "read_bytes_corrected_x2": rd, "write_bytes": wr,
                   "hbm_bytes_per_launch": rd + wr}
         json.dump(d, open(path, "w"), indent=1)

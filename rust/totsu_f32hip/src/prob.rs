@@ -143,7 +143,7 @@ impl HipSolver {
     pub fn par<P: FnOnce(&mut SolverParam<f32>)>(mut self, f: P) -> Self { f(&mut self.inner.param); self }
     pub fn solve<C>(self, prob: HipProblem<'_, C>) -> Result<(Vec<f32>, Vec<f32>), SolverError>
     where C: FnOnce(&Solver<F32HIP>) -> Result<(&[f32], &[f32]), SolverError> {
-        if self.fused { FusedSolver::with_state_arith(prob.dense, &self.inner.param, THIP_SCHED_CARRIED, self.state_arith).solve() }
+        if self.fused { FusedSolver::with_state_arith(prob.dense, &self.inner.param, THIP_SCHED_SWEEP, self.state_arith).solve() }
         else { (prob.by_calls)(&self.inner).map(|(x, y)| (x.to_vec(), y.to_vec())) }
     }
 }

@@ -449,7 +449,7 @@ def test_unchanged_caller_takes_the_fused_path(T):
     s = T.Solver(T.F32HIP)
     s.param.eps_acc = 1e-3
     x, y = s.solve(lp.problem())
-    assert s.fused == "carried" and s.iters > 10
+    assert s.fused == "sweep" and s.iters > 10          # the asked-for schedule; a 60 x 30 problem runs "carried" (thip_solver_schedule_in_use)
     assert np.array_equal(lp.w_solver[:30], x) and np.array_equal(lp.w_solver[30:90], y)
     ro = O.solve_lp(O.param(eps_acc=1e-3), c, G, h, np.zeros((0, 30)), [])
     assert abs(s.iters - ro.iters) <= max(3, 0.02 * ro.iters)

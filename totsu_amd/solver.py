@@ -123,7 +123,7 @@ class Solver:
         # drop-in fast path: when L is F32HIP and the operators come from one of this package's problem builders
         # (dense MatOps), solve() runs the device-resident fused loop with this schedule; None = always take the
         # trait-level loop below (one L call per reference call)
-        self.fused = "carried"
+        self.fused = "sweep"            # one pass over A per iteration where the kernel takes the problem, else "carried"
         self.iters = -1
 
     @staticmethod
