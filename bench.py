@@ -589,7 +589,7 @@ def run(a):
         "frac": achieved / HBM_PEAK_GBPS,
         "traffic": None,
         "traffic_source": None,
-        "timer": "hip_events on the launch stream around every dual_gemv_k launch of the timed region (thip_prof_*)",
+        "timer": "hip_events on the launch stream around every launch of that kernel in the timed region (thip_prof_*)",
         "bytes_per_launch": bytes_per_pass / lpp,
         "launches_per_pass": lpp,
         "avg_launch_ms": avg_ms,

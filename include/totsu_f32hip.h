@@ -369,6 +369,13 @@ int thip_solver_schedule_in_use(thip_solver *s, int *host_schedule);
 /* THIP_SCHED_SWEEP is used for matrices of at least this many bytes (default 32 MiB: below that an iteration is a handful
  * of launches whatever the schedule); 0 = whenever the kernel can take the shape.  Before thip_solver_init. */
 int thip_solver_set_sweep_min_bytes(thip_solver *s, size_t bytes);
+/* N > 1 with THIP_SCHED_SWEEP: the problem given to thip_solver_create is this rank's block of COLUMNS -- mat_a is
+ * m x n_local (all m rows), vec_c its n_local entries, vec_b and the cone segments the whole problem's -- the n-vectors are
+ * sharded, the m-vectors replicated and updated redundantly, and the hook of thip_solver_set_allreduce is called ONCE per
+ * iteration on 2 * roundup(m, 64) + 2048 floats (the two N products and the block partials of the sums over n; one call
+ * more in thip_solver_init).  Every rank must get bitwise the same sums back (RCCL, the one-shot transport and a host sum
+ * all do).  thip_solver_solution / _iterate return this rank's block of x and the whole y.  Before thip_solver_init. */
+int thip_solver_set_column_shard(thip_solver *s, int on);
 
 /* test entry point of the one-pass kernel (thip_sweep.hip): one sweep over the m x n matrix A (device, column-major),
  *   gT = A^T v ; g3 = A^T xy ; u <- u + Su o (-(gP - 2 g3) - c rtau) unless `first` ; gP <- g3 ;

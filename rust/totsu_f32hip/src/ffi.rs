@@ -148,6 +148,7 @@ extern "C" {
     pub fn thip_solver_passes(s: *const thip_solver, host_passes: *mut c_int, host_bytes_per_pass: *mut usize) -> c_int;
     pub fn thip_solver_schedule_in_use(s: *mut thip_solver, host_schedule: *mut c_int) -> c_int;
     pub fn thip_solver_set_sweep_min_bytes(s: *mut thip_solver, bytes: usize) -> c_int;
+    pub fn thip_solver_set_column_shard(s: *mut thip_solver, on: c_int) -> c_int;
     pub fn thip_test_sweep(t: *const thip_sweep_test, host_ms: *mut f32, host_info: *mut c_int) -> c_int;
     pub fn thip_solver_gemv_plan(s: *const thip_solver, host_nj: *mut c_int, host_blocks: *mut c_int, host_ms: *mut f32) -> c_int;
 

@@ -273,3 +273,113 @@ def test_sweep_at_a_size_where_it_is_the_default(T):
     pc, ps = float(c @ res["carried"][0]), float(c @ res["sweep"][0])
     assert abs(pc - ps) <= 1e-4 * (1 + abs(pc)), (pc, ps)
     assert abs(res["sweep"][1] - res["carried"][1]) <= max(5, res["carried"][1] // 100)
+
+
+# ---- N > 1: column shards (thip_solver_set_column_shard) -----------------------------------------------------
+
+def _run_col_sharded(T, dense, cuts, param, max_steps, poll_every=16):
+    """ranks emulated by threads in one process (the pattern of tests/test_gpu_sharded.py): each drives its own solver
+    over its block of columns; the hook meets at a barrier and sums the device buffers on the shared stream"""
+    import threading
+    from totsu_amd._lib import lib
+    n, m = dense.n, dense.m
+    A = np.asarray(dense.mat_a).reshape((n, m))           # row j = column j of the column-major m x n matrix
+    parts = [dict(n=hi - lo, mat_a=A[lo:hi].ravel().copy(), vec_c=np.asarray(dense.vec_c)[lo:hi]) for lo, hi in zip(cuts[:-1], cuts[1:])]
+    world = len(parts)
+    barrier = threading.Barrier(world)
+    bufs, out, errs = [None] * world, [None] * world, []
+
+    def make_hook(rank):
+        def hook(ctx, ptr, cnt, stream):
+            try:
+                bufs[rank] = ptr
+                barrier.wait(timeout=120)
+                if rank == 0:
+                    for r in range(1, world):
+                        lib.thip_add(cnt, 1.0, bufs[r], bufs[0])
+                    for r in range(1, world):
+                        lib.thip_copy(cnt, bufs[0], bufs[r])
+                barrier.wait(timeout=120)
+                return 0
+            except Exception as e:      # noqa
+                errs.append(e)
+                return 1
+        return hook
+
+    def worker(rank):
+        try:
+            p = parts[rank]
+            fs = T.FusedSolver(p["n"], m, p["mat_a"], dense.vec_b, p["vec_c"], dense.seg_type, dense.seg_len, param, "sweep",
+                               vec_b_rowabs=dense.vec_b_rowabs, allreduce=make_hook(rank), col_shard=True)
+            assert fs.schedule_in_use() == "sweep"
+            r = fs.run(max_steps, poll_every=poll_every)
+            out[rank] = (r, fs.iterate(), fs.precond())
+            fs.destroy()
+        except Exception as e:          # noqa
+            errs.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t_.start() for t_ in th]
+    [t_.join() for t_ in th]
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_column_sharded_sweep_matches_the_unsharded_run_and_the_oracle(T, world):
+    socp = _socp(T, 260, [15, 40, 3, 66, 99, 21], seed=12)
+    d = socp.dense()
+    n, m = d.n, d.m
+    iters = [0, 1, 9, 59]
+    ro = _oracle_snaps(d, iters)
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    cuts = [0, 90, 260] if world == 2 else [0, 80, 170, 260]
+    one = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0)
+    N = n + 2 * m + 1
+    done = 0
+    for q, (it, tol) in enumerate(zip(iters, [2e-5, 2e-5, 1e-4, 1e-3])):
+        out = _run_col_sharded(T, d, cuts, p, it + 1)
+        one.run(it + 1 - done, poll_every=64)
+        done = it + 1
+        x1, y1 = one.iterate()
+        # every rank holds its block of x_x and of u, and the WHOLE of x_y, x_s, tau, v, kappa -- bitwise the same on all
+        xs = np.concatenate([o[1][0][:hi - lo] for o, lo, hi in zip(out, cuts[:-1], cuts[1:])])
+        us = np.concatenate([o[1][1][:hi - lo] for o, lo, hi in zip(out, cuts[:-1], cuts[1:])])
+        for o, lo, hi in zip(out, cuts[:-1], cuts[1:]):
+            nl = hi - lo
+            assert np.array_equal(o[1][0][nl:], out[0][1][0][cuts[1]:]) and np.array_equal(o[1][1][nl:], out[0][1][1][cuts[1]:])
+            assert o[0].iters == it + 1
+        x = np.concatenate([xs, out[0][1][0][cuts[1]:]])
+        y = np.concatenate([us, out[0][1][1][cuts[1]:]])
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        sx, sy = max(np.abs(rx).max(), 1e-6), max(np.abs(ry).max(), 1e-6)
+        assert np.abs(x - rx).max() <= tol * sx and np.abs(y - ry).max() <= tol * sy, (it, np.abs(x - rx).max() / sx, np.abs(y - ry).max() / sy)
+        assert np.abs(x - x1).max() <= tol * sx and np.abs(y - y1).max() <= tol * sy
+        assert np.allclose(out[0][0].cri, ro.trace[it][2:], rtol=max(50 * tol, 1e-3), atol=1e-5)
+    # the preconditioners: each rank's block of dp_tau_x / dp_sigma_n, the whole of the m-parts
+    t1, s1 = one.precond()
+    for o, lo, hi in zip(out, cuts[:-1], cuts[1:]):
+        t, s = o[2]
+        nl = hi - lo
+        assert np.allclose(t[:nl], t1[lo:hi], rtol=1e-6) and np.allclose(t[nl:], t1[n:], rtol=1e-6)
+        assert np.allclose(s[:nl], s1[lo:hi], rtol=1e-6) and np.allclose(s[nl:], s1[n:], rtol=1e-6)
+    one.destroy()
+
+
+def test_column_sharded_sweep_converges_like_the_unsharded_run(T):
+    lp, (c, G, h) = _lp(T, 150, 7)
+    d = lp.dense()
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 200_000, 1e-4
+    one = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0)
+    x1, _ = one.solve(poll_every=50)
+    it1 = one.status().iters
+    one.destroy()
+    out = _run_col_sharded(T, d, [0, 64, 150], p, -1, poll_every=50)
+    assert all(o[0].state == 0 for o in out)
+    assert abs(out[0][0].iters - it1) <= max(3, it1 // 200)
+    tau = out[0][0].tau
+    x = np.concatenate([out[0][1][0][:64], out[1][1][0][:86]])          # the terminated iterate comes back scaled by 1 / tau
+    assert np.abs(x - x1).max() <= 2e-3 * max(np.abs(x1).max(), 1.0), (tau,)

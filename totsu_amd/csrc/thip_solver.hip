@@ -487,7 +487,7 @@ __global__ __launch_bounds__(BLK) void sw_scal_k(DevStatus *st, const float *ps_
 __global__ __launch_bounds__(BLK) void sw_post_k(int n, const float *__restrict__ c, const float *__restrict__ xcur,
                                                 const float *__restrict__ xnxt, const float *__restrict__ u,
                                                 const float *__restrict__ gP, float eps_zero, const DevStatus *st,
-                                                float *__restrict__ part)
+                                                float *__restrict__ part, int pstride)
 {
     if (st->stop != 0) return;
     __shared__ float sh[16];
@@ -506,8 +506,23 @@ __global__ __launch_bounds__(BLK) void sw_post_k(int n, const float *__restrict_
     }
     dd = block_sum(dd, sh); cx = block_sum(cx, sh); cu = block_sum(cu, sh); crx = block_sum(crx, sh);
     if (threadIdx.x == 0) {
-        part[blockIdx.x] = dd; part[gridDim.x + blockIdx.x] = cx;
-        part[2 * gridDim.x + blockIdx.x] = cu; part[3 * gridDim.x + blockIdx.x] = crx;
+        part[blockIdx.x] = dd; part[pstride + blockIdx.x] = cx;
+        part[2 * pstride + blockIdx.x] = cu; part[3 * pstride + blockIdx.x] = crx;
+    }
+}
+
+// column-sharded runs: the groups' shares of the two N products summed into the buffer that is all-reduced
+__global__ __launch_bounds__(BLK) void sw_gsum_k(int m, int ngroups, size_t mpad, const float *__restrict__ partH,
+                                                float *__restrict__ out, const DevStatus *st)
+{
+    if (st->stop != 0) return;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += (size_t)gridDim.x * BLK) {
+        float a = 0.0f, b = 0.0f;
+        for (int g = 0; g < ngroups; ++g) {
+            a += partH[((size_t)g * 2 + 0) * mpad + i];
+            b += partH[((size_t)g * 2 + 1) * mpad + i];
+        }
+        out[i] = a; out[mpad + i] = b;
     }
 }
 
@@ -745,6 +760,11 @@ struct thip_solver {
     float *sw_partH = nullptr; unsigned long long *sw_gran = nullptr; unsigned *sw_census = nullptr;
     float *sw_part = nullptr;     // 8 * EG block partials
     unsigned sw_seq = 0, sw_tag = 0;
+    // column-sharded sweep (thip_solver_set_column_shard): this rank holds a block of COLUMNS of A (all m rows), the
+    // n-vectors are its block, the m-vectors are replicated; one all-reduce per iteration of cs_buf = [A u (mpad) ;
+    // A x_x (mpad) ; 4 x EG block partials of the sums over n]
+    bool col_shard = false;
+    float *cs_buf = nullptr; size_t cs_n = 0;
     size_t sweep_min_bytes = (size_t)32 << 20;      // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
@@ -1039,6 +1059,7 @@ bool split_active(const thip_solver *s)
 }
 
 int autotune_gemv(thip_solver *s);
+bool sweep_active(const thip_solver *s);
 
 // decides the form of the next run: column-split (its own tuned plan, its split column) or one launch per pass
 int prepare_split(thip_solver *s)
@@ -1046,7 +1067,7 @@ int prepare_split(thip_solver *s)
     s->split_plan = s->overlap >= 2 && s->allreduce != nullptr && !s->sparse && s->carried_like()
                     && s->m > 0 && s->n > 0;
     s->n1 = 0;
-    if (s->inited) THIP_RC(autotune_gemv(s));        // once per stored form and launch form (a no-op afterwards)
+    if (s->inited && !sweep_active(s)) THIP_RC(autotune_gemv(s));        // once per stored form and launch form (a no-op afterwards)
     if (!s->split_plan) return 0;
     s->n1 = split_column(s);
     if (s->n1 == 0 || s->n1 >= s->n) { s->split_plan = false; s->n1 = 0; return 0; }
@@ -1291,7 +1312,8 @@ int rebuild_carried(thip_solver *s)
 int sweep_prepare(thip_solver *s)
 {
     if (s->schedule != THIP_SCHED_SWEEP) return 0;
-    if (s->allreduce != nullptr || s->sparse || s->is16() || s->m == 0 || s->n == 0) return 0;      // not now (may change)
+    if ((s->allreduce != nullptr) != s->col_shard) return 0;      // row shards run the carried schedule; column shards need the hook
+    if (s->sparse || s->is16() || s->m == 0 || s->n == 0) return 0;      // not now (may change)
     if (s->sweep_state != 0) return 0;
     s->sweep_state = -1;
     static const int env_off = getenv("THIP_SWEEP_OFF") ? atoi(getenv("THIP_SWEEP_OFF")) : 0;
@@ -1299,7 +1321,7 @@ int sweep_prepare(thip_solver *s)
     size_t m_eff = s->m;
     // a library-owned padded copy has zero rows behind row m, and every m-vector of the arena has zeros behind entry m
     if (m_eff % 4 != 0 && s->Apad != nullptr && s->ldpad >= (m_eff + 3) / 4 * 4) m_eff = (m_eff + 3) / 4 * 4;
-    if (s->m * s->n * sizeof(float) < s->sweep_min_bytes) return 0;
+    if (!s->col_shard && s->m * s->n * sizeof(float) < s->sweep_min_bytes) return 0;
     SweepGeom g;
     if (sweep_plan(m_eff, s->n, s->alda(), s->amat(), &g) != 0) return 0;
     hipStream_t st = ctx().stream;
@@ -1320,6 +1342,15 @@ int sweep_prepare(thip_solver *s)
     THIP_TRY(hipMalloc((void **)&s->sw_gran, sweep_gran_words(g) * sizeof(unsigned long long)));
     THIP_TRY(hipMemsetAsync(s->sw_partH, 0, (size_t)g.ngroups * 2 * g.mpad * sizeof(float), st));
     THIP_TRY(hipMemsetAsync(s->sw_gran, 0, sweep_gran_words(g) * sizeof(unsigned long long), st));
+    if (s->col_shard) {
+        const size_t need = 2 * g.mpad + 4 * EG;
+        if (s->cs_n != need) {
+            if (s->cs_buf) { THIP_TRY(hipFree(s->cs_buf)); s->cs_buf = nullptr; }
+            THIP_TRY(hipMalloc((void **)&s->cs_buf, need * sizeof(float)));
+            s->cs_n = need;
+        }
+        THIP_TRY(hipMemsetAsync(s->cs_buf, 0, need * sizeof(float), st));
+    }
     s->sgeom = g;
     s->sgeom.m_eff = (int)m_eff;
     s->sweep_state = 1;
@@ -1328,7 +1359,8 @@ int sweep_prepare(thip_solver *s)
 
 bool sweep_active(const thip_solver *s)
 {
-    return s->schedule == THIP_SCHED_SWEEP && s->sweep_state == 1 && s->allreduce == nullptr && !s->sparse && !s->is16();
+    return s->schedule == THIP_SCHED_SWEEP && s->sweep_state == 1 && (s->allreduce != nullptr) == s->col_shard && !s->sparse
+           && !s->is16();
 }
 
 int sweep_pass(thip_solver *s, int first)
@@ -1371,29 +1403,39 @@ int one_iteration_sweep(thip_solver *s)
     const int n = (int)s->n, m = (int)s->m;
     const unsigned gn = egrid(s->n), gm = egrid(s->m);
     const float ez = s->par.eps_zero;
-    float *const pn = s->sw_part;                 // [0] ||d||^2 [1] c.x_x [2] c.u [3] c.rx_x, gn partials each
-    float *const pm = s->sw_part + 4 * EG;        // [0] b.v [1] b.rx_y [2] ||p||^2 [3] b.x_y, gm partials each
+    const bool cols = s->col_shard;
+    // sums over n: [0] ||d||^2 [1] c.x_x [2] c.u [3] c.rx_x -- gn block partials each; column-sharded: EG slots each (the
+    // same on every rank, the unused ones stay zero) behind the two N products in the buffer that is all-reduced
+    float *const pn = cols ? s->cs_buf + 2 * s->sgeom.mpad : s->sw_part;
+    const int pns = cols ? (int)EG : (int)gn;
+    float *const pm = s->sw_part + 4 * EG;        // sums over m: [0] b.v [1] b.rx_y [2] ||p||^2 [3] b.x_y, gm partials each
     float *const ky = s->comp() ? s->ky : nullptr, *const ks = s->comp() ? s->ks : nullptr;
     float *const kv = s->comp() ? s->kv : nullptr;
-    auto post = [&]() {
-        hipLaunchKernelGGL(sw_post_k, dim3(gn), dim3(BLK), 0, st, n, s->c, s->xx, sweep_next(s), s->u, s->gP, ez, s->dst, pn);
+    auto post = [&]() -> int {
+        hipLaunchKernelGGL(sw_post_k, dim3(gn), dim3(BLK), 0, st, n, s->c, s->xx, sweep_next(s), s->u, s->gP, ez, s->dst, pn, pns);
+        if (cols) {
+            hipLaunchKernelGGL(sw_gsum_k, dim3(gm), dim3(BLK), 0, st, m, s->sgeom.ngroups, s->sgeom.mpad, s->sw_partH, s->cs_buf, s->dst);
+            THIP_RC(do_allreduce(s, s->cs_buf, s->cs_n));
+        }
+        return 0;
     };
     if (s->sw_first) {
         // from a consistent iterate (x_0, or wherever a run stopped): u is current, so the sweep leaves it alone
         THIP_RC(sweep_pass(s, 1));
-        post();
+        THIP_RC(post());
         s->sw_first = false;
     }
-    hipLaunchKernelGGL(sw_xm_k, dim3(gm), dim3(BLK), 0, st, m, s->sgeom.ngroups, s->sgeom.mpad, s->sw_partH, s->h3, s->b, s->v,
-                       s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs, s->dst, pn + 2 * gn, (int)gn, pm, (int)gm, ky, ks);
+    hipLaunchKernelGGL(sw_xm_k, dim3(gm), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
+                       cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
+                       s->dst, pn + 2 * pns, pns, pm, (int)gm, ky, ks);
     THIP_RC(project_blocks(s));
     hipLaunchKernelGGL(sw_vm_k, dim3(gm), dim3(BLK), 0, st, m, s->h3, s->hP, s->b, s->rxs, s->rxy, s->Sv, s->v, kv, s->xs,
                        s->xy, ez, s->dst, pm);
-    hipLaunchKernelGGL(sw_scal_k, dim3(1), dim3(BLK), 0, st, s->dst, pn + 3 * gn, (int)gn, pm + gm, (int)gm);
+    hipLaunchKernelGGL(sw_scal_k, dim3(1), dim3(BLK), 0, st, s->dst, pn + 3 * pns, pns, pm + gm, (int)gm);
     sweep_swap(s);                                // x_x_k (formed by the previous sweep) is now the iterate
     THIP_RC(sweep_pass(s, 0));
-    post();
-    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)gn, pn, s->par.eps_acc, s->par.eps_inf, ez,
+    THIP_RC(post());
+    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, pns, pn, s->par.eps_acc, s->par.eps_inf, ez,
                        (long long)s->par.max_iter, s->dst, pm + 2 * gm, pm + 3 * gm, (int)gm, s->xbuf);
     THIP_LAUNCH_CHECK();
     return 0;
@@ -1685,7 +1727,21 @@ int thip_solver_init(thip_solver *s)
         THIP_RC(finalize_partials(st, m, gp.partN, gp.nN, gp.strideN, 1.0f, 0.0f, rowabs, nullptr));
         THIP_RC(finalize_partials(st, n, gp.partT, gp.nT, gp.strideT, 1.0f, 0.0f, colabs, nullptr));
     }
-    THIP_RC(do_allreduce(s, s->g1, n + 2));
+    if (s->col_shard) {
+        // this rank holds a block of columns: b and the m-vectors are replicated, c is its block.  What the ranks have to
+        // add up is the |A| row sums and sum c^2, sum |c| (the b sums and the column sums are complete as they are)
+        if (!sweep_active(s))
+            return fail(THIP_E_INVALID, "a column-sharded run needs THIP_SCHED_SWEEP and a shape its kernel takes", __FILE__, __LINE__);
+        if (s->cs_n < m + 2) return fail(THIP_E_INVALID, "column-shard buffer too small", __FILE__, __LINE__);
+        THIP_TRY(hipMemcpyAsync(s->cs_buf, rowabs, m * sizeof(float), hipMemcpyDeviceToDevice, st));
+        THIP_TRY(hipMemcpyAsync(s->cs_buf + m, loc, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        THIP_RC(do_allreduce(s, s->cs_buf, s->cs_n));
+        THIP_TRY(hipMemcpyAsync(rowabs, s->cs_buf, m * sizeof(float), hipMemcpyDeviceToDevice, st));
+        THIP_TRY(hipMemcpyAsync(loc, s->cs_buf + m, 2 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        THIP_TRY(hipMemsetAsync(s->cs_buf, 0, s->cs_n * sizeof(float), st));
+    } else {
+        THIP_RC(do_allreduce(s, s->g1, n + 2));
+    }
     hipLaunchKernelGGL(init_scalars_k, dim3(1), dim3(1), 0, st, sums, loc, s->par.eps_zero, s->dst);
     hipLaunchKernelGGL(precond_k, dim3(g), dim3(BLK), 0, st, (int)n, (int)m, colabs, rowabs, s->c, s->b, s->b_rowabs,
                        s->par.eps_zero, s->Tx, s->Ty, s->Ts, s->Su, s->Sv);
@@ -1697,7 +1753,7 @@ int thip_solver_init(thip_solver *s)
     THIP_TRY(hipMemsetAsync(s->h1, 0, (m ? m : 1) * sizeof(float), st));
     THIP_LAUNCH_CHECK();
     s->split_plan = false;           // the one-launch form here; the column-split form is tuned by the first run that uses it
-    THIP_RC(autotune_gemv(s));
+    if (!sweep_active(s)) THIP_RC(autotune_gemv(s));      // (a run that falls back to the dual GEMV tunes it then: prepare_split)
     s->inited = true;
     return 0;
 }
@@ -1710,10 +1766,10 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
     int64_t done = 0;
     THIP_RC(poll(s, host_status));
     if (s->carried_stale && s->hst->state == THIP_ST_RUNNING) THIP_RC(rebuild_carried(s));
-    THIP_RC(prepare_split(s));
-    const bool split = split_active(s);
     THIP_RC(sweep_prepare(s));
     const bool sweep = sweep_active(s);
+    THIP_RC(prepare_split(s));
+    const bool split = split_active(s);
     if (!sweep) s->sw_first = true;         // whatever runs instead leaves a consistent iterate and gP / hP of it
     while (s->hst->state == THIP_ST_RUNNING && (max_steps < 0 || done < max_steps)) {
         int64_t batch = poll_every;
@@ -1904,6 +1960,14 @@ int thip_solver_schedule_in_use(thip_solver *s, int *host_schedule)
     return 0;
 }
 
+int thip_solver_set_column_shard(thip_solver *s, int on)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    s->col_shard = on != 0;
+    s->sweep_state = 0;
+    return 0;
+}
+
 int thip_solver_set_sweep_min_bytes(thip_solver *s, size_t bytes)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
@@ -2006,7 +2070,7 @@ int thip_solver_destroy(thip_solver *s)
     for (auto &g : s->psd_groups) hipFree(g.dev_offs);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
     hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->Apad); if (s->A16_owned) hipFree(s->A16); if (s->inv_s_owned) hipFree(s->inv_s);
-    hipFree(s->sw_partH); hipFree(s->sw_gran); hipFree(s->sw_census); hipFree(s->sw_part);
+    hipFree(s->sw_partH); hipFree(s->sw_gran); hipFree(s->sw_census); hipFree(s->sw_part); hipFree(s->cs_buf);
     if (s->hst) hipHostFree(s->hst);
     delete s;
     return 0;

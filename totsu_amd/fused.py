@@ -121,7 +121,7 @@ class FusedResult:
 class FusedSolver:
     def __init__(self, n, m, mat_a, vec_b, vec_c, seg_type, seg_len, param=None, schedule="fused",
                  vec_b_rowabs=None, allreduce=None, a_storage="f32", overlap=None, gemv_autotune=None, lda_pad=None,
-                 sweep_min_bytes=None):
+                 sweep_min_bytes=None, col_shard=False):
         """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded).
         a_storage: "f32" (the matrix as given), "bf16" or "f16" (a rounded 16-bit copy streamed at half the bytes; f16
         is column-scaled and rounds 8x finer; see set_a_storage / include/totsu_f32hip.h).
@@ -181,6 +181,9 @@ class FusedSolver:
             lib.thip_solver_set_gemv_autotune(self.h, 1 if gemv_autotune else 0)     # False: bit-reproducible across runs
         if lda_pad is not None:
             lib.thip_solver_set_lda_pad(self.h, int(lda_pad))
+        if col_shard:
+            # this rank's block of COLUMNS (n = its column count, vec_c its block, vec_b / cones the whole problem's); "sweep" only
+            lib.thip_solver_set_column_shard(self.h, 1)
         if sweep_min_bytes is not None:
             lib.thip_solver_set_sweep_min_bytes(self.h, int(sweep_min_bytes))   # 0: "sweep" whenever the kernel takes the shape
         self.a_storage = "f32"
