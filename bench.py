@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--schedule", default="sweep", choices=["reference", "fused", "carried", "sweep"],
                     help="sweep = one pass over A per iteration (one GPU, dense f32 A); where it cannot run the library "
                          "executes the carried schedule (2 passes) and the line says so")
+    ap.add_argument("--shard", default="auto", choices=["auto", "rows", "cols"],
+                    help="N > 1: rows = cone-aligned row blocks, 2 passes per iteration (carried schedule) and an all-reduce "
+                         "per A^T product; cols = column blocks, ONE pass per iteration (sweep schedule) and one all-reduce "
+                         "of the two N products; auto = cols for --schedule sweep on the f32 fused path, else rows")
     ap.add_argument("--a-storage", default="f32", choices=["f32", "bf16", "f16", "mixed", "mixed-bf16"],
                     help="stored form of A streamed by the iteration (default f32 = the reference's data). bf16: a rounded copy, "
                          "half the bytes per pass, f32 accumulation -- solves the ROUNDED problem, not the headline metric. "
@@ -404,6 +408,13 @@ def run(a):
             sys.stderr.write("bench.py: %d ranks on %d GPU(s): --collective %s -> gloo (staged through host memory; "
                              "plumbing mode, not a performance configuration)\n" % (world, n_dev, a.collective))
         a.collective = "gloo"
+    if shared_gpu and (a.schedule == "sweep" or a.shard == "cols"):
+        # the one-pass kernel is persistent and needs every CU of its GPU: two ranks on one device would wait for each
+        # other's workgroups (bounded, then an error).  Ranks sharing a GPU are a plumbing mode: carried schedule, row shards
+        if rank == 0:
+            sys.stderr.write("bench.py: ranks share a GPU: --schedule %s / --shard %s -> carried / rows\n" % (a.schedule, a.shard))
+        a.schedule = "carried" if a.schedule == "sweep" else a.schedule
+        a.shard = "rows"
     # the process group (bootstrap, host-side reductions, barriers): RCCL needs one device per rank
     pg_gloo = a.collective == "gloo" or shared_gpu
     if pg_gloo:
@@ -433,7 +444,17 @@ def run(a):
         return t.cpu().numpy()
 
     t_gen0 = time.perf_counter()
-    if a.workload == "socp":
+    cols = use_dist and a.path == "fused" and a.workload in ("socp", "lp") and a.a_storage == "f32" \
+        and (a.shard == "cols" or (a.shard == "auto" and a.schedule == "sweep")) and not (a.bf16_direct or a.f16_direct)
+    if a.workload == "socp" and cols:
+        n = a.n or 50_000
+        inst = synth.SocpInstanceCols(n, a.cones, 99, seed=0, rank=rank, world=world, allreduce_host=allreduce_host)
+        wl = "random dense SOCP n=%d, %d second-order cones of 1+99 rows (m=%d), f32" % (n, a.cones, inst.m_total)
+    elif a.workload == "lp" and cols:
+        n = a.n or 10_000
+        inst = synth.LpInstanceCols(n, seed=0, rank=rank, world=world)
+        wl = "benchmark_lp dense LP n=%d m=%d, f32" % (n, inst.m_total)
+    elif a.workload == "socp":
         n = a.n or 50_000
         inst = synth.SocpInstance(n, a.cones, 99, seed=0, rank=rank, world=world, allreduce_host=allreduce_host)
         wl = "random dense SOCP n=%d, %d second-order cones of 1+99 rows (m=%d), f32" % (n, a.cones, inst.m_total)
@@ -470,7 +491,7 @@ def run(a):
         # slots for the longest message of the loop (n + the 1024 block partials), handles exchanged through the group
         import ctypes as C
         hb = (C.c_uint8 * 64)()
-        lib.thip_oneshot_init(rank, world, n + 2048, hb)
+        lib.thip_oneshot_init(rank, world, max(n + 2048, 2 * ((inst.m + 63) // 64 * 64) + 2048 + 64), hb)
         mine = torch.frombuffer(bytearray(bytes(hb)), dtype=torch.uint8).to(dev_pg)
         allh = [torch.zeros(64, dtype=torch.uint8, device=dev_pg) for _ in range(world)]
         dist.all_gather(allh, mine)
@@ -514,9 +535,10 @@ def run(a):
                 sys.stderr.write("falling back to the torch.distributed all-reduce hook\n")
         if hook is None:
             hook, coll = TorchAllreduce(torch, dist), "torch.distributed.all_reduce hook (nccl)"
-    fs = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, a.schedule,
+    n_loc = inst.n_local if cols else n          # the solver's n: this rank's columns when column-sharded
+    fs = T.FusedSolver(n_loc, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, a.schedule,
                        allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"),
-                       overlap=None)
+                       overlap=None, col_shard=cols)
 
     def barrier():
         if use_dist:
@@ -525,7 +547,7 @@ def run(a):
 
     overlap_pick, overlap_times = None, None
     OVM = {"off": 0, "on": 1, "pipeline": 2, "pipeline-inorder": 3}
-    if hook is not None and a.collective != "gloo":
+    if hook is not None and a.collective != "gloo" and not cols:
         if a.overlap == "auto":
             # untimed: 3 x 20 iterations per mode (max over ranks), keep the fastest -- like the GEMV plan autotune
             best = {}
@@ -635,7 +657,9 @@ def run(a):
                 "unit variance, not exact Gaussians)",
         "state_arith": a.state,
         "config": {"workload": wl, "schedule": fs.schedule_in_use(), "schedule_asked": a.schedule, "passes_over_A_per_iter": passes,
-                   "rows_per_gpu": inst.m, "parallelism": "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll, "overlap": overlap_pick,
+                   "rows_per_gpu": inst.m, "cols_per_gpu": n_loc,
+                   "parallelism": ("column-sharded A x%d, one all-reduce of the two N products (2 m floats) per iteration" % world) if cols
+                                  else "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll, "overlap": overlap_pick,
                    "overlap_mode_run": ovi["mode"], "overlap_split_col": ovi["split_col"], "overlap_autotune_ms_per_iter": overlap_times,
                    "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan(), "a_storage": a.a_storage},
         "roofline": roofline,
@@ -673,9 +697,9 @@ def run(a):
 
         barrier()
         t0 = time.perf_counter()
-        fs2 = T.FusedSolver(n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
+        fs2 = T.FusedSolver(n_loc, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p2,
                             a.schedule, allreduce=hook, a_storage={"f32": "f32", "f16": "f16", "mixed": "f16"}.get(a.a_storage, "bf16"),
-                            overlap=overlap_pick)
+                            overlap=overlap_pick, col_shard=cols)
         r2 = run_to_end(fs2)
         barrier()
         phase1 = None
@@ -708,9 +732,16 @@ def run(a):
             x, y = x / np.float32(r2.tau), y / np.float32(r2.tau)
         pobj = float(inst.vec_c_host.astype(np.float64) @ x.astype(np.float64))
         dloc = -float(inst.vec_b_host.astype(np.float64) @ y.astype(np.float64))
-        dobj = float(allreduce_host(np.array([dloc], dtype=np.float32))[0]) if use_dist else dloc
+        if cols:          # x is this rank's block of columns (c.x adds up over ranks), y is the whole dual vector everywhere
+            pobj = float(allreduce_host(np.array([pobj], dtype=np.float32))[0]) if use_dist else pobj
+            dobj = dloc
+        else:
+            dobj = float(allreduce_host(np.array([dloc], dtype=np.float32))[0]) if use_dist else dloc
         out["time_to_eps"].update({"primal_obj": pobj, "dual_obj": dobj})
-        if a.workload == "socp" and not a.no_gate:
+        if cols and world > 1:
+            out["objective_gate"]["this_run"] = {"skipped": "column-sharded run: the f64 re-evaluation is written for the "
+                                                 "unsharded and the row-sharded answer; see the N = 1 line of the same build"}
+        elif a.workload == "socp" and not a.no_gate:
             try:
                 gate = kkt_f64(inst, x, y, allreduce_host)
                 gate.update({"eps_acc": a.to_eps, "gpu_criteria_f32": list(r2.cri), "state": r2.state})

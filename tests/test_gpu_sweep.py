@@ -383,3 +383,31 @@ def test_column_sharded_sweep_converges_like_the_unsharded_run(T):
     tau = out[0][0].tau
     x = np.concatenate([out[0][1][0][:64], out[1][1][0][:86]])          # the terminated iterate comes back scaled by 1 / tau
     assert np.abs(x - x1).max() <= 2e-3 * max(np.abs(x1).max(), 1.0), (tau,)
+
+
+def test_bench_column_shard_path_at_world_1():
+    """bench.py's N > 1 form of the one-pass schedule (column blocks, one all-reduce per iteration through native RCCL),
+    forced at world 1: one JSON line, the sweep schedule in use, and the answer of the plain single-GPU run"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29583")
+    base = [sys.executable, os.path.join(root, "bench.py"), "--size", "3000", "--cones", "60", "--steps", "5", "--warmup", "1",
+            "--no-cpu", "--to-eps", "1e-3"]
+    outs = []
+    for extra in ([], ["--force-collective", "--shard", "cols"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, lines
+        outs.append(json.loads(lines[0]))
+    plain, cols = outs
+    assert plain["config"]["schedule"] == "sweep" and cols["config"]["schedule"] == "sweep"
+    assert cols["config"]["passes_over_A_per_iter"] == 1 and "column-sharded" in cols["config"]["parallelism"]
+    assert "RCCL" in cols["config"]["collective"] and cols["rccl_ranks"] == 1
+    tp, tc = plain["time_to_eps"], cols["time_to_eps"]
+    assert tp["state"] == 0 and tc["state"] == 0 and abs(tp["iterations"] - tc["iterations"]) <= 3
+    assert abs(tp["primal_obj"] - tc["primal_obj"]) <= 1e-5 * (1 + abs(tp["primal_obj"]))
+    assert abs(tc["primal_obj"] - tc["dual_obj"]) <= 2e-3 * (1 + abs(tc["primal_obj"]))

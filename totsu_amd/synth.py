@@ -98,6 +98,90 @@ class SocpInstance:
             d.free()
 
 
+def shard_cols(n, world, rank):
+    """contiguous column blocks (a column-sharded sweep, thip_solver_set_column_shard)"""
+    base, rem = divmod(n, world)
+    c0 = rank * base + min(rank, rem)
+    return c0, c0 + base + (1 if rank < rem else 0)
+
+
+class SocpInstanceCols:
+    """device-resident COLUMN shard of the same synthetic SOCP (identical entries: the generator is keyed by the global
+    index): mat_a is m_total x n_local, vec_c this rank's block of f, vec_b and the cones the whole problem's.
+    allreduce_host sums an m-vector over the ranks once, at construction (A x0)."""
+
+    def __init__(self, n, n_cones, ni=99, seed=0, rank=0, world=1, allreduce_host=None):
+        _lib.ensure_init()
+        self.n, self.n_cones, self.ni, self.seed = n, n_cones, ni, seed
+        rows = 1 + ni
+        self.col0, self.col1 = shard_cols(n, world, rank)
+        nl = self.n_local = self.col1 - self.col0
+        m = self.m = self.m_total = n_cones * rows
+        self.mat_a = DeviceBuffer(max(m * nl, 1))
+        lib.thip_gen_matrix(self.mat_a.ptr, m, nl, m, seed, STREAM_A, 0, self.col0, m, 1, -1.0 / math.sqrt(n), 0.0)
+        x0 = DeviceBuffer(max(nl, 1))
+        lib.thip_gen_vector(x0.ptr, nl, seed, STREAM_X0, self.col0, 1, 1.0, 0.0)
+        w = DeviceBuffer(m)
+        lib.thip_transform_ge(0, m, nl, 1.0, self.mat_a.ptr, x0.ptr, 0.0, w.ptr)
+        wv = w.to_host()
+        if allreduce_host is not None:
+            wv = allreduce_host(wv)           # A x0 summed over the column blocks
+        wh = wv.astype(np.float64).reshape(n_cones, rows)
+        hh = _gen(m, seed, STREAM_H, 0, 1).astype(np.float64).reshape(n_cones, rows)
+        margin = _gen(n_cones, seed, STREAM_D, 0, 0, 1.0, 0.1).astype(np.float64)
+        d = np.linalg.norm(hh[:, 1:] - wh[:, 1:], axis=1) + wh[:, 0] + margin
+        b = hh.copy()
+        b[:, 0] = d
+        self.vec_b_host = b.reshape(-1).astype(np.float32)
+        self.vec_b = DeviceBuffer.from_host(self.vec_b_host)
+        t = _gen(n_cones, seed, STREAM_T, 0, 0, 1.0, 0.5).astype(np.float64)
+        wd = _gen(m, seed, STREAM_W, 0, 1).astype(np.float64).reshape(n_cones, rows)[:, 1:]
+        ws = _gen(n_cones, seed, STREAM_WS, 0, 0).astype(np.float64)
+        wd = wd * (0.9 * t * ws / np.maximum(np.linalg.norm(wd, axis=1), 1e-9))[:, None]
+        z = np.concatenate([t[:, None], wd], axis=1).reshape(-1).astype(np.float32)
+        zd = DeviceBuffer.from_host(z)
+        f = DeviceBuffer(max(nl, 1))
+        lib.thip_transform_ge(1, m, nl, -1.0, self.mat_a.ptr, zd.ptr, 0.0, f.ptr)      # this rank's block of f: no exchange
+        self.vec_c_host = f.to_host()[:nl]
+        self.vec_c = f
+        self.seg_type = [_lib.CONE_SOC] * n_cones
+        self.seg_len = [rows] * n_cones
+        for d_ in (x0, w, zd):
+            d_.free()
+
+    def free(self):
+        for d in (self.mat_a, self.vec_b, self.vec_c):
+            d.free()
+
+
+class LpInstanceCols:
+    """device-resident COLUMN shard of the benchmark_lp construction: mat_a = [-I ; U](:, col0:col1), 2 n x n_local"""
+
+    def __init__(self, n, seed=0, rank=0, world=1):
+        _lib.ensure_init()
+        self.n = n
+        m = self.m = self.m_total = 2 * n
+        self.col0, self.col1 = shard_cols(n, world, rank)
+        nl = self.n_local = self.col1 - self.col0
+        self.mat_a = DeviceBuffer(max(m * nl, 1))
+        lib.thip_gen_matrix(self.mat_a.ptr, m, nl, m, seed, STREAM_A, 0, self.col0, m, 0, 1.0, 0.0)
+        # rows r < n are -I: the entry of local column c sits in row col0 + c, i.e. row0 + r == c with row0 = -col0
+        lib.thip_gen_identity(self.mat_a.ptr, n, nl, m, (-self.col0) & 0xFFFFFFFFFFFFFFFF, -1.0)
+        h = _gen(m, seed, STREAM_H, 0, 0)
+        h[:n] = 0.0
+        self.vec_b_host = h
+        self.vec_b = DeviceBuffer.from_host(h)
+        c = -_gen(max(nl, 1), seed, STREAM_C, self.col0, 0)[:nl]
+        self.vec_c_host = c
+        self.vec_c = DeviceBuffer.from_host(c) if nl else DeviceBuffer(1)
+        self.seg_type = [_lib.CONE_RPOS]
+        self.seg_len = [m]
+
+    def free(self):
+        for d in (self.mat_a, self.vec_b, self.vec_c):
+            d.free()
+
+
 class LpInstance:
     """device-resident row shard of the benchmark_lp construction (rows split evenly; nonneg cone is separable)"""
 
