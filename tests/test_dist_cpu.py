@@ -69,3 +69,50 @@ def test_sharded_lp_gloo(tmp_path):
     assert res[0]["iters"] == res[1]["iters"] == ro.iters
     assert np.allclose(res[0]["x"], ro.x, rtol=1e-7, atol=1e-9)
     assert np.allclose(np.concatenate([res[0]["y"], res[1]["y"]]), ro.y, rtol=1e-7, atol=1e-9)
+
+
+def _launch_sweep(tmp_path, case, port):
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "dist_sweep_worker.py"), str(tmp_path), case]
+    subprocess.run(cmd, check=True, env=env, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    return [json.load(open(os.path.join(tmp_path, "rank%d.json" % r))) for r in range(2)]
+
+
+@pytest.mark.parametrize("case,port", [("socp", 29651), ("lp", 29652)])
+def test_column_sharded_sweep_gloo(tmp_path, case, port):
+    """the N > 1 form of the one-pass schedule (column blocks, m-vectors replicated, ONE all-reduce per iteration),
+    restated in numpy f64 (tests/sweep_numpy.py) and run on two gloo ranks: iterates and criteria of the reference
+    iteration (the oracle) to f64 round-off -- the skewed order changes no value"""
+    res = _launch_sweep(tmp_path, case, port)
+    if case == "socp":
+        n, cones = 16, [4, 9, 0, 2, 7, 5]
+        f, Gs, hs, cs, d = random_socp(n, cones, seed=11)
+        A = np.vstack([np.vstack([-c.reshape(1, n), -G]) for G, c in zip(Gs, cs)]).astype(np.float64)
+        b = np.concatenate([np.concatenate([[dd], h]) for dd, h in zip(d, hs)]).astype(np.float64)
+        c = f.astype(np.float64)
+        seg_type, seg_len = [O.CONE_SOC] * len(cones), [1 + k for k in cones]
+    else:
+        c32, G, h = benchmark_lp(20, seed=12)
+        A, b, c = G.astype(np.float64), h.astype(np.float64), c32.astype(np.float64)
+        seg_type, seg_len = [O.CONE_RPOS], [40]
+    n, m = c.size, b.size
+    its = [1, 2, 10, 60]
+    ro = O.solve_matop_cones(O.param(max_iter=100, eps_acc=1e-30), c, A, b, seg_type, seg_len,
+                             snap_iters=[k - 1 for k in its], trace_cap=70)
+    N = n + 2 * m + 1
+    assert res[0]["cols"][1] == res[1]["cols"][0]
+    for q, k in enumerate(its):
+        s0, s1 = res[0]["snaps"][str(k)], res[1]["snaps"][str(k)]
+        assert s0["xm"] == s1["xm"] and s0["ym"] == s1["ym"]        # the replicated m-vectors: identical on both ranks
+        x = np.concatenate([s0["xx"], s1["xx"], s0["xm"]])
+        y = np.concatenate([s0["u"], s1["u"], s0["ym"]])
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        assert np.allclose(x, rx, rtol=1e-9, atol=1e-12), (k, np.abs(x - rx).max())
+        assert np.allclose(y, ry, rtol=1e-9, atol=1e-12), (k, np.abs(y - ry).max())
+    for k in range(60):
+        assert np.allclose(res[0]["cri"][k], ro.trace[k][2:], rtol=1e-8, atol=1e-13), (k, res[0]["cri"][k], ro.trace[k])
+    # one all-reduce per sweep (61 sweeps for 60 iterations) + the one of the preconditioner
+    assert res[0]["collectives"] == 62
