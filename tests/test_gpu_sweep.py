@@ -411,3 +411,34 @@ def test_bench_column_shard_path_at_world_1():
     assert tp["state"] == 0 and tc["state"] == 0 and abs(tp["iterations"] - tc["iterations"]) <= 3
     assert abs(tp["primal_obj"] - tc["primal_obj"]) <= 1e-5 * (1 + abs(tp["primal_obj"]))
     assert abs(tc["primal_obj"] - tc["dual_obj"]) <= 2e-3 * (1 + abs(tc["primal_obj"]))
+
+
+def test_sweep_infeasible_and_unbounded_certificates(T):
+    """the tau -> 0 branch of the criteria (criteria_inf, solver.rs:614-656) through the one-pass schedule: an infeasible
+    and an unbounded LP end with the reference's verdict, at the carried schedule's iteration"""
+    n = 64
+    eye = np.eye(n, dtype=np.float32)
+    cases = {
+        # totsu/tests/lp.rs:13-46 (x <= -5, -x <= -10 has no solution) in the form x >= 1, x <= 0, 64 variables
+        "infeasible": (np.ones(n, np.float32), np.vstack([-eye, eye]), np.concatenate([-np.ones(n), np.zeros(n)]).astype(np.float32), 2),
+        # totsu/tests/lp.rs:48-82 (min x s.t. x <= 5, x <= 10), 64 variables
+        "unbounded": (np.ones(n, np.float32), np.vstack([eye, eye]), np.concatenate([5 * np.ones(n), 10 * np.ones(n)]).astype(np.float32), 1),
+    }
+    for name, (c, G, h, want) in cases.items():
+        lp = T.ProbLP(_mb(T, T.MatType.General(n, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(2 * n, n)).set_array(G),
+                      _mb(T, T.MatType.General(2 * n, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(0, n)),
+                      _mb(T, T.MatType.General(0, 1)))
+        d = lp.dense()
+        p = T.SolverParam()
+        p.max_iter, p.eps_acc, p.eps_inf = 100_000, 1e-5, 1e-5
+        got = {}
+        for sched in ("carried", "sweep"):
+            fs = T.FusedSolver.from_dense(d, p, sched, sweep_min_bytes=0)
+            assert fs.schedule_in_use() == sched
+            r = fs.run(-1, poll_every=25)
+            got[sched] = (r.state, r.iters)
+            fs.destroy()
+        assert got["sweep"][0] == got["carried"][0] == want, (name, got)
+        assert abs(got["sweep"][1] - got["carried"][1]) <= 2, (name, got)
+        ro = O.solve_lp(O.param(max_iter=100000, eps_acc=1e-5, eps_inf=1e-5), c, G, h, np.zeros((0, n)), [])
+        assert ro.status == want and abs(ro.iters - got["sweep"][1]) <= max(3, ro.iters // 50), (name, ro.status, ro.iters, got)

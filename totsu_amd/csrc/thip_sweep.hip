@@ -155,6 +155,13 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_census_k(unsigned *census, u
 // panel q - 16 is free.  Per-column data of panel q is fetched in interval q + DLAG and has arrived before the member
 // publishes q in interval q + DLAG + 1; the writer of panel q's columns stores u / gP (in place) only after it has gathered
 // q, i.e. after every member holds its copy.
+// THIP_SWEEP_DBG (experiments of DESIGN.md 4.7: 1 no polling, 2 no wave reduction of the dots, 4 no barrier, 8 service wave
+// idle, 16 no arithmetic) exists only in a -DSW_DEBUG build; otherwise the switches fold away
+#ifdef SW_DEBUG
+#define SW_DBG(a) ((a).dbg)
+#else
+#define SW_DBG(a) 0
+#endif
 template <int NSLOT, int W, int LAGL, int DLAG, int LS>
 __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 {
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             }                                                                                                  \
         } while (0)
 #define SW_DOTS(S, P)                                                                                          \
-        if (a.dbg & 16) { asm volatile("" :: "v"(stg[S][0][0][0]), "v"(stg[S][W - 1][NSLOT - 1][3])); } else  \
+        if (SW_DBG(a) & 16) { asm volatile("" :: "v"(stg[S][0][0][0]), "v"(stg[S][W - 1][NSLOT - 1][3])); } else  \
         do {                                                                                                   \
             float p_[2 * W];                                                                                   \
             _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
@@ -232,14 +239,14 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                     }                                                                                          \
                 p_[q] = d1; p_[W + q] = d2;                                                                    \
             }                                                                                                  \
-            if (a.dbg & 2) { if (lane < 2 * W) dotbuf[(P) & 1][wave][lane] = p_[0]; }                          \
+            if (SW_DBG(a) & 2) { if (lane < 2 * W) dotbuf[(P) & 1][wave][lane] = p_[0]; }                          \
             else {                                                                                             \
             const float r_ = sw_reduce<2 * W>(p_, lane);                                                       \
             if ((lane & (64 / (2 * W) - 1)) == 0) dotbuf[(P) & 1][wave][lane / (64 / (2 * W))] = r_;          \
             }                                                                                                  \
         } while (0)
 #define SW_AXPY(S, P)                                                                                          \
-        if (a.dbg & 16) { asm volatile("" :: "v"(stg[S][0][0][1]), "v"(stg[S][W - 1][NSLOT - 1][2])); } else  \
+        if (SW_DBG(a) & 16) { asm volatile("" :: "v"(stg[S][0][0][1]), "v"(stg[S][W - 1][NSLOT - 1][2])); } else  \
         do {                                                                                                   \
             _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
                 const float s1 = scal[(P) & 1][q], s2 = scal[(P) & 1][W + q];                                  \
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             const int it = (IT0) + s;                                                                          \
             if (it < npan) SW_LOADS(s, it);                                                                    \
             if (it - DLAG >= 0 && it - DLAG < npan) SW_DOTS((s + NS - DLAG) % NS, it - DLAG);                  \
-            if (it < total) sw_barrier_dbg(a.dbg);                                                                      \
+            if (it < total) sw_barrier_dbg(SW_DBG(a));                                                                      \
             if constexpr (LS == 0) {                                                                           \
                 if (it - LAGL >= 0 && it - LAGL < npan) SW_AXPY((s + 1) % NS, it - LAGL);                      \
             } else {                                                                                           \
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                 const int it = it0 + s;
                 SW_LOADS(s, it);
                 SW_DOTS((s + NS - DLAG) % NS, it - DLAG);
-                sw_barrier_dbg(a.dbg);
+                sw_barrier_dbg(SW_DBG(a));
                 if constexpr (LS == 0) { SW_AXPY((s + 1) % NS, it - LAGL); }
                 else { SW_AXPY_LDS(it - LAGT); SW_SPILL((s + 1) % NS, it - LAGL); }
             }
@@ -367,7 +374,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 #define SW_STAMP(i) do { } while (0)
 #endif
         auto interval = [&](const int it, unsigned long long (&xg)[NL], float &cv) {
-            if (a.dbg & 8) { sw_barrier_dbg(a.dbg); return; }
+            if (SW_DBG(a) & 8) { sw_barrier_dbg(SW_DBG(a)); return; }
             asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL + 1) : "memory");
             SW_STAMP(0);
             // per-column data fetched two intervals ago: panel it - 2 - (LAGL - PF - 1)
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 #pragma unroll
                     for (int w = 1; w < SW_CW; ++w) sum += dotbuf[pp & 1][w][lane];
                     unsigned long long *g = gbase + ((size_t)(pp % SW_RING) * a.G + member) * (2 * W) + lane;
-                    if (a.dbg & 32) __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (SW_DBG(a) & 32) __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                     }
                 }
                 int spins = 0;
-                if (a.dbg & 1) pend = 0;
+                if (SW_DBG(a) & 1) pend = 0;
 #ifdef SW_PROFILE
                 if (!__all(pend == 0u)) {
                     if (group == 0 && member == 0 && nmiss < 40) {
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                 cv = __hip_atomic_load(fp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             SW_STAMP(4);
-            sw_barrier_dbg(a.dbg);
+            sw_barrier_dbg(SW_DBG(a));
             SW_STAMP(5);
         };
         int it = 0;
