@@ -366,8 +366,10 @@ int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_byte
  * m or lda not a multiple of 4, fewer than 40 column panels per group, a device that is not 8 XCDs x 32 CUs, a failed
  * placement census) */
 int thip_solver_schedule_in_use(thip_solver *s, int *host_schedule);
-/* THIP_SCHED_SWEEP is used for matrices of at least this many bytes (default 32 MiB: below that an iteration is a handful
- * of launches whatever the schedule); 0 = whenever the kernel can take the shape.  Before thip_solver_init. */
+/* THIP_SCHED_SWEEP is used for matrices of at least this many bytes (default 384 MiB; measured on square-ish SOCPs: at
+ * 128 MB the carried schedule is 2x faster -- few panels per column group, the ring's fill and drain dominate --, at 512 MB
+ * the sweep is 1.24x faster, at 2 GB 1.7x, at 20 GB 2.0x); 0 = whenever the kernel can take the shape.  Before
+ * thip_solver_init. */
 int thip_solver_set_sweep_min_bytes(thip_solver *s, size_t bytes);
 /* N > 1 with THIP_SCHED_SWEEP: the problem given to thip_solver_create is this rank's block of COLUMNS -- mat_a is
  * m x n_local (all m rows), vec_c its n_local entries, vec_b and the cone segments the whole problem's -- the n-vectors are

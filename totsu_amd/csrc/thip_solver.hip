@@ -765,7 +765,7 @@ struct thip_solver {
     // A x_x (mpad) ; 4 x EG block partials of the sums over n]
     bool col_shard = false;
     float *cs_buf = nullptr; size_t cs_n = 0;
-    size_t sweep_min_bytes = (size_t)32 << 20;      // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
+    size_t sweep_min_bytes = (size_t)384 << 20;     // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
     bool inited = false;
@@ -1359,8 +1359,10 @@ int sweep_prepare(thip_solver *s)
 
 bool sweep_active(const thip_solver *s)
 {
-    return s->schedule == THIP_SCHED_SWEEP && s->sweep_state == 1 && (s->allreduce != nullptr) == s->col_shard && !s->sparse
-           && !s->is16();
+    if (!(s->schedule == THIP_SCHED_SWEEP && s->sweep_state == 1 && (s->allreduce != nullptr) == s->col_shard && !s->sparse
+          && !s->is16())) return false;
+    // planned on the padded copy (m not a multiple of 4): only while that copy is the matrix in use
+    return (size_t)s->sgeom.m_eff == s->m || (s->Apad != nullptr && s->ldpad >= (size_t)s->sgeom.m_eff);
 }
 
 int sweep_pass(thip_solver *s, int first)

@@ -548,6 +548,8 @@ int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g)
     }
     if (cls == 3) return 1;
     const int W = g_classes[cls].w;
+    // few columns: fewer, larger groups, so that every group has its 40 panels and no workgroup idles
+    while (G < 32 && (size_t)(256 / G) * 40 * W > n) { G *= 2; rpm = ((m + G - 1) / G + 3) / 4 * 4; }
     const int ngroups = 256 / G;
     // at least 40 panels per group that has columns at all (the ring's fill and drain); with few columns some groups idle
     size_t cpg = (n + ngroups - 1) / ngroups;
