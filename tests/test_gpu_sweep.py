@@ -442,3 +442,28 @@ def test_sweep_infeasible_and_unbounded_certificates(T):
         assert abs(got["sweep"][1] - got["carried"][1]) <= 2, (name, got)
         ro = O.solve_lp(O.param(max_iter=100000, eps_acc=1e-5, eps_inf=1e-5), c, G, h, np.zeros((0, n)), [])
         assert ro.status == want and abs(ro.iters - got["sweep"][1]) <= max(3, ro.iters // 50), (name, ro.status, ro.iters, got)
+
+
+def test_sweep_and_carried_runs_interleave_on_one_solver(T):
+    """a solver that leaves the one-pass schedule (here: the size threshold raised between runs; in the product: a switch to
+    16-bit storage of A) goes on with the carried schedule from the same iterate and comes back -- whichever of the two
+    x_x buffers holds the iterate at the hand-over"""
+    socp = _socp(T, 120, [15, 40, 3, 66], seed=21)
+    d = socp.dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    ref = T.FusedSolver.from_dense(d, p, "carried")
+    fs = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0)
+    done = 0
+    for steps, big in ((15, False), (10, True), (13, False), (1, True), (8, False)):
+        fs.set_sweep_min_bytes(1 << 60 if big else 0)
+        assert fs.schedule_in_use() == ("carried" if big else "sweep")
+        fs.run(steps, poll_every=7)
+        ref.run(steps, poll_every=7)
+        done += steps
+        x, y = fs.iterate()
+        xr, yr = ref.iterate()
+        assert fs.status().iters == ref.status().iters == done
+        assert np.abs(x - xr).max() <= 2e-5 * max(np.abs(xr).max(), 1e-6) and np.abs(y - yr).max() <= 2e-5 * max(np.abs(yr).max(), 1e-6), done
+    fs.destroy()
+    ref.destroy()

@@ -511,6 +511,19 @@ __global__ __launch_bounds__(BLK) void sw_post_k(int n, const float *__restrict_
     }
 }
 
+// (re)start of the one-pass schedule from a consistent iterate: block partials of b.v (a step leaves them for the next
+// one's tau update; whatever ran before this -- nothing, or the carried schedule -- did not)
+__global__ __launch_bounds__(BLK) void sw_bv_k(int m, const float *__restrict__ b, const float *__restrict__ v,
+                                              float *__restrict__ part, const DevStatus *st)
+{
+    if (st->stop != 0) return;
+    __shared__ float sh[16];
+    float q = 0.0f;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += (size_t)gridDim.x * BLK) q = fmaf(b[i], v[i], q);
+    q = block_sum(q, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = q;
+}
+
 // column-sharded runs: the groups' shares of the two N products summed into the buffer that is all-reduced
 __global__ __launch_bounds__(BLK) void sw_gsum_k(int m, int ngroups, size_t mpad, const float *__restrict__ partH,
                                                 float *__restrict__ out, const DevStatus *st)
@@ -1002,7 +1015,7 @@ int one_iteration(thip_solver *s)
     if (split && carried) { ycrit(0, 1); THIP_RC(allreduce_end(s)); ycrit(1, 0); }
     else                  { THIP_RC(allreduce_end(s)); ycrit(1, 1); }
     hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part_y, s->par.eps_acc, s->par.eps_inf,
-                       ez, (long long)s->par.max_iter, s->dst, shp(s->g3) + 2 * gq, shp(s->g3) + 3 * gq, (int)gq, 0);
+                       ez, (long long)s->par.max_iter, s->dst, shp(s->g3) + 2 * gq, shp(s->g3) + 3 * gq, (int)gq, s->xbuf);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1157,7 +1170,7 @@ int split_tail(thip_solver *s)
     THIP_RC(ar_wait(s, 3));
     split_ycrit(c, 1, 0, 1);
     hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, c.st, 2 * (int)c.g, c.part_y, s->par.eps_acc, s->par.eps_inf, c.ez,
-                       (long long)s->par.max_iter, s->dst, s->g3 + s->n + 2 * NPS, s->g3 + s->n + 3 * NPS, (int)NPS, 0);
+                       (long long)s->par.max_iter, s->dst, s->g3 + s->n + 2 * NPS, s->g3 + s->n + 3 * NPS, (int)NPS, s->xbuf);
     THIP_LAUNCH_CHECK();
     s->tail_pending = false;
     return 0;
@@ -1425,6 +1438,7 @@ int one_iteration_sweep(thip_solver *s)
         // from a consistent iterate (x_0, or wherever a run stopped): u is current, so the sweep leaves it alone
         THIP_RC(sweep_pass(s, 1));
         THIP_RC(post());
+        hipLaunchKernelGGL(sw_bv_k, dim3(gm), dim3(BLK), 0, st, m, s->b, s->v, pm, s->dst);
         s->sw_first = false;
     }
     hipLaunchKernelGGL(sw_xm_k, dim3(gm), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
