@@ -41,6 +41,10 @@ def parse():
                     help="N > 1: rows = cone-aligned row blocks, 2 passes per iteration (carried schedule) and an all-reduce "
                          "per A^T product; cols = column blocks, ONE pass per iteration (sweep schedule) and one all-reduce "
                          "of the two N products; auto = cols for --schedule sweep on the f32 fused path, else rows")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="one GPU: build RANK 0's shard of a run over this many GPUs and iterate it alone (the collective is a "
+                         "stand-in that takes --emulate-latency microseconds): the per-GPU rate of that run, not a solve")
+    ap.add_argument("--emulate-latency", type=int, default=0)
     ap.add_argument("--a-storage", default="f32", choices=["f32", "bf16", "f16", "mixed", "mixed-bf16"],
                     help="stored form of A streamed by the iteration (default f32 = the reference's data). bf16: a rounded copy, "
                          "half the bytes per pass, f32 accumulation -- solves the ROUNDED problem, not the headline metric. "
@@ -421,6 +425,9 @@ def run(a):
         local_rank = local_rank % n_dev      # ranks may share a GPU
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_collective
+    emu = a.emulate_world if (a.emulate_world > 1 and world == 1 and not a.force_collective) else 0
+    if emu:
+        a.no_to_eps, a.no_gate, a.no_cpu = True, True, True
     if use_dist and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -444,19 +451,19 @@ def run(a):
         return t.cpu().numpy()
 
     t_gen0 = time.perf_counter()
-    cols = use_dist and a.path == "fused" and a.workload in ("socp", "lp") and a.a_storage == "f32" \
+    cols = (use_dist or emu) and a.path == "fused" and a.workload in ("socp", "lp") and a.a_storage == "f32" \
         and (a.shard == "cols" or (a.shard == "auto" and a.schedule == "sweep")) and not (a.bf16_direct or a.f16_direct)
     if a.workload == "socp" and cols:
         n = a.n or 50_000
-        inst = synth.SocpInstanceCols(n, a.cones, 99, seed=0, rank=rank, world=world, allreduce_host=allreduce_host)
+        inst = synth.SocpInstanceCols(n, a.cones, 99, seed=0, rank=rank, world=emu or world, allreduce_host=allreduce_host)
         wl = "random dense SOCP n=%d, %d second-order cones of 1+99 rows (m=%d), f32" % (n, a.cones, inst.m_total)
     elif a.workload == "lp" and cols:
         n = a.n or 10_000
-        inst = synth.LpInstanceCols(n, seed=0, rank=rank, world=world)
+        inst = synth.LpInstanceCols(n, seed=0, rank=rank, world=emu or world)
         wl = "benchmark_lp dense LP n=%d m=%d, f32" % (n, inst.m_total)
     elif a.workload == "socp":
         n = a.n or 50_000
-        inst = synth.SocpInstance(n, a.cones, 99, seed=0, rank=rank, world=world, allreduce_host=allreduce_host)
+        inst = synth.SocpInstance(n, a.cones, 99, seed=0, rank=rank, world=emu or world, allreduce_host=allreduce_host)
         wl = "random dense SOCP n=%d, %d second-order cones of 1+99 rows (m=%d), f32" % (n, a.cones, inst.m_total)
     elif a.workload == "sdp":
         assert world == 1, "one PSD cone does not shard"
@@ -467,7 +474,7 @@ def run(a):
         n = a.n or 10_000
         if a.bf16_direct or a.f16_direct:
             a.a_storage = "f16" if a.f16_direct else "bf16"
-        inst = synth.LpInstance(n, seed=0, rank=rank, world=world,
+        inst = synth.LpInstance(n, seed=0, rank=rank, world=emu or world,
                                 bf16_direct="f16" if a.f16_direct else a.bf16_direct)
         wl = "benchmark_lp dense LP n=%d m=%d, f32" % (n, inst.m_total)
     lib.thip_sync()
@@ -484,6 +491,8 @@ def run(a):
             and a.a_storage == "f32":
         a.to_eps = 1e-3
     hook, coll = None, "none"
+    if emu:
+        hook, coll = ("spin", a.emulate_latency), "stand-in collective of %d us (rank 0's shard of a %d-GPU run iterated alone)" % (a.emulate_latency, emu)
     dev_pg = "cpu" if pg_gloo else "cuda"
     if use_dist and a.collective == "gloo":
         hook, coll = GlooAllreduce(torch, dist, lib), "gloo through host memory (plumbing test mode)"
@@ -657,7 +666,7 @@ def run(a):
                 "unit variance, not exact Gaussians)",
         "state_arith": a.state,
         "config": {"workload": wl, "schedule": fs.schedule_in_use(), "schedule_asked": a.schedule, "passes_over_A_per_iter": passes,
-                   "rows_per_gpu": inst.m, "cols_per_gpu": n_loc,
+                   "rows_per_gpu": inst.m, "cols_per_gpu": n_loc, "emulated_world": emu or None,
                    "parallelism": ("column-sharded A x%d, one all-reduce of the two N products (2 m floats) per iteration" % world) if cols
                                   else "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll, "overlap": overlap_pick,
                    "overlap_mode_run": ovi["mode"], "overlap_split_col": ovi["split_col"], "overlap_autotune_ms_per_iter": overlap_times,
