@@ -165,7 +165,7 @@ def test_c4_gemv_unaligned_lda_properties(T):
         d.free()
 
 
-@pytest.mark.parametrize("schedule", ["fused", "carried"])
+@pytest.mark.parametrize("schedule", ["fused", "carried", "sweep"])
 def test_c4_full_size_sdp_iterates_vs_oracle(T, schedule):
     """the bench's configs[3] instance (k = 500, n = 2000, A 1 GB) for three iterations: preconditioner and iterates
     against the oracle (f64; its PSD projection is Householder + QL at k = 500)"""
@@ -185,6 +185,7 @@ def test_c4_full_size_sdp_iterates_vs_oracle(T, schedule):
     p = T.SolverParam()
     p.eps_acc = 1e-30
     fs = T.FusedSolver(n, m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule)
+    assert fs.schedule_in_use() == schedule          # "sweep": the one-pass kernel takes this size by itself
     t, s = fs.precond()
     N = n + 2 * m + 1
     assert np.allclose(t, ro.precond[:N], rtol=5e-5, atol=0)
@@ -206,7 +207,7 @@ def test_c4_full_size_sdp_iterates_vs_oracle(T, schedule):
 
 # ---- configs[2] at the full n ---------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("schedule", ["fused", "carried"])
+@pytest.mark.parametrize("schedule", ["fused", "carried", "sweep"])
 def test_c3_first_328_cones_at_full_n_iterates_vs_oracle(T, schedule):
     """BASELINE configs[2] at its full n = 50 000: the standalone problem made of the first 328 of the 1000 cones (A_sub
     32 800 x 50 000, 6.6 GB f32 on the GPU, 13 GB f64 in the oracle -- the sub-instance bench.py's cpu_baseline leg
@@ -242,6 +243,7 @@ def test_c3_first_328_cones_at_full_n_iterates_vs_oracle(T, schedule):
     p = T.SolverParam()
     p.eps_acc = 1e-30
     fs = T.FusedSolver(n, m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule)
+    assert fs.schedule_in_use() == schedule          # "sweep": the one-pass kernel takes this size by itself
     t, s = fs.precond()
     N = n + 2 * m + 1
     assert np.allclose(t, ro.precond[:N], rtol=5e-5, atol=0), np.abs(t / ro.precond[:N] - 1).max()
@@ -263,7 +265,7 @@ def test_c3_first_328_cones_at_full_n_iterates_vs_oracle(T, schedule):
 
 # ---- configs[1] at full size ----------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("schedule", ["reference", "carried"])
+@pytest.mark.parametrize("schedule", ["reference", "carried", "sweep"])
 def test_c2_full_size_lp_iterates_vs_oracle(T, schedule):
     """BASELINE configs[1]: the benchmark_lp construction at n = 10 000, m = 20 000 (A 0.8 GB f32 on the GPU, 1.6 GB f64 in
     the oracle, the device's own entries widened): preconditioner, iterates after iterations 0, 1, 2, 9 and the criteria
@@ -285,6 +287,7 @@ def test_c2_full_size_lp_iterates_vs_oracle(T, schedule):
     p = T.SolverParam()
     p.eps_acc = 1e-30
     fs = T.FusedSolver(n, m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule)
+    assert fs.schedule_in_use() == schedule          # "sweep": the one-pass kernel takes this size by itself
     t, s = fs.precond()
     N = n + 2 * m + 1
     assert np.allclose(t, ro.precond[:N], rtol=5e-5, atol=0), np.abs(t / ro.precond[:N] - 1).max()

@@ -242,6 +242,7 @@ struct SweepArgs {
     const int *stop; const float *kappa_p, *rtau_p;
 };
 int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g);
+int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *out, int max_out);
 size_t sweep_gran_words(const SweepGeom &g);
 int sweep_census_dry_run(hipStream_t st, unsigned *census, unsigned seq);
 int sweep_launch(hipStream_t st, const SweepGeom &g, const SweepArgs &a);

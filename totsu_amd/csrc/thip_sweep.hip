@@ -530,39 +530,59 @@ int sweep_variant()
 }
 }  // namespace
 
-// geometry for an m x n matrix; 0 when the sweep kernel can take it
-int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g)
+// One candidate geometry: W columns per panel (1 or 2: the two families of kernel instances), the smallest group size
+// the family's row capacity allows times gmul.  0 when the kernel can take the matrix that way.
+static int sweep_plan_one(size_t m, size_t n, size_t lda, const void *mat, int W, int gmul, SweepGeom *g)
 {
     if (m == 0 || n == 0 || m % 4 != 0 || lda % 4 != 0 || ((uintptr_t)mat & 15u) != 0) return 1;
-    if (m > (size_t)SW_MAXROWS * 32 || n > ((size_t)1 << 30)) return 1;
+    if (n > ((size_t)1 << 30) || n < (size_t)40 * W) return 1;
     if (ctx().num_cu != 256) return 1;
-    int cls = sweep_class();
-    int G = 32;
-    size_t rpm = 0;
-    for (; cls < 3; ++cls) {
-        const size_t cap = (size_t)SW_CT * 4 * g_classes[cls].nslot_max;
-        G = 1;
-        while (G < 32 && ((m + G - 1) / G + 3) / 4 * 4 > cap) G *= 2;
-        rpm = ((m + G - 1) / G + 3) / 4 * 4;
-        if (rpm <= cap) break;
-    }
-    if (cls == 3) return 1;
-    const int W = g_classes[cls].w;
+    const size_t slot_rows = (size_t)SW_CT * 4;
+    const size_t cap = slot_rows * (W == 1 ? 7 : 2);
+    int G = 1;
+    while (G < 32 && ((m + G - 1) / G + 3) / 4 * 4 > cap) G *= 2;
+    if (((m + G - 1) / G + 3) / 4 * 4 > cap) return 1;
+    for (int k = 1; k < gmul; k *= 2) { if (G >= 32) return 1; G *= 2; }
     // few columns: fewer, larger groups, so that every group has its 40 panels and no workgroup idles
-    while (G < 32 && (size_t)(256 / G) * 40 * W > n) { G *= 2; rpm = ((m + G - 1) / G + 3) / 4 * 4; }
+    while (G < 32 && (size_t)(256 / G) * 40 * W > n) { if (gmul > 1) return 1; G *= 2; }
+    const size_t rpm = ((m + G - 1) / G + 3) / 4 * 4;
     const int ngroups = 256 / G;
-    // at least 40 panels per group that has columns at all (the ring's fill and drain); with few columns some groups idle
     size_t cpg = (n + ngroups - 1) / ngroups;
-    if (cpg < (size_t)40 * W) cpg = (size_t)40 * W;
+    if (cpg < (size_t)40 * W) cpg = (size_t)40 * W;      // with few columns some groups idle
     cpg = (cpg + W - 1) / W * W;
-    if (n < (size_t)40 * W) return 1;
+    const int need = (int)((rpm + slot_rows - 1) / slot_rows);
     g->G = G; g->ngroups = ngroups; g->rows_per_member = (int)rpm; g->cols_per_group = (int)cpg;
-    const int need = (int)((rpm + (size_t)SW_CT * 4 - 1) / ((size_t)SW_CT * 4));
-    g->nslot = cls == 0 ? (need <= 1 ? 1 : 2) : (cls == 1 ? 4 : 7);
+    g->nslot = W == 2 ? (need <= 1 ? 1 : 2) : (need <= 4 ? 4 : 7);
     g->mpad = (m + 63) / 64 * 64;
     g->w = W; g->variant = sweep_variant();
     g->npan = (int)(cpg / W);
+    g->m_eff = (int)m;
     return 0;
+}
+
+// geometry for an m x n matrix; 0 when the sweep kernel can take it.  The default: one column per panel, the fewest
+// workgroups per column the rows allow (8 at BASELINE configs[2]); THIP_SWEEP_CLASS = 0 / 1 force the others
+int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g)
+{
+    const int cls = sweep_class();
+    if (cls == 0 && sweep_plan_one(m, n, lda, mat, 2, 1, g) == 0) return 0;
+    if (cls == 1 && sweep_plan_one(m, n, lda, mat, 1, 2, g) == 0) return 0;
+    return sweep_plan_one(m, n, lda, mat, 1, 1, g);
+}
+
+// the geometries worth timing on a given matrix (thip_solver.hip times them on the actual matrix, like the GEMV plans)
+int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *out, int max_out)
+{
+    static const int cand[6][2] = { { 1, 1 }, { 1, 2 }, { 1, 4 }, { 2, 1 }, { 2, 2 }, { 1, 8 } };
+    int k = 0;
+    for (int c = 0; c < 6 && k < max_out; ++c) {
+        SweepGeom g;
+        if (sweep_plan_one(m, n, lda, mat, cand[c][0], cand[c][1], &g) != 0) continue;
+        bool dup = false;
+        for (int j = 0; j < k; ++j) dup = dup || (out[j].G == g.G && out[j].w == g.w && out[j].nslot == g.nslot);
+        if (!dup) out[k++] = g;
+    }
+    return k;
 }
 
 size_t sweep_gran_words(const SweepGeom &g) { return (size_t)g.ngroups * SW_RING * g.G * (2 * g.w); }
