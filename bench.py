@@ -670,7 +670,7 @@ def run(a):
                    "parallelism": ("column-sharded A x%d, one all-reduce of the two N products (2 m floats) per iteration" % world) if cols
                                   else "row-sharded A x%d, all-reduce of A^T y" % world, "collective": coll, "overlap": overlap_pick,
                    "overlap_mode_run": ovi["mode"], "overlap_split_col": ovi["split_col"], "overlap_autotune_ms_per_iter": overlap_times,
-                   "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan(), "a_storage": a.a_storage},
+                   "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan(), "sweep_plan": fs.sweep_plan(), "a_storage": a.a_storage},
         "roofline": roofline,
         # north_star: "same primal/dual objective as the f64 CPU reference within 1e-4 relative".  The f64 oracle runs the
         # full-size instance at ~0.24 iter/s (1e5 iterations = 5 days), so at this size the gate is (a) THIS run's answer

@@ -371,6 +371,10 @@ int thip_solver_schedule_in_use(thip_solver *s, int *host_schedule);
  * the sweep is 1.24x faster, at 2 GB 1.7x, at 20 GB 2.0x); 0 = whenever the kernel can take the shape.  Before
  * thip_solver_init. */
 int thip_solver_set_sweep_min_bytes(thip_solver *s, size_t bytes);
+/* the geometry of the one-pass kernel chosen for this solver (thip_solver_init times the candidates on the actual matrix
+ * unless thip_solver_set_gemv_autotune(s, 0)): workgroups per column group, columns per panel, 16-byte slots per thread,
+ * and its measured time per sweep in ms (0 = not timed); all 0 when the one-pass schedule is not in use */
+int thip_solver_sweep_plan(thip_solver *s, int *host_members, int *host_cols_per_panel, int *host_slots, float *host_ms);
 /* N > 1 with THIP_SCHED_SWEEP: the problem given to thip_solver_create is this rank's block of COLUMNS -- mat_a is
  * m x n_local (all m rows), vec_c its n_local entries, vec_b and the cone segments the whole problem's -- the n-vectors are
  * sharded, the m-vectors replicated and updated redundantly, and the hook of thip_solver_set_allreduce is called ONCE per

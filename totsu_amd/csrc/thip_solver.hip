@@ -20,6 +20,7 @@
 // scalars riding in its tail) per transposed product.
 #include "thip_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -773,6 +774,7 @@ struct thip_solver {
     float *sw_partH = nullptr; unsigned long long *sw_gran = nullptr; unsigned *sw_census = nullptr;
     float *sw_part = nullptr;     // 8 * EG block partials
     unsigned sw_seq = 0, sw_tag = 0;
+    float sw_plan_ms = 0.0f;      // the chosen geometry's time per sweep as measured by the plan autotune (0: not tuned)
     // column-sharded sweep (thip_solver_set_column_shard): this rank holds a block of COLUMNS of A (all m rows), the
     // n-vectors are its block, the m-vectors are replicated; one all-reduce per iteration of cs_buf = [A u (mpad) ;
     // A x_x (mpad) ; 4 x EG block partials of the sums over n]
@@ -1322,6 +1324,8 @@ int rebuild_carried(thip_solver *s)
 // ---------------------------------------------------------------------------------------------------
 // Can the next run use the one-pass kernel?  Dense f32 A on one GPU in a shape sweep_plan() takes, on a device whose
 // placement census came out as 8 x 32 in a dry run.  Examined once per (re)initialisation.
+int sweep_pass(thip_solver *s, int first);
+
 int sweep_prepare(thip_solver *s)
 {
     if (s->schedule != THIP_SCHED_SWEEP) return 0;
@@ -1335,8 +1339,12 @@ int sweep_prepare(thip_solver *s)
     // a library-owned padded copy has zero rows behind row m, and every m-vector of the arena has zeros behind entry m
     if (m_eff % 4 != 0 && s->Apad != nullptr && s->ldpad >= (m_eff + 3) / 4 * 4) m_eff = (m_eff + 3) / 4 * 4;
     if (!s->col_shard && s->m * s->n * sizeof(float) < s->sweep_min_bytes) return 0;
-    SweepGeom g;
-    if (sweep_plan(m_eff, s->n, s->alda(), s->amat(), &g) != 0) return 0;
+    // the geometries the kernel offers for this matrix (group size, columns per panel); THIP_SWEEP_CLASS pins one
+    SweepGeom cand[6];
+    int nc = 0;
+    if (getenv("THIP_SWEEP_CLASS")) { if (sweep_plan(m_eff, s->n, s->alda(), s->amat(), &cand[0]) == 0) nc = 1; }
+    else nc = sweep_candidates(m_eff, s->n, s->alda(), s->amat(), cand, 6);
+    if (nc == 0) return 0;
     hipStream_t st = ctx().stream;
     if (!s->sw_census) {
         THIP_TRY(hipMalloc((void **)&s->sw_census, 64 * sizeof(unsigned)));
@@ -1349,12 +1357,49 @@ int sweep_prepare(thip_solver *s)
     THIP_TRY(hipMemcpyAsync(hc, s->sw_census, sizeof(hc), hipMemcpyDeviceToHost, st));
     THIP_TRY(hipStreamSynchronize(st));
     if (hc[9] != 0u) return 0;                      // not 32 workgroups per XCD: the carried schedule runs
+    size_t maxH = 0, maxG = 0;
+    for (int c = 0; c < nc; ++c) {
+        cand[c].m_eff = (int)m_eff;
+        maxH = std::max(maxH, (size_t)cand[c].ngroups * 2 * cand[c].mpad);
+        maxG = std::max(maxG, sweep_gran_words(cand[c]));
+    }
     if (s->sw_partH) { THIP_TRY(hipFree(s->sw_partH)); s->sw_partH = nullptr; }
     if (s->sw_gran) { THIP_TRY(hipFree(s->sw_gran)); s->sw_gran = nullptr; }
-    THIP_TRY(hipMalloc((void **)&s->sw_partH, (size_t)g.ngroups * 2 * g.mpad * sizeof(float)));
-    THIP_TRY(hipMalloc((void **)&s->sw_gran, sweep_gran_words(g) * sizeof(unsigned long long)));
-    THIP_TRY(hipMemsetAsync(s->sw_partH, 0, (size_t)g.ngroups * 2 * g.mpad * sizeof(float), st));
-    THIP_TRY(hipMemsetAsync(s->sw_gran, 0, sweep_gran_words(g) * sizeof(unsigned long long), st));
+    THIP_TRY(hipMalloc((void **)&s->sw_partH, maxH * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&s->sw_gran, maxG * sizeof(unsigned long long)));
+    THIP_TRY(hipMemsetAsync(s->sw_partH, 0, maxH * sizeof(float), st));
+    THIP_TRY(hipMemsetAsync(s->sw_gran, 0, maxG * sizeof(unsigned long long), st));
+    SweepGeom g = cand[0];
+    s->sw_plan_ms = 0.0f;
+    const char *env_at = getenv("THIP_GEMV_AUTOTUNE");
+    const bool tune = nc > 1 && !(s->autotune == 0 || (s->autotune < 0 && env_at && atoi(env_at) == 0));
+    if (tune) {
+        // time every geometry on the actual matrix, like the GEMV plans: idempotent sweeps (first = 1: u stays, x_x goes
+        // to the buffer that is not the iterate, gP is rewritten with what it has to hold anyway); one warm-up, two timed
+        hipEvent_t e0, e1;
+        THIP_TRY(hipEventCreate(&e0));
+        THIP_TRY(hipEventCreate(&e1));
+        float best = 1e30f;
+        for (int c = 0; c < nc; ++c) {
+            s->sgeom = cand[c];
+            THIP_TRY(hipMemsetAsync(s->sw_gran, 0, maxG * sizeof(unsigned long long), st));
+            THIP_RC(sweep_pass(s, 1));
+            THIP_TRY(hipEventRecord(e0, st));
+            THIP_RC(sweep_pass(s, 1));
+            THIP_RC(sweep_pass(s, 1));
+            THIP_TRY(hipEventRecord(e1, st));
+            THIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            THIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            unsigned err = 0;
+            THIP_TRY(hipMemcpy(&err, s->sw_census + 9, sizeof(err), hipMemcpyDeviceToHost));
+            if (err != 0u) { hipEventDestroy(e0); hipEventDestroy(e1); return 0; }      // a spin ran out: the carried schedule runs
+            if (ms < best) { best = ms; g = cand[c]; }
+        }
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        s->sw_plan_ms = best / 2;
+        THIP_TRY(hipMemsetAsync(s->sw_gran, 0, maxG * sizeof(unsigned long long), st));
+    }
     if (s->col_shard) {
         const size_t need = 2 * g.mpad + 4 * EG;
         if (s->cs_n != need) {
@@ -1717,11 +1762,12 @@ int thip_solver_init(thip_solver *s)
     if (!s->is16()) THIP_RC(ensure_apad(s, true));      // a fresh solve re-reads the caller's A (it may have changed in place)
     s->xx = s->xx_home; s->kx = s->kx_home; s->xbuf = 0;
     s->sw_first = true; s->sweep_state = 0;
-    THIP_RC(sweep_prepare(s));
-    if (s->sw_part) THIP_TRY(hipMemsetAsync(s->sw_part, 0, 8 * EG * sizeof(float), st));
     // init_vecs (solver.rs:483-494): x = 0, y = 0, tau = 1
     THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
     hipLaunchKernelGGL(init_status_k, dim3(1), dim3(1), 0, st, s->dst, 0.0f);
+    THIP_RC(sweep_prepare(s));        // (its plan autotune runs idempotent sweeps: after the stop flag has been cleared)
+    if (s->sw_part) THIP_TRY(hipMemsetAsync(s->sw_part, 0, 8 * EG * sizeof(float), st));
+    THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
 
     // calc_norms (solver.rs:460-481) + scalar parts of abssum (solver.rs:171-172)
     hipLaunchKernelGGL(init_sums_k, dim3(g), dim3(BLK), 0, st, (int)m, s->b, (int)n, s->c, s->part);
@@ -2046,6 +2092,19 @@ int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, 
     if (host_nj) *host_nj = h ? h->nj : 0;
     if (host_blocks) *host_blocks = h ? h->target_blocks : 0;
     if (host_ms) *host_ms = s->split_plan ? (s->is16() ? s->tuned16_sp_ms : s->tuned_sp_ms) : (s->is16() ? s->tuned16_ms : s->tuned_ms);
+    return 0;
+}
+
+int thip_solver_sweep_plan(thip_solver *s, int *host_members, int *host_cols_per_panel, int *host_slots, float *host_ms)
+{
+    THIP_NEED_INIT();
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (s->inited) THIP_RC(sweep_prepare(s));
+    const bool on = sweep_active(s);
+    if (host_members) *host_members = on ? s->sgeom.G : 0;
+    if (host_cols_per_panel) *host_cols_per_panel = on ? s->sgeom.w : 0;
+    if (host_slots) *host_slots = on ? s->sgeom.nslot : 0;
+    if (host_ms) *host_ms = on ? s->sw_plan_ms : 0.0f;
     return 0;
 }
 

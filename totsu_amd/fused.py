@@ -285,6 +285,12 @@ class FusedSolver:
         lib.thip_solver_schedule_in_use(self.h, C.byref(v))
         return {v_: k for k, v_ in SCHEDULES.items()}[v.value]
 
+    def sweep_plan(self):
+        g, w, sl, ms = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+        lib.thip_solver_sweep_plan(self.h, C.byref(g), C.byref(w), C.byref(sl), C.byref(ms))
+        return {"workgroups_per_column_group": g.value, "columns_per_panel": w.value, "slots_per_thread": sl.value,
+                "autotune_ms_per_sweep": ms.value}
+
     def set_sweep_min_bytes(self, nbytes):
         lib.thip_solver_set_sweep_min_bytes(self.h, int(nbytes))
 
