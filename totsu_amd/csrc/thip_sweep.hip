@@ -15,17 +15,20 @@
 // obtained differently from the carried schedule except for the order of the floating-point sums.
 //
 // The kernel.  A column (m floats, 400 KB at BASELINE configs[2]) does not fit one CU, and the dot must be complete
-// before the axpy can start.  So the 32 CUs of an XCD form a GROUP (or several groups of G = 16, 8, .. CUs when m is
-// small): a member owns a fixed range of rows -- its slices of v and x_y and its N accumulators live in registers for
-// the whole sweep -- the group walks its share of the columns in PANELS of 2, and the only thing that crosses CUs is an
-// all-gather of the members' 4 partial dots per panel through the L2 the group shares (8-byte {value, tag} granules:
-// plain stores stay in that L2, sc1 loads are served by it; the hand-off thip_eig.hip's one-XCD Householder reduction
-// uses).  The gather takes ~3 us under load, a panel ~1 us of HBM stream, so a panel stays in REGISTERS from its loads
-// to its axpy through a ring of 9 stages (statically indexed: the loop is unrolled by the ring length): loads of panel
-// p + 8 are issued while panel p + 5 is multiplied with v / x_y and panel p gets its axpy.  7 waves of a workgroup stream;
-// the 8th is a service wave (publishes the workgroup's partial dots, polls the group's granules, does the scalar
-// updates, prefetches the per-column data): a polling wave has to drain its own loads (vmcnt is in order), so it must
-// not be one that prefetches A.
+// before the axpy can start.  So G workgroups on one XCD form a GROUP (G = 8 or 16 at configs[2]; 1 .. 32, chosen by
+// sweep_plan_one / timed by thip_solver.hip): a member owns a fixed range of rows -- its slices of v and x_y and its N
+// accumulators live in registers for the whole sweep -- the group walks its share of the columns in PANELS of W = 1 or
+// 2 columns, and the only thing that crosses CUs is an all-gather of the members' 2 W partial dots per panel through the
+// L2 the group shares (8-byte {value, tag} granules: plain stores stay in that L2, sc1 loads are served by it; the
+// hand-off thip_eig.hip's one-XCD Householder reduction uses).  A gather takes microseconds under load, a panel
+// 1 - 2 us of HBM stream, so a panel stays ON THE CHIP from its loads to its axpy: a ring of LAGL + 1 register stages
+// (statically indexed: the loop is unrolled by the ring length), then LS more panels parked in LDS by the thread that
+// loaded them.  7 waves of a workgroup stream; the 8th is a service wave (publishes the workgroup's partial dots, gathers
+// the group's granules, does the scalar updates, prefetches the per-column data): a polling wave has to drain its own
+// loads (vmcnt is in order), so it must not be one that prefetches A.  What a geometry fixes is the BYTES a workgroup
+// stages per panel (W x rows x 4): fewer members per group (more rows each, one column per panel) buy longer intervals
+// for the service wave's dependent chain and fewer workgroups that can hold a group up -- 32 members with 2-column
+// panels ran at 0.65 of the HBM peak, 8 members with 1-column panels at 0.85 - 0.89 (DESIGN.md 4.7 has the steps).
 // Every spin is bounded; a workgroup that gives up raises the error word and the host reports a failed run.  A census at
 // kernel entry (XCC_ID + tickets) checks that exactly 32 workgroups sit on every XCD -- i.e. one per CU, all resident --
 // before anything is written; thip_solver.hip runs it once as a dry run and falls back to the carried schedule if the
