@@ -453,6 +453,22 @@ def run(a):
     t_gen0 = time.perf_counter()
     cols = (use_dist or emu) and a.path == "fused" and a.workload in ("socp", "lp") and a.a_storage == "f32" \
         and (a.shard == "cols" or (a.shard == "auto" and a.schedule == "sweep")) and not (a.bf16_direct or a.f16_direct)
+    if cols:
+        # every rank must be able to run the one-pass kernel on its block (256 CUs in 8 XCDs, a shape the kernel takes):
+        # agree BEFORE anything column-sharded is built -- a rank that found out in its solver's init would leave the
+        # others waiting in their first all-reduce
+        import ctypes as C_
+        nn = a.n or (50_000 if a.workload == "socp" else 10_000)
+        mm = a.cones * 100 if a.workload == "socp" else 2 * nn
+        c0_, c1_ = synth.shard_cols(nn, emu or world, rank)
+        ok_ = C_.c_int(0)
+        lib.thip_sweep_probe(mm, c1_ - c0_, mm, C_.byref(ok_))
+        all_ok = (int(round(float(allreduce_host(np.array([float(ok_.value)], dtype=np.float32))[0]))) == world) if use_dist else ok_.value
+        if not all_ok:
+            if rank == 0:
+                sys.stderr.write("bench.py: the one-pass kernel cannot run on every rank: row shards, carried schedule\n")
+            cols = False
+            a.schedule = "carried" if a.schedule == "sweep" else a.schedule
     if a.workload == "socp" and cols:
         n = a.n or 50_000
         inst = synth.SocpInstanceCols(n, a.cones, 99, seed=0, rank=rank, world=emu or world, allreduce_host=allreduce_host)

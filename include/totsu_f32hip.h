@@ -382,6 +382,10 @@ int thip_solver_sweep_plan(thip_solver *s, int *host_members, int *host_cols_per
  * more in thip_solver_init).  Every rank must get bitwise the same sums back (RCCL, the one-shot transport and a host sum
  * all do).  thip_solver_solution / _iterate return this rank's block of x and the whole y.  Before thip_solver_init. */
 int thip_solver_set_column_shard(thip_solver *s, int on);
+/* Can the one-pass kernel run on this device for an m x n_local block (geometry + one placement census, no collective)?
+ * A multi-rank host asks every rank and takes the minimum BEFORE building column-sharded solvers: a rank that found out
+ * inside thip_solver_init would leave the others waiting in their first all-reduce. */
+int thip_sweep_probe(size_t m, size_t n_local, size_t lda, int *host_ok);
 
 /* test entry point of the one-pass kernel (thip_sweep.hip): one sweep over the m x n matrix A (device, column-major),
  *   gT = A^T v ; g3 = A^T xy ; u <- u + Su o (-(gP - 2 g3) - c rtau) unless `first` ; gP <- g3 ;

@@ -149,6 +149,7 @@ extern "C" {
     pub fn thip_solver_schedule_in_use(s: *mut thip_solver, host_schedule: *mut c_int) -> c_int;
     pub fn thip_solver_set_sweep_min_bytes(s: *mut thip_solver, bytes: usize) -> c_int;
     pub fn thip_solver_set_column_shard(s: *mut thip_solver, on: c_int) -> c_int;
+    pub fn thip_sweep_probe(m: usize, n_local: usize, lda: usize, host_ok: *mut c_int) -> c_int;
     pub fn thip_solver_sweep_plan(s: *mut thip_solver, host_members: *mut c_int, host_cols_per_panel: *mut c_int, host_slots: *mut c_int, host_ms: *mut f32) -> c_int;
     pub fn thip_test_sweep(t: *const thip_sweep_test, host_ms: *mut f32, host_info: *mut c_int) -> c_int;
     pub fn thip_solver_gemv_plan(s: *const thip_solver, host_nj: *mut c_int, host_blocks: *mut c_int, host_ms: *mut f32) -> c_int;

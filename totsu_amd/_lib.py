@@ -145,6 +145,7 @@ PROTOTYPES = {
     "thip_solver_schedule_in_use": (_i, [_vp, C.POINTER(_i)]),
     "thip_solver_set_sweep_min_bytes": (_i, [_vp, _sz]),
     "thip_solver_set_column_shard": (_i, [_vp, _i]),
+    "thip_sweep_probe": (_i, [_sz, _sz, _sz, C.POINTER(_i)]),
     "thip_solver_sweep_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),
     "thip_test_sweep": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
     "thip_test_gemm_sym": (_i, [_i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),

@@ -700,3 +700,27 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     hipFree(gran); hipFree(census); hipFree(partH); hipFree(scal);
     return 0;
 }
+
+// Can the one-pass kernel run on THIS device for an m x n_local block (leading dimension lda)?  Geometry + one placement
+// census, no collective: a multi-rank host asks every rank and takes the minimum BEFORE it builds column-sharded solvers
+// (a rank that found out inside thip_solver_init would leave the others waiting in their first all-reduce).
+extern "C" int thip_sweep_probe(size_t m, size_t n_local, size_t lda, int *host_ok)
+{
+    THIP_NEED_INIT();
+    if (!host_ok) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    *host_ok = 0;
+    SweepGeom g;
+    // (the matrix itself is not needed: any 16-byte aligned address stands for it)
+    if (sweep_plan((m + 3) / 4 * 4, n_local, (lda + 3) / 4 * 4, reinterpret_cast<const void *>((uintptr_t)4096), &g) != 0) return 0;
+    unsigned *census = nullptr;
+    THIP_TRY(hipMalloc((void **)&census, 16 * sizeof(unsigned)));
+    hipStream_t st = ctx().stream;
+    THIP_TRY(hipMemsetAsync(census, 0, 16 * sizeof(unsigned), st));
+    THIP_RC(sweep_census_dry_run(st, census, 0));
+    unsigned hc[10];
+    THIP_TRY(hipMemcpyAsync(hc, census, sizeof(hc), hipMemcpyDeviceToHost, st));
+    THIP_TRY(hipStreamSynchronize(st));
+    hipFree(census);
+    *host_ok = hc[9] == 0u ? 1 : 0;
+    return 0;
+}
