@@ -488,3 +488,67 @@ def test_bench_emulated_rank_of_a_column_sharded_run():
     assert d["n_gpus"] == 1 and c["emulated_world"] == 4 and c["schedule"] == "sweep" and c["passes_over_A_per_iter"] == 1
     assert c["cols_per_gpu"] == 750 and c["rows_per_gpu"] == 6000 and "column-sharded" in c["parallelism"]
     assert "time_to_eps" not in d or d["time_to_eps"] is None or True
+
+
+def test_sweep_lp_with_equality_rows_and_qp_rotated_cone(T):
+    """the cone classes the m-tail handles element-wise or through the block projections: ConeZero next to ConeRPos (an LP
+    with equality rows, lp.rs:100-135) and a rotated second-order cone (a QP, qp.rs:130-170) -- iterates vs the carried
+    schedule, answers vs the oracle"""
+    rng = np.random.default_rng(31)
+    n, m, p_ = 60, 100, 8
+    x0 = rng.uniform(0.1, 1.0, n)
+    G = np.vstack([-np.eye(n), rng.uniform(0, 1, (m - n, n))])
+    h = np.concatenate([np.zeros(n), G[n:] @ x0 + rng.uniform(0.1, 1, m - n)])
+    A = rng.standard_normal((p_, n))
+    b = A @ x0
+    c = rng.uniform(0.1, 1, n)
+    ro = O.solve_lp(O.param(max_iter=400000, eps_acc=1e-5), c, G, h, A, b)
+    assert ro.status == O.OK
+    lp = T.ProbLP(_mb(T, T.MatType.General(n, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(m, n)).set_array(G),
+                  _mb(T, T.MatType.General(m, 1)).set_array(h.reshape(-1, 1)), _mb(T, T.MatType.General(p_, n)).set_array(A),
+                  _mb(T, T.MatType.General(p_, 1)).set_array(b.reshape(-1, 1)))
+    d = lp.dense()
+    assert d.m % 4 == 0 and 0 in list(d.seg_type)
+    pr = T.SolverParam()
+    pr.eps_acc = 1e-30
+    fs = T.FusedSolver.from_dense(d, pr, "sweep", sweep_min_bytes=0)
+    fc = T.FusedSolver.from_dense(d, pr, "carried")
+    assert fs.schedule_in_use() == "sweep"
+    for steps in (1, 9, 90):
+        fs.run(steps, poll_every=32)
+        fc.run(steps, poll_every=32)
+        for a_, b_ in zip(fs.iterate(), fc.iterate()):
+            assert np.abs(a_ - b_).max() <= 2e-4 * max(np.abs(b_).max(), 1e-6)
+    fs.destroy()
+    fc.destroy()
+    pr2 = T.SolverParam()
+    pr2.max_iter, pr2.eps_acc = 400_000, 1e-4
+    fs = T.FusedSolver.from_dense(d, pr2, "sweep", sweep_min_bytes=0)
+    x, _ = fs.solve()
+    fs.destroy()
+    pobj = float(c @ ro.x)
+    assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj))
+    assert np.abs(A @ x.astype(np.float64) - b).max() <= 5e-3 * (1 + np.abs(b).max())
+    lp.drop()
+    # QP: min 1/2 x^T P x + q^T x  s.t.  G x <= h   (ProbQP: one rotated SOC of n + 2 rows + nonneg rows)
+    n = 48
+    B = rng.standard_normal((n, n)) / np.sqrt(n)
+    P = (B @ B.T + 0.5 * np.eye(n)).astype(np.float32)
+    q = rng.standard_normal(n).astype(np.float32)
+    Gq = np.vstack([np.eye(n), -np.eye(n)]).astype(np.float32)
+    hq = np.ones(2 * n, np.float32)
+    qp = T.ProbQP(_mb(T, T.MatType.SymPack(n)).set_by_fn(lambda r, cc: P[r, cc]), _mb(T, T.MatType.General(n, 1)).set_array(q.reshape(-1, 1)),
+                  _mb(T, T.MatType.General(2 * n, n)).set_array(Gq), _mb(T, T.MatType.General(2 * n, 1)).set_array(hq.reshape(-1, 1)),
+                  _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)), 1e-6)
+    dq = qp.dense()
+    res = {}
+    for sched in ("carried", "sweep"):
+        f = T.FusedSolver.from_dense(dq, pr2, sched, sweep_min_bytes=0)
+        if sched == "sweep":
+            assert f.schedule_in_use() == "sweep", (dq.m, dq.n)
+        xq, _ = f.solve()
+        res[sched] = (xq[:n].astype(np.float64), f.status().iters)
+        f.destroy()
+    obj = lambda v: 0.5 * v @ P.astype(np.float64) @ v + q.astype(np.float64) @ v
+    assert abs(obj(res["sweep"][0]) - obj(res["carried"][0])) <= 1e-3 * (1 + abs(obj(res["carried"][0])))
+    assert abs(res["sweep"][1] - res["carried"][1]) <= max(5, res["carried"][1] // 50)
