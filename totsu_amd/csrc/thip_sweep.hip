@@ -48,8 +48,6 @@ constexpr int SW_CT = SW_CW * 64;          // streaming threads
 constexpr int SW_RING = 32;                // granule slots per group (> 2 (LAGL - DLAG) - 1: see the header of sweep_k)
 constexpr int SW_CR = 16;                  // slots of the per-column LDS ring (> LAGL - DLAG)
 constexpr int SW_SPIN_MAX = 2000000;
-constexpr int SW_MAXSLOT = 7;               // 16-byte slots of a column per streaming thread, at most
-constexpr int SW_MAXROWS = SW_CT * 4 * SW_MAXSLOT;  // rows a member can own
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -230,8 +228,8 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             }                                                                                                  \
         } while (0)
 #define SW_DOTS(S, P)                                                                                          \
-        if (SW_DBG(a) & 16) { asm volatile("" :: "v"(stg[S][0][0][0]), "v"(stg[S][W - 1][NSLOT - 1][3])); } else  \
         do {                                                                                                   \
+            if (SW_DBG(a) & 16) { asm volatile("" :: "v"(stg[S][0][0][0]), "v"(stg[S][W - 1][NSLOT - 1][3])); break; } \
             float p_[2 * W];                                                                                   \
             _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
                 float d1 = 0.0f, d2 = 0.0f;                                                                    \
@@ -249,8 +247,8 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             }                                                                                                  \
         } while (0)
 #define SW_AXPY(S, P)                                                                                          \
-        if (SW_DBG(a) & 16) { asm volatile("" :: "v"(stg[S][0][0][1]), "v"(stg[S][W - 1][NSLOT - 1][2])); } else  \
         do {                                                                                                   \
+            if (SW_DBG(a) & 16) { asm volatile("" :: "v"(stg[S][0][0][1]), "v"(stg[S][W - 1][NSLOT - 1][2])); break; } \
             _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
                 const float s1 = scal[(P) & 1][q], s2 = scal[(P) & 1][W + q];                                  \
                 _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl)                                           \
@@ -515,12 +513,8 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 namespace thip {
 
 namespace {
-// Kernel classes: (columns per panel W, 16-byte slots per thread NSLOT, load lead LAGL, dot lead DLAG, LDS panels LS).  What a
-// class fixes is the BYTES a workgroup stages per panel, W x rows x 4: the ring's depth in time is (bytes staged) / (the
-// workgroup's share of the HBM stream) whatever the shape, so fewer members per group (more rows each, one column per
-// panel) buy longer intervals for the service wave and fewer workgroups that can hold a group up.
-struct SwClass { int w, nslot_max; };
-const SwClass g_classes[3] = { { 2, 2 }, { 1, 4 }, { 1, 7 } };
+// THIP_SWEEP_CLASS (experiments): 0 = two columns per panel, 1 = one column per panel with twice the default group size,
+// 2 / unset = the default geometry of sweep_plan_one(W = 1)
 int sweep_class()
 {
     static const int v = getenv("THIP_SWEEP_CLASS") ? atoi(getenv("THIP_SWEEP_CLASS")) : 2;
