@@ -303,6 +303,14 @@ public:
 
     // THIP_A_F32 / THIP_A_BF16 / THIP_A_F16; before init(), or between run() calls (then resume() if it had finished)
     void set_a_storage(int kind) { chk(thip_solver_set_a_storage(h_, kind)); }
+    // THIP_SCHED_SWEEP (the default schedule) runs for matrices of at least this many bytes; before init()
+    void set_sweep_min_bytes(size_t bytes) { chk(thip_solver_set_sweep_min_bytes(h_, bytes)); }
+    // N > 1: this solver holds a block of COLUMNS (a, c: the block; b, segments: the whole problem's); needs an all-reduce
+    // hook (thip_solver_use_rccl / _use_oneshot / _set_allreduce on handle()); before init()
+    void set_column_shard(bool on) { chk(thip_solver_set_column_shard(h_, on ? 1 : 0)); }
+    // the schedule the next run() executes: THIP_SCHED_CARRIED when THIP_SCHED_SWEEP cannot take the problem
+    int schedule_in_use() { int v = 0; chk(thip_solver_schedule_in_use(h_, &v)); return v; }
+    thip_solver *handle() { return h_; }
     void init() { chk(thip_solver_init(h_)); inited_ = true; }
     // runs until termination (max_steps < 0) or for max_steps iterations; returns the reference's SolverError
     SolverError run(int64_t max_steps = -1, int64_t poll_every = 64)

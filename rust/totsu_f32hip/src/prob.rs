@@ -120,6 +120,13 @@ impl FusedSolver {
         chk(unsafe { thip_solver_init(h) });
         FusedSolver { h, n: d.n, m: d.m }
     }
+    /// the schedule the next run executes: THIP_SCHED_CARRIED when THIP_SCHED_SWEEP (one pass over A per iteration) cannot
+    /// take the problem (include/totsu_f32hip.h: thip_solver_schedule_in_use)
+    pub fn schedule_in_use(&mut self) -> c_int {
+        let mut v: c_int = 0;
+        chk(unsafe { thip_solver_schedule_in_use(self.h, &mut v) });
+        v
+    }
     /// runs to termination; Ok((x, y)) or the reference's SolverError (solver_error.rs:3-17)
     pub fn solve(&mut self) -> Result<(Vec<f32>, Vec<f32>), SolverError> {
         let mut st: thip_status = unsafe { std::mem::zeroed() };

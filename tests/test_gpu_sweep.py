@@ -552,3 +552,22 @@ def test_sweep_lp_with_equality_rows_and_qp_rotated_cone(T):
     obj = lambda v: 0.5 * v @ P.astype(np.float64) @ v + q.astype(np.float64) @ v
     assert abs(obj(res["sweep"][0]) - obj(res["carried"][0])) <= 1e-3 * (1 + abs(obj(res["carried"][0])))
     assert abs(res["sweep"][1] - res["carried"][1]) <= max(5, res["carried"][1] // 50)
+
+
+def test_sweep_probe_and_plan_queries(T):
+    from totsu_amd import _lib
+    lib = _lib.lib
+    ok = C.c_int(-1)
+    lib.thip_sweep_probe(100_000, 6250, 100_000, C.byref(ok))
+    assert ok.value == 1                       # an MI355X: 8 XCDs x 32 CUs, one resident workgroup each
+    lib.thip_sweep_probe(100_000, 20, 100_000, C.byref(ok))
+    assert ok.value == 0                       # fewer than 40 columns: the kernel does not take the block
+    lp, _ = _lp(T, 120, 3)
+    p = T.SolverParam()
+    fs = T.FusedSolver.from_dense(lp.dense(), p, "sweep", sweep_min_bytes=0)
+    pl = fs.sweep_plan()
+    assert pl["workgroups_per_column_group"] in (1, 2, 4, 8, 16, 32) and pl["columns_per_panel"] in (1, 2)
+    fs.destroy()
+    fc = T.FusedSolver.from_dense(lp.dense(), p, "carried")
+    assert fc.sweep_plan()["workgroups_per_column_group"] == 0
+    fc.destroy()
