@@ -3,7 +3,9 @@ at a given shape (default BASELINE configs[2]: m = 100 000, n = 50 000).
 
     python tools/sweep_probe.py [--check] [--m M --n N --reps R]
 
-THIP_SWEEP_VARIANT=0..3 picks the (columns per panel, load lead, dot lead) form of the kernel."""
+The geometry is sweep_plan()'s default (one column per panel, the fewest workgroups per column the rows allow);
+THIP_SWEEP_CLASS=0|1 and THIP_SWEEP_VARIANT=1 pick the other forms (totsu_amd/csrc/thip_sweep.hip), THIP_SWEEP_DBG the
+experiment switches of a -DSW_DEBUG build, and a -DSW_PROFILE build prints the service wave's phase stamps."""
 import argparse
 import ctypes as C
 import os
@@ -94,8 +96,8 @@ def main():
         print("check:", "PASS" if bad == 0 else "FAIL (%d)" % bad)
     r = run_case(lib, torch, a.m, a.n, 1, 1, reps=a.reps, check=False)
     gb = 4.0 * a.m * a.n / 1e9
-    print("time m %d n %d variant %s: best %.4f ms (%.0f GB/s), avg %.4f ms (%.0f GB/s) %s"
-          % (a.m, a.n, os.environ.get("THIP_SWEEP_VARIANT", "0"), r["ms_best"], gb / r["ms_best"] * 1e3, r["ms_avg"],
+    print("time m %d n %d class/variant %s: best %.4f ms (%.0f GB/s), avg %.4f ms (%.0f GB/s) %s"
+          % (a.m, a.n, os.environ.get("THIP_SWEEP_CLASS", "-") + "/" + os.environ.get("THIP_SWEEP_VARIANT", "0"), r["ms_best"], gb / r["ms_best"] * 1e3, r["ms_avg"],
              gb / r["ms_avg"] * 1e3, r))
 
 
