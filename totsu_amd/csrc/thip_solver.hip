@@ -408,29 +408,41 @@ __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, 
         db = block_sum_of_partials(ps_bv, np_m, shd);
     }
     const float kappa = st->kappa;
-    const size_t gstride = (size_t)gridDim.x * BLK;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += gstride) {
-        // the groups' shares, four at a time (eight independent loads in flight instead of a chain of waits)
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
-        int g = 0;
-        for (; g + 4 <= ngroups; g += 4) {
-            const float *q = partH + (size_t)g * 2 * mpad + i;
-            a0 += q[0]; b0 += q[mpad]; a1 += q[2 * mpad]; b1 += q[3 * mpad];
-            a2 += q[4 * mpad]; b2 += q[5 * mpad]; a3 += q[6 * mpad]; b3 += q[7 * mpad];
+    // 256 threads = 64 rows x 4 group lanes (post_k's shape): the sum over the groups' shares of one row -- up to 256 of
+    // them, 128 at the 10 000-variable LP -- is split four ways, combined through LDS, and lane 0 of a row does the update
+    __shared__ float comb[2][3][64];
+    const int e = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const size_t gstride = (size_t)gridDim.x * 64;
+    for (size_t i0 = blockIdx.x * (size_t)64; i0 < (size_t)m; i0 += gstride) {
+        const size_t i = i0 + e;
+        float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
+        if (i < (size_t)m) {
+            int g = kq;
+            for (; g + 4 < ngroups; g += 8) {
+                const float *q = partH + (size_t)g * 2 * mpad + i;
+                sa0 += q[0]; sb0 += q[mpad]; sa1 += q[8 * mpad]; sb1 += q[9 * mpad];
+            }
+            if (g < ngroups) { sa0 += partH[((size_t)g * 2 + 0) * mpad + i]; sb0 += partH[((size_t)g * 2 + 1) * mpad + i]; }
         }
-        for (; g < ngroups; ++g) { a0 += partH[((size_t)g * 2 + 0) * mpad + i]; b0 += partH[((size_t)g * 2 + 1) * mpad + i]; }
-        const float hN = (a0 + a1) + (a2 + a3), hx = (b0 + b1) + (b2 + b3);
-        h3[i] = hx;
-        const unsigned char k = cls[i];
-        const float oy = xy[i], os = xs[i];
-        float ny = comp_add(oy, Ty[i] * (b[i] * kappa - hN), ky, i);
-        float ns = comp_add(os, Ts[i] * v[i], ks, i);
-        if (k == 1) { ny = fmaxf(ny, 0.0f); ns = fmaxf(ns, 0.0f); }
-        else if (k == 0) { ns = 0.0f; }
-        xy[i] = ny;
-        xs[i] = ns;
-        rxy[i] = (k < 2) ? oy - 2.0f * ny : oy;
-        rxs[i] = (k < 2) ? os - 2.0f * ns : os;
+        const float sa = sa0 + sa1, sb = sb0 + sb1;
+        if (kq > 0) { comb[0][kq - 1][e] = sa; comb[1][kq - 1][e] = sb; }
+        __syncthreads();
+        if (kq == 0 && i < (size_t)m) {
+            const float hN = (sa + comb[0][0][e]) + (comb[0][1][e] + comb[0][2][e]);
+            const float hx = (sb + comb[1][0][e]) + (comb[1][1][e] + comb[1][2][e]);
+            h3[i] = hx;
+            const unsigned char k = cls[i];
+            const float oy = xy[i], os = xs[i];
+            float ny = comp_add(oy, Ty[i] * (b[i] * kappa - hN), ky, i);
+            float ns = comp_add(os, Ts[i] * v[i], ks, i);
+            if (k == 1) { ny = fmaxf(ny, 0.0f); ns = fmaxf(ns, 0.0f); }
+            else if (k == 0) { ns = 0.0f; }
+            xy[i] = ny;
+            xs[i] = ns;
+            rxy[i] = (k < 2) ? oy - 2.0f * ny : oy;
+            rxs[i] = (k < 2) ? os - 2.0f * ns : os;
+        }
+        __syncthreads();
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const float old = st->tau;
@@ -1494,7 +1506,7 @@ int one_iteration_sweep(thip_solver *s)
         hipLaunchKernelGGL(sw_bv_k, dim3(gm), dim3(BLK), 0, st, m, s->b, s->v, pm, s->dst);
         s->sw_first = false;
     }
-    hipLaunchKernelGGL(sw_xm_k, dim3(gm), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
+    hipLaunchKernelGGL(sw_xm_k, dim3(grid_for(s->m, 64, 4096)), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
                        cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
                        s->dst, pn + 2 * pns, pns, pm, (int)gm, ky, ks);
     THIP_RC(project_blocks(s));
