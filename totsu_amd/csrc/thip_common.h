@@ -240,6 +240,10 @@ struct SweepArgs {
     int first;                              // 1: u is current (a (re)start): no u update
     int dbg;                                // experiments (THIP_SWEEP_DBG): 1 no polling, 2 no wave reduction of the dots
     const int *stop; const float *kappa_p, *rtau_p;
+    // the sums over n of the criteria and of the scalar updates, accumulated by the workgroup that writes a column:
+    // pn[q * pn_stride + workgroup], q = 0 ||d||^2 (d = c + A^T x_y / tau, or A^T x_y when tau <= eps_zero), 1 c.x_x_k,
+    // 2 c.u_k, 3 c.(x_x_k - 2 x_x_{k+1}); every one of the 256 workgroups writes its four
+    float *pn; int pn_stride; const float *tau_p; float eps_zero;
 };
 int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g);
 int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *out, int max_out);

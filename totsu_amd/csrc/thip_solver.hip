@@ -387,8 +387,8 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
 //   [block cones]
 //   sw_vm_k   v_k from h2 = hP - 2 h3 (h3 = A x_x_k, carried form) ; partial sums of b.v_k, b.rx_y, ||p_k||^2, b.x_y_k
 //   sw_scal_k kappa_k
-//   SWEEP     u_k, x_x_{k+1}, gP = A^T x_y_k, the shares of A u_k and A x_x_{k+1}
-//   sw_post_k partial sums over n: ||d_k||^2, c.x_x_k, c.u_k, c.rx_x_k
+//   SWEEP     u_k, x_x_{k+1}, gP = A^T x_y_k, the shares of A u_k and A x_x_{k+1}, and -- per workgroup, over the columns it
+//             writes -- the partial sums over n: ||d_k||^2, c.x_x_k, c.u_k, c.rx_x_k
 //   status_k  the termination test of iterate k (solver.rs:381-451)
 // The arithmetic of every update is xupdate_k's / ycrit_k's / post_k's.
 // ---------------------------------------------------------------------------------------------------
@@ -498,34 +498,6 @@ __global__ __launch_bounds__(BLK) void sw_scal_k(DevStatus *st, const float *ps_
     if (threadIdx.x == 0) {
         const float k = st->kappa + st->s_kappa * (dc + db);
         st->kappa = fminf(k, 0.0f);       // solver.rs:566-567
-    }
-}
-
-// part: [0] ||d_k||^2, [1] c.x_x_k (the layout status_k reads), [2] c.u_k, [3] c.rx_x_k, gridDim.x block partials each
-__global__ __launch_bounds__(BLK) void sw_post_k(int n, const float *__restrict__ c, const float *__restrict__ xcur,
-                                                const float *__restrict__ xnxt, const float *__restrict__ u,
-                                                const float *__restrict__ gP, float eps_zero, const DevStatus *st,
-                                                float *__restrict__ part, int pstride)
-{
-    if (st->stop != 0) return;
-    __shared__ float sh[16];
-    const float tau = st->tau;
-    const bool conv = tau > eps_zero;
-    const float rt = conv ? 1.0f / tau : 1.0f;
-    float dd = 0.0f, cx = 0.0f, cu = 0.0f, crx = 0.0f;
-    const size_t gstride = (size_t)gridDim.x * BLK;
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)n; i += gstride) {
-        const float ci = c[i], xo = xcur[i];
-        const float d = conv ? fmaf(rt, gP[i], ci) : gP[i];
-        dd = fmaf(d, d, dd);
-        cx = fmaf(ci, xo, cx);
-        cu = fmaf(ci, u[i], cu);
-        crx = fmaf(ci, xo - 2.0f * xnxt[i], crx);
-    }
-    dd = block_sum(dd, sh); cx = block_sum(cx, sh); cu = block_sum(cu, sh); crx = block_sum(crx, sh);
-    if (threadIdx.x == 0) {
-        part[blockIdx.x] = dd; part[pstride + blockIdx.x] = cx;
-        part[2 * pstride + blockIdx.x] = cu; part[3 * pstride + blockIdx.x] = crx;
     }
 }
 
@@ -1460,6 +1432,10 @@ int sweep_pass(thip_solver *s, int first)
     a.seq = s->sw_seq++; a.tagbase = s->sw_tag; s->sw_tag += (unsigned)g.npan + 1u;
     a.first = first; a.dbg = 0;
     a.stop = &s->dst->stop; a.kappa_p = &s->dst->kappa; a.rtau_p = &s->dst->r_tau;
+    a.tau_p = &s->dst->tau; a.eps_zero = s->par.eps_zero;
+    a.pn = s->col_shard ? s->cs_buf + 2 * g.mpad : s->sw_part;       // (the plan autotune of a column shard runs before cs_buf
+    a.pn_stride = s->col_shard ? (int)EG : 256;                      //  exists: its sums go nowhere)
+    if (s->col_shard && s->cs_buf == nullptr) a.pn = nullptr;
     prof_begin(st);
     THIP_RC(sweep_launch(st, g, a));
     prof_end(st);
@@ -1480,19 +1456,20 @@ float *sweep_next(thip_solver *s) { return s->xbuf == 0 ? s->xx2 : s->xx_home; }
 int one_iteration_sweep(thip_solver *s)
 {
     hipStream_t st = ctx().stream;
-    const int n = (int)s->n, m = (int)s->m;
-    const unsigned gn = egrid(s->n), gm = egrid(s->m);
+    const int m = (int)s->m;
+    const unsigned gm = egrid(s->m);
     const float ez = s->par.eps_zero;
     const bool cols = s->col_shard;
-    // sums over n: [0] ||d||^2 [1] c.x_x [2] c.u [3] c.rx_x -- gn block partials each; column-sharded: EG slots each (the
-    // same on every rank, the unused ones stay zero) behind the two N products in the buffer that is all-reduced
+    // sums over n: [0] ||d||^2 [1] c.x_x [2] c.u [3] c.rx_x -- one partial per workgroup of the sweep; column-sharded: EG
+    // slots each (the same on every rank, the unused ones stay zero) behind the two N products in the buffer that is
+    // all-reduced
     float *const pn = cols ? s->cs_buf + 2 * s->sgeom.mpad : s->sw_part;
-    const int pns = cols ? (int)EG : (int)gn;
+    const int pns = cols ? (int)EG : 256;         // one slot per workgroup of the sweep (256), EG in the all-reduced buffer
     float *const pm = s->sw_part + 4 * EG;        // sums over m: [0] b.v [1] b.rx_y [2] ||p||^2 [3] b.x_y, gm partials each
     float *const ky = s->comp() ? s->ky : nullptr, *const ks = s->comp() ? s->ks : nullptr;
     float *const kv = s->comp() ? s->kv : nullptr;
     auto post = [&]() -> int {
-        hipLaunchKernelGGL(sw_post_k, dim3(gn), dim3(BLK), 0, st, n, s->c, s->xx, sweep_next(s), s->u, s->gP, ez, s->dst, pn, pns);
+        // (the sums over n -- ||d||^2, c.x_x, c.u, c.rx_x -- come out of the sweep itself: SweepArgs::pn)
         if (cols) {
             hipLaunchKernelGGL(sw_gsum_k, dim3(gm), dim3(BLK), 0, st, m, s->sgeom.ngroups, s->sgeom.mpad, s->sw_partH, s->cs_buf, s->dst);
             THIP_RC(do_allreduce(s, s->cs_buf, s->cs_n));

@@ -344,6 +344,10 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         // but the loads of the previous interval has arrived" -- and never waits for a round trip.  (Issued one interval
         // ahead and waited with vmcnt(0), every interval paid an L2 round trip: 1.59 us per panel instead of ~1.)
         const float kappa = *a.kappa_p, rtau = *a.rtau_p;
+        const float tau = *a.tau_p;
+        const bool conv = tau > a.eps_zero;
+        const float rt = conv ? 1.0f / tau : 1.0f;
+        float sdd = 0.0f, scx = 0.0f, scu = 0.0f, scrx = 0.0f;      // lanes < W: sums over the columns this workgroup writes
         const bool comp_u = a.ku != nullptr, comp_x = a.kx_in != nullptr;
         // per-column data: lane l < 8 W fetches field l / W of column l % W
         const int cf = lane / W, cq = lane % W;
@@ -468,6 +472,11 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                         a.xx_out[j] = x_new;
                         if (comp_x) a.kx_out[j] = kxj;
                         a.gP[j] = g3;
+                        const float dj = conv ? fmaf(rt, g3, cj) : g3;      // solver.rs:596-597 / 634
+                        sdd = fmaf(dj, dj, sdd);
+                        scx = fmaf(cj, xxj, scx);
+                        scu = fmaf(cj, u_new, scu);
+                        scrx = fmaf(cj, xxj - 2.0f * x_new, scrx);
                     }
                 }
             }
@@ -497,6 +506,16 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         int it = 0;
         for (; it + 1 < total; it += 2) { interval(it, xgA, cvA); interval(it + 1, xgB, cvB); }
         if (it < total) interval(it, xgA, cvA);
+        if (a.pn != nullptr) {
+            if constexpr (W == 2) {
+                sdd += __shfl_xor(sdd, 1, 64); scx += __shfl_xor(scx, 1, 64);
+                scu += __shfl_xor(scu, 1, 64); scrx += __shfl_xor(scrx, 1, 64);
+            }
+            if (lane == 0) {
+                float *o = a.pn + blockIdx.x;
+                o[0] = sdd; o[a.pn_stride] = scx; o[2 * a.pn_stride] = scu; o[3 * a.pn_stride] = scrx;
+            }
+        }
 #ifdef SW_PROFILE
         if (group == 0 && member == 0 && lane == 0)
         {
@@ -651,7 +670,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     THIP_TRY(hipMemsetAsync(gran, 0, sweep_gran_words(g) * sizeof(unsigned long long), st));
     THIP_TRY(hipMemsetAsync(census, 0, 160 * sizeof(unsigned), st));
     THIP_TRY(hipMemsetAsync(partH, 0, (size_t)g.ngroups * 2 * g.mpad * sizeof(float), st));
-    const float hs[4] = { 0.0f, t->kappa, t->rtau, 0.0f };       // [0] doubles as the stop flag (int 0)
+    const float hs[4] = { 0.0f, t->kappa, t->rtau, 1.0f };       // [0] doubles as the stop flag (int 0)
     THIP_TRY(hipMemcpyAsync(scal, hs, sizeof(hs), hipMemcpyHostToDevice, st));
     SweepArgs a;
     a.A = t->mat_a; a.lda = t->lda; a.m = (int)t->m; a.n = (int)t->n;
@@ -660,6 +679,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     a.xx_in = t->xx_in; a.kx_in = t->kx_in; a.xx_out = t->xx_out; a.kx_out = t->kx_out; a.gP = t->gp;
     a.partH = partH; a.mpad = g.mpad; a.gran = gran; a.census = census;
     a.first = t->first;
+    a.pn = nullptr; a.pn_stride = 0; a.tau_p = scal + 3; a.eps_zero = 1e-12f;
     a.dbg = getenv("THIP_SWEEP_DBG") ? atoi(getenv("THIP_SWEEP_DBG")) : 0;
     a.stop = reinterpret_cast<const int *>(scal); a.kappa_p = scal + 1; a.rtau_p = scal + 2;
     unsigned seq = 0, tagbase = 0;
