@@ -244,6 +244,10 @@ struct SweepArgs {
     // pn[q * pn_stride + workgroup], q = 0 ||d||^2 (d = c + A^T x_y / tau, or A^T x_y when tau <= eps_zero), 1 c.x_x_k,
     // 2 c.u_k, 3 c.(x_x_k - 2 x_x_{k+1}); every one of the 256 workgroups writes its four
     float *pn; int pn_stride; const float *tau_p; float eps_zero;
+    // kappa_out != NULL and first == 0: the sweep opens with the kappa update (solver.rs:566-567) -- every workgroup forms
+    // kappa_k = min(*kappa_p + *skappa_p (sum pn[3][0 .. pn_count) + sum pm_brx[0 .. np_m)), 0) for itself (same inputs, same
+    // order, same value) and one of them stores it; *kappa_p is then the copy sw_vm_k left of kappa_{k-1}
+    float *kappa_out; const float *skappa_p; const float *pm_brx; int np_m, pn_count;
 };
 int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g);
 int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *out, int max_out);

@@ -49,7 +49,8 @@ struct DevStatus {
     float     norm_b, norm_c;
     float     t_tau, s_kappa;    // preconditioner entries of tau / kappa
     float     r_tau;             // rx_tau
-    float     pad2[2];
+    float     kappa_in;          // sweep schedule: kappa_{k-1} as sw_vm_k left it for the sweep that forms kappa_k
+    float     pad2[1];
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -386,8 +387,7 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
 //   sw_xm_k   tau_k ; x_y_k, x_s_k from hN = A u_{k-1} (the groups' shares summed here), element-wise cones, rx
 //   [block cones]
 //   sw_vm_k   v_k from h2 = hP - 2 h3 (h3 = A x_x_k, carried form) ; partial sums of b.v_k, b.rx_y, ||p_k||^2, b.x_y_k
-//   sw_scal_k kappa_k
-//   SWEEP     u_k, x_x_{k+1}, gP = A^T x_y_k, the shares of A u_k and A x_x_{k+1}, and -- per workgroup, over the columns it
+//   SWEEP     kappa_k (every workgroup for itself, at entry) ; u_k, x_x_{k+1}, gP = A^T x_y_k, the shares of A u_k and A x_x_{k+1}, and -- per workgroup, over the columns it
 //             writes -- the partial sums over n: ||d_k||^2, c.x_x_k, c.u_k, c.rx_x_k
 //   status_k  the termination test of iterate k (solver.rs:381-451)
 // The arithmetic of every update is xupdate_k's / ycrit_k's / post_k's.
@@ -458,11 +458,12 @@ __global__ __launch_bounds__(BLK) void sw_vm_k(int m, const float *__restrict__ 
                                               const float *__restrict__ b, const float *__restrict__ rxs,
                                               const float *__restrict__ rxy, const float *__restrict__ Sv,
                                               float *__restrict__ v, float *__restrict__ kv, const float *__restrict__ xs,
-                                              const float *__restrict__ xy, float eps_zero, const DevStatus *st,
+                                              const float *__restrict__ xy, float eps_zero, DevStatus *st,
                                               float *__restrict__ part)
 {
     if (st->stop != 0) return;
     __shared__ float sh[16];
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->kappa_in = st->kappa;      // nobody writes kappa between here and the sweep
     const float rtau = st->r_tau, tau = st->tau;
     const bool conv = tau > eps_zero;
     const float rt = conv ? 1.0f / tau : 1.0f;
@@ -1433,6 +1434,14 @@ int sweep_pass(thip_solver *s, int first)
     a.first = first; a.dbg = 0;
     a.stop = &s->dst->stop; a.kappa_p = &s->dst->kappa; a.rtau_p = &s->dst->r_tau;
     a.tau_p = &s->dst->tau; a.eps_zero = s->par.eps_zero;
+    a.kappa_out = nullptr; a.skappa_p = &s->dst->s_kappa; a.pm_brx = nullptr; a.np_m = 0; a.pn_count = 0;
+    if (!first) {
+        // the sweep of a regular step opens with the kappa update: c.rx_x from the previous sweep's partials, b.rx_y from sw_vm_k
+        const unsigned gm_ = egrid(s->m);
+        a.kappa_p = &s->dst->kappa_in; a.kappa_out = &s->dst->kappa;
+        a.pm_brx = s->sw_part + 4 * EG + gm_; a.np_m = (int)gm_;
+        a.pn_count = s->col_shard ? (int)EG : 256;
+    }
     a.pn = s->col_shard ? s->cs_buf + 2 * g.mpad : s->sw_part;       // (the plan autotune of a column shard runs before cs_buf
     a.pn_stride = s->col_shard ? (int)EG : 256;                      //  exists: its sums go nowhere)
     if (s->col_shard && s->cs_buf == nullptr) a.pn = nullptr;
@@ -1489,7 +1498,7 @@ int one_iteration_sweep(thip_solver *s)
     THIP_RC(project_blocks(s));
     hipLaunchKernelGGL(sw_vm_k, dim3(gm), dim3(BLK), 0, st, m, s->h3, s->hP, s->b, s->rxs, s->rxy, s->Sv, s->v, kv, s->xs,
                        s->xy, ez, s->dst, pm);
-    hipLaunchKernelGGL(sw_scal_k, dim3(1), dim3(BLK), 0, st, s->dst, pn + 3 * pns, pns, pm + gm, (int)gm);
+    // (kappa_k is formed by the sweep's workgroups at entry: SweepArgs::kappa_out)
     sweep_swap(s);                                // x_x_k (formed by the previous sweep) is now the iterate
     THIP_RC(sweep_pass(s, 0));
     THIP_RC(post());

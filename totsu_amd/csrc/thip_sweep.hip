@@ -343,7 +343,18 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         // addresses clamped, no branches around them): the interval then opens with s_waitcnt vmcnt(NL + 1) -- "everything
         // but the loads of the previous interval has arrived" -- and never waits for a round trip.  (Issued one interval
         // ahead and waited with vmcnt(0), every interval paid an L2 round trip: 1.59 us per panel instead of ~1.)
-        const float kappa = *a.kappa_p, rtau = *a.rtau_p;
+        float kappa = *a.kappa_p;
+        const float rtau = *a.rtau_p;
+        if (a.kappa_out != nullptr && !a.first) {
+            // c.rx_x of the previous sweep (its workgroups' partials) + b.rx_y of the m-tail, in f64 like the other single-block sums
+            double dc = 0.0, db = 0.0;
+            for (int k = lane; k < a.pn_count; k += 64) dc += (double)a.pn[3 * a.pn_stride + k];
+            for (int k = lane; k < a.np_m; k += 64) db += (double)a.pm_brx[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { dc += __shfl_xor(dc, o, 64); db += __shfl_xor(db, o, 64); }
+            kappa = fminf(kappa + *a.skappa_p * ((float)dc + (float)db), 0.0f);
+            if (group == 0 && member == 0 && lane == 0) *a.kappa_out = kappa;
+        }
         const float tau = *a.tau_p;
         const bool conv = tau > a.eps_zero;
         const float rt = conv ? 1.0f / tau : 1.0f;
@@ -680,6 +691,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     a.partH = partH; a.mpad = g.mpad; a.gran = gran; a.census = census;
     a.first = t->first;
     a.pn = nullptr; a.pn_stride = 0; a.tau_p = scal + 3; a.eps_zero = 1e-12f;
+    a.kappa_out = nullptr; a.skappa_p = nullptr; a.pm_brx = nullptr; a.np_m = 0; a.pn_count = 0;
     a.dbg = getenv("THIP_SWEEP_DBG") ? atoi(getenv("THIP_SWEEP_DBG")) : 0;
     a.stop = reinterpret_cast<const int *>(scal); a.kappa_p = scal + 1; a.rtau_p = scal + 2;
     unsigned seq = 0, tagbase = 0;
