@@ -490,18 +490,6 @@ __global__ __launch_bounds__(BLK) void sw_vm_k(int m, const float *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(BLK) void sw_scal_k(DevStatus *st, const float *ps_crx, int np_n, const float *ps_brx, int np_m)
-{
-    if (st->stop != 0) return;
-    __shared__ double shd[16];
-    const float dc = block_sum_of_partials(ps_crx, np_n, shd);
-    const float db = block_sum_of_partials(ps_brx, np_m, shd);
-    if (threadIdx.x == 0) {
-        const float k = st->kappa + st->s_kappa * (dc + db);
-        st->kappa = fminf(k, 0.0f);       // solver.rs:566-567
-    }
-}
-
 // (re)start of the one-pass schedule from a consistent iterate: block partials of b.v (a step leaves them for the next
 // one's tau update; whatever ran before this -- nothing, or the carried schedule -- did not)
 __global__ __launch_bounds__(BLK) void sw_bv_k(int m, const float *__restrict__ b, const float *__restrict__ v,
