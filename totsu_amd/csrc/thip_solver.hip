@@ -1353,7 +1353,7 @@ int sweep_prepare(thip_solver *s)
     SweepGeom g = cand[0];
     s->sw_plan_ms = 0.0f;
     const char *env_at = getenv("THIP_GEMV_AUTOTUNE");
-    const bool tune = nc > 1 && !(s->autotune == 0 || (s->autotune < 0 && env_at && atoi(env_at) == 0));
+    const bool tune = !(s->autotune == 0 || (s->autotune < 0 && env_at && atoi(env_at) == 0));
     if (tune) {
         // time every geometry on the actual matrix, like the GEMV plans: idempotent sweeps (first = 1: u stays, x_x goes
         // to the buffer that is not the iterate, gP is rewritten with what it has to hold anyway); one warm-up, two timed
@@ -1383,6 +1383,11 @@ int sweep_prepare(thip_solver *s)
         hipEventDestroy(e0); hipEventDestroy(e1);
         s->sw_plan_ms = best / 2;
         THIP_TRY(hipMemsetAsync(s->sw_gran, 0, maxG * sizeof(unsigned long long), st));
+        // a safety net for shapes the kernel takes badly (e.g. very few rows per workgroup): a sweep that is not faster
+        // than the two passes of the carried schedule would be (at the dual GEMV's 6.2 TB/s) gives way to it -- unless the
+        // caller asked for the one-pass schedule "whenever the kernel can take the shape" (sweep_min_bytes = 0)
+        const double carried_ms = 2.0 * (double)s->m * (double)s->n * sizeof(float) / 6.2e12 * 1e3 + 0.03;
+        if (!s->col_shard && s->sweep_min_bytes != 0 && (double)s->sw_plan_ms > carried_ms) return 0;
     }
     if (s->col_shard) {
         const size_t need = 2 * g.mpad + 4 * EG;
