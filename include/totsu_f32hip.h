@@ -366,11 +366,11 @@ int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_byte
  * m or lda not a multiple of 4, fewer than 40 column panels per group, a device that is not 8 XCDs x 32 CUs, a failed
  * placement census) */
 int thip_solver_schedule_in_use(thip_solver *s, int *host_schedule);
-/* THIP_SCHED_SWEEP is used for matrices of at least this many bytes (default 384 MiB; measured on square-ish SOCPs: at
- * 128 MB the carried schedule is 2x faster -- few panels per column group, the ring's fill and drain dominate --, at 512 MB
- * the sweep is 1.24x faster, at 2 GB 1.7x, at 20 GB 2.0x); above it thip_solver_init also times the kernel's geometries
- * on the matrix and keeps the carried schedule if none beats an estimate of its two passes; 0 = whenever the kernel can
- * take the shape, unconditionally.  Before thip_solver_init. */
+/* THIP_SCHED_SWEEP is considered for matrices of at least this many bytes (default 128 MiB); above it thip_solver_init
+ * times the kernel's geometries on the matrix and keeps the carried schedule if none beats an estimate of its two passes
+ * (measured on square-ish SOCPs: the carried schedule stays at 190 MB, the sweep is 1.37x faster at 274 MB, 1.58x at
+ * 512 MB, 1.7x at 2 GB, 2.0x at 20 GB; a 1 200 x 100 000 matrix keeps the carried schedule, 100 000 x 1 200 gains 1.53x);
+ * 0 = whenever the kernel can take the shape, unconditionally.  Before thip_solver_init. */
 int thip_solver_set_sweep_min_bytes(thip_solver *s, size_t bytes);
 /* the geometry of the one-pass kernel chosen for this solver (thip_solver_init times the candidates on the actual matrix
  * unless thip_solver_set_gemv_autotune(s, 0)): workgroups per column group, columns per panel, 16-byte slots per thread,

@@ -761,7 +761,7 @@ struct thip_solver {
     // A x_x (mpad) ; 4 x EG block partials of the sums over n]
     bool col_shard = false;
     float *cs_buf = nullptr; size_t cs_n = 0;
-    size_t sweep_min_bytes = (size_t)384 << 20;     // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
+    size_t sweep_min_bytes = (size_t)128 << 20;     // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
     bool inited = false;
