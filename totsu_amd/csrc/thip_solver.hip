@@ -2027,6 +2027,8 @@ int thip_solver_schedule_in_use(thip_solver *s, int *host_schedule)
 int thip_solver_set_column_shard(thip_solver *s, int on)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (s->inited && (on != 0) != s->col_shard)
+        return fail(THIP_E_INVALID, "thip_solver_set_column_shard comes before thip_solver_init (the norms and preconditioners depend on it)", __FILE__, __LINE__);
     s->col_shard = on != 0;
     s->sweep_state = 0;
     return 0;
