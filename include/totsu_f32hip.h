@@ -37,6 +37,8 @@ extern "C" {
 #define THIP_E_NOGPU     10003   /* no HIP device: the product path fails loudly, there is no CPU fallback */
 #define THIP_E_WORK      10004   /* work buffer too short */
 #define THIP_E_NOCONV    10005   /* eigen iteration did not converge */
+#define THIP_E_TIMEOUT   10006   /* a bounded device-side wait ran out (a peer rank or its host stalled, or the one-pass kernel
+                                  * gave up on some rank of a column-sharded run): the solve cannot go on consistently */
 
 /* ---------------------------------------------------------------------------------------------
  * Context.  Replaces totsu_f32cuda/src/cuda_mgr.rs:24-111 (context + cuBLAS/cuSOLVER handles,
@@ -388,11 +390,34 @@ int thip_solver_set_column_shard(thip_solver *s, int on);
  * inside thip_solver_init would leave the others waiting in their first all-reduce. */
 int thip_sweep_probe(size_t m, size_t n_local, size_t lda, int *host_ok);
 
+/* What THIS device streams: a bare non-temporal read of `bytes` at dev_ptr (device memory, 16-byte aligned -- e.g. the
+ * solver's own A), best and average of `reps` timed launches per grid (HIP events).  bench.py prints it beside the
+ * sweep's rate: the boxes of one pool differ by several percent, and a roofline fraction means little without it. */
+int thip_stream_probe(const void *dev_ptr, size_t bytes, int reps, float *host_best_ms, float *host_avg_ms);
+
+/* The one-pass kernel is persistent and every wait in it is bounded.  When a workgroup gives up (placement changed under
+ * it, a peer workgroup was withheld), thip_solver_run restores the iterate of the last completed batch from a device
+ * snapshot and goes on with the 2-pass carried schedule (thip_solver_schedule_in_use then says THIP_SCHED_CARRIED); a
+ * column-sharded run, which has no 2-pass form, raises the fault through its all-reduce so that every rank restores the
+ * same iterate and retries together, and fails with THIP_E_TIMEOUT on every rank at once after two retries.
+ * host_faults = recoveries so far in this solve, host_last_word = the kernel's error word of the last one (1, 2 census,
+ * 3 a gather ran out of spins), host_restored_iter = the iteration the restored snapshot held (-1: none). */
+int thip_solver_sweep_faults(thip_solver *s, int *host_faults, int *host_last_word, int64_t *host_restored_iter);
+/* TEST HOOK: kind 1 = the placement census of the next plan (thip_solver_init) reports a bad placement; kind 2 = one
+ * workgroup of the after_sweeps-th regular sweep from now withholds its partial dots; spin_max > 0 shortens the
+ * bound of the gathers' polling loops (default ~2 s) so that a test does not wait for it.  kind 0 clears. */
+int thip_test_sweep_fault(thip_solver *s, int kind, int64_t after_sweeps, int spin_max);
+/* partial dots published with agent-scope (sc1) stores (1) or with plain stores that stay in the group's L2 (0, default);
+ * between thip_solver_run calls */
+int thip_solver_set_sweep_publish(thip_solver *s, int agent_scope);
+
 /* test entry point of the one-pass kernel (thip_sweep.hip): one sweep over the m x n matrix A (device, column-major),
  *   gT = A^T v ; g3 = A^T xy ; u <- u + Su o (-(gP - 2 g3) - c rtau) unless `first` ; gP <- g3 ;
  *   xx_out = xx_in + Tx o (gT + c kappa) ; hN = A u ; h3 = A xx_out            (Kahan terms ku / kx_* may be NULL)
- * `reps` launches are timed with HIP events (reps > 1 only with first != 0, which is idempotent); host_info[0] = the
- * kernel's error word (0 = ok), [1] = members per group, [2] = groups, [3] = panels per group */
+ * `reps` launches are timed with HIP events (reps > 1 only with first != 0, which is idempotent); host_info (8 ints):
+ * [0] = the kernel's error word (0 = ok), [1] = members per group, [2] = groups, [3] = panels per group, [4] = 16-byte
+ * slots per streaming thread.  force_members > 0: that many workgroups per column group instead of the planner's choice
+ * (a power of two the rows fit); pub_agent != 0: partial dots published with agent-scope (sc1) stores. */
 typedef struct thip_sweep_test {
     size_t m, n, lda;
     const float *mat_a, *v, *xy, *c, *su, *tx;
@@ -401,6 +426,7 @@ typedef struct thip_sweep_test {
     float *xx_out, *kx_out, *gp, *hn, *h3;
     float kappa, rtau;
     int32_t first, reps;
+    int32_t force_members, pub_agent;
 } thip_sweep_test;
 int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *host_info);
 

@@ -41,34 +41,52 @@ def counters(*dbs):
             print("%-30s %-44s launches %-6d avg %-12.5g avg_us %.2f" % (cname, short, calls, val, dur / 1e3))
 
 
+def _short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
 def pmc(fetch_db, write_db, key):
-    out = {}
+    """FETCH_SIZE and WRITE_SIZE of ONE kernel instance: the matching instance (sweep_k<...> / dual_gemv_k<.., DO_N, DO_T, ..>)
+    with the most launches in the FETCH pass -- the loop's kernel, not a geometry the plan autotune timed -- and the SAME
+    instance's row of the WRITE pass (round 3 paired the first row of each pass: two different instances when the two runs'
+    autotunes disagreed)."""
+    rows = {}
     for label, db in (("FETCH_SIZE", fetch_db), ("WRITE_SIZE", write_db)):
         cur = sqlite3.connect(db).cursor()
         q = ("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
              "where counter_name = ? group by kernel_name order by avg(value) * count(*) desc")
         print("# rocprofv3 --pmc %s   source: %s" % (label, db))
         print("%-6s %-16s %-12s %s" % ("calls", "avg_KiB", "avg_us", "kernel"))
+        rows[label] = {}
         for name, calls, val, dur in cur.execute(q, (label,)):
-            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            short = _short(name)
             print("%-6d %-16.1f %-12.1f %s" % (calls, val, dur / 1e3, short))
-            if key.endswith("_sweep"):
-                if "sweep_k<" in short:
-                    out.setdefault(label, val)
-            elif short.startswith("dual_gemv_k<") and ", true, true, false" in short \
-                    and ("unsigned short" in short) == key.endswith("_bf16"):                # DO_N, DO_T, !ABS; storage type
-                out.setdefault(label, val)      # rows are ordered by total traffic: keep the dominant plan
+            rows[label][short] = (calls, val, dur / 1e3)
         print()
-    if "FETCH_SIZE" in out:
-        rd = 2.0 * out["FETCH_SIZE"] * 1024.0
-        wr = out.get("WRITE_SIZE", 0.0) * 1024.0
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hbm_traffic.json")
-        d = json.load(open(path)) if os.path.exists(path) else {}
-        d[key] = {"kernel": "sweep_k" if key.endswith("_sweep") else "dual_gemv_k<DO_N, DO_T>", "fetch_size_KiB_raw": out["FETCH_SIZE"],
-                  "write_size_KiB_raw": out.get("WRITE_SIZE"), "read_bytes_corrected_x2": rd, "write_bytes": wr,
-                  "hbm_bytes_per_launch": rd + wr}
-        json.dump(d, open(path, "w"), indent=1)
-        print("# %s: corrected HBM bytes per launch = 2*FETCH + WRITE = %.4g" % (key, rd + wr))
+
+    def wanted(short):
+        if key.endswith("_sweep"):
+            return "sweep_k<" in short
+        return short.startswith("dual_gemv_k<") and ", true, true, false" in short and ("unsigned short" in short) == key.endswith("_bf16")
+    cand = [(v[0], k) for k, v in rows["FETCH_SIZE"].items() if wanted(k)]
+    if not cand:
+        print("# %s: no matching kernel in the FETCH pass" % key)
+        return
+    inst = max(cand)[1]
+    fetch = rows["FETCH_SIZE"][inst]
+    write = rows["WRITE_SIZE"].get(inst)
+    if write is None:
+        print("# %s: instance %s is not in the WRITE pass (another geometry was autotuned there): WRITE_SIZE left out" % (key, inst))
+    rd = 2.0 * fetch[1] * 1024.0
+    wr = (write[1] if write else 0.0) * 1024.0
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hbm_traffic.json")
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d[key] = {"kernel": inst, "launches_fetch_pass": fetch[0], "launches_write_pass": write[0] if write else 0,
+              "fetch_size_KiB_raw": fetch[1], "write_size_KiB_raw": write[1] if write else None,
+              "read_bytes_corrected_x2": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
+              "avg_us_fetch_pass": fetch[2]}
+    json.dump(d, open(path, "w"), indent=1)
+    print("# %s: %s: corrected HBM bytes per launch = 2*FETCH + WRITE = %.4g" % (key, inst, rd + wr))
 
 
 if __name__ == "__main__":

@@ -30,6 +30,7 @@ pub struct thip_sweep_test {
     pub xx_in: *const f32, pub kx_in: *const f32,
     pub xx_out: *mut f32, pub kx_out: *mut f32, pub gp: *mut f32, pub hn: *mut f32, pub h3: *mut f32,
     pub kappa: f32, pub rtau: f32, pub first: i32, pub reps: i32,
+    pub force_members: i32, pub pub_agent: i32,
 }
 
 pub enum thip_solver {}
@@ -152,6 +153,10 @@ extern "C" {
     pub fn thip_sweep_probe(m: usize, n_local: usize, lda: usize, host_ok: *mut c_int) -> c_int;
     pub fn thip_solver_sweep_plan(s: *mut thip_solver, host_members: *mut c_int, host_cols_per_panel: *mut c_int, host_slots: *mut c_int, host_ms: *mut f32) -> c_int;
     pub fn thip_test_sweep(t: *const thip_sweep_test, host_ms: *mut f32, host_info: *mut c_int) -> c_int;
+    pub fn thip_stream_probe(dev_ptr: *const c_void, bytes: usize, reps: c_int, host_best_ms: *mut f32, host_avg_ms: *mut f32) -> c_int;
+    pub fn thip_solver_sweep_faults(s: *mut thip_solver, host_faults: *mut c_int, host_last_word: *mut c_int, host_restored_iter: *mut i64) -> c_int;
+    pub fn thip_test_sweep_fault(s: *mut thip_solver, kind: c_int, after_sweeps: i64, spin_max: c_int) -> c_int;
+    pub fn thip_solver_set_sweep_publish(s: *mut thip_solver, agent_scope: c_int) -> c_int;
     pub fn thip_solver_gemv_plan(s: *const thip_solver, host_nj: *mut c_int, host_blocks: *mut c_int, host_ms: *mut f32) -> c_int;
 
     pub fn thip_comm_unique_id(host_id128: *mut u8) -> c_int;

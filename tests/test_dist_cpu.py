@@ -116,3 +116,44 @@ def test_column_sharded_sweep_gloo(tmp_path, case, port):
         assert np.allclose(res[0]["cri"][k], ro.trace[k][2:], rtol=1e-8, atol=1e-13), (k, res[0]["cri"][k], ro.trace[k])
     # one all-reduce per sweep (61 sweeps for 60 iterations) + the one of the preconditioner
     assert res[0]["collectives"] == 62
+
+
+def test_ranks_agree_on_column_shards_gloo(tmp_path):
+    """a rank whose thip_sweep_probe says no makes EVERY rank take row shards (bench.py: agree_on_column_shards), whichever
+    rank it is -- nobody is left alone in a column-sharded all-reduce"""
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29661", os.path.join(HERE, "dist_agree_worker.py"), str(tmp_path)]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    res = [json.load(open(os.path.join(tmp_path, "rank%d.json" % r))) for r in range(2)]
+    assert res[0] == res[1] == {"all_yes": True, "rank1_no": False, "rank0_no": False}
+
+
+def test_kernel_resource_guard_fails_a_build_that_spills(tmp_path):
+    """tools/check_kernel_resources.py (run by the Makefile on hipcc's -Rpass-analysis remarks): passes the budget the
+    one-pass kernel has today, fails when an enforced instance spills beyond 16 bytes per lane or drops below two waves"""
+    tool = os.path.join(os.path.dirname(HERE), "tools", "check_kernel_resources.py")
+
+    def remarks(vgprs, spill, scratch, occ, inst="Li7ELi1ELi2ELi1ELi3E"):
+        pre = "thip_sweep.hip:168:1: remark: "
+        return "\n".join([pre + "Function Name: _ZN4thip7sweep_kI%sEEvNS_9SweepArgsE [-Rpass-analysis=kernel-resource-usage]" % inst,
+                          pre + "    VGPRs: %d [-Rpass-analysis=kernel-resource-usage]" % vgprs,
+                          pre + "    ScratchSize [bytes/lane]: %d [-Rpass-analysis=kernel-resource-usage]" % scratch,
+                          pre + "    Occupancy [waves/SIMD]: %d [-Rpass-analysis=kernel-resource-usage]" % occ,
+                          pre + "    SGPRs Spill: 6 [-Rpass-analysis=kernel-resource-usage]",
+                          pre + "    VGPRs Spill: %d [-Rpass-analysis=kernel-resource-usage]" % spill,
+                          pre + "    LDS Size [bytes/block]: 656 [-Rpass-analysis=kernel-resource-usage]"]) + "\n"
+    cases = [(remarks(255, 2, 12, 2), 0), (remarks(256, 14, 60, 2), 1), (remarks(128, 0, 0, 1), 1),
+             (remarks(256, 17, 68, 2, inst="Li7ELi1ELi3ELi1ELi2E") + remarks(255, 2, 12, 2), 0),      # an experiment variant may spill
+             ("no kernels here\n", 2)]
+    for k, (txt, want) in enumerate(cases):
+        f = tmp_path / ("r%d.txt" % k)
+        f.write_text(txt)
+        rc = subprocess.run([sys.executable, tool, str(f)], capture_output=True).returncode
+        assert rc == want, (k, rc, want)
+    # and the remarks of the library as built here pass
+    built = os.path.join(os.path.dirname(HERE), "totsu_amd", "csrc", "thip_sweep.remarks.txt")
+    if os.path.exists(built):
+        assert subprocess.run([sys.executable, tool, built], capture_output=True).returncode == 0

@@ -207,18 +207,15 @@ def test_c4_full_size_sdp_iterates_vs_oracle(T, schedule):
 
 # ---- configs[2] at the full n ---------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("schedule", ["fused", "carried", "sweep"])
-def test_c3_first_328_cones_at_full_n_iterates_vs_oracle(T, schedule):
-    """BASELINE configs[2] at its full n = 50 000: the standalone problem made of the first 328 of the 1000 cones (A_sub
-    32 800 x 50 000, 6.6 GB f32 on the GPU, 13 GB f64 in the oracle -- the sub-instance bench.py's cpu_baseline leg
-    times).  Preconditioner (solver.rs:496-524), iterates after iterations 0, 1, 2 (solver.rs:526-571) and the criteria
-    triple (solver.rs:573-612) against the f64 oracle on the SAME inputs: the HIP path compared with the restated
-    reference at the headline's column count, not with itself."""
+def _c3_vs_oracle(T, schedule, sub, want_members=None):
+    """the standalone problem made of the first `sub` of the 1000 cones of BASELINE configs[2] at its full n = 50 000 (sub =
+    1000: the headline instance itself): preconditioner (solver.rs:496-524), iterates after iterations 0, 1, 2
+    (solver.rs:526-571) and the criteria triple (solver.rs:573-612) against the f64 oracle on the SAME inputs"""
     import math
     import os
     from totsu_amd import synth
     from totsu_amd._lib import lib
-    n, cones_full, sub, ni = 50_000, 1000, 328, 99
+    n, cones_full, ni = 50_000, 1000, 99
     rows = 1 + ni
     inst = synth.SocpInstance(n, cones_full, ni, seed=0, first_cones=sub)
     m = inst.m
@@ -242,8 +239,13 @@ def test_c3_first_328_cones_at_full_n_iterates_vs_oracle(T, schedule):
     del a
     p = T.SolverParam()
     p.eps_acc = 1e-30
-    fs = T.FusedSolver(n, m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule)
+    # (the default geometry, no timing: the test pins WHICH kernel instance it checks)
+    fs = T.FusedSolver(n, m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule,
+                       gemv_autotune=False if want_members else None)
     assert fs.schedule_in_use() == schedule          # "sweep": the one-pass kernel takes this size by itself
+    if want_members:
+        pl = fs.sweep_plan()
+        assert (pl["workgroups_per_column_group"], pl["columns_per_panel"], pl["slots_per_thread"]) == want_members, pl
     t, s = fs.precond()
     N = n + 2 * m + 1
     assert np.allclose(t, ro.precond[:N], rtol=5e-5, atol=0), np.abs(t / ro.precond[:N] - 1).max()
@@ -260,6 +262,92 @@ def test_c3_first_328_cones_at_full_n_iterates_vs_oracle(T, schedule):
         tr = ro.trace[it]
         assert np.allclose(fs.status().cri, tr[2:], rtol=5e-3, atol=1e-5), (it, fs.status().cri, tr)
     fs.destroy()
+    inst.free()
+
+
+@pytest.mark.parametrize("schedule", ["fused", "carried", "sweep"])
+def test_c3_first_328_cones_at_full_n_iterates_vs_oracle(T, schedule):
+    """A_sub 32 800 x 50 000, 6.6 GB f32 on the GPU, 13 GB f64 in the oracle -- the sub-instance bench.py's cpu_baseline leg
+    times: the HIP path compared with the restated reference at the headline's column count, not with itself."""
+    _c3_vs_oracle(T, schedule, 328)
+
+
+def test_c3_full_size_sweep_vs_oracle(T):
+    """BASELINE configs[2] ITSELF -- 1000 cones, m = 100 000, n = 50 000, A 20 GB f32 on the GPU -- through the one-pass
+    schedule in the geometry of the headline line (8 workgroups per column group x 12 500 rows, 7 slots per thread,
+    sweep_k<7,1,2,1,3>) against the f64 oracle, whose A is 40 GB: needs a host with that much memory to spare."""
+    import psutil
+    free = psutil.virtual_memory().available
+    if free < 64 * 2 ** 30:
+        pytest.skip("the oracle's f64 copy of A is 40 GB; only %.0f GiB of host memory available" % (free / 2 ** 30))
+    _c3_vs_oracle(T, "sweep", 1000, want_members=(8, 1, 7))
+
+
+def test_c5_column_shard_through_the_one_pass_kernel(T):
+    """rank 7's COLUMN shard of configs[4] (LP n = 200 000, m = 400 000 over 8 GPUs: 400 000 x 25 000 f32 = 40 GB) through
+    sweep_k alone (thip_test_sweep): the geometry with 32 workgroups per column x 7 slots per thread that only this
+    height reaches.  Checked against entries regenerated from the counter-based generator in f64: whole columns (both
+    dots -> u, x_x, gP) and whole rows (both axpys -> A u, A x_x)."""
+    import ctypes as C
+    from totsu_amd import _lib, synth
+    lib = _lib.lib
+    D = T.DeviceBuffer
+    inst = synth.LpInstanceCols(N5, seed=0, rank=7, world=WORLD5)
+    m, nl, col0 = inst.m, inst.n_local, inst.col0
+    assert (m, nl, col0) == (400_000, 25_000, 175_000)
+    vec = {}
+    for k, (ln, stream, kind, sc, sh) in dict(v=(m, 21, 1, 1.0, 0.0), xy=(m, 22, 1, 1.0, 0.0), c=(nl, 23, 1, 1.0, 0.0),
+                                              su=(nl, 24, 0, 1e-5, 1e-6), tx=(nl, 25, 0, 1e-5, 1e-6), u=(nl, 26, 1, 1.0, 0.0),
+                                              xx=(nl, 27, 1, 1.0, 0.0), gp=(nl, 28, 1, 1.0, 0.0)).items():
+        vec[k] = D(ln)
+        lib.thip_gen_vector(vec[k].ptr, ln, 5, stream, 0, kind, sc, sh)
+    host = {k: d.to_host().astype(np.float64) for k, d in vec.items()}
+    outs = {k: D(ln, zero=True) for k, ln in dict(xx_out=nl, hn=m, h3=m).items()}
+    t = _lib.SweepTest()
+    t.m, t.n, t.lda = m, nl, m
+    t.mat_a, t.v, t.xy, t.c, t.su, t.tx = inst.mat_a.ptr, vec["v"].ptr, vec["xy"].ptr, vec["c"].ptr, vec["su"].ptr, vec["tx"].ptr
+    t.u, t.ku, t.xx_in, t.kx_in, t.xx_out, t.kx_out = vec["u"].ptr, None, vec["xx"].ptr, None, outs["xx_out"].ptr, None
+    t.gp, t.hn, t.h3 = vec["gp"].ptr, outs["hn"].ptr, outs["h3"].ptr
+    kappa, rtau = -0.37, 0.81
+    t.kappa, t.rtau, t.first, t.reps = kappa, rtau, 0, 1
+    ms, info = (C.c_float * 2)(), (C.c_int * 8)()
+    lib.thip_test_sweep(C.byref(t), ms, info)
+    assert info[0] == 0, "the kernel raised its error word: %d" % info[0]
+    assert info[1] == 32 and info[2] == 8, list(info)          # 32 workgroups per column, 8 column groups
+    u_new, x_new, g3 = vec["u"].to_host().astype(np.float64), outs["xx_out"].to_host().astype(np.float64), vec["gp"].to_host().astype(np.float64)
+    hn, h3 = outs["hn"].to_host().astype(np.float64), outs["h3"].to_host().astype(np.float64)
+    n_glob = N5
+
+    def entry_col(cl):
+        col = np.array([O.rng_uniform(0, synth.STREAM_A, r + (col0 + cl) * m) for r in range(n_glob, m)])
+        full = np.zeros(m)
+        full[n_glob:] = col
+        full[col0 + cl] = -1.0           # the -I block: row == global column
+        return full
+
+    # columns from different groups (8 groups of 3125 columns), first / last / interior
+    for cl in (0, 3124, 3125, 12_345, nl - 1):
+        a = entry_col(cl)
+        dT, d3 = a @ host["v"], a @ host["xy"]
+        sc = np.abs(a) @ np.abs(host["v"])
+        assert abs(g3[cl] - d3) <= 2e-5 * (np.abs(a) @ np.abs(host["xy"])), cl
+        u_ref = host["u"][cl] + host["su"][cl] * (-(host["gp"][cl] - 2 * d3) - host["c"][cl] * rtau)
+        x_ref = host["xx"][cl] + host["tx"][cl] * (dT + host["c"][cl] * kappa)
+        assert abs(u_new[cl] - u_ref) <= 1e-6 * abs(u_ref) + 2e-5 * host["su"][cl] * 2 * (np.abs(a) @ np.abs(host["xy"])), cl
+        assert abs(x_new[cl] - x_ref) <= 1e-6 * abs(x_ref) + 2e-5 * host["tx"][cl] * sc, cl
+    # rows owned by different members (32 members of 12 500 rows): a -I row (exact), dense rows
+    for r in (col0 + 17, n_glob, n_glob + 12_499, n_glob + 12_500, 333_333, m - 1):
+        if r < n_glob:
+            cl = r - col0
+            assert abs(hn[r] + u_new[cl]) <= 1e-6 * abs(u_new[cl]) and abs(h3[r] + x_new[cl]) <= 1e-6 * abs(x_new[cl])
+            continue
+        row = np.array([O.rng_uniform(0, synth.STREAM_A, r + (col0 + cl) * m) for cl in range(nl)])
+        assert abs(hn[r] - row @ u_new) <= 2e-5 * (np.abs(row) @ np.abs(u_new)), r
+        assert abs(h3[r] - row @ x_new) <= 2e-5 * (np.abs(row) @ np.abs(x_new)), r
+    # -I rows that belong to other ranks' columns are zero rows of this shard
+    assert not hn[:col0].any() and not h3[:col0].any()
+    for d in list(vec.values()) + list(outs.values()):
+        d.free()
     inst.free()
 
 

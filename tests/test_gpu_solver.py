@@ -338,8 +338,10 @@ def _oracle_few_threads(key, fn):
     return _ORACLE_CACHE[key]
 
 
-@pytest.mark.parametrize("schedule", ["fused", "carried"])
+@pytest.mark.parametrize("schedule", ["fused", "carried", "sweep"])
 def test_synth_socp_converges_to_oracle_objective(T, schedule):
+    """north_star's objective gate -- the f64 CPU reference's primal / dual objective within 1e-4 relative -- through every
+    schedule the bench can report, the one-pass schedule (bench.py's default) included"""
     from totsu_amd import synth
     inst = synth.SocpInstance(500, 10, 99, seed=3)
     a, b, c = _synth_dense_to_host(inst)
@@ -352,7 +354,9 @@ def test_synth_socp_converges_to_oracle_objective(T, schedule):
     # the f64 oracle at 1e-5 is the objective being matched, within 1e-4 relative (BASELINE.json north_star)
     p = T.SolverParam()
     p.eps_acc, p.max_iter = 1e-4, 400_000
-    fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule)
+    fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule,
+                       sweep_min_bytes=0 if schedule == "sweep" else None)
+    assert fs.schedule_in_use() == schedule
     x, y = fs.solve(poll_every=256)
     gp, gd = float(c @ x.astype(np.float64)), -float(b @ y.astype(np.float64))
     assert abs(gp - pobj) <= 1e-4 * (1 + abs(pobj)), (gp, pobj)
@@ -363,8 +367,9 @@ def test_synth_socp_converges_to_oracle_objective(T, schedule):
     inst.free()
 
 
-@pytest.mark.parametrize("nk", [(12, 20), (10, 33)])
-def test_synth_sdp_converges_to_oracle_objective(T, nk):
+@pytest.mark.parametrize("nk,schedule", [((12, 20), "carried"), ((10, 33), "carried"), ((48, 20), "sweep"), ((60, 33), "sweep")])
+def test_synth_sdp_converges_to_oracle_objective(T, nk, schedule):
+    # (the one-pass kernel wants >= 40 columns: its two instances have n = 48 and 60)
     from totsu_amd import synth
     inst = synth.SdpInstance(nk[0], nk[1], seed=4)
     a, b, c = _synth_dense_to_host(inst)
@@ -373,7 +378,9 @@ def test_synth_sdp_converges_to_oracle_objective(T, nk):
     pobj = float(c @ ro.x)
     p = T.SolverParam()
     p.eps_acc, p.max_iter = 1e-4, 200_000
-    fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried")
+    fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, schedule,
+                       sweep_min_bytes=0 if schedule == "sweep" else None)
+    assert fs.schedule_in_use() == schedule
     x, y = fs.solve(poll_every=64)
     gobj = float(c @ x.astype(np.float64))
     assert abs(gobj - pobj) <= 3e-4 * (1 + abs(pobj))            # eps 1e-4 stop vs the eps 1e-5 answer
@@ -797,23 +804,27 @@ def test_toruscompl_socp_example_gpu_vs_oracle(T):
 
 def test_schedules_agree_at_the_full_socp_size(T):
     # BASELINE.json configs[2] (n = 50 000, 1000 cones, A = 20 GB): no CPU oracle finishes here, so parity is carried by
-    # a size-independent property -- the reference's own op sequence (6 GEMVs, `reference`) and the 2-pass `carried`
-    # schedule are the same iteration, whose small-size parity with the oracle is pinned by test_iterates_socp
+    # a size-independent property -- the reference's own op sequence (6 GEMVs, `reference`), the 2-pass `carried`
+    # schedule and the one-pass `sweep` (the headline's) are the same iteration, whose small-size parity with the oracle is
+    # pinned by test_iterates_socp / test_sweep_iterates_socp (the oracle itself at THIS size:
+    # test_gpu_configs.py::test_c3_full_size_sweep_vs_oracle)
     from totsu_amd import synth
     inst = synth.SocpInstance(50_000, 1000, 99, seed=0)
     p = T.SolverParam()
     p.eps_acc = 0.0
     out = {}
-    for sched in ("reference", "carried"):
+    for sched in ("reference", "carried", "sweep"):
         fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, sched)
+        assert fs.schedule_in_use() == sched
         r = fs.run(15, poll_every=15)
         out[sched] = (fs.iterate(), r)
         fs.destroy()
     (xr, yr), rr = out["reference"]
-    (xc, yc), rc = out["carried"]
-    assert rr.iters == rc.iters == 15
-    assert np.abs(xr - xc).max() <= 2e-4 * np.abs(xr).max() and np.abs(yr - yc).max() <= 2e-4 * np.abs(yr).max()
-    assert np.allclose(rr.cri, rc.cri, rtol=2e-3, atol=1e-6)
+    for sched in ("carried", "sweep"):
+        (xc, yc), rc = out[sched]
+        assert rr.iters == rc.iters == 15
+        assert np.abs(xr - xc).max() <= 2e-4 * np.abs(xr).max() and np.abs(yr - yc).max() <= 2e-4 * np.abs(yr).max(), sched
+        assert np.allclose(rr.cri, rc.cri, rtol=2e-3, atol=1e-6), sched
     inst.free()
 
 

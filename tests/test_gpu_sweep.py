@@ -48,7 +48,7 @@ def _sweep_case(m, n, first, comp, seed, lda=None):
     t.gp, t.hn, t.h3 = bufs["gp"].ptr, outs["hn"].ptr, outs["h3"].ptr
     t.kappa, t.rtau, t.first, t.reps = kappa, rtau, int(first), 1
     ms = (C.c_float * 2)()
-    info = (C.c_int * 4)()
+    info = (C.c_int * 8)()
     lib.thip_test_sweep(C.byref(t), ms, info)
     assert info[0] == 0, "the kernel raised its error word: %d" % info[0]
     Ad = A[:, :m].astype(np.float64)
@@ -278,7 +278,7 @@ def test_sweep_at_a_size_where_it_is_the_default(T):
 
 # ---- N > 1: column shards (thip_solver_set_column_shard) -----------------------------------------------------
 
-def _run_col_sharded(T, dense, cuts, param, max_steps, poll_every=16):
+def _run_col_sharded(T, dense, cuts, param, max_steps, poll_every=16, fault=None, pre_steps=0):
     """ranks emulated by threads in one process (the pattern of tests/test_gpu_sharded.py): each drives its own solver
     over its block of columns; the hook meets at a barrier and sums the device buffers on the shared stream"""
     import threading
@@ -313,8 +313,14 @@ def _run_col_sharded(T, dense, cuts, param, max_steps, poll_every=16):
             fs = T.FusedSolver(p["n"], m, p["mat_a"], dense.vec_b, p["vec_c"], dense.seg_type, dense.seg_len, param, "sweep",
                                vec_b_rowabs=dense.vec_b_rowabs, allreduce=make_hook(rank), col_shard=True)
             assert fs.schedule_in_use() == "sweep"
+            if pre_steps:
+                fs.run(pre_steps, poll_every=poll_every)
+            if fault is not None and fault[0] == rank:
+                fs.inject_sweep_fault(2, fault[1], fault[2])          # this rank's kernel gives up in that sweep
+            elif fault is not None:
+                fs.inject_sweep_fault(0, 0, fault[2])                 # (the same polling bound everywhere)
             r = fs.run(max_steps, poll_every=poll_every)
-            out[rank] = (r, fs.iterate(), fs.precond())
+            out[rank] = (r, fs.iterate(), fs.precond(), fs.sweep_faults())
             fs.destroy()
         except Exception as e:          # noqa
             errs.append(e)
@@ -571,3 +577,112 @@ def test_sweep_probe_and_plan_queries(T):
     fc = T.FusedSolver.from_dense(lp.dense(), p, "carried")
     assert fc.sweep_plan()["workgroups_per_column_group"] == 0
     fc.destroy()
+
+
+# ---- the persistent kernel gives up: recovery (thip_solver_run's snapshot, thip_solver_sweep_faults) ------------------------
+
+def test_bad_placement_census_at_init_runs_the_carried_schedule(T):
+    """the dry-run census of thip_solver_init says "not 32 workgroups on every XCD" (test hook): the solver plans the 2-pass
+    schedule by itself and is bit for bit a solver that was asked for it"""
+    lp, _ = _lp(T, 128, 5)
+    d = lp.dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    fs = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    assert fs.schedule_in_use() == "sweep"
+    fs.inject_sweep_fault(1)
+    fs.reinit()
+    assert fs.schedule_in_use() == "carried" and fs.passes()[0] == 2
+    fc = T.FusedSolver.from_dense(d, p, "carried", gemv_autotune=False)
+    fs.run(40, poll_every=16)
+    fc.run(40, poll_every=16)
+    assert all(np.array_equal(a, b) for a, b in zip(fs.iterate(), fc.iterate()))
+    assert fs.sweep_faults()["faults"] == 0
+    fs.reinit()                                   # the hook was one-shot: the next plan is the one-pass schedule again
+    assert fs.schedule_in_use() == "sweep"
+    fs.destroy()
+    fc.destroy()
+
+
+@pytest.mark.parametrize("kind", ["lp", "socp"])
+def test_sweep_that_gives_up_mid_run_restores_its_snapshot_and_finishes_on_the_carried_schedule(T, kind):
+    """one workgroup withholds its partial dots in the 4th sweep of a batch (test hook): its group runs out of spins, the
+    batch's iterates are garbage.  thip_solver_run must come back with the iterate of the last completed batch restored,
+    the 2-pass schedule in use, and the answer of a run that switched schedules at that iterate on purpose -- no
+    THIP_E_INVALID, no garbage"""
+    d = (_lp(T, 128, 11)[0] if kind == "lp" else _socp(T, 120, [15, 40, 3, 66], seed=9)).dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    ref = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    ref.run(20, poll_every=10)
+    ref.set_sweep_min_bytes(1 << 60)              # hands over to the carried schedule at iterate 20
+    ref.run(30, poll_every=10)
+    xr, yr = ref.iterate()
+    ref.destroy()
+    fs = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    fs.run(20, poll_every=10)
+    fs.inject_sweep_fault(2, after_sweeps=3, spin_max=20_000)
+    r = fs.run(30, poll_every=10)
+    assert r.state == -1 and r.iters == 50
+    f = fs.sweep_faults()
+    assert f["faults"] == 1 and f["last_word"] == 3 and f["restored_iter"] == 20, f
+    assert fs.schedule_in_use() == "carried"
+    x, y = fs.iterate()
+    assert np.isfinite(x).all() and np.isfinite(y).all()
+    sx, sy = max(np.abs(xr).max(), 1e-6), max(np.abs(yr).max(), 1e-6)
+    assert np.abs(x - xr).max() <= 2e-5 * sx and np.abs(y - yr).max() <= 2e-5 * sy, (np.abs(x - xr).max() / sx, np.abs(y - yr).max() / sy)
+    # and it still converges to the oracle-checked answer of an undisturbed run
+    fs.destroy()
+
+
+def test_sweep_fault_in_the_first_batch_restarts_from_the_initial_iterate(T):
+    lp, (c, G, h) = _lp(T, 150, 7)
+    d = lp.dense()
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 200_000, 1e-4
+    res = {}
+    for fault in (False, True):
+        fs = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0)
+        if fault:
+            fs.inject_sweep_fault(2, after_sweeps=5, spin_max=20_000)
+        x, _ = fs.solve(poll_every=50)
+        res[fault] = (x, fs.status().iters, fs.sweep_faults(), fs.schedule_in_use())
+        fs.destroy()
+    assert res[True][2]["faults"] == 1 and res[True][2]["restored_iter"] == 0 and res[True][3] == "carried"
+    assert res[False][2]["faults"] == 0 and res[False][3] == "sweep"
+    assert abs(res[True][1] - res[False][1]) <= max(3, res[False][1] // 200)
+    pobj = float(c.astype(np.float64) @ res[False][0])
+    assert abs(float(c.astype(np.float64) @ res[True][0]) - pobj) <= 2e-4 * (1 + abs(pobj))
+
+
+def test_column_sharded_fault_on_one_rank_is_seen_by_all_and_retried_together(T):
+    """2 emulated ranks; rank 1's kernel gives up in one sweep.  The flag travels in the tail of the iteration's all-reduce:
+    both ranks stop at the same iteration, restore the same snapshot, retry -- and end where the undisturbed run ends"""
+    socp = _socp(T, 260, [15, 40, 3, 66, 99, 21], seed=12)
+    d = socp.dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    cuts = [0, 90, 260]
+    clean = _run_col_sharded(T, d, cuts, p, 24, poll_every=8, pre_steps=16)
+    hit = _run_col_sharded(T, d, cuts, p, 24, poll_every=8, pre_steps=16, fault=(1, 2, 20_000))
+    for o, c_ in zip(hit, clean):
+        assert o[0].state == -1 and o[0].iters == c_[0].iters == 40
+        assert o[3]["faults"] == 1 and o[3]["restored_iter"] == 16, o[3]
+        assert c_[3]["faults"] == 0
+        for a, b in zip(o[1], c_[1]):
+            assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-6)
+    assert hit[0][3]["last_word"] == 4 and hit[1][3]["last_word"] == 3      # rank 0 learnt it from its peer
+    # replicated m-vectors stay bitwise identical across the ranks through the recovery
+    n0, n1 = 90, 170
+    assert np.array_equal(hit[0][1][0][n0:], hit[1][1][0][n1:]) and np.array_equal(hit[0][1][1][n0:], hit[1][1][1][n1:])
+
+
+def test_stream_probe_reports_a_plausible_rate(T):
+    import ctypes as C
+    from totsu_amd import _lib
+    buf = T.DeviceBuffer(256 * 1024 * 1024)          # 1 GiB
+    best, avg = C.c_float(), C.c_float()
+    _lib.lib.thip_stream_probe(buf.ptr, 4 * buf.n, 3, C.byref(best), C.byref(avg))
+    gbps = 4 * buf.n / (best.value * 1e-3) / 1e9
+    assert 2000 < gbps < 9000, gbps
+    buf.free()

@@ -42,7 +42,7 @@ def run_case(lib, torch, m, n, first, comp, seed=0, reps=1, check=True, lda=None
     t.gp, t.hn, t.h3 = P(gp), P(hn), P(h3)
     t.kappa, t.rtau, t.first, t.reps = kappa, rtau, int(first), reps
     ms = (C.c_float * 2)()
-    info = (C.c_int * 4)()
+    info = (C.c_int * 8)()
     torch.cuda.synchronize()
     lib.thip_test_sweep(C.byref(t), ms, info)
     torch.cuda.synchronize()

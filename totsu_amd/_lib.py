@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libtotsu_f32hip.so")
 
-E_INVALID, E_NOTINIT, E_NOGPU, E_WORK, E_NOCONV = 10001, 10002, 10003, 10004, 10005
+E_INVALID, E_NOTINIT, E_NOGPU, E_WORK, E_NOCONV, E_TIMEOUT = 10001, 10002, 10003, 10004, 10005, 10006
 
 ST_RUNNING, ST_OK, ST_UNBOUNDED, ST_INFEASIBLE, ST_EXCESS_ITER, ST_INVALID_OP, ST_WORK_SHORTAGE, ST_CONE_FAILURE = \
     -1, 0, 1, 2, 3, 4, 5, 6
@@ -46,7 +46,8 @@ class SweepTest(C.Structure):
     _fields_ = [("m", C.c_size_t), ("n", C.c_size_t), ("lda", C.c_size_t)] + \
                [(k, C.c_void_p) for k in ("mat_a", "v", "xy", "c", "su", "tx", "u", "ku", "xx_in", "kx_in", "xx_out",
                                           "kx_out", "gp", "hn", "h3")] + \
-               [("kappa", C.c_float), ("rtau", C.c_float), ("first", C.c_int32), ("reps", C.c_int32)]
+               [("kappa", C.c_float), ("rtau", C.c_float), ("first", C.c_int32), ("reps", C.c_int32),
+                ("force_members", C.c_int32), ("pub_agent", C.c_int32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -148,6 +149,10 @@ PROTOTYPES = {
     "thip_sweep_probe": (_i, [_sz, _sz, _sz, C.POINTER(_i)]),
     "thip_solver_sweep_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),
     "thip_test_sweep": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
+    "thip_stream_probe": (_i, [_vp, _sz, _i, C.POINTER(_f), C.POINTER(_f)]),
+    "thip_solver_sweep_faults": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int64)]),
+    "thip_test_sweep_fault": (_i, [_vp, _i, C.c_int64, _i]),
+    "thip_solver_set_sweep_publish": (_i, [_vp, _i]),
     "thip_test_gemm_sym": (_i, [_i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_test_gemm_chain": (_i, [_i, _i, _i, _i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_solver_gemv_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),

@@ -223,6 +223,7 @@ int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_
                       float *y, const int *stop);
 
 // thip_sweep.hip: one pass over A per iteration (THIP_SCHED_SWEEP)
+constexpr int SW_SPIN_MAX = 2000000;       // polls of a gather before a workgroup gives up (~2-4 s)
 struct SweepGeom { int G, ngroups, rows_per_member, cols_per_group, nslot, npan, w, variant, m_eff; size_t mpad; };
 struct SweepArgs {
     const float *A; size_t lda; int m, n;
@@ -244,6 +245,12 @@ struct SweepArgs {
     // pn[q * pn_stride + workgroup], q = 0 ||d||^2 (d = c + A^T x_y / tau, or A^T x_y when tau <= eps_zero), 1 c.x_x_k,
     // 2 c.u_k, 3 c.(x_x_k - 2 x_x_{k+1}); every one of the 256 workgroups writes its four
     float *pn; int pn_stride; const float *tau_p; float eps_zero;
+    // where the kappa update reads c.rx_x of the PREVIOUS sweep: never the buffer this launch writes (two buffers by launch
+    // parity; column-sharded: the all-reduced tail) -- a fast workgroup's exit must not overtake a slow one's entry
+    const float *pn_in; int pn_in_stride;
+    int spin_max;                           // bound of a gather's polling loop (SW_SPIN_MAX; tests shorten it)
+    int fault;                              // TEST HOOK: != 0: one workgroup withholds its publishes from the middle of the sweep on
+    int pub_agent;                          // != 0: partial dots published with agent-scope (sc1) stores
     // kappa_out != NULL and first == 0: the sweep opens with the kappa update (solver.rs:566-567) -- every workgroup forms
     // kappa_k = min(*kappa_p + *skappa_p (sum pn[3][0 .. pn_count) + sum pm_brx[0 .. np_m)), 0) for itself (same inputs, same
     // order, same value) and one of them stores it; *kappa_p is then the copy sw_vm_k left of kappa_{k-1}
@@ -254,6 +261,10 @@ int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom 
 size_t sweep_gran_words(const SweepGeom &g);
 int sweep_census_dry_run(hipStream_t st, unsigned *census, unsigned seq);
 int sweep_launch(hipStream_t st, const SweepGeom &g, const SweepArgs &a);
+
+// thip_oneshot.hip: the hook thip_solver_use_oneshot installs and the device address of its error word (NULL: not set up)
+thip_allreduce_fn oneshot_hook();
+const unsigned *oneshot_error_word();
 
 void prof_release();      // destroys the HIP events of thip_prof_* (thip_shutdown)
 

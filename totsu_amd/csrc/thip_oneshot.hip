@@ -122,6 +122,11 @@ int oneshot_allreduce(void *, float *buf, size_t n, void *stream)
 
 }  // namespace
 
+namespace thip {
+thip_allreduce_fn oneshot_hook() { return oneshot_allreduce; }
+const unsigned *oneshot_error_word() { return g.mem ? err_word() : nullptr; }
+}  // namespace thip
+
 extern "C" {
 
 int thip_oneshot_init(int rank, int world, size_t max_floats, uint8_t *host_handle64)

@@ -50,7 +50,8 @@ struct DevStatus {
     float     t_tau, s_kappa;    // preconditioner entries of tau / kappa
     float     r_tau;             // rx_tau
     float     kappa_in;          // sweep schedule: kappa_{k-1} as sw_vm_k left it for the sweep that forms kappa_k
-    float     pad2[1];
+    int       fault;             // column-sharded sweep: some rank's one-pass kernel gave up (seen by every rank in the same
+                                 // all-reduce, thip_solver_run restores the snapshot on all of them together)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -338,9 +339,16 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
 // ps_pp / ps_by: post_k's block partials of ||p||^2 and b.x_y (all-reduced block partials when sharded).
 __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict__ part,
                                                float eps_acc, float eps_inf, float eps_zero, long long max_iter,
-                                               DevStatus *st, const float *ps_pp, const float *ps_by, int npsum, int xbuf)
+                                               DevStatus *st, const float *ps_pp, const float *ps_by, int npsum, int xbuf,
+                                               const float *fault_flag)
 {
     if (st->stop != 0) return;
+    if (fault_flag != nullptr && *fault_flag > 0.0f) {
+        // column-sharded: the sum over ranks of "my one-pass kernel gave up" came back non-zero -- on every rank, in this
+        // iteration: nothing after this sweep is to be trusted; stop here (state stays RUNNING) and let the host restore
+        if (threadIdx.x == 0) { st->fault = 1; st->stop = 1; }
+        return;
+    }
     __shared__ double shd[16];
     const float pp = block_sum_of_partials(ps_pp, npsum, shd);
     const float by = block_sum_of_partials(ps_by, npsum, shd);
@@ -504,10 +512,18 @@ __global__ __launch_bounds__(BLK) void sw_bv_k(int m, const float *__restrict__ 
 }
 
 // column-sharded runs: the groups' shares of the two N products summed into the buffer that is all-reduced
+// + this rank's 4 x 256 sums over n (the sweep wrote them to its own buffer) into the 4 x EG slots of the tail, and this
+// rank's "my kernel gave up" flag behind them
 __global__ __launch_bounds__(BLK) void sw_gsum_k(int m, int ngroups, size_t mpad, const float *__restrict__ partH,
-                                                float *__restrict__ out, const DevStatus *st)
+                                                float *__restrict__ out, const DevStatus *st, const float *__restrict__ pn_loc,
+                                                const unsigned *__restrict__ errw)
 {
     if (st->stop != 0) return;
+    if (blockIdx.x == 0) {
+        float *tail = out + 2 * mpad;
+        for (int q = 0; q < 4; ++q) tail[q * (int)EG + threadIdx.x] = pn_loc[q * 256 + threadIdx.x];      // BLK == 256 workgroups of the sweep
+        if (threadIdx.x == 0) tail[4 * EG] = *errw != 0u ? 1.0f : 0.0f;
+    }
     for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < (size_t)m; i += (size_t)gridDim.x * BLK) {
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;      // as in sw_xm_k
         int g = 0;
@@ -567,7 +583,7 @@ __global__ void sum_partials_k(int nq, int np, const float *__restrict__ part, f
 __global__ void init_status_k(DevStatus *st, float norm_b_sq_dummy)
 {
     (void)norm_b_sq_dummy;
-    st->stop = 0; st->state = THIP_ST_RUNNING; st->kind = 0; st->iter = 0;
+    st->stop = 0; st->state = THIP_ST_RUNNING; st->kind = 0; st->iter = 0; st->fault = 0;
     st->cri[0] = st->cri[1] = st->cri[2] = 0.0f;
     st->tau = 1.0f; st->kappa = 0.0f; st->r_tau = 0.0f;
 }
@@ -633,12 +649,18 @@ __global__ void signal_k(unsigned *flag, unsigned val)
 {
     __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void gate_k(const unsigned *flag, unsigned val, long long timeout_ticks, unsigned *err)
+__global__ void gate_k(const unsigned *flag, unsigned val, long long timeout_ticks, unsigned *err, int *stop)
 {
     const long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - val) < 0) {
         __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > timeout_ticks) { atomicExch(err, 1u); break; }
+        if (wall_clock64() - t0 > timeout_ticks) {
+            // the sums this gate waits for never came: nothing enqueued behind it may touch the iterate (every kernel of the
+            // loop returns at entry on the stop flag); the host reads the error word after the batch (thip_solver_run)
+            atomicExch(err, 1u);
+            __hip_atomic_store(stop, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
     }
 }
 
@@ -648,6 +670,21 @@ __global__ void spin_k(long long ticks)
 {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// the snapshot of the consistent iterate the one-pass schedule keeps per batch (and its restore): six contiguous pieces of
+// the arena and the status block in ONE launch
+struct SnapArgs { const float *src[6]; float *dst[6]; size_t len[6]; const DevStatus *st_src; DevStatus *st_dst; };
+__global__ __launch_bounds__(BLK) void snap_copy_k(const SnapArgs a)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * BLK;
+    for (int q = 0; q < 6; ++q) {
+        const f4 *sp = reinterpret_cast<const f4 *>(a.src[q]);
+        f4 *dp = reinterpret_cast<f4 *>(a.dst[q]);
+        for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < a.len[q] / 4; i += stride) dp[i] = sp[i];      // lengths are multiples of 64
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.st_dst = *a.st_src;
 }
 
 }  // namespace
@@ -762,6 +799,15 @@ struct thip_solver {
     bool col_shard = false;
     float *cs_buf = nullptr; size_t cs_n = 0;
     size_t sweep_min_bytes = (size_t)128 << 20;     // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
+    int pn_par = 0;               // which of the two buffers of sums over n (sw_part + par * 2 EG) the LAST sweep wrote
+    int pub_agent = 0;            // thip_solver_set_sweep_publish
+    // recovery when the persistent kernel gives up (thip_solver_run): a device copy of the consistent iterate of the last
+    // completed batch -- x_x, u, (x_y x_s v), their Kahan terms, the status block
+    float *snap = nullptr; DevStatus *snap_st = nullptr; long long snap_iter = -1;
+    size_t pn_len = 0, pm_len = 0;                  // padded lengths of an n- / m-vector of the arena
+    unsigned *hflags = nullptr;                     // pinned: [0] sweep error word [1] gate error [2] one-shot error [3] DevStatus.fault
+    int sweep_faults = 0; unsigned sweep_fault_word = 0; long long sweep_fault_iter = -1;
+    int fault_kind = 0; long long fault_after = -1; int spin_max = 0;      // thip_test_sweep_fault
     DevStatus *dst = nullptr;
     DevStatus *hst = nullptr;                        // pinned
     bool inited = false;
@@ -998,7 +1044,7 @@ int one_iteration(thip_solver *s)
     if (split && carried) { ycrit(0, 1); THIP_RC(allreduce_end(s)); ycrit(1, 0); }
     else                  { THIP_RC(allreduce_end(s)); ycrit(1, 1); }
     hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part_y, s->par.eps_acc, s->par.eps_inf,
-                       ez, (long long)s->par.max_iter, s->dst, shp(s->g3) + 2 * gq, shp(s->g3) + 3 * gq, (int)gq, s->xbuf);
+                       ez, (long long)s->par.max_iter, s->dst, shp(s->g3) + 2 * gq, shp(s->g3) + 3 * gq, (int)gq, s->xbuf, (const float *)nullptr);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1078,7 +1124,7 @@ int ar_begin(thip_solver *s, int slot, float *buf, size_t count)
     if (s->use_gates) {
         const unsigned v = ++s->gseq[slot];
         hipLaunchKernelGGL(signal_k, dim3(1), dim3(1), 0, st, s->gflags + slot, v);
-        hipLaunchKernelGGL(gate_k, dim3(1), dim3(1), 0, s->side, s->gflags + slot, v, s->gate_ticks, s->gflags + 8);
+        hipLaunchKernelGGL(gate_k, dim3(1), dim3(1), 0, s->side, s->gflags + slot, v, s->gate_ticks, s->gflags + 8, &s->dst->stop);
         const int rc = s->allreduce(s->allreduce_ctx, buf, count, (void *)s->side);
         if (rc != 0) return fail(rc, "all-reduce callback failed", __FILE__, __LINE__);
         hipLaunchKernelGGL(signal_k, dim3(1), dim3(1), 0, s->side, s->gflags + 4 + slot, v);
@@ -1098,7 +1144,7 @@ int ar_wait(thip_solver *s, int slot)
     if (s->overlap != 2) return 0;
     if (s->use_gates) {
         hipLaunchKernelGGL(gate_k, dim3(1), dim3(1), 0, ctx().stream, s->gflags + 4 + slot, s->gseq[slot], s->gate_ticks,
-                           s->gflags + 8);
+                           s->gflags + 8, &s->dst->stop);
         THIP_LAUNCH_CHECK();
         return 0;
     }
@@ -1153,7 +1199,7 @@ int split_tail(thip_solver *s)
     THIP_RC(ar_wait(s, 3));
     split_ycrit(c, 1, 0, 1);
     hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, c.st, 2 * (int)c.g, c.part_y, s->par.eps_acc, s->par.eps_inf, c.ez,
-                       (long long)s->par.max_iter, s->dst, s->g3 + s->n + 2 * NPS, s->g3 + s->n + 3 * NPS, (int)NPS, s->xbuf);
+                       (long long)s->par.max_iter, s->dst, s->g3 + s->n + 2 * NPS, s->g3 + s->n + 3 * NPS, (int)NPS, s->xbuf, (const float *)nullptr);
     THIP_LAUNCH_CHECK();
     s->tail_pending = false;
     return 0;
@@ -1314,6 +1360,9 @@ int sweep_prepare(thip_solver *s)
     if (s->sparse || s->is16() || s->m == 0 || s->n == 0) return 0;      // not now (may change)
     if (s->sweep_state != 0) return 0;
     s->sweep_state = -1;
+    // a (re-)plan restarts the schedule from the consistent iterate: the timing sweeps below rewrite the groups' shares and
+    // the granule ring, so whatever a previous run left of them is gone (a first = 1 sweep rebuilds all of it)
+    s->sw_first = true;
     static const int env_off = getenv("THIP_SWEEP_OFF") ? atoi(getenv("THIP_SWEEP_OFF")) : 0;
     if (env_off) return 0;
     size_t m_eff = s->m;
@@ -1337,6 +1386,7 @@ int sweep_prepare(thip_solver *s)
     unsigned hc[10];
     THIP_TRY(hipMemcpyAsync(hc, s->sw_census, sizeof(hc), hipMemcpyDeviceToHost, st));
     THIP_TRY(hipStreamSynchronize(st));
+    if (s->fault_kind == 1) { hc[9] = 2u; s->fault_kind = 0; }      // TEST HOOK: "the placement is not 8 x 32"
     if (hc[9] != 0u) return 0;                      // not 32 workgroups per XCD: the carried schedule runs
     size_t maxH = 0, maxG = 0;
     for (int c = 0; c < nc; ++c) {
@@ -1356,41 +1406,62 @@ int sweep_prepare(thip_solver *s)
     const bool tune = !(s->autotune == 0 || (s->autotune < 0 && env_at && atoi(env_at) == 0));
     if (tune) {
         // time every geometry on the actual matrix, like the GEMV plans: idempotent sweeps (first = 1: u stays, x_x goes
-        // to the buffer that is not the iterate, gP is rewritten with what it has to hold anyway); one warm-up, two timed
+        // to the buffer that is not the iterate, gP is rewritten with what it has to hold anyway); one warm-up, five timed
+        // one by one
         hipEvent_t e0, e1;
         THIP_TRY(hipEventCreate(&e0));
         THIP_TRY(hipEventCreate(&e1));
-        float best = 1e30f;
+        constexpr int REP = 5;
+        float med[6], spread[6], cost[6];
         for (int c = 0; c < nc; ++c) {
             s->sgeom = cand[c];
             THIP_TRY(hipMemsetAsync(s->sw_gran, 0, maxG * sizeof(unsigned long long), st));
             THIP_RC(sweep_pass(s, 1));
-            THIP_TRY(hipEventRecord(e0, st));
-            THIP_RC(sweep_pass(s, 1));
-            THIP_RC(sweep_pass(s, 1));
-            THIP_TRY(hipEventRecord(e1, st));
-            THIP_TRY(hipEventSynchronize(e1));
-            float ms = 0.0f;
-            THIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            float t[REP];
+            for (int r = 0; r < REP; ++r) {
+                THIP_TRY(hipEventRecord(e0, st));
+                THIP_RC(sweep_pass(s, 1));
+                THIP_TRY(hipEventRecord(e1, st));
+                THIP_TRY(hipEventSynchronize(e1));
+                THIP_TRY(hipEventElapsedTime(&t[r], e0, e1));
+            }
             unsigned err = 0;
             THIP_TRY(hipMemcpy(&err, s->sw_census + 9, sizeof(err), hipMemcpyDeviceToHost));
             if (err != 0u) { hipEventDestroy(e0); hipEventDestroy(e1); return 0; }      // a spin ran out: the carried schedule runs
-            // the default geometry (candidate 0) keeps its place unless another one is clearly faster: two timed sweeps
-            // are within ~2 % of each other from run to run, and a geometry that flips with the noise flips the order of
-            // the sums (the bits) with it
-            if (c == 0 || ms < 0.97f * best) { best = ms; g = cand[c]; }
+            std::sort(t, t + REP);
+            med[c] = t[REP / 2];
+            spread[c] = (t[REP - 1] - t[0]) / t[REP / 2];
+            // what a geometry costs OUTSIDE the kernel: the next step's m-tail reads every group's share of the two N
+            // products (2 m floats per group; 20 MB at the 10 000-variable LP with 128 groups) at a few TB/s
+            cost[c] = med[c] + (float)((double)cand[c].ngroups * 2.0 * (double)s->m * sizeof(float) / 3.0e12 * 1e3);
         }
         hipEventDestroy(e0); hipEventDestroy(e1);
-        s->sw_plan_ms = best / 2;
+        // the default geometry (candidate 0) keeps its place unless another one wins by more than repeated sweeps of either
+        // differ among themselves (at least 2 %): a geometry that flips with the noise flips the order of the sums -- the
+        // bits of every later iterate -- with it
+        int bi = 0;
+        for (int c = 1; c < nc; ++c) {
+            const float margin = std::max(0.02f, std::max(spread[bi], spread[c]));
+            if (cost[c] < cost[bi] * (1.0f - margin)) bi = c;
+        }
+        g = cand[bi];
+        s->sw_plan_ms = med[bi];
         THIP_TRY(hipMemsetAsync(s->sw_gran, 0, maxG * sizeof(unsigned long long), st));
         // a safety net for shapes the kernel takes badly (e.g. very few rows per workgroup): a sweep that is not faster
-        // than the two passes of the carried schedule would be (at the dual GEMV's 6.2 TB/s) gives way to it -- unless the
-        // caller asked for the one-pass schedule "whenever the kernel can take the shape" (sweep_min_bytes = 0)
-        const double carried_ms = 2.0 * (double)s->m * (double)s->n * sizeof(float) / 6.2e12 * 1e3 + 0.03;
-        if (!s->col_shard && s->sweep_min_bytes != 0 && (double)s->sw_plan_ms > carried_ms) return 0;
+        // than the two passes of the carried schedule gives way to it -- unless the caller asked for the one-pass schedule
+        // "whenever the kernel can take the shape" (sweep_min_bytes = 0).  The two passes are priced at the dual GEMV's
+        // usual 6.2 TB/s first, and when that is anywhere near, with the carried plan's own MEASURED pass
+        if (!s->col_shard && s->sweep_min_bytes != 0) {
+            double carried_ms = 2.0 * (double)s->m * (double)s->n * sizeof(float) / 6.2e12 * 1e3 + 0.03;
+            if ((double)s->sw_plan_ms > 0.75 * carried_ms) {
+                THIP_RC(autotune_gemv(s));
+                if (s->tuned && s->tuned_ms > 0.0f) carried_ms = 2.0 * (double)s->tuned_ms + 0.03;
+            }
+            if ((double)s->sw_plan_ms > carried_ms) return 0;
+        }
     }
     if (s->col_shard) {
-        const size_t need = 2 * g.mpad + 4 * EG;
+        const size_t need = 2 * g.mpad + 4 * EG + 64;      // [A u ; A x_x ; 4 x EG sums over n ; "my kernel gave up" flag]
         if (s->cs_n != need) {
             if (s->cs_buf) { THIP_TRY(hipFree(s->cs_buf)); s->cs_buf = nullptr; }
             THIP_TRY(hipMalloc((void **)&s->cs_buf, need * sizeof(float)));
@@ -1431,16 +1502,24 @@ int sweep_pass(thip_solver *s, int first)
     a.stop = &s->dst->stop; a.kappa_p = &s->dst->kappa; a.rtau_p = &s->dst->r_tau;
     a.tau_p = &s->dst->tau; a.eps_zero = s->par.eps_zero;
     a.kappa_out = nullptr; a.skappa_p = &s->dst->s_kappa; a.pm_brx = nullptr; a.np_m = 0; a.pn_count = 0;
+    // the sums over n: two buffers by launch parity -- this launch writes one, its kappa update reads what the previous
+    // sweep left in the other (column-sharded: what came back from the all-reduce, which no sweep writes)
+    const int par = s->pn_par ^ 1;
+    a.pn = s->sw_part + (size_t)par * 2 * EG; a.pn_stride = 256;
+    a.pn_in = s->sw_part + (size_t)s->pn_par * 2 * EG; a.pn_in_stride = 256;
     if (!first) {
         // the sweep of a regular step opens with the kappa update: c.rx_x from the previous sweep's partials, b.rx_y from sw_vm_k
         const unsigned gm_ = egrid(s->m);
         a.kappa_p = &s->dst->kappa_in; a.kappa_out = &s->dst->kappa;
         a.pm_brx = s->sw_part + 4 * EG + gm_; a.np_m = (int)gm_;
-        a.pn_count = s->col_shard ? (int)EG : 256;
+        a.pn_count = 256;
+        if (s->col_shard) { a.pn_in = s->cs_buf + 2 * g.mpad; a.pn_in_stride = (int)EG; a.pn_count = (int)EG; }
     }
-    a.pn = s->col_shard ? s->cs_buf + 2 * g.mpad : s->sw_part;       // (the plan autotune of a column shard runs before cs_buf
-    a.pn_stride = s->col_shard ? (int)EG : 256;                      //  exists: its sums go nowhere)
-    if (s->col_shard && s->cs_buf == nullptr) a.pn = nullptr;
+    s->pn_par = par;
+    a.spin_max = s->spin_max > 0 ? s->spin_max : SW_SPIN_MAX;
+    a.pub_agent = s->pub_agent;
+    a.fault = 0;
+    if (!first && s->fault_kind == 2 && s->fault_after >= 0 && s->fault_after-- == 0) { a.fault = 1; s->fault_kind = 0; }
     prof_begin(st);
     THIP_RC(sweep_launch(st, g, a));
     prof_end(st);
@@ -1468,7 +1547,8 @@ int one_iteration_sweep(thip_solver *s)
     // sums over n: [0] ||d||^2 [1] c.x_x [2] c.u [3] c.rx_x -- one partial per workgroup of the sweep; column-sharded: EG
     // slots each (the same on every rank, the unused ones stay zero) behind the two N products in the buffer that is
     // all-reduced
-    float *const pn = cols ? s->cs_buf + 2 * s->sgeom.mpad : s->sw_part;
+    // (the sweep itself writes 4 x 256 to one of two buffers by launch parity: pn_now(); sw_gsum_k moves them into the tail)
+    auto pn_now = [&]() -> float * { return cols ? s->cs_buf + 2 * s->sgeom.mpad : s->sw_part + (size_t)s->pn_par * 2 * EG; };
     const int pns = cols ? (int)EG : 256;         // one slot per workgroup of the sweep (256), EG in the all-reduced buffer
     float *const pm = s->sw_part + 4 * EG;        // sums over m: [0] b.v [1] b.rx_y [2] ||p||^2 [3] b.x_y, gm partials each
     float *const ky = s->comp() ? s->ky : nullptr, *const ks = s->comp() ? s->ks : nullptr;
@@ -1476,7 +1556,8 @@ int one_iteration_sweep(thip_solver *s)
     auto post = [&]() -> int {
         // (the sums over n -- ||d||^2, c.x_x, c.u, c.rx_x -- come out of the sweep itself: SweepArgs::pn)
         if (cols) {
-            hipLaunchKernelGGL(sw_gsum_k, dim3(gm), dim3(BLK), 0, st, m, s->sgeom.ngroups, s->sgeom.mpad, s->sw_partH, s->cs_buf, s->dst);
+            hipLaunchKernelGGL(sw_gsum_k, dim3(gm), dim3(BLK), 0, st, m, s->sgeom.ngroups, s->sgeom.mpad, s->sw_partH, s->cs_buf, s->dst,
+                               s->sw_part + (size_t)s->pn_par * 2 * EG, s->sw_census + 9);
             THIP_RC(do_allreduce(s, s->cs_buf, s->cs_n));
         }
         return 0;
@@ -1490,7 +1571,7 @@ int one_iteration_sweep(thip_solver *s)
     }
     hipLaunchKernelGGL(sw_xm_k, dim3(grid_for(s->m, 64, 4096)), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
                        cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
-                       s->dst, pn + 2 * pns, pns, pm, (int)gm, ky, ks);
+                       s->dst, pn_now() + 2 * pns, pns, pm, (int)gm, ky, ks);
     THIP_RC(project_blocks(s));
     hipLaunchKernelGGL(sw_vm_k, dim3(gm), dim3(BLK), 0, st, m, s->h3, s->hP, s->b, s->rxs, s->rxy, s->Sv, s->v, kv, s->xs,
                        s->xy, ez, s->dst, pm);
@@ -1498,8 +1579,9 @@ int one_iteration_sweep(thip_solver *s)
     sweep_swap(s);                                // x_x_k (formed by the previous sweep) is now the iterate
     THIP_RC(sweep_pass(s, 0));
     THIP_RC(post());
-    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, pns, pn, s->par.eps_acc, s->par.eps_inf, ez,
-                       (long long)s->par.max_iter, s->dst, pm + 2 * gm, pm + 3 * gm, (int)gm, s->xbuf);
+    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, pns, pn_now(), s->par.eps_acc, s->par.eps_inf, ez,
+                       (long long)s->par.max_iter, s->dst, pm + 2 * gm, pm + 3 * gm, (int)gm, s->xbuf,
+                       cols ? (const float *)(s->cs_buf + 2 * s->sgeom.mpad + 4 * EG) : (const float *)nullptr);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1540,6 +1622,73 @@ int ensure_apad(thip_solver *s, bool refresh)
     if (fresh || refresh)
         THIP_TRY(hipMemcpy2DAsync(s->Apad, ld * sizeof(float), s->A, m * sizeof(float), m * sizeof(float), n,
                                   hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int poll(thip_solver *s, thip_status *out);
+
+// x_x, u, (x_y x_s v) and their Kahan terms, the status block <-> the snapshot; restore = the other direction, into
+// whichever x_x buffer is the iterate's now
+int snapshot(thip_solver *s, bool restore)
+{
+    hipStream_t st = ctx().stream;
+    const size_t pn = s->pn_len, pm = s->pm_len;
+    if (!s->snap) {
+        THIP_TRY(hipMalloc((void **)&s->snap, (4 * pn + 6 * pm) * sizeof(float)));
+        THIP_TRY(hipMalloc((void **)&s->snap_st, sizeof(DevStatus)));
+    }
+    float *live[6] = { s->xx, s->u, s->xy, s->kx, s->ku, s->ky };        // xy xs v and ky ks kv are contiguous in the arena
+    const size_t len[6] = { pn, pn, 3 * pm, pn, pn, 3 * pm };
+    SnapArgs a;
+    float *p = s->snap;
+    for (int q = 0; q < 6; ++q) {
+        a.src[q] = restore ? p : live[q]; a.dst[q] = restore ? live[q] : p; a.len[q] = len[q];
+        p += len[q];
+    }
+    a.st_src = restore ? s->snap_st : s->dst; a.st_dst = restore ? s->dst : s->snap_st;
+    hipLaunchKernelGGL(snap_copy_k, dim3(256), dim3(BLK), 0, st, a);
+    THIP_LAUNCH_CHECK();
+    if (restore) {
+        s->finalized = false;
+        s->sw_first = true;             // the restored iterate is a consistent one: the next sweep step starts from it
+        THIP_RC(poll(s, nullptr));      // host copy of the status block (state RUNNING again)
+    } else {
+        s->snap_iter = s->hst->iter;
+    }
+    return 0;
+}
+
+// after a failed batch of a column-sharded run: clean census words, granule ring and error word for the retry
+int sweep_rearm(thip_solver *s)
+{
+    hipStream_t st = ctx().stream;
+    THIP_TRY(hipMemsetAsync(s->sw_census, 0, 64 * sizeof(unsigned), st));
+    THIP_TRY(hipMemsetAsync(s->sw_gran, 0, sweep_gran_words(s->sgeom) * sizeof(unsigned long long), st));
+    s->sw_seq = 0;
+    THIP_RC(sweep_census_dry_run(st, s->sw_census, s->sw_seq++));
+    return 0;
+}
+
+// the error words of every bounded device-side wait, read once per batch (one synchronisation): the one-pass kernel's
+// (recoverable: *sw_err, and in a column-sharded run the all-reduced *peer_fault), the gates of the column-split pipeline and
+// the one-shot all-reduce (a peer rank stalled: the ranks' states have diverged -- THIP_E_TIMEOUT)
+int batch_faults(thip_solver *s, bool sweep, unsigned *sw_err, unsigned *peer_fault)
+{
+    hipStream_t st = ctx().stream;
+    unsigned *h = s->hflags;
+    h[0] = h[1] = h[2] = h[3] = 0u;
+    const unsigned *os_err = s->allreduce != nullptr && s->allreduce == oneshot_hook() ? oneshot_error_word() : nullptr;
+    if (!sweep && !s->use_gates && !os_err) return 0;
+    if (sweep) THIP_TRY(hipMemcpyAsync(h + 0, s->sw_census + 9, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    if (sweep && s->col_shard) THIP_TRY(hipMemcpyAsync(h + 3, &s->dst->fault, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (s->use_gates && s->gflags) THIP_TRY(hipMemcpyAsync(h + 1, s->gflags + 8, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    if (os_err) THIP_TRY(hipMemcpyAsync(h + 2, os_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    THIP_TRY(hipStreamSynchronize(st));
+    if (h[1] != 0u)
+        return fail(THIP_E_TIMEOUT, "a hand-off of the column-split pipeline waited > 2 s for a collective (a peer rank stalled): the ranks have diverged", __FILE__, __LINE__);
+    if (h[2] != 0u)
+        return fail(THIP_E_TIMEOUT, "the one-shot all-reduce waited > 4 s for a peer: the sums of this batch are partial", __FILE__, __LINE__);
+    *sw_err = h[0]; *peer_fault = h[3];
     return 0;
 }
 
@@ -1676,6 +1825,8 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
     s->kx = take(pn); s->ku = take(pn); s->ky = take(pm); s->ks = take(pm); s->kv = take(pm); s->kx2 = take(pn);
     s->kahan_n = 3 * pn + 3 * pm;
     s->xx_home = s->xx; s->kx_home = s->kx;
+    s->pn_len = pn; s->pm_len = pm;
+    THIP_TRY(hipHostMalloc((void **)&s->hflags, 8 * sizeof(unsigned), hipHostMallocDefault));
 
     THIP_TRY(hipMalloc((void **)&s->part, (4 * PG + 4 * EG) * sizeof(float)));
     // the dense GEMV partial-sum scratch (~ m n / 256 floats) is allocated by thip_solver_init, and only for a dense A
@@ -1763,7 +1914,8 @@ int thip_solver_init(thip_solver *s)
     THIP_RC(ensure_gemv_scratch(s));
     if (!s->is16()) THIP_RC(ensure_apad(s, true));      // a fresh solve re-reads the caller's A (it may have changed in place)
     s->xx = s->xx_home; s->kx = s->kx_home; s->xbuf = 0;
-    s->sw_first = true; s->sweep_state = 0;
+    s->sw_first = true; s->sweep_state = 0; s->pn_par = 0;
+    s->sweep_faults = 0; s->sweep_fault_word = 0; s->sweep_fault_iter = -1; s->snap_iter = -1;
     // init_vecs (solver.rs:483-494): x = 0, y = 0, tau = 1
     THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
     hipLaunchKernelGGL(init_status_k, dim3(1), dim3(1), 0, st, s->dst, 0.0f);
@@ -1831,23 +1983,45 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
     THIP_RC(poll(s, host_status));
     if (s->carried_stale && s->hst->state == THIP_ST_RUNNING) THIP_RC(rebuild_carried(s));
     THIP_RC(sweep_prepare(s));
-    const bool sweep = sweep_active(s);
+    bool sweep = sweep_active(s);
     THIP_RC(prepare_split(s));
-    const bool split = split_active(s);
+    bool split = split_active(s);
     if (!sweep) s->sw_first = true;         // whatever runs instead leaves a consistent iterate and gP / hP of it
+    if (sweep && s->hst->state == THIP_ST_RUNNING) THIP_RC(snapshot(s, false));      // the iterate this run starts from
+    int retries = 0;
     while (s->hst->state == THIP_ST_RUNNING && (max_steps < 0 || done < max_steps)) {
         int64_t batch = poll_every;
         if (max_steps >= 0 && done + batch > max_steps) batch = max_steps - done;
         for (int64_t k = 0; k < batch; ++k) THIP_RC(sweep ? one_iteration_sweep(s) : (split ? one_iteration_split(s) : one_iteration(s)));
-        if (sweep) {
-            unsigned err = 0;
-            THIP_TRY(hipMemcpyAsync(&err, s->sw_census + 9, sizeof(err), hipMemcpyDeviceToHost, ctx().stream));
-            THIP_TRY(hipStreamSynchronize(ctx().stream));
-            if (err != 0u) return fail(THIP_E_INVALID, "the one-pass kernel gave up (placement changed or a spin ran out)", __FILE__, __LINE__);
-        }
         if (s->tail_pending) THIP_RC(split_tail(s));       // drain the pipeline before the host looks
+        // every bounded device-side wait of the batch: did one run out?
+        unsigned sw_err = 0, peer_fault = 0;
+        THIP_RC(batch_faults(s, sweep, &sw_err, &peer_fault));
+        // column-sharded: the verdict is the all-reduced one, so that every rank takes the same branch at the same batch
+        if (sweep && (s->col_shard ? peer_fault != 0u : sw_err != 0u)) {
+            s->sweep_faults += 1;
+            s->sweep_fault_word = sw_err != 0u ? sw_err : 4u;       // 4: a peer rank's kernel
+            s->sweep_fault_iter = s->snap_iter;
+            THIP_RC(snapshot(s, true));                            // back to the last batch that completed
+            if (s->col_shard) {
+                // a column shard has no 2-pass form to fall back to: every rank restores and retries together (a transient --
+                // another process on the GPU for a moment -- passes; a placement that stays wrong fails cleanly everywhere)
+                if (++retries > 2)
+                    return fail(THIP_E_TIMEOUT, "the one-pass kernel gave up on some rank of a column-sharded run (3 attempts from the same iterate)", __FILE__, __LINE__);
+                THIP_RC(sweep_rearm(s));
+            } else {
+                s->sweep_state = -1;                               // for the rest of this solve: the 2-pass schedule
+                THIP_RC(prepare_split(s));                         // (tunes the GEMV plan if that has not happened yet)
+                split = split_active(s);
+                THIP_RC(rebuild_carried(s));
+                sweep = false;
+            }
+            continue;                                              // the batch is run again (done has not moved)
+        }
+        retries = 0;
         done += batch;
         THIP_RC(poll(s, host_status));
+        if (sweep && s->hst->state == THIP_ST_RUNNING) THIP_RC(snapshot(s, false));
     }
     return 0;
 }
@@ -2038,7 +2212,31 @@ int thip_solver_set_sweep_min_bytes(thip_solver *s, size_t bytes)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
     s->sweep_min_bytes = bytes;
-    s->sweep_state = 0;
+    s->sweep_state = 0;           // re-planned by the next run / query; sweep_prepare restarts the schedule (sw_first) when it does
+    return 0;
+}
+
+int thip_solver_sweep_faults(thip_solver *s, int *host_faults, int *host_last_word, int64_t *host_restored_iter)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (host_faults) *host_faults = s->sweep_faults;
+    if (host_last_word) *host_last_word = (int)s->sweep_fault_word;
+    if (host_restored_iter) *host_restored_iter = s->sweep_faults ? (int64_t)s->sweep_fault_iter : -1;
+    return 0;
+}
+
+int thip_test_sweep_fault(thip_solver *s, int kind, int64_t after_sweeps, int spin_max)
+{
+    if (!s || kind < 0 || kind > 2) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
+    s->fault_kind = kind; s->fault_after = kind == 2 ? (long long)after_sweeps : -1;
+    s->spin_max = spin_max > 0 ? spin_max : 0;
+    return 0;
+}
+
+int thip_solver_set_sweep_publish(thip_solver *s, int agent_scope)
+{
+    if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    s->pub_agent = agent_scope != 0;
     return 0;
 }
 
@@ -2151,6 +2349,8 @@ int thip_solver_destroy(thip_solver *s)
     hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->Apad); if (s->A16_owned) hipFree(s->A16); if (s->inv_s_owned) hipFree(s->inv_s);
     hipFree(s->sw_partH); hipFree(s->sw_gran); hipFree(s->sw_census); hipFree(s->sw_part); hipFree(s->cs_buf);
     if (s->hst) hipHostFree(s->hst);
+    if (s->hflags) hipHostFree(s->hflags);
+    hipFree(s->snap); hipFree(s->snap_st);
     delete s;
     return 0;
 }

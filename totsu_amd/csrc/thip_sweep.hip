@@ -47,7 +47,6 @@ constexpr int SW_CW = 7;
 constexpr int SW_CT = SW_CW * 64;          // streaming threads
 constexpr int SW_RING = 32;                // granule slots per group (> 2 (LAGL - DLAG) - 1: see the header of sweep_k)
 constexpr int SW_CR = 16;                  // slots of the per-column LDS ring (> LAGL - DLAG)
-constexpr int SW_SPIN_MAX = 2000000;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -187,7 +186,9 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
     __syncthreads();
     // the census comes first even when the loop has stopped: the host numbers the launches, and one that left before
     // counting itself would leave every later census short
-    if (s_role[2] == 0 || *a.stop != 0) return;
+    // (a raised error word -- this launch's census, or an earlier sweep of the batch that gave up -- ends every later sweep
+    // at entry: the host restores its snapshot of the iterate, thip_solver.hip sweep_recover)
+    if (s_role[2] == 0 || *a.stop != 0 || __hip_atomic_load(a.census + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const int group = s_role[0], member = s_role[1];
 
     const int c0 = group * a.cols_per_group;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         if (a.kappa_out != nullptr && !a.first) {
             // c.rx_x of the previous sweep (its workgroups' partials) + b.rx_y of the m-tail, in f64 like the other single-block sums
             double dc = 0.0, db = 0.0;
-            for (int k = lane; k < a.pn_count; k += 64) dc += (double)a.pn[3 * a.pn_stride + k];
+            for (int k = lane; k < a.pn_count; k += 64) dc += (double)a.pn_in[3 * a.pn_in_stride + k];
             for (int k = lane; k < a.np_m; k += 64) db += (double)a.pm_brx[k];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { dc += __shfl_xor(dc, o, 64); db += __shfl_xor(db, o, 64); }
@@ -406,7 +407,12 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 #pragma unroll
                     for (int w = 1; w < SW_CW; ++w) sum += dotbuf[pp & 1][w][lane];
                     unsigned long long *g = gbase + ((size_t)(pp % SW_RING) * a.G + member) * (2 * W) + lane;
-                    if (SW_DBG(a) & 32) __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // TEST HOOK (thip_test_sweep_fault): one workgroup stops publishing half-way -- its group runs out of spins
+                    const bool withheld = a.fault != 0 && blockIdx.x == 37u && pp >= npan / 2;
+                    // pub_agent: the documented form (sc1 store, MI355X_MICROARCH.md inter-workgroup visibility); else a plain
+                    // store that stays in the L2 the group shares (DESIGN.md 4.7 has the measured difference)
+                    if (withheld) { }
+                    else if (a.pub_agent) __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 #ifdef SW_PROFILE
                     ++npoll;
 #endif
-                    if (spins > SW_SPIN_MAX || ((spins & 255) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    if (spins > a.spin_max || ((spins & 255) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
                         if (lane == 0) atomicExch(errflag, 3u);
                         dead = true;
                     }
@@ -559,7 +565,7 @@ int sweep_variant()
 
 // One candidate geometry: W columns per panel (1 or 2: the two families of kernel instances), the smallest group size
 // the family's row capacity allows times gmul.  0 when the kernel can take the matrix that way.
-static int sweep_plan_one(size_t m, size_t n, size_t lda, const void *mat, int W, int gmul, SweepGeom *g)
+static int sweep_plan_one(size_t m, size_t n, size_t lda, const void *mat, int W, int gmul, SweepGeom *g, int force_G = 0)
 {
     if (m == 0 || n == 0 || m % 4 != 0 || lda % 4 != 0 || ((uintptr_t)mat & 15u) != 0) return 1;
     if (n > ((size_t)1 << 30) || n < (size_t)40 * W) return 1;
@@ -572,6 +578,10 @@ static int sweep_plan_one(size_t m, size_t n, size_t lda, const void *mat, int W
     for (int k = 1; k < gmul; k *= 2) { if (G >= 32) return 1; G *= 2; }
     // few columns: fewer, larger groups, so that every group has its 40 panels and no workgroup idles
     while (G < 32 && (size_t)(256 / G) * 40 * W > n) { if (gmul > 1) return 1; G *= 2; }
+    if (force_G) {          // thip_test_sweep: a given group size (a power of two the rows fit)
+        if (force_G < G || force_G > 32 || (force_G & (force_G - 1)) != 0) return 1;
+        G = force_G;
+    }
     const size_t rpm = ((m + G - 1) / G + 3) / 4 * 4;
     const int ngroups = 256 / G;
     size_t cpg = (n + ngroups - 1) / ngroups;
@@ -579,7 +589,9 @@ static int sweep_plan_one(size_t m, size_t n, size_t lda, const void *mat, int W
     cpg = (cpg + W - 1) / W * W;
     const int need = (int)((rpm + slot_rows - 1) / slot_rows);
     g->G = G; g->ngroups = ngroups; g->rows_per_member = (int)rpm; g->cols_per_group = (int)cpg;
-    g->nslot = W == 2 ? (need <= 1 ? 1 : 2) : (need <= 4 ? 4 : 7);
+    // 16-byte slots per streaming thread: what the member's rows need (round 3 offered 4 or 7 only: the 10 000 rows per member
+    // of the n = 10 000 LP ran 7 slots at 80 % of their lanes, the 7 829 of the k = 500 SDP at 62 %)
+    g->nslot = W == 2 ? (need <= 1 ? 1 : 2) : need;
     g->mpad = (m + 63) / 64 * 64;
     g->w = W; g->variant = sweep_variant();
     g->npan = (int)(cpg / W);
@@ -642,8 +654,16 @@ int sweep_launch(hipStream_t st, const SweepGeom &g, const SweepArgs &a)
         if (g.nslot == 2) return g.variant == 1 ? sweep_go<2, 2, 8, 3, 0>(st, a) : sweep_go<2, 2, 8, 3, 5>(st, a);
         return g.variant == 1 ? sweep_go<1, 2, 8, 3, 0>(st, a) : sweep_go<1, 2, 8, 3, 5>(st, a);
     }
-    if (g.nslot == 4) return g.variant == 1 ? sweep_go<4, 1, 8, 3, 3>(st, a) : sweep_go<4, 1, 8, 3, 5>(st, a);
-    return g.variant == 1 ? sweep_go<7, 1, 3, 1, 2>(st, a) : sweep_go<7, 1, 2, 1, 3>(st, a);
+    // <slots, columns per panel, LAGL, DLAG, LS>: register stages + LDS panels sized to the 512 VGPRs / 160 KB of a CU
+    switch (g.nslot) {
+    case 1: return sweep_go<1, 1, 8, 3, 8>(st, a);
+    case 2: return sweep_go<2, 1, 8, 3, 8>(st, a);
+    case 3: return sweep_go<3, 1, 8, 3, 6>(st, a);
+    case 4: return g.variant == 1 ? sweep_go<4, 1, 8, 3, 3>(st, a) : sweep_go<4, 1, 8, 3, 5>(st, a);
+    case 5: return sweep_go<5, 1, 3, 1, 4>(st, a);
+    case 6: return sweep_go<6, 1, 3, 1, 3>(st, a);
+    default: return g.variant == 1 ? sweep_go<7, 1, 3, 1, 2>(st, a) : sweep_go<7, 1, 2, 1, 3>(st, a);
+    }
 }
 
 }  // namespace thip
@@ -668,7 +688,8 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     THIP_NEED_INIT();
     if (!t) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
     SweepGeom g;
-    if (sweep_plan(t->m, t->n, t->lda, t->mat_a, &g) != 0)
+    if ((t->force_members > 0 ? sweep_plan_one(t->m, t->n, t->lda, t->mat_a, 1, 1, &g, t->force_members)
+                              : sweep_plan(t->m, t->n, t->lda, t->mat_a, &g)) != 0)
         return fail(THIP_E_INVALID, "the one-pass kernel cannot take this shape", __FILE__, __LINE__);
     hipStream_t st = ctx().stream;
     unsigned long long *gran = nullptr;
@@ -692,6 +713,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     a.first = t->first;
     a.pn = nullptr; a.pn_stride = 0; a.tau_p = scal + 3; a.eps_zero = 1e-12f;
     a.kappa_out = nullptr; a.skappa_p = nullptr; a.pm_brx = nullptr; a.np_m = 0; a.pn_count = 0;
+    a.pn_in = nullptr; a.pn_in_stride = 0; a.spin_max = SW_SPIN_MAX; a.fault = 0; a.pub_agent = t->pub_agent != 0;
     a.dbg = getenv("THIP_SWEEP_DBG") ? atoi(getenv("THIP_SWEEP_DBG")) : 0;
     a.stop = reinterpret_cast<const int *>(scal); a.kappa_p = scal + 1; a.rtau_p = scal + 2;
     unsigned seq = 0, tagbase = 0;
@@ -716,7 +738,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     THIP_TRY(hipMemcpyAsync(hc, census, sizeof(hc), hipMemcpyDeviceToHost, st));
     THIP_TRY(hipStreamSynchronize(st));
     if (host_ms) { host_ms[0] = best; host_ms[1] = tot / reps; }
-    if (host_info) { host_info[0] = (int)hc[9]; host_info[1] = g.G; host_info[2] = g.ngroups; host_info[3] = g.npan; }
+    if (host_info) { host_info[0] = (int)hc[9]; host_info[1] = g.G; host_info[2] = g.ngroups; host_info[3] = g.npan; host_info[4] = g.nslot; }
 #ifdef SW_PROFILE
     fprintf(stderr, "service wave, 10 ns ticks: wait %u, cold+publish %u, tags+poll %u, reduce+math+stores %u, loads %u, barrier %u; intervals that polled %u, polls %u\n",
             hc[10], hc[11], hc[12], hc[13], hc[14], hc[15], hc[16], hc[17]);
@@ -748,5 +770,62 @@ extern "C" int thip_sweep_probe(size_t m, size_t n_local, size_t lda, int *host_
     THIP_TRY(hipStreamSynchronize(st));
     hipFree(census);
     *host_ok = hc[9] == 0u ? 1 : 0;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// thip_stream_probe: what THIS device streams -- a bare non-temporal read of `bytes` at dev_ptr (16-byte aligned; e.g. the
+// solver's own A), eight 16-byte loads in flight per lane, nothing else.  bench.py prints it beside the sweep's rate, so
+// that "fraction of what the box can read" is known for the box a line was measured on (boxes of one pool differ by 7 %).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void stream_read_k(const f32x4 *__restrict__ p, size_t n4, float *out)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; i < n4; i += stride) acc += __builtin_nontemporal_load(p + i);
+    const float s = acc[0] + acc[1] + acc[2] + acc[3];
+    if (s == 123.456f) out[0] = s;      // keeps the loads alive
+}
+}  // namespace
+
+extern "C" int thip_stream_probe(const void *dev_ptr, size_t bytes, int reps, float *host_best_ms, float *host_avg_ms)
+{
+    THIP_NEED_INIT();
+    if (!dev_ptr || bytes < 16 || ((uintptr_t)dev_ptr & 15u) != 0) return fail(THIP_E_INVALID, "bad buffer", __FILE__, __LINE__);
+    hipStream_t st = ctx().stream;
+    const size_t n4 = bytes / 16;
+    hipEvent_t e0, e1;
+    THIP_TRY(hipEventCreate(&e0)); THIP_TRY(hipEventCreate(&e1));
+    if (reps < 1) reps = 1;
+    float best = 1e30f, tot = 0.0f;
+    int cnt = 0;
+    // the grids tools/stream_probe.hip found within 2 % of each other at 0.4 - 20 GB; the best of them, one warm-up each
+    for (unsigned blocks : { 4096u, 8192u, 16384u }) {
+        if ((size_t)blocks * 256 * 8 > n4 && blocks != 4096u) continue;
+        for (int r = 0; r <= reps; ++r) {
+            THIP_TRY(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(stream_read_k, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(dev_ptr), n4, ctx().dev_scalar);
+            THIP_TRY(hipEventRecord(e1, st));
+            THIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            THIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (r == 0) continue;
+            tot += ms; ++cnt;
+            if (ms < best) best = ms;
+        }
+    }
+    THIP_LAUNCH_CHECK();
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (host_best_ms) *host_best_ms = best;
+    if (host_avg_ms) *host_avg_ms = cnt ? tot / cnt : 0.0f;
     return 0;
 }

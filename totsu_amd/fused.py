@@ -294,6 +294,21 @@ class FusedSolver:
     def set_sweep_min_bytes(self, nbytes):
         lib.thip_solver_set_sweep_min_bytes(self.h, int(nbytes))
 
+    def sweep_faults(self):
+        """recoveries from a one-pass kernel that gave up (thip_solver_sweep_faults): how many in this solve, the kernel's
+        error word of the last one, the iteration of the snapshot it went back to (-1: none)"""
+        k, w, it = C.c_int(), C.c_int(), C.c_int64()
+        lib.thip_solver_sweep_faults(self.h, C.byref(k), C.byref(w), C.byref(it))
+        return {"faults": k.value, "last_word": w.value, "restored_iter": it.value}
+
+    def inject_sweep_fault(self, kind, after_sweeps=0, spin_max=0):
+        """TEST HOOK (thip_test_sweep_fault): kind 1 = the next plan's placement census fails; 2 = one workgroup of the
+        after_sweeps-th regular sweep from now withholds its partial dots; spin_max shortens the polling bound"""
+        lib.thip_test_sweep_fault(self.h, int(kind), int(after_sweeps), int(spin_max))
+
+    def set_sweep_publish(self, agent_scope):
+        lib.thip_solver_set_sweep_publish(self.h, 1 if agent_scope else 0)
+
     def passes(self):
         p, b = C.c_int(), C.c_size_t()
         lib.thip_solver_passes(self.h, C.byref(p), C.byref(b))

@@ -14,6 +14,16 @@ from .linalg import splitm
 from .solver import Solver, SolverError, _SelfDualEmbed, _SolverCore
 
 
+def agree_on_column_shards(ok_local, allreduce_sum, world):
+    """Every rank of a column-sharded one-pass run must be able to run the persistent kernel (thip_sweep_probe: 8 XCDs x 32
+    CUs, a shape the kernel takes).  The ranks agree BEFORE anything column-sharded is built: `allreduce_sum` sums a float
+    over the ranks; True only when every one of the `world` ranks said yes -- otherwise ALL of them take row shards and
+    the 2-pass schedule (a rank that found out alone, inside thip_solver_init, would leave the others in their first
+    all-reduce)."""
+    total = float(allreduce_sum(np.array([1.0 if ok_local else 0.0], dtype=np.float32))[0])
+    return int(round(total)) == int(world)
+
+
 def shard_segments(seg_len, world, rank):
     """contiguous split of the cone segments into `world` blocks with balanced row counts; a cone never
     straddles a boundary.  Returns (first_segment, last_segment_exclusive, first_row, last_row_exclusive)."""
