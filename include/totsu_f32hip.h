@@ -405,7 +405,9 @@ int thip_stream_probe(const void *dev_ptr, size_t bytes, int reps, float *host_b
 int thip_solver_sweep_faults(thip_solver *s, int *host_faults, int *host_last_word, int64_t *host_restored_iter);
 /* TEST HOOK: kind 1 = the placement census of the next plan (thip_solver_init) reports a bad placement; kind 2 = one
  * workgroup of the after_sweeps-th regular sweep from now withholds its partial dots; spin_max > 0 shortens the
- * bound of the gathers' polling loops (default ~2 s) so that a test does not wait for it.  kind 0 clears. */
+ * bound of the gathers' polling loops (default ~2 s) so that a test does not wait for it.  kind 0 clears.
+ * kind 3 / 4 (no fault): run the two m-kernels of a step as two launches also where the cones are all element-wise
+ * (the form problems with block cones always take) / merged again -- lets a test compare the two forms. */
 int thip_test_sweep_fault(thip_solver *s, int kind, int64_t after_sweeps, int spin_max);
 /* partial dots published with agent-scope (sc1) stores (1) or with plain stores that stay in the group's L2 (0, default);
  * between thip_solver_run calls */
@@ -427,6 +429,7 @@ typedef struct thip_sweep_test {
     float kappa, rtau;
     int32_t first, reps;
     int32_t force_members, pub_agent;
+    int32_t variant, reserved;      /* variant: 0 = the library's ring depth; 1 - 3 = experiment forms (thip_sweep.hip sweep_launch) */
 } thip_sweep_test;
 int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *host_info);
 

@@ -686,3 +686,24 @@ def test_stream_probe_reports_a_plausible_rate(T):
     gbps = 4 * buf.n / (best.value * 1e-3) / 1e9
     assert 2000 < gbps < 9000, gbps
     buf.free()
+
+
+def test_merged_m_kernel_is_the_two_launch_form(T):
+    """an LP has element-wise cones only: the step's two m-kernels (x_y / x_s and cones; v and the sums over m) run as ONE
+    launch.  Every per-row value has the arithmetic of the two-launch form (what SOCPs / SDPs take); only the block
+    partials of the four sums over m are grouped differently -- iterates agree to round-off, and with the oracle"""
+    lp, _ = _lp(T, 160, 17)
+    d = lp.dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    a = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    b = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    b.inject_sweep_fault(3)                    # two launches
+    for steps in (1, 1, 8, 90):
+        a.run(steps, poll_every=16)
+        b.run(steps, poll_every=16)
+        for u_, v_ in zip(a.iterate(), b.iterate()):
+            assert np.abs(u_ - v_).max() <= 2e-6 * max(np.abs(v_).max(), 1e-6)
+        assert np.allclose(a.status().cri, b.status().cri, rtol=1e-4, atol=1e-7)
+    a.destroy()
+    b.destroy()

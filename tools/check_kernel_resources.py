@@ -12,7 +12,7 @@ import re
 import sys
 
 # instances that are experiment variants only (THIP_SWEEP_VARIANT=1): reported, not enforced
-VARIANTS = {(7, 1, 3, 1, 2), (4, 1, 8, 3, 3), (2, 2, 8, 3, 0), (1, 2, 8, 3, 0)}
+VARIANTS = {(7, 1, 3, 1, 2), (4, 1, 8, 3, 3), (2, 2, 8, 3, 0), (1, 2, 8, 3, 0)} | {(n, 1, 2, 1, k) for n in range(1, 8) for k in (2, 3)} - {(7, 1, 2, 1, 3)}
 MAX_SCRATCH, MIN_OCC = 16, 2
 
 

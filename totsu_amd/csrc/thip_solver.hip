@@ -50,6 +50,8 @@ struct DevStatus {
     float     t_tau, s_kappa;    // preconditioner entries of tau / kappa
     float     r_tau;             // rx_tau
     float     kappa_in;          // sweep schedule: kappa_{k-1} as sw_vm_k left it for the sweep that forms kappa_k
+    float     tau_next, r_tau_next;   // sweep schedule: tau_{k+1} and rx_tau as the termination test of iterate k left them for the
+                                 // next step's m-kernel (which commits them): no block of that kernel reads what another writes
     int       fault;             // column-sharded sweep: some rank's one-pass kernel gave up (seen by every rank in the same
                                  // all-reduce, thip_solver_run restores the snapshot on all of them together)
 };
@@ -340,7 +342,8 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
 __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict__ part,
                                                float eps_acc, float eps_inf, float eps_zero, long long max_iter,
                                                DevStatus *st, const float *ps_pp, const float *ps_by, int npsum, int xbuf,
-                                               const float *fault_flag)
+                                               const float *fault_flag, const float *ps_cu = nullptr, int np_cu = 0,
+                                               const float *ps_bv = nullptr, int np_bv = 0)
 {
     if (st->stop != 0) return;
     if (fault_flag != nullptr && *fault_flag > 0.0f) {
@@ -349,13 +352,31 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
         if (threadIdx.x == 0) { st->fault = 1; st->stop = 1; }
         return;
     }
-    __shared__ double shd[16];
-    const float pp = block_sum_of_partials(ps_pp, npsum, shd);
-    const float by = block_sum_of_partials(ps_by, npsum, shd);
-    double a0 = 0.0, a1 = 0.0;
-    for (int k = threadIdx.x; k < np; k += BLK) { a0 += (double)part[k]; a1 += (double)part[np + k]; }
-    a0 = block_sum_d(a0, shd);
-    a1 = block_sum_d(a1, shd);
+    // six sums of block partials (f64 accumulation), each by ONE wave, two per wave, all loads in flight together and one
+    // barrier -- done one after the other by the whole block (round 3) this launch took 7 us, a tenth of it arithmetic
+    __shared__ double sums[8];
+    {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const float *src[2] = { nullptr, nullptr };
+        int cnt[2] = { 0, 0 };
+        switch (w) {
+        case 0: src[0] = ps_pp; cnt[0] = npsum; src[1] = ps_cu; cnt[1] = ps_cu ? np_cu : 0; break;
+        case 1: src[0] = ps_by; cnt[0] = npsum; src[1] = ps_bv; cnt[1] = ps_bv ? np_bv : 0; break;
+        case 2: src[0] = part; cnt[0] = np; break;
+        default: src[0] = part + np; cnt[0] = np; break;
+        }
+        double acc[2] = { 0.0, 0.0 };
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            for (int k = lane; k < cnt[q]; k += 64) acc[q] += (double)src[q][k];
+        acc[0] = wave_sum_d(acc[0]);
+        acc[1] = wave_sum_d(acc[1]);
+        if (lane == 0) { sums[w] = acc[0]; sums[4 + w] = acc[1]; }
+    }
+    __syncthreads();
+    const float pp = (float)sums[0], by = (float)sums[1];
+    const double a0 = sums[2], a1 = sums[3];
+    const float dcu = (float)sums[4], dbv = (float)sums[5];
     if (threadIdx.x != 0) return;
     const float dd = (float)a0, cx = (float)a1;
     const long long i = st->iter;
@@ -386,7 +407,14 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
         else if (term_infeas) state = THIP_ST_INFEASIBLE;
         else if (excess_iter) state = THIP_ST_EXCESS_ITER;
     }
-    if (state == THIP_ST_RUNNING) st->iter = i + 1;
+    if (state == THIP_ST_RUNNING) {
+        st->iter = i + 1;
+        if (ps_cu != nullptr) {
+            const float t = fmaxf(tau + st->t_tau * (-dcu - dbv), 0.0f);
+            st->tau_next = t;
+            st->r_tau_next = tau - 2.0f * t;
+        }
+    }
     else { st->state = state; st->xbuf = xbuf; st->stop = 1; }     // one block, last kernel of the iteration: later launches are no-ops
 }
 
@@ -400,22 +428,25 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
 //   status_k  the termination test of iterate k (solver.rs:381-451)
 // The arithmetic of every update is xupdate_k's / ycrit_k's / post_k's.
 // ---------------------------------------------------------------------------------------------------
+// MERGE (no block cones: every row's projection is element-wise): the same launch also does sw_vm_k's part of the row -- v_k,
+// the sums over m -- with tau_k / rx_tau as the previous termination test left them (DevStatus::tau_next), and leaves its
+// four block partials in `part` (gridDim.x each)
+template <bool MERGE>
 __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, const float *__restrict__ partH,
                                               float *__restrict__ h3, const float *__restrict__ b,
-                                              const float *__restrict__ v, const float *__restrict__ Ty,
+                                              float *__restrict__ v, const float *__restrict__ Ty,
                                               const float *__restrict__ Ts, const unsigned char *__restrict__ cls,
                                               float *__restrict__ xy, float *__restrict__ xs, float *__restrict__ rxy,
-                                              float *__restrict__ rxs, DevStatus *st, const float *ps_cu, int np_n,
-                                              const float *ps_bv, int np_m, float *__restrict__ ky, float *__restrict__ ks)
+                                              float *__restrict__ rxs, DevStatus *st, float *__restrict__ ky, float *__restrict__ ks,
+                                              float *__restrict__ hP, const float *__restrict__ Sv, float *__restrict__ kv,
+                                              float eps_zero, float *__restrict__ part)
 {
     if (st->stop != 0) return;
-    float dc = 0.0f, db = 0.0f;
-    if (blockIdx.x == 0) {
-        __shared__ double shd[16];
-        dc = block_sum_of_partials(ps_cu, np_n, shd);
-        db = block_sum_of_partials(ps_bv, np_m, shd);
-    }
     const float kappa = st->kappa;
+    const float tau = st->tau_next, rtau = st->r_tau_next;       // tau_k, rx_tau (read-only here: block 0 commits them at its end)
+    const bool conv = tau > eps_zero;
+    const float rt = conv ? 1.0f / tau : 1.0f;
+    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
     // 256 threads = 64 rows x 4 group lanes (post_k's shape): the sum over the groups' shares of one row -- up to 256 of
     // them, 128 at the 10 000-variable LP -- is split four ways, combined through LDS, and lane 0 of a row does the update
     __shared__ float comb[2][3][64];
@@ -438,26 +469,75 @@ __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, 
         if (kq == 0 && i < (size_t)m) {
             const float hN = (sa + comb[0][0][e]) + (comb[0][1][e] + comb[0][2][e]);
             const float hx = (sb + comb[1][0][e]) + (comb[1][1][e] + comb[1][2][e]);
-            h3[i] = hx;
             const unsigned char k = cls[i];
-            const float oy = xy[i], os = xs[i];
-            float ny = comp_add(oy, Ty[i] * (b[i] * kappa - hN), ky, i);
-            float ns = comp_add(os, Ts[i] * v[i], ks, i);
+            const float oy = xy[i], os = xs[i], bi = b[i], vi = v[i];
+            float ny = comp_add(oy, Ty[i] * (bi * kappa - hN), ky, i);
+            float ns = comp_add(os, Ts[i] * vi, ks, i);
             if (k == 1) { ny = fmaxf(ny, 0.0f); ns = fmaxf(ns, 0.0f); }
             else if (k == 0) { ns = 0.0f; }
             xy[i] = ny;
             xs[i] = ns;
-            rxy[i] = (k < 2) ? oy - 2.0f * ny : oy;
-            rxs[i] = (k < 2) ? os - 2.0f * ns : os;
+            const float ry = (k < 2) ? oy - 2.0f * ny : oy, rs = (k < 2) ? os - 2.0f * ns : os;
+            rxy[i] = ry;
+            rxs[i] = rs;
+            if constexpr (MERGE) {
+                // sw_vm_k's row: v_k from h2 = hP - 2 h3 (h3 = A x_x_k) ; the criteria sums over m
+                const float h2 = hP[i] - 2.0f * hx;
+                hP[i] = hx;
+                const float vn = comp_add(vi, Sv[i] * (h2 + rs - bi * rtau), kv, i);
+                v[i] = vn;
+                q0 = fmaf(bi, vn, q0);
+                q1 = fmaf(bi, ry, q1);
+                float p;
+                if (conv) { p = ns * rt - bi; p = fmaf(rt, hx, p); }
+                else p = ns + hx;
+                q2 = fmaf(p, p, q2);
+                q3 = fmaf(bi, ny, q3);
+            } else {
+                h3[i] = hx;
+            }
         }
         __syncthreads();
     }
+    if constexpr (MERGE) {
+        __shared__ float sh[16];
+        q0 = block_sum(q0, sh); q1 = block_sum(q1, sh); q2 = block_sum(q2, sh); q3 = block_sum(q3, sh);
+        if (threadIdx.x == 0) {
+            part[blockIdx.x] = q0; part[gridDim.x + blockIdx.x] = q1;
+            part[2 * gridDim.x + blockIdx.x] = q2; part[3 * gridDim.x + blockIdx.x] = q3;
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->tau = tau;
+        st->r_tau = rtau;
+        if (MERGE) st->kappa_in = kappa;          // nobody writes kappa between here and the sweep
+    }
+}
+
+// (re)start of the one-pass schedule: the tau update a regular step takes from the previous termination test
+__global__ __launch_bounds__(BLK) void sw_tau_k(DevStatus *st, const float *ps_cu, int np_cu, const float *ps_bv, int np_bv)
+{
+    if (st->stop != 0) return;
+    // (summed as status_k sums them: one wave per quantity)
+    __shared__ double sums[2];
+    {
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (w < 2) {
+            const float *src = w == 0 ? ps_cu : ps_bv;
+            const int cnt = w == 0 ? np_cu : np_bv;
+            double acc = 0.0;
+            for (int k = lane; k < cnt; k += 64) acc += (double)src[k];
+            acc = wave_sum_d(acc);
+            if (lane == 0) sums[w] = acc;
+        }
+    }
+    __syncthreads();
+    const float dc = (float)sums[0], db = (float)sums[1];
+    if (threadIdx.x == 0) {
         const float old = st->tau;
-        float t = old + st->t_tau * (-dc - db);
-        t = fmaxf(t, 0.0f);
-        st->tau = t;
-        st->r_tau = old - 2.0f * t;
+        const float t = fmaxf(old + st->t_tau * (-dc - db), 0.0f);
+        st->tau_next = t;
+        st->r_tau_next = old - 2.0f * t;
     }
 }
 
@@ -672,14 +752,14 @@ __global__ void spin_k(long long ticks)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
-// the snapshot of the consistent iterate the one-pass schedule keeps per batch (and its restore): six contiguous pieces of
-// the arena and the status block in ONE launch
-struct SnapArgs { const float *src[6]; float *dst[6]; size_t len[6]; const DevStatus *st_src; DevStatus *st_dst; };
+// the snapshot of the consistent iterate the one-pass schedule keeps per batch (and its restore): seven contiguous pieces
+// of the arena and the status block in ONE launch
+struct SnapArgs { const float *src[7]; float *dst[7]; size_t len[7]; const DevStatus *st_src; DevStatus *st_dst; };
 __global__ __launch_bounds__(BLK) void snap_copy_k(const SnapArgs a)
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const size_t stride = (size_t)gridDim.x * BLK;
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 7; ++q) {
         const f4 *sp = reinterpret_cast<const f4 *>(a.src[q]);
         f4 *dp = reinterpret_cast<f4 *>(a.dst[q]);
         for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < a.len[q] / 4; i += stride) dp[i] = sp[i];      // lengths are multiples of 64
@@ -799,6 +879,7 @@ struct thip_solver {
     bool col_shard = false;
     float *cs_buf = nullptr; size_t cs_n = 0;
     size_t sweep_min_bytes = (size_t)128 << 20;     // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
+    bool no_merge = false;        // thip_test_sweep_fault(kind 3): the two m-kernels of a step as two launches also without block cones
     int pn_par = 0;               // which of the two buffers of sums over n (sw_part + par * 2 EG) the LAST sweep wrote
     int pub_agent = 0;            // thip_solver_set_sweep_publish
     // recovery when the persistent kernel gives up (thip_solver_run): a device copy of the consistent iterate of the last
@@ -1351,7 +1432,7 @@ int rebuild_carried(thip_solver *s)
 // ---------------------------------------------------------------------------------------------------
 // Can the next run use the one-pass kernel?  Dense f32 A on one GPU in a shape sweep_plan() takes, on a device whose
 // placement census came out as 8 x 32 in a dry run.  Examined once per (re)initialisation.
-int sweep_pass(thip_solver *s, int first);
+int sweep_pass(thip_solver *s, int first, int np_m = 0);
 
 int sweep_prepare(thip_solver *s)
 {
@@ -1427,7 +1508,13 @@ int sweep_prepare(thip_solver *s)
             }
             unsigned err = 0;
             THIP_TRY(hipMemcpy(&err, s->sw_census + 9, sizeof(err), hipMemcpyDeviceToHost));
-            if (err != 0u) { hipEventDestroy(e0); hipEventDestroy(e1); return 0; }      // a spin ran out: the carried schedule runs
+            if (err != 0u) {
+                // a ticket was off or a spin ran out: the carried schedule runs.  Inside a running solve (a re-plan after
+                // thip_solver_set_sweep_min_bytes) the timing sweeps have rewritten gP: rebuilt before the next step
+                hipEventDestroy(e0); hipEventDestroy(e1);
+                s->carried_stale = true;
+                return 0;
+            }
             std::sort(t, t + REP);
             med[c] = t[REP / 2];
             spread[c] = (t[REP - 1] - t[0]) / t[REP / 2];
@@ -1483,7 +1570,7 @@ bool sweep_active(const thip_solver *s)
     return (size_t)s->sgeom.m_eff == s->m || (s->Apad != nullptr && s->ldpad >= (size_t)s->sgeom.m_eff);
 }
 
-int sweep_pass(thip_solver *s, int first)
+int sweep_pass(thip_solver *s, int first, int np_m)
 {
     hipStream_t st = ctx().stream;
     const SweepGeom &g = s->sgeom;
@@ -1509,7 +1596,7 @@ int sweep_pass(thip_solver *s, int first)
     a.pn_in = s->sw_part + (size_t)s->pn_par * 2 * EG; a.pn_in_stride = 256;
     if (!first) {
         // the sweep of a regular step opens with the kappa update: c.rx_x from the previous sweep's partials, b.rx_y from sw_vm_k
-        const unsigned gm_ = egrid(s->m);
+        const unsigned gm_ = np_m > 0 ? (unsigned)np_m : egrid(s->m);      // block partials per sum over m (the m-kernel's grid)
         a.kappa_p = &s->dst->kappa_in; a.kappa_out = &s->dst->kappa;
         a.pm_brx = s->sw_part + 4 * EG + gm_; a.np_m = (int)gm_;
         a.pn_count = 256;
@@ -1562,26 +1649,38 @@ int one_iteration_sweep(thip_solver *s)
         }
         return 0;
     };
+    // no block cones (an LP: zero / nonneg rows only): the two m-kernels of a step are one launch
+    const bool merge = s->n_soc == 0 && s->n_rot == 0 && s->psd.empty() && !s->no_merge;
+    const unsigned gx = merge ? grid_for(s->m, 64, EG) : grid_for(s->m, 64, 4096);      // (merged: its block partials fill gm slots)
+    const unsigned gmm = merge ? gx : gm;           // block partials per sum over m
     if (s->sw_first) {
         // from a consistent iterate (x_0, or wherever a run stopped): u is current, so the sweep leaves it alone
-        THIP_RC(sweep_pass(s, 1));
+        THIP_RC(sweep_pass(s, 1, (int)gmm));
         THIP_RC(post());
-        hipLaunchKernelGGL(sw_bv_k, dim3(gm), dim3(BLK), 0, st, m, s->b, s->v, pm, s->dst);
+        hipLaunchKernelGGL(sw_bv_k, dim3(gmm), dim3(BLK), 0, st, m, s->b, s->v, pm, s->dst);
+        hipLaunchKernelGGL(sw_tau_k, dim3(1), dim3(BLK), 0, st, s->dst, pn_now() + 2 * pns, pns, pm, (int)gmm);
         s->sw_first = false;
     }
-    hipLaunchKernelGGL(sw_xm_k, dim3(grid_for(s->m, 64, 4096)), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
-                       cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
-                       s->dst, pn_now() + 2 * pns, pns, pm, (int)gm, ky, ks);
-    THIP_RC(project_blocks(s));
-    hipLaunchKernelGGL(sw_vm_k, dim3(gm), dim3(BLK), 0, st, m, s->h3, s->hP, s->b, s->rxs, s->rxy, s->Sv, s->v, kv, s->xs,
-                       s->xy, ez, s->dst, pm);
+    if (merge) {
+        hipLaunchKernelGGL(sw_xm_k<true>, dim3(gx), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
+                           cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
+                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm);
+    } else {
+        hipLaunchKernelGGL(sw_xm_k<false>, dim3(gx), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
+                           cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
+                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm);
+        THIP_RC(project_blocks(s));
+        hipLaunchKernelGGL(sw_vm_k, dim3(gm), dim3(BLK), 0, st, m, s->h3, s->hP, s->b, s->rxs, s->rxy, s->Sv, s->v, kv, s->xs,
+                           s->xy, ez, s->dst, pm);
+    }
     // (kappa_k is formed by the sweep's workgroups at entry: SweepArgs::kappa_out)
     sweep_swap(s);                                // x_x_k (formed by the previous sweep) is now the iterate
-    THIP_RC(sweep_pass(s, 0));
+    THIP_RC(sweep_pass(s, 0, (int)gmm));
     THIP_RC(post());
     hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, pns, pn_now(), s->par.eps_acc, s->par.eps_inf, ez,
-                       (long long)s->par.max_iter, s->dst, pm + 2 * gm, pm + 3 * gm, (int)gm, s->xbuf,
-                       cols ? (const float *)(s->cs_buf + 2 * s->sgeom.mpad + 4 * EG) : (const float *)nullptr);
+                       (long long)s->par.max_iter, s->dst, pm + 2 * gmm, pm + 3 * gmm, (int)gmm, s->xbuf,
+                       cols ? (const float *)(s->cs_buf + 2 * s->sgeom.mpad + 4 * EG) : (const float *)nullptr,
+                       (const float *)(pn_now() + 2 * pns), pns, (const float *)pm, (int)gmm);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1627,21 +1726,23 @@ int ensure_apad(thip_solver *s, bool refresh)
 
 int poll(thip_solver *s, thip_status *out);
 
-// x_x, u, (x_y x_s v) and their Kahan terms, the status block <-> the snapshot; restore = the other direction, into
+// x_x, u, (x_y x_s v), their Kahan terms, hP and the status block <-> the snapshot; restore = the other direction, into
 // whichever x_x buffer is the iterate's now
 int snapshot(thip_solver *s, bool restore)
 {
     hipStream_t st = ctx().stream;
     const size_t pn = s->pn_len, pm = s->pm_len;
     if (!s->snap) {
-        THIP_TRY(hipMalloc((void **)&s->snap, (4 * pn + 6 * pm) * sizeof(float)));
+        THIP_TRY(hipMalloc((void **)&s->snap, (4 * pn + 7 * pm) * sizeof(float)));
         THIP_TRY(hipMalloc((void **)&s->snap_st, sizeof(DevStatus)));
     }
-    float *live[6] = { s->xx, s->u, s->xy, s->kx, s->ku, s->ky };        // xy xs v and ky ks kv are contiguous in the arena
-    const size_t len[6] = { pn, pn, 3 * pm, pn, pn, 3 * pm };
+    // xy xs v and ky ks kv are contiguous in the arena; hP = A x_x of the iterate is carried state too (the v update takes
+    // A (x_k - 2 x_{k+1}) from it), and unlike gP no (re)start of the schedule recomputes it
+    float *live[7] = { s->xx, s->u, s->xy, s->kx, s->ku, s->ky, s->hP };
+    const size_t len[7] = { pn, pn, 3 * pm, pn, pn, 3 * pm, pm };
     SnapArgs a;
     float *p = s->snap;
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 7; ++q) {
         a.src[q] = restore ? p : live[q]; a.dst[q] = restore ? live[q] : p; a.len[q] = len[q];
         p += len[q];
     }
@@ -2227,7 +2328,8 @@ int thip_solver_sweep_faults(thip_solver *s, int *host_faults, int *host_last_wo
 
 int thip_test_sweep_fault(thip_solver *s, int kind, int64_t after_sweeps, int spin_max)
 {
-    if (!s || kind < 0 || kind > 2) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
+    if (!s || kind < 0 || kind > 4) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
+    if (kind >= 3) { s->no_merge = kind == 3; return 0; }       // 3 / 4: the step's m-kernels as two launches / merged again
     s->fault_kind = kind; s->fault_after = kind == 2 ? (long long)after_sweeps : -1;
     s->spin_max = spin_max > 0 ? spin_max : 0;
     return 0;

@@ -114,25 +114,45 @@ __device__ __forceinline__ float sw_reduce(float *v, int lane)
     }
 }
 
-// census: every workgroup counts itself on its XCD; once all have, every workgroup sees the same eight counts.
-// Returns 1 and (group, member) when each XCD holds exactly 32 of the 256 workgroups.
-__device__ __forceinline__ int sw_census(unsigned *census, unsigned seq, int G, int *group, int *member)
+// census.  Every workgroup counts itself on its XCD: the ticket it draws is its place (group, member) among the 32 of that
+// XCD.  sweep_census_k (the dry run of thip_solver_init and of thip_sweep_probe) ALSO waits until all 256 have counted
+// themselves and checks that every XCD holds exactly 32 -- the placement the kernel needs.  The sweeps themselves do not wait
+// (round 3 did: device-clock stamps put the wait at 15 us per launch, a tenth of a short sweep): a workgroup that draws a
+// ticket >= 32 raises the error word at once, and a group that is short of a member runs out of its bounded spins and
+// raises it too -- thip_solver_run then restores its snapshot of the iterate and goes on with the 2-pass schedule.
+__device__ __forceinline__ int sw_ticket(unsigned *census, unsigned seq, int G, int *group, int *member)
 {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;        // HW_REG_XCC_ID, bits 3:0
     if (xcc >= 8u) { atomicExch(census + 9, 1u); return 0; }
     const unsigned idx = atomicAdd(census + xcc, 1u) - seq * 32u;
-    __threadfence();
-    atomicAdd(census + 8, 1u);
-    const unsigned want = (seq + 1u) * 256u;
+    if (idx >= 32u) { atomicExch(census + 9, 2u); return 0; }
+    *group = (int)xcc * (32 / G) + (int)idx / G;
+    *member = (int)idx % G;
+    return 1;
+}
+
+__device__ __forceinline__ int sw_census(unsigned *census, unsigned seq, int G, int *group, int *member)
+{
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;
+    if (xcc >= 8u) { atomicExch(census + 9, 1u); return 0; }
+    const unsigned idx = atomicAdd(census + xcc, 1u) - seq * 32u;
+    const unsigned want = (seq + 1u) * 32u;
     int spins = 0;
-    while ((int)(__hip_atomic_load(census + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+    for (;;) {
+        // the eight counts in one round trip; done when they add up to everybody
+        unsigned c[8], sum = 0u;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) c[x] = __hip_atomic_load(census + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { sum += c[x]; ok = ok && c[x] == want; }
+        if (sum == 8u * want) {
+            if (!ok || idx >= 32u) { atomicExch(census + 9, 2u); return 0; }
+            break;
+        }
         __builtin_amdgcn_s_sleep(2);
         if (++spins > SW_SPIN_MAX) { atomicExch(census + 9, 1u); return 0; }
     }
-    bool ok = idx < 32u;
-    for (int x = 0; x < 8; ++x)
-        ok = ok && __hip_atomic_load(census + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (seq + 1u) * 32u;
-    if (!ok) { atomicExch(census + 9, 2u); return 0; }
     *group = (int)xcc * (32 / G) + (int)idx / G;
     *member = (int)idx % G;
     return 1;
@@ -177,19 +197,29 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
     extern __shared__ f32x4 sw_lds[];                 // LS panels the streaming threads park between registers and axpy
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SW_PROFILE
+    // phase stamps of streaming wave 0 of (group 0, member 0): census[150 ..] = 10 ns ticks since kernel entry at: census done,
+    // v / x_y in registers, fill block, steady loop, drain, stores
+    const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
+#define SW_PHASE(i) do { if (wave == 0 && group == 0 && member == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if (lane == 0) a.census[150 + (i)] = (unsigned)(__builtin_amdgcn_s_memrealtime() - tp0); } } while (0)
+#else
+#define SW_PHASE(i) do { } while (0)
+#endif
 
     if (tid == 0) {
         int g = 0, mbr = 0;
-        s_role[2] = sw_census(a.census, a.seq, a.G, &g, &mbr);
+        s_role[2] = sw_ticket(a.census, a.seq, a.G, &g, &mbr);
         s_role[0] = g; s_role[1] = mbr;
     }
     __syncthreads();
-    // the census comes first even when the loop has stopped: the host numbers the launches, and one that left before
-    // counting itself would leave every later census short
+    // the ticket comes first even when the loop has stopped: the host numbers the launches, and one that left before
+    // counting itself would leave every later launch's tickets off by one
     // (a raised error word -- this launch's census, or an earlier sweep of the batch that gave up -- ends every later sweep
     // at entry: the host restores its snapshot of the iterate, thip_solver.hip sweep_recover)
     if (s_role[2] == 0 || *a.stop != 0 || __hip_atomic_load(a.census + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const int group = s_role[0], member = s_role[1];
+    SW_PHASE(0);
 
     const int c0 = group * a.cols_per_group;
     const int c1 = min(a.n, c0 + a.cols_per_group);
@@ -216,6 +246,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                 acc1[sl][k] = 0.0f; acc2[sl][k] = 0.0f;
             }
         }
+        SW_PHASE(1);
         f32x4 stg[NS][W][NSLOT];
         const int jmax = a.n - 1;
 
@@ -309,6 +340,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         // have one assignment per loop (two forms of the body inside ONE loop doubled them)
         int it0 = 0;
         for (; it0 < LAGT; it0 += NS) { SW_GUARDED_BLOCK(it0); }
+        SW_PHASE(2);
         for (; it0 + NS <= npan; it0 += NS) {
             // every phase active, no guards: the waits on the loads are counted, not drained
 #pragma unroll
@@ -321,7 +353,9 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                 else { SW_AXPY_LDS(it - LAGT); SW_SPILL((s + 1) % NS, it - LAGL); }
             }
         }
+        SW_PHASE(3);
         for (; it0 < total; it0 += NS) { SW_GUARDED_BLOCK(it0); }
+        SW_PHASE(4);
 #undef SW_GUARDED_BLOCK
 #undef SW_LOADS
 #undef SW_DOTS
@@ -337,6 +371,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                 *reinterpret_cast<float4 *>(h1 + r) = make_float4(acc1[sl][0], acc1[sl][1], acc1[sl][2], acc1[sl][3]);
                 *reinterpret_cast<float4 *>(h2 + r) = make_float4(acc2[sl][0], acc2[sl][1], acc2[sl][2], acc2[sl][3]);
             }
+        SW_PHASE(5);
     } else {
         // ---------------- service wave ----------------
         // Its global loads (the granules of a panel, the per-column data of a panel) are issued TWO intervals before they
@@ -408,7 +443,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                     for (int w = 1; w < SW_CW; ++w) sum += dotbuf[pp & 1][w][lane];
                     unsigned long long *g = gbase + ((size_t)(pp % SW_RING) * a.G + member) * (2 * W) + lane;
                     // TEST HOOK (thip_test_sweep_fault): one workgroup stops publishing half-way -- its group runs out of spins
-                    const bool withheld = a.fault != 0 && blockIdx.x == 37u && pp >= npan / 2;
+                    const bool withheld = a.fault != 0 && group == 0 && member == a.G - 1 && pp >= npan / 2;
                     // pub_agent: the documented form (sc1 store, MI355X_MICROARCH.md inter-workgroup visibility); else a plain
                     // store that stays in the L2 the group shares (DESIGN.md 4.7 has the measured difference)
                     if (withheld) { }
@@ -559,7 +594,7 @@ int sweep_class()
 int sweep_variant()
 {
     static const int v = getenv("THIP_SWEEP_VARIANT") ? atoi(getenv("THIP_SWEEP_VARIANT")) : 0;
-    return v >= 0 && v < 2 ? v : 0;
+    return v >= 0 && v < 4 ? v : 0;
 }
 }  // namespace
 
@@ -654,16 +689,29 @@ int sweep_launch(hipStream_t st, const SweepGeom &g, const SweepArgs &a)
         if (g.nslot == 2) return g.variant == 1 ? sweep_go<2, 2, 8, 3, 0>(st, a) : sweep_go<2, 2, 8, 3, 5>(st, a);
         return g.variant == 1 ? sweep_go<1, 2, 8, 3, 0>(st, a) : sweep_go<1, 2, 8, 3, 5>(st, a);
     }
-    // <slots, columns per panel, LAGL, DLAG, LS>: register stages + LDS panels sized to the 512 VGPRs / 160 KB of a CU
+    // <slots, columns per panel, LAGL, DLAG, LS>: register stages + LDS panels sized to the 512 VGPRs / 160 KB of a CU.
+    // variant 2 / 3 (experiments, thip_sweep_test.variant): shallower rings -- a launch runs npan + LAGL + LS intervals, and the
+    // last LAGL + LS of them load nothing
+#define SW_CASE(N, L0, D0, S0)                                                          \
+    case N:                                                                             \
+        if (g.variant == 2) return sweep_go<N, 1, 2, 1, 3>(st, a);                      \
+        if (g.variant == 3) return sweep_go<N, 1, 2, 1, 2>(st, a);                      \
+        return sweep_go<N, 1, L0, D0, S0>(st, a);
     switch (g.nslot) {
-    case 1: return sweep_go<1, 1, 8, 3, 8>(st, a);
-    case 2: return sweep_go<2, 1, 8, 3, 8>(st, a);
-    case 3: return sweep_go<3, 1, 8, 3, 6>(st, a);
-    case 4: return g.variant == 1 ? sweep_go<4, 1, 8, 3, 3>(st, a) : sweep_go<4, 1, 8, 3, 5>(st, a);
-    case 5: return sweep_go<5, 1, 3, 1, 4>(st, a);
-    case 6: return sweep_go<6, 1, 3, 1, 3>(st, a);
-    default: return g.variant == 1 ? sweep_go<7, 1, 3, 1, 2>(st, a) : sweep_go<7, 1, 2, 1, 3>(st, a);
+    SW_CASE(1, 8, 3, 8)
+    SW_CASE(2, 8, 3, 8)
+    SW_CASE(3, 8, 3, 6)
+    case 4:
+        if (g.variant == 2) return sweep_go<4, 1, 2, 1, 3>(st, a);
+        if (g.variant == 3) return sweep_go<4, 1, 2, 1, 2>(st, a);
+        return g.variant == 1 ? sweep_go<4, 1, 8, 3, 3>(st, a) : sweep_go<4, 1, 8, 3, 5>(st, a);
+    SW_CASE(5, 2, 1, 3)      // (3 register stages + 3 LDS panels measured 2 - 5 % ahead of 4 + 3 / 4 + 4 on short sweeps: fewer
+    SW_CASE(6, 2, 1, 3)      //  intervals that load nothing at the end of a launch)
+    default:
+        if (g.variant == 3) return sweep_go<7, 1, 2, 1, 2>(st, a);
+        return g.variant == 1 ? sweep_go<7, 1, 3, 1, 2>(st, a) : sweep_go<7, 1, 2, 1, 3>(st, a);
     }
+#undef SW_CASE
 }
 
 }  // namespace thip
@@ -691,6 +739,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     if ((t->force_members > 0 ? sweep_plan_one(t->m, t->n, t->lda, t->mat_a, 1, 1, &g, t->force_members)
                               : sweep_plan(t->m, t->n, t->lda, t->mat_a, &g)) != 0)
         return fail(THIP_E_INVALID, "the one-pass kernel cannot take this shape", __FILE__, __LINE__);
+    if (t->variant > 0) g.variant = t->variant;
     hipStream_t st = ctx().stream;
     unsigned long long *gran = nullptr;
     unsigned *census = nullptr;
@@ -742,7 +791,10 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
 #ifdef SW_PROFILE
     fprintf(stderr, "service wave, 10 ns ticks: wait %u, cold+publish %u, tags+poll %u, reduce+math+stores %u, loads %u, barrier %u; intervals that polled %u, polls %u\n",
             hc[10], hc[11], hc[12], hc[13], hc[14], hc[15], hc[16], hc[17]);
-    for (int i = 0; i < 40; ++i) fprintf(stderr, "miss %d: panel %u lanes %08x%08x\n", i, hc[24 + 3 * i], hc[26 + 3 * i], hc[25 + 3 * i]);
+    if (getenv("SW_PROFILE_MISSES"))
+        for (int i = 0; i < 5; ++i) fprintf(stderr, "miss %d: panel %u lanes %08x%08x\n", i, hc[24 + 3 * i], hc[26 + 3 * i], hc[25 + 3 * i]);
+    fprintf(stderr, "streaming wave 0 of workgroup (0, 0), us since kernel entry: census done %.2f, v / x_y loaded %.2f, fill done %.2f, steady loop done %.2f, drain done %.2f, stores done %.2f\n",
+            hc[150] * 0.01, hc[151] * 0.01, hc[152] * 0.01, hc[153] * 0.01, hc[154] * 0.01, hc[155] * 0.01);
 #endif
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(gran); hipFree(census); hipFree(partH); hipFree(scal);
@@ -795,6 +847,26 @@ __global__ __launch_bounds__(256) void stream_read_k(const f32x4 *__restrict__ p
     const float s = acc[0] + acc[1] + acc[2] + acc[3];
     if (s == 123.456f) out[0] = s;      // keeps the loads alive
 }
+
+// the same bytes as 32 KB contiguous pieces per workgroup and step (what a persistent kernel's workgroup reads per column):
+// DRAM pages are walked in longer runs than by the grid-stride form; the probe reports the better of the two
+__global__ __launch_bounds__(256) void stream_read_chunks_k(const f32x4 *__restrict__ p, size_t n4, float *out)
+{
+    constexpr size_t CH = 256 * 8;                  // 16-byte vectors per chunk
+    const size_t nch = n4 / CH;
+    f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+    for (size_t c = blockIdx.x; c < nch; c += gridDim.x) {
+        const f32x4 *q = p + c * CH + threadIdx.x;
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(q + u * 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (size_t i = nch * CH + (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) acc += __builtin_nontemporal_load(p + i);
+    const float s = acc[0] + acc[1] + acc[2] + acc[3];
+    if (s == 123.456f) out[0] = s;
+}
 }  // namespace
 
 extern "C" int thip_stream_probe(const void *dev_ptr, size_t bytes, int reps, float *host_best_ms, float *host_avg_ms)
@@ -806,26 +878,32 @@ extern "C" int thip_stream_probe(const void *dev_ptr, size_t bytes, int reps, fl
     hipEvent_t e0, e1;
     THIP_TRY(hipEventCreate(&e0)); THIP_TRY(hipEventCreate(&e1));
     if (reps < 1) reps = 1;
-    float best = 1e30f, tot = 0.0f;
-    int cnt = 0;
-    // the grids tools/stream_probe.hip found within 2 % of each other at 0.4 - 20 GB; the best of them, one warm-up each
-    for (unsigned blocks : { 4096u, 8192u, 16384u }) {
-        if ((size_t)blocks * 256 * 8 > n4 && blocks != 4096u) continue;
+    float best = 1e30f, best_avg = 1e30f;
+    // grid-stride form at the grids tools/stream_probe.hip found within 2 % of each other at 0.4 - 20 GB, and the chunked form
+    // at 8 and 16 resident workgroups per CU; one warm-up each; the best form's best and average launch
+    const unsigned grids[5] = { 4096u, 8192u, 16384u, 2048u, 4096u };
+    for (int f = 0; f < 5; ++f) {
+        const unsigned blocks = grids[f];
+        const bool chunks = f >= 3;
+        if ((size_t)blocks * 256 * 8 > n4 && f != 0) continue;
+        float tot = 0.0f, mn = 1e30f;
         for (int r = 0; r <= reps; ++r) {
             THIP_TRY(hipEventRecord(e0, st));
-            hipLaunchKernelGGL(stream_read_k, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(dev_ptr), n4, ctx().dev_scalar);
+            if (chunks) hipLaunchKernelGGL(stream_read_chunks_k, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(dev_ptr), n4, ctx().dev_scalar);
+            else hipLaunchKernelGGL(stream_read_k, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(dev_ptr), n4, ctx().dev_scalar);
             THIP_TRY(hipEventRecord(e1, st));
             THIP_TRY(hipEventSynchronize(e1));
             float ms = 0.0f;
             THIP_TRY(hipEventElapsedTime(&ms, e0, e1));
             if (r == 0) continue;
-            tot += ms; ++cnt;
-            if (ms < best) best = ms;
+            tot += ms;
+            if (ms < mn) mn = ms;
         }
+        if (mn < best) { best = mn; best_avg = tot / reps; }
     }
     THIP_LAUNCH_CHECK();
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (host_best_ms) *host_best_ms = best;
-    if (host_avg_ms) *host_avg_ms = cnt ? tot / cnt : 0.0f;
+    if (host_avg_ms) *host_avg_ms = best_avg;
     return 0;
 }
