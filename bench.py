@@ -80,6 +80,9 @@ def parse():
                     help="--path trait: the reference's literal cone code (host loop over get_mut / get + norm + scale per "
                          "cone) or the device-side projections (thip_proj_*)")
     ap.add_argument("--no-to-eps", action="store_true", help="skip the time-to-eps leg (iterations/sec only)")
+    ap.add_argument("--no-row-leg", action="store_true",
+                    help="column-sharded runs also time a short row-sharded (carried schedule) leg on the same ranks and report it as "
+                         "`row_sharded`; this skips it")
     ap.add_argument("--to-eps-budget", type=float, default=1200.0,
                     help="stop the time-to-eps leg after this many seconds and report the criteria reached (state -1)")
     ap.add_argument("--state", default="compensated", choices=["compensated", "plain"],
@@ -610,30 +613,35 @@ def run(a):
             dist.barrier()
         torch.cuda.synchronize()
 
-    overlap_pick, overlap_times = None, None
     OVM = {"off": 0, "on": 1, "pipeline": 2, "pipeline-inorder": 3}
+
+    def tune_overlap(fs_):
+        """row-sharded runs: where the all-reduce goes relative to the other work (thip_solver_set_overlap).  --overlap auto
+        times 3 x 20 iterations per mode on the real communicator (untimed warm-up work, max over ranks) and keeps the fastest
+        -- like the GEMV plan autotune.  Returns (mode, ms per iteration per mode or None, iterations spent)."""
+        if a.overlap != "auto":
+            lib.thip_solver_set_overlap(fs_.h, OVM[a.overlap])
+            return a.overlap, None, 0
+        best = {}
+        cand = ("off", "on", "pipeline")
+        for mode in cand * 3:
+            lib.thip_solver_set_overlap(fs_.h, OVM[mode])
+            barrier()
+            t0_ = time.perf_counter()
+            fs_.run(20, poll_every=20)
+            barrier()
+            best[mode] = min(best.get(mode, 1e30), time.perf_counter() - t0_)
+        tt_ = torch.tensor([best[c] for c in cand], dtype=torch.float64, device=dev_pg)
+        if use_dist:
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+        tl = [float(v) for v in tt_]
+        pick = cand[tl.index(min(tl))]
+        lib.thip_solver_set_overlap(fs_.h, OVM[pick])
+        return pick, {c: 1e3 * v / 20 for c, v in zip(cand, tl)}, 20 * 3 * len(cand)
+
+    overlap_pick, overlap_times = None, None
     if hook is not None and a.collective != "gloo" and not cols:
-        if a.overlap == "auto":
-            # untimed: 3 x 20 iterations per mode (max over ranks), keep the fastest -- like the GEMV plan autotune
-            best = {}
-            cand = ("off", "on", "pipeline")
-            for mode in cand * 3:
-                lib.thip_solver_set_overlap(fs.h, OVM[mode])
-                barrier()
-                t0 = time.perf_counter()
-                fs.run(20, poll_every=20)
-                barrier()
-                best[mode] = min(best.get(mode, 1e30), time.perf_counter() - t0)
-            tt = torch.tensor([best[c] for c in cand], dtype=torch.float64, device=dev_pg)
-            if use_dist:
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tl = [float(v) for v in tt]
-            overlap_pick = cand[tl.index(min(tl))]
-            overlap_times = {c: 1e3 * v / 20 for c, v in zip(cand, tl)}          # ms per iteration, as timed
-            a.warmup_extra = 20 * 3 * len(cand)
-        else:
-            overlap_pick = a.overlap
-        lib.thip_solver_set_overlap(fs.h, OVM[overlap_pick])
+        overlap_pick, overlap_times, a.warmup_extra = tune_overlap(fs)
     # what THIS box streams: a bare non-temporal read of the solver's own A (the whole of it up to 20 GB), outside every
     # timed region -- the boxes of one pool differ by several percent, so the line carries its own yardstick
     box_read = None
@@ -755,6 +763,41 @@ def run(a):
                                                 % fs.schedule_in_use()},
         "sweep_faults": fs.sweep_faults(),
     }
+
+    if cols and use_dist and a.workload in ("socp", "lp") and not a.no_row_leg:
+        # north_star / configs[4] name ROW blocks with the A^T y all-reduce overlapped on a side stream; the default at N > 1
+        # is column blocks (one pass, one collective).  A short leg of the row-sharded carried run on the same ranks, same
+        # transport, so that every multi-GPU line carries both figures
+        try:
+            if a.workload == "socp":
+                inst_r = synth.SocpInstance(n, a.cones, 99, seed=0, rank=rank, world=world, allreduce_host=allreduce_host)
+            else:
+                inst_r = synth.LpInstance(n, seed=0, rank=rank, world=world)
+            lib.thip_sync()
+            fs_r = T.FusedSolver(n, inst_r.m, inst_r.mat_a, inst_r.vec_b, inst_r.vec_c, inst_r.seg_type, inst_r.seg_len, p, "carried",
+                                 allreduce=hook, overlap=None)
+            pick_r, times_r, _ = tune_overlap(fs_r) if a.collective != "gloo" else (None, None, 0)
+            fs_r.run(a.warmup, poll_every=max(a.warmup, 1))
+            barrier()
+            t0 = time.perf_counter()
+            rr = fs_r.run(a.steps, poll_every=a.steps)
+            barrier()
+            el_r = time.perf_counter() - t0
+            if use_dist:
+                tt = torch.tensor([el_r], dtype=torch.float64, device=dev_pg)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el_r = float(tt.item())
+            assert rr.state == _lib.ST_RUNNING and math.isfinite(rr.cri[0])
+            out["row_sharded"] = {"value": a.steps / el_r, "unit": "iter/s", "ms_per_step": 1e3 * el_r / a.steps, "steps": a.steps,
+                                  "schedule": fs_r.schedule_in_use(), "passes_over_A_per_iter": fs_r.passes()[0],
+                                  "rows_per_gpu": inst_r.m, "overlap": pick_r, "overlap_mode_run": fs_r.overlap_info()["mode"],
+                                  "overlap_autotune_ms_per_iter": times_r,
+                                  "parallelism": "row-sharded A x%d (cone-aligned row blocks), all-reduce of A^T y per transposed "
+                                                 "product: the partitioning north_star and configs[4] name" % world}
+            fs_r.destroy()
+            inst_r.free()
+        except Exception as e:          # the extra leg must never cost the line
+            out["row_sharded"] = {"error": repr(e)}
 
     if a.to_eps is not None:
         p2 = T.SolverParam()

@@ -418,7 +418,8 @@ int thip_solver_set_sweep_publish(thip_solver *s, int agent_scope);
  *   xx_out = xx_in + Tx o (gT + c kappa) ; hN = A u ; h3 = A xx_out            (Kahan terms ku / kx_* may be NULL)
  * `reps` launches are timed with HIP events (reps > 1 only with first != 0, which is idempotent); host_info (8 ints):
  * [0] = the kernel's error word (0 = ok), [1] = members per group, [2] = groups, [3] = panels per group, [4] = 16-byte
- * slots per streaming thread.  force_members > 0: that many workgroups per column group instead of the planner's choice
+ * slots per streaming thread, [5] = polls of all gathers that found a granule missing (summed over workgroups and launches),
+ * [6] = the most polls any one gather needed.  force_members > 0: that many workgroups per column group instead of the planner's choice
  * (a power of two the rows fit); pub_agent != 0: partial dots published with agent-scope (sc1) stores. */
 typedef struct thip_sweep_test {
     size_t m, n, lda;

@@ -418,6 +418,14 @@ def test_bench_column_shard_path_at_world_1():
     assert tp["state"] == 0 and tc["state"] == 0 and abs(tp["iterations"] - tc["iterations"]) <= 3
     assert abs(tp["primal_obj"] - tc["primal_obj"]) <= 1e-5 * (1 + abs(tp["primal_obj"]))
     assert abs(tc["primal_obj"] - tc["dual_obj"]) <= 2e-3 * (1 + abs(tc["primal_obj"]))
+    # the column-sharded line also carries north_star's own partitioning (row blocks, carried schedule) as a short leg,
+    # and the f64 re-evaluation of the column-sharded answer
+    rs = cols["row_sharded"]
+    assert "error" not in rs and rs["value"] > 0 and rs["schedule"] == "carried" and rs["passes_over_A_per_iter"] == 2
+    g = cols["objective_gate"]["this_run"]
+    assert "error" not in g and "skipped" not in g, g
+    assert abs(g["primal_obj_f64"] - tc["primal_obj"]) <= 1e-4 * (1 + abs(tc["primal_obj"]))
+    assert g["primal_cone_violation_rel_to_norm_b"] <= 1e-3 and g["dual_residual_rel_f64"] <= 2e-3
 
 
 def test_sweep_infeasible_and_unbounded_certificates(T):
@@ -707,3 +715,88 @@ def test_merged_m_kernel_is_the_two_launch_form(T):
         assert np.allclose(a.status().cri, b.status().cri, rtol=1e-4, atol=1e-7)
     a.destroy()
     b.destroy()
+
+
+def test_ten_thousand_sweeps_at_32_members_never_stall_on_the_hand_off(T):
+    """The members of a group hand their partial dots over with plain 8-byte {value, tag} stores that stay in the L2 their
+    XCD shares (agent-scope / sc1 stores measured 3 - 5 % slower); a gather that sees an old tag polls.  If
+    that hand-off could stall, the widest group (32 workgroups = a whole XCD) under ten thousand back-to-back launches is
+    where it would show: the kernel's own counters of polls must stay tiny next to the 2 000 000-poll bound, and the
+    results must be the single sweep's."""
+    import ctypes as C
+    from totsu_amd import _lib
+    D = T.DeviceBuffer
+    rng = np.random.default_rng(3)
+    m, n = 8192, 2560
+    A = (rng.standard_normal((n, m)) / np.sqrt(n)).astype(np.float32)
+    host = dict(v=rng.standard_normal(m), xy=rng.standard_normal(m), c=rng.standard_normal(n), su=rng.random(n) + 0.5,
+                tx=rng.random(n) + 0.5, u=rng.standard_normal(n), xx=rng.standard_normal(n), gp=rng.standard_normal(n))
+    bufs = {k: D.from_host(np.asarray(a, dtype=np.float32)) for k, a in dict(A=A.ravel(), **host).items()}
+    outs = {k: D(sz, zero=True) for k, sz in dict(xx_out=n, hn=m, h3=m).items()}
+    t = _lib.SweepTest()
+    t.m, t.n, t.lda = m, n, m
+    t.mat_a, t.v, t.xy, t.c, t.su, t.tx = (bufs[k].ptr for k in ("A", "v", "xy", "c", "su", "tx"))
+    t.u, t.ku, t.xx_in, t.kx_in, t.xx_out, t.kx_out = bufs["u"].ptr, None, bufs["xx"].ptr, None, outs["xx_out"].ptr, None
+    t.gp, t.hn, t.h3 = bufs["gp"].ptr, outs["hn"].ptr, outs["h3"].ptr
+    t.kappa, t.rtau, t.first, t.reps, t.force_members = -0.37, 0.81, 1, 10_000, 32
+    ms, info = (C.c_float * 2)(), (C.c_int * 8)()
+    _lib.lib.thip_test_sweep(C.byref(t), ms, info)
+    assert info[0] == 0 and info[1] == 32, list(info)
+    panels = 10_000 * info[3] * 8            # gathers per workgroup x launches, per group... an upper scale for the counters
+    assert info[6] < 2000, "a gather needed %d polls" % info[6]
+    assert info[5] < panels, (info[5], panels)
+    Ad = A.astype(np.float64)
+    g3 = Ad @ host["xy"]
+    x_ref = host["xx"] + host["tx"] * (Ad @ host["v"] + host["c"] * (-0.37))
+    assert np.abs(bufs["gp"].to_host() - g3).max() <= 5e-6 * np.abs(g3).max()
+    assert np.abs(outs["xx_out"].to_host() - x_ref).max() <= 5e-6 * np.abs(x_ref).max()
+    assert np.abs(outs["h3"].to_host() - Ad.T @ x_ref).max() <= 5e-6 * np.abs(Ad.T @ x_ref).max()
+    print("10000 sweeps, 32 members: %.4f ms each, polls %d, most for one gather %d" % (ms[1], info[5], info[6]))
+    for b in list(bufs.values()) + list(outs.values()):
+        b.free()
+
+
+def test_column_shard_exposes_its_one_collective_once_per_iteration(T):
+    """the N > 1 form of the one-pass schedule has ONE collective per iteration and nothing to hide it under (the m-tail
+    needs the sums, the next sweep needs the m-tail: DESIGN.md 6.2).  On rank 0's 1/8 column shard of BASELINE configs[2]
+    (100 000 x 6 250, 2.5 GB) with a stand-in collective of L us (thip_test_spin_allreduce): an iteration grows by L, not
+    by more -- L + 10 us is the bound (launch jitter) -- whereas the row-sharded carried run in order pays 2 L"""
+    import json
+    import os
+    import time
+    from totsu_amd import synth
+    from totsu_amd._lib import lib
+    inst = synth.SocpInstanceCols(50_000, 1000, 99, seed=0, rank=0, world=8)
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    fs = T.FusedSolver(inst.n_local, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "sweep",
+                       allreduce=("spin", 0), col_shard=True)
+    assert fs.schedule_in_use() == "sweep"
+    K = 300
+
+    def rate():
+        fs.run(40, poll_every=40)
+        best = 1e30
+        for _ in range(3):
+            lib.thip_sync()
+            t0 = time.perf_counter()
+            fs.run(K, poll_every=K)
+            lib.thip_sync()
+            best = min(best, (time.perf_counter() - t0) / K)
+        return best * 1e6
+
+    t = {}
+    for L in (0, 30, 60, 0):
+        fs.set_spin_latency(L)
+        t[L] = min(t.get(L, 1e30), rate())
+    rec = {"what": "us per iteration of the column-sharded one-pass run on rank 0's 1/8 column shard of configs[2] (100 000 x 6 250) "
+                   "with a stand-in collective of L us", "us_per_iteration": {"L%d" % k: round(v, 1) for k, v in t.items()},
+           "sweep_plan": fs.sweep_plan()}
+    print(json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(rec, open(os.path.join(out, "column_shard_latency_injection.json"), "w"))
+    fs.destroy()
+    inst.free()
+    for L in (30, 60):
+        assert 0.6 * L <= t[L] - t[0] <= L + 10, t

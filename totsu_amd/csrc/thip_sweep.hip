@@ -412,6 +412,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         const int nq = a.G * 2 * W;                   // granules per slot (<= 64 NL)
         const int jlast = max(c1 - 1, 0);
         bool dead = false;                            // a gather timed out (here or elsewhere): no more polling
+        unsigned polls_total = 0u, polls_max = 0u;    // gathers that had to poll: how often, and the longest (census[18], [19])
         // register sets A / B alternate by interval parity
         unsigned long long xgA[NL], xgB[NL];
         float cvA = 0.0f, cvB = 0.0f;
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (spins > 0) { polls_total += (unsigned)spins; polls_max = max(polls_max, (unsigned)spins); }
                 SW_STAMP(2);
                 // lane l holds members l / 2W + 32 i / W .. of quantity l % 2W: sum over the lanes of equal l % 2W
                 float sum = vsum;
@@ -558,6 +560,8 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         int it = 0;
         for (; it + 1 < total; it += 2) { interval(it, xgA, cvA); interval(it + 1, xgB, cvB); }
         if (it < total) interval(it, xgA, cvA);
+        // what the hand-off through the group's L2 costs in polls (a visibility stall would show here long before a time-out)
+        if (polls_total != 0u && lane == 0) { atomicAdd(a.census + 18, polls_total); atomicMax(a.census + 19, polls_max); }
         if (a.pn != nullptr) {
             if constexpr (W == 2) {
                 sdd += __shfl_xor(sdd, 1, 64); scx += __shfl_xor(scx, 1, 64);
@@ -787,7 +791,10 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     THIP_TRY(hipMemcpyAsync(hc, census, sizeof(hc), hipMemcpyDeviceToHost, st));
     THIP_TRY(hipStreamSynchronize(st));
     if (host_ms) { host_ms[0] = best; host_ms[1] = tot / reps; }
-    if (host_info) { host_info[0] = (int)hc[9]; host_info[1] = g.G; host_info[2] = g.ngroups; host_info[3] = g.npan; host_info[4] = g.nslot; }
+    if (host_info) {
+        host_info[0] = (int)hc[9]; host_info[1] = g.G; host_info[2] = g.ngroups; host_info[3] = g.npan; host_info[4] = g.nslot;
+        host_info[5] = (int)hc[18]; host_info[6] = (int)hc[19];
+    }
 #ifdef SW_PROFILE
     fprintf(stderr, "service wave, 10 ns ticks: wait %u, cold+publish %u, tags+poll %u, reduce+math+stores %u, loads %u, barrier %u; intervals that polled %u, polls %u\n",
             hc[10], hc[11], hc[12], hc[13], hc[14], hc[15], hc[16], hc[17]);
