@@ -224,9 +224,10 @@ int finalize_partials(hipStream_t st, size_t n, const float *part, int np, size_
 
 // thip_sweep.hip: one pass over A per iteration (THIP_SCHED_SWEEP)
 constexpr int SW_SPIN_MAX = 2000000;       // polls of a gather before a workgroup gives up (~2-4 s)
-struct SweepGeom { int G, ngroups, rows_per_member, cols_per_group, nslot, npan, w, variant, m_eff; size_t mpad; };
+struct SweepGeom { int G, ngroups, rows_per_member, cols_per_group, nslot, npan, w, variant, m_eff; size_t mpad; int elem; };
 struct SweepArgs {
-    const float *A; size_t lda; int m, n;
+    const float *A; size_t lda; int m, n;  // A: the matrix as stored (f32, or 16-bit: elem = THIP_A_BF16 / THIP_A_F16), lda in elements
+    const float *inv_s;                     // f16 storage: 1 / scale per column (else NULL)
     int G, rows_per_member, cols_per_group;
     const float *v, *xy;                    // the m-vectors every column is multiplied with
     const float *c, *Su, *Tx;               // per column
@@ -256,8 +257,9 @@ struct SweepArgs {
     // order, same value) and one of them stores it; *kappa_p is then the copy sw_vm_k left of kappa_{k-1}
     float *kappa_out; const float *skappa_p; const float *pm_brx; int np_m, pn_count;
 };
-int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g);
-int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *out, int max_out);
+int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g, int elem = 0);
+int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *out, int max_out, int elem = 0);
+int sweep_launch16(hipStream_t st, const SweepGeom &g, const SweepArgs &a);       // thip_sweep16.hip
 size_t sweep_gran_words(const SweepGeom &g);
 int sweep_census_dry_run(hipStream_t st, unsigned *census, unsigned seq);
 int sweep_launch(hipStream_t st, const SweepGeom &g, const SweepArgs &a);

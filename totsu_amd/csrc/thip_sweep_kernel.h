@@ -1,0 +1,605 @@
+// thip_sweep_kernel.h -- the one-pass kernel itself (sweep_k) and its launcher template, shared by thip_sweep.hip (f32 A) and
+// thip_sweep16.hip (A stored as bf16 / column-scaled f16): two translation units so that the instances compile in parallel.
+// The description of the kernel is at the top of thip_sweep.hip.
+#pragma once
+#include "thip_common.h"
+
+namespace thip {
+
+constexpr int SW_THREADS = 512;            // 7 streaming waves + 1 service wave
+constexpr int SW_CW = 7;
+constexpr int SW_CT = SW_CW * 64;          // streaming threads
+constexpr int SW_RING = 32;                // granule slots per group (> 2 (LAGL - DLAG) - 1: see the header of sweep_k)
+constexpr int SW_CR = 16;                  // slots of the per-column LDS ring (> LAGL - DLAG)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned long long sw_pack(float v, unsigned tag)
+{
+    return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+// One 16-byte slot of a column as f32 values.  ELEM 0: four f32.  ELEM 1 (THIP_A_BF16): eight bf16 -- a bf16 is the high half
+// of an f32, so widening is a shift or a mask.  ELEM 2 (THIP_A_F16): eight f16 (v_cvt_f32_f16); the column's power-of-two scale
+// is applied to the dots and to the axpy scalars by the service wave, once per column.
+template <int ELEM> struct SwElem { static constexpr int EPV = ELEM == 0 ? 4 : 8; static constexpr int ESIZE = ELEM == 0 ? 4 : 2; };
+template <int ELEM>
+__device__ __forceinline__ void sw_unpack(const f32x4 &raw, float (&e)[SwElem<ELEM>::EPV])
+{
+    if constexpr (ELEM == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = raw[k];
+    } else if constexpr (ELEM == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned u = __float_as_uint(raw[k]);
+            e[2 * k] = __uint_as_float(u << 16);
+            e[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+        }
+    } else {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const h2 h = __builtin_bit_cast(h2, raw[k]);
+            e[2 * k] = (float)h[0];
+            e[2 * k + 1] = (float)h[1];
+        }
+    }
+}
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() carries a workgroup-scope fence, which on this part
+// waits for EVERY outstanding global load of the wave (vmcnt(0)) -- it would drain the ring of prefetched panels at
+// every interval
+__device__ __forceinline__ void sw_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ void sw_barrier_dbg(int dbg)
+{
+    if (dbg & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else sw_barrier();
+}
+
+// x + inc with an optional Kahan term (the arithmetic of thip_solver.hip's comp_add)
+__device__ __forceinline__ float sw_comp_add(float x, float inc, bool comp, float &k)
+{
+    if (!comp) return x + inc;
+    const float y = inc - k;
+    const float t = x + y;
+    k = (t - x) - y;
+    return t;
+}
+
+template <int K, int O>
+__device__ __forceinline__ void sw_halve(float *v, int lane)
+{
+    const bool hi = (lane & O) != 0;
+#pragma unroll
+    for (int i = 0; i < K / 2; ++i) {
+        const float send = hi ? v[i] : v[i + K / 2];
+        const float keep = hi ? v[i + K / 2] : v[i];
+        v[i] = keep + __shfl_xor(send, O, 64);
+    }
+}
+
+// K per-lane values on 64 lanes -> the K wave sums; the lanes with (lane >> (6 - log2 K)) == c hold sum c
+template <int K>
+__device__ __forceinline__ float sw_reduce(float *v, int lane)
+{
+    static_assert(K == 2 || K == 4 || K == 8, "1, 2 or 4 columns per panel");
+    if constexpr (K == 2) {
+        sw_halve<2, 32>(v, lane);
+        float r = v[0];
+        r += __shfl_xor(r, 16, 64); r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 4, 64);
+        r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
+        return r;
+    } else if constexpr (K == 8) {
+        sw_halve<8, 32>(v, lane); sw_halve<4, 16>(v, lane); sw_halve<2, 8>(v, lane);
+        float r = v[0];
+        r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
+        return r;
+    } else {
+        sw_halve<4, 32>(v, lane); sw_halve<2, 16>(v, lane);
+        float r = v[0];
+        r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
+        return r;
+    }
+}
+
+// census.  Every workgroup counts itself on its XCD: the ticket it draws is its place (group, member) among the 32 of that
+// XCD.  sweep_census_k (the dry run of thip_solver_init and of thip_sweep_probe) ALSO waits until all 256 have counted
+// themselves and checks that every XCD holds exactly 32 -- the placement the kernel needs.  The sweeps themselves do not wait
+// (round 3 did: device-clock stamps put the wait at 15 us per launch, a tenth of a short sweep): a workgroup that draws a
+// ticket >= 32 raises the error word at once, and a group that is short of a member runs out of its bounded spins and
+// raises it too -- thip_solver_run then restores its snapshot of the iterate and goes on with the 2-pass schedule.
+__device__ __forceinline__ int sw_ticket(unsigned *census, unsigned seq, int G, int *group, int *member)
+{
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;        // HW_REG_XCC_ID, bits 3:0
+    if (xcc >= 8u) { atomicExch(census + 9, 1u); return 0; }
+    const unsigned idx = atomicAdd(census + xcc, 1u) - seq * 32u;
+    if (idx >= 32u) { atomicExch(census + 9, 2u); return 0; }
+    *group = (int)xcc * (32 / G) + (int)idx / G;
+    *member = (int)idx % G;
+    return 1;
+}
+
+__device__ __forceinline__ int sw_census(unsigned *census, unsigned seq, int G, int *group, int *member)
+{
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;
+    if (xcc >= 8u) { atomicExch(census + 9, 1u); return 0; }
+    const unsigned idx = atomicAdd(census + xcc, 1u) - seq * 32u;
+    const unsigned want = (seq + 1u) * 32u;
+    int spins = 0;
+    for (;;) {
+        // the eight counts in one round trip; done when they add up to everybody
+        unsigned c[8], sum = 0u;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) c[x] = __hip_atomic_load(census + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { sum += c[x]; ok = ok && c[x] == want; }
+        if (sum == 8u * want) {
+            if (!ok || idx >= 32u) { atomicExch(census + 9, 2u); return 0; }
+            break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > SW_SPIN_MAX) { atomicExch(census + 9, 1u); return 0; }
+    }
+    *group = (int)xcc * (32 / G) + (int)idx / G;
+    *member = (int)idx % G;
+    return 1;
+}
+
+// W columns per panel; loads run LAGL panels ahead of the axpy and DLAG ahead of the dots; NS = LAGL + 1 register stages.
+// Timeline of a workgroup, interval `it` (one barrier per interval), written for (W, LAGL, DLAG) = (2, 8, 3):
+//   streaming waves: issue the loads of panel it (stage it % 9) ; dots of panel it - 3 -> dotbuf ; BARRIER ;
+//                    axpy of panel it - 8 with the scalars the service wave left in `scal`
+//   service wave:    [per-column data: store what the last interval fetched, fetch panel it - 3] ;
+//                    publish the workgroup's dots of panel it - 4 ; gather panel it - 8 (its granules were requested in
+//                    the previous interval; polling only if they are late), scalar updates -> scal ; BARRIER
+// A panel is published LAGL - DLAG - 1 intervals before it is gathered.  A member publishing panel q has gathered panel
+// q + DLAG - LAGL, so every member has published that one and is gathering q + 2 DLAG - 2 LAGL + 1 or later: the slot of
+// panel q - 16 is free.  Per-column data of panel q is fetched in interval q + DLAG and has arrived before the member
+// publishes q in interval q + DLAG + 1; the writer of panel q's columns stores u / gP (in place) only after it has gathered
+// q, i.e. after every member holds its copy.
+// THIP_SWEEP_DBG (experiments of DESIGN.md 4.7: 1 no polling, 2 no wave reduction of the dots, 4 no barrier, 8 service wave
+// idle, 16 no arithmetic) exists only in a -DSW_DEBUG build; otherwise the switches fold away
+#ifdef SW_DEBUG
+#define SW_DBG(a) ((a).dbg)
+#else
+#define SW_DBG(a) 0
+#endif
+template <int NSLOT, int W, int LAGL, int DLAG, int LS, int ELEM = 0>
+__global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
+{
+    constexpr int EPV = SwElem<ELEM>::EPV;            // rows per 16-byte slot
+    constexpr int ESIZE = SwElem<ELEM>::ESIZE;
+    constexpr int NS = LAGL + 1;
+    constexpr int LAGT = LAGL + LS;                   // loads run this far ahead of the axpy: LAGL in registers, LS more in LDS
+    constexpr int PF = LAGL - DLAG;
+    constexpr int NL = (2 * W * 32 + 63) / 64;        // granule loads per service lane (G = 32)
+    static_assert(SW_RING > 2 * (LAGT - DLAG) - 1 && SW_CR > LAGT - DLAG, "ring depths");
+    __shared__ int s_role[4];
+    __shared__ float dotbuf[2][SW_CW][2 * W];
+    __shared__ float scal[2][2 * W];
+    __shared__ float cold[SW_CR][9][W];
+    extern __shared__ f32x4 sw_lds[];                 // LS panels the streaming threads park between registers and axpy
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SW_PROFILE
+    // phase stamps of streaming wave 0 of (group 0, member 0): census[150 ..] = 10 ns ticks since kernel entry at: census done,
+    // v / x_y in registers, fill block, steady loop, drain, stores
+    const unsigned long long tp0 = __builtin_amdgcn_s_memrealtime();
+#define SW_PHASE(i) do { if (wave == 0 && group == 0 && member == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        if (lane == 0) a.census[150 + (i)] = (unsigned)(__builtin_amdgcn_s_memrealtime() - tp0); } } while (0)
+#else
+#define SW_PHASE(i) do { } while (0)
+#endif
+
+    if (tid == 0) {
+        int g = 0, mbr = 0;
+        s_role[2] = sw_ticket(a.census, a.seq, a.G, &g, &mbr);
+        s_role[0] = g; s_role[1] = mbr;
+    }
+    __syncthreads();
+    // the ticket comes first even when the loop has stopped: the host numbers the launches, and one that left before
+    // counting itself would leave every later launch's tickets off by one
+    // (a raised error word -- this launch's census, or an earlier sweep of the batch that gave up -- ends every later sweep
+    // at entry: the host restores its snapshot of the iterate, thip_solver.hip sweep_recover)
+    if (s_role[2] == 0 || *a.stop != 0 || __hip_atomic_load(a.census + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    const int group = s_role[0], member = s_role[1];
+    SW_PHASE(0);
+
+    const int c0 = group * a.cols_per_group;
+    const int c1 = min(a.n, c0 + a.cols_per_group);
+    const int npan = c1 > c0 ? (c1 - c0 + W - 1) / W : 0;
+    const int total = npan + LAGT;
+    const int row0 = member * a.rows_per_member;
+    const int row1 = min(a.m, row0 + a.rows_per_member);
+    unsigned *const errflag = a.census + 9;
+
+    if (wave < SW_CW) {
+        // ---------------- streaming waves ----------------
+        float vv[NSLOT][EPV], yv[NSLOT][EPV], acc1[NSLOT][EPV], acc2[NSLOT][EPV];
+        int roff[NSLOT];
+        bool valid[NSLOT];
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int r = row0 + EPV * (tid + SW_CT * sl);
+            valid[sl] = r + EPV <= row1;
+            roff[sl] = valid[sl] ? r : (row0 + EPV <= a.m ? row0 : 0);
+#pragma unroll
+            for (int k = 0; k < EPV; ++k) {
+                vv[sl][k] = valid[sl] ? a.v[r + k] : 0.0f;
+                yv[sl][k] = valid[sl] ? a.xy[r + k] : 0.0f;
+                acc1[sl][k] = 0.0f; acc2[sl][k] = 0.0f;
+            }
+        }
+        SW_PHASE(1);
+        f32x4 stg[NS][W][NSLOT];
+        const int jmax = a.n - 1;
+
+#define SW_LOADS(S, P)                                                                                         \
+        do {                                                                                                   \
+            _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
+                const int j = min(c0 + (P) * W + q, jmax);                                                     \
+                const char *colp = reinterpret_cast<const char *>(a.A) + (size_t)j * a.lda * ESIZE;            \
+                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl)                                           \
+                    stg[S][q][sl] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(colp + (size_t)roff[sl] * ESIZE)); \
+            }                                                                                                  \
+        } while (0)
+#define SW_DOTS(S, P)                                                                                          \
+        do {                                                                                                   \
+            if (SW_DBG(a) & 16) { asm volatile("" :: "v"(stg[S][0][0][0]), "v"(stg[S][W - 1][NSLOT - 1][3])); break; } \
+            float p_[2 * W];                                                                                   \
+            _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
+                float d1 = 0.0f, d2 = 0.0f;                                                                    \
+                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl) {                                         \
+                    float e_[EPV];                                                                             \
+                    sw_unpack<ELEM>(stg[S][q][sl], e_);                                                        \
+                    _Pragma("unroll") for (int k = 0; k < EPV; ++k) {                                          \
+                        d1 = fmaf(e_[k], vv[sl][k], d1);                                                       \
+                        d2 = fmaf(e_[k], yv[sl][k], d2);                                                       \
+                    }                                                                                          \
+                }                                                                                              \
+                p_[q] = d1; p_[W + q] = d2;                                                                    \
+            }                                                                                                  \
+            if (SW_DBG(a) & 2) { if (lane < 2 * W) dotbuf[(P) & 1][wave][lane] = p_[0]; }                          \
+            else {                                                                                             \
+            const float r_ = sw_reduce<2 * W>(p_, lane);                                                       \
+            if ((lane & (64 / (2 * W) - 1)) == 0) dotbuf[(P) & 1][wave][lane / (64 / (2 * W))] = r_;          \
+            }                                                                                                  \
+        } while (0)
+#define SW_AXPY(S, P)                                                                                          \
+        do {                                                                                                   \
+            if (SW_DBG(a) & 16) { asm volatile("" :: "v"(stg[S][0][0][1]), "v"(stg[S][W - 1][NSLOT - 1][2])); break; } \
+            _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
+                const float s1 = scal[(P) & 1][q], s2 = scal[(P) & 1][W + q];                                  \
+                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl) {                                         \
+                    float e_[EPV];                                                                             \
+                    sw_unpack<ELEM>(stg[S][q][sl], e_);                                                        \
+                    _Pragma("unroll") for (int k = 0; k < EPV; ++k) {                                          \
+                        acc1[sl][k] = fmaf(e_[k], s1, acc1[sl][k]);                                            \
+                        acc2[sl][k] = fmaf(e_[k], s2, acc2[sl][k]);                                            \
+                    }                                                                                          \
+                }                                                                                              \
+            }                                                                                                  \
+            /* pin the sums here: the optimiser otherwise sinks the axpys of all NS intervals to the end of the */ \
+            /* unrolled block and keeps every stage and every interval's scalars alive until then */           \
+            _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl)                                               \
+                _Pragma("unroll") for (int k = 0; k < EPV; ++k) {                                              \
+                    asm volatile("" : "+v"(acc1[sl][k]));                                                      \
+                    asm volatile("" : "+v"(acc2[sl][k]));                                                      \
+                }                                                                                              \
+        } while (0)
+
+#define SW_SPILL(S, P)                                                                                         \
+        do {                                                                                                   \
+            f32x4 *slot_ = sw_lds + (size_t)((P) % LS) * (W * NSLOT * SW_CT) + tid;                            \
+            _Pragma("unroll") for (int q = 0; q < W; ++q)                                                      \
+                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl) slot_[(q * NSLOT + sl) * SW_CT] = stg[S][q][sl]; \
+        } while (0)
+#define SW_AXPY_LDS(P)                                                                                         \
+        do {                                                                                                   \
+            const f32x4 *slot_ = sw_lds + (size_t)((P) % LS) * (W * NSLOT * SW_CT) + tid;                      \
+            _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
+                const float s1 = scal[(P) & 1][q], s2 = scal[(P) & 1][W + q];                                  \
+                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl) {                                         \
+                    const f32x4 d_ = slot_[(q * NSLOT + sl) * SW_CT];                                          \
+                    float e_[EPV];                                                                             \
+                    sw_unpack<ELEM>(d_, e_);                                                                   \
+                    _Pragma("unroll") for (int k = 0; k < EPV; ++k) {                                          \
+                        acc1[sl][k] = fmaf(e_[k], s1, acc1[sl][k]);                                            \
+                        acc2[sl][k] = fmaf(e_[k], s2, acc2[sl][k]);                                            \
+                    }                                                                                          \
+                }                                                                                              \
+            }                                                                                                  \
+            _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl)                                               \
+                _Pragma("unroll") for (int k = 0; k < EPV; ++k) {                                              \
+                    asm volatile("" : "+v"(acc1[sl][k]));                                                      \
+                    asm volatile("" : "+v"(acc2[sl][k]));                                                      \
+                }                                                                                              \
+        } while (0)
+#define SW_GUARDED_BLOCK(IT0)                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                       \
+            const int it = (IT0) + s;                                                                          \
+            if (it < npan) SW_LOADS(s, it);                                                                    \
+            if (it - DLAG >= 0 && it - DLAG < npan) SW_DOTS((s + NS - DLAG) % NS, it - DLAG);                  \
+            if (it < total) sw_barrier_dbg(SW_DBG(a));                                                                      \
+            if constexpr (LS == 0) {                                                                           \
+                if (it - LAGL >= 0 && it - LAGL < npan) SW_AXPY((s + 1) % NS, it - LAGL);                      \
+            } else {                                                                                           \
+                if (it - LAGT >= 0 && it - LAGT < npan) SW_AXPY_LDS(it - LAGT);                                \
+                if (it - LAGL >= 0 && it - LAGL < npan) SW_SPILL((s + 1) % NS, it - LAGL);                     \
+            }                                                                                                  \
+        }
+        // fill (one block of NS intervals: LAGL < NS), steady state, drain -- three loops, so that the stage registers
+        // have one assignment per loop (two forms of the body inside ONE loop doubled them)
+        int it0 = 0;
+        for (; it0 < LAGT; it0 += NS) { SW_GUARDED_BLOCK(it0); }
+        SW_PHASE(2);
+        for (; it0 + NS <= npan; it0 += NS) {
+            // every phase active, no guards: the waits on the loads are counted, not drained
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int it = it0 + s;
+                SW_LOADS(s, it);
+                SW_DOTS((s + NS - DLAG) % NS, it - DLAG);
+                sw_barrier_dbg(SW_DBG(a));
+                if constexpr (LS == 0) { SW_AXPY((s + 1) % NS, it - LAGL); }
+                else { SW_AXPY_LDS(it - LAGT); SW_SPILL((s + 1) % NS, it - LAGL); }
+            }
+        }
+        SW_PHASE(3);
+        for (; it0 < total; it0 += NS) { SW_GUARDED_BLOCK(it0); }
+        SW_PHASE(4);
+#undef SW_GUARDED_BLOCK
+#undef SW_LOADS
+#undef SW_DOTS
+#undef SW_AXPY
+#undef SW_AXPY_LDS
+#undef SW_SPILL
+        float *h1 = a.partH + ((size_t)group * 2 + 0) * a.mpad;
+        float *h2 = a.partH + ((size_t)group * 2 + 1) * a.mpad;
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl)
+            if (valid[sl]) {
+                const int r = row0 + EPV * (tid + SW_CT * sl);
+#pragma unroll
+                for (int k = 0; k < EPV; k += 4) {
+                    *reinterpret_cast<float4 *>(h1 + r + k) = make_float4(acc1[sl][k], acc1[sl][k + 1], acc1[sl][k + 2], acc1[sl][k + 3]);
+                    *reinterpret_cast<float4 *>(h2 + r + k) = make_float4(acc2[sl][k], acc2[sl][k + 1], acc2[sl][k + 2], acc2[sl][k + 3]);
+                }
+            }
+        SW_PHASE(5);
+    } else {
+        // ---------------- service wave ----------------
+        // Its global loads (the granules of a panel, the per-column data of a panel) are issued TWO intervals before they
+        // are used, as the last memory operations of an interval and always the same number of instructions (NL + 1,
+        // addresses clamped, no branches around them): the interval then opens with s_waitcnt vmcnt(NL + 1) -- "everything
+        // but the loads of the previous interval has arrived" -- and never waits for a round trip.  (Issued one interval
+        // ahead and waited with vmcnt(0), every interval paid an L2 round trip: 1.59 us per panel instead of ~1.)
+        float kappa = *a.kappa_p;
+        const float rtau = *a.rtau_p;
+        if (a.kappa_out != nullptr && !a.first) {
+            // c.rx_x of the previous sweep (its workgroups' partials) + b.rx_y of the m-tail, in f64 like the other single-block sums
+            double dc = 0.0, db = 0.0;
+            for (int k = lane; k < a.pn_count; k += 64) dc += (double)a.pn_in[3 * a.pn_in_stride + k];
+            for (int k = lane; k < a.np_m; k += 64) db += (double)a.pm_brx[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { dc += __shfl_xor(dc, o, 64); db += __shfl_xor(db, o, 64); }
+            kappa = fminf(kappa + *a.skappa_p * ((float)dc + (float)db), 0.0f);
+            if (group == 0 && member == 0 && lane == 0) *a.kappa_out = kappa;
+        }
+        const float tau = *a.tau_p;
+        const bool conv = tau > a.eps_zero;
+        const float rt = conv ? 1.0f / tau : 1.0f;
+        float sdd = 0.0f, scx = 0.0f, scu = 0.0f, scrx = 0.0f;      // lanes < W: sums over the columns this workgroup writes
+        const bool comp_u = a.ku != nullptr, comp_x = a.kx_in != nullptr;
+        // per-column data: lane l < 9 W fetches field l / W of column l % W (field 8: 1 / scale of an f16-stored column)
+        const int cf = lane / W, cq = lane % W;
+        const bool clane = lane < 9 * W;
+        const float *fp = a.c;                       // lanes without a field read c (a valid address) and drop the value
+        bool fvalid = clane;
+        if (clane) {
+            switch (cf) {
+            case 0: fp = a.c; break;      case 1: fp = a.Su; break;    case 2: fp = a.Tx; break;   case 3: fp = a.u; break;
+            case 4: fp = a.ku; break;     case 5: fp = a.xx_in; break; case 6: fp = a.kx_in; break; case 7: fp = a.gP; break;
+            default: fp = a.inv_s; break;
+            }
+            if (fp == nullptr) { fp = a.c; fvalid = false; }
+        }
+        unsigned long long *const gbase = a.gran + (size_t)group * SW_RING * a.G * (2 * W);
+        const int nq = a.G * 2 * W;                   // granules per slot (<= 64 NL)
+        const int jlast = max(c1 - 1, 0);
+        bool dead = false;                            // a gather timed out (here or elsewhere): no more polling
+        unsigned polls_total = 0u, polls_max = 0u;    // gathers that had to poll: how often, and the longest (census[18], [19])
+        // register sets A / B alternate by interval parity
+        unsigned long long xgA[NL], xgB[NL];
+        float cvA = 0.0f, cvB = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) { xgA[i] = 0ull; xgB[i] = 0ull; }
+
+#ifdef SW_PROFILE
+        unsigned long long tacc[6] = { 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memrealtime();
+        unsigned nmiss = 0, npoll = 0;
+#define SW_STAMP(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tacc[i] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define SW_STAMP(i) do { } while (0)
+#endif
+        auto interval = [&](const int it, unsigned long long (&xg)[NL], float &cv) {
+            if (SW_DBG(a) & 8) { sw_barrier_dbg(SW_DBG(a)); return; }
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL + 1) : "memory");
+            SW_STAMP(0);
+            // per-column data fetched two intervals ago: panel it - 2 - (LAGL - PF - 1)
+            {
+                const int pc = it - 2 - LAGL + PF + 1;
+                if (pc >= 0 && pc < npan && clane) cold[pc % SW_CR][cf][cq] = (fvalid && c0 + pc * W + cq < c1) ? cv : (cf == 8 ? 1.0f : 0.0f);
+            }
+            // publish the workgroup's partial dots
+            {
+                const int pp = it - DLAG - 1;
+                if (pp >= 0 && pp < npan && lane < 2 * W) {
+                    float sum = dotbuf[pp & 1][0][lane];
+#pragma unroll
+                    for (int w = 1; w < SW_CW; ++w) sum += dotbuf[pp & 1][w][lane];
+                    unsigned long long *g = gbase + ((size_t)(pp % SW_RING) * a.G + member) * (2 * W) + lane;
+                    // TEST HOOK (thip_test_sweep_fault): one workgroup stops publishing half-way -- its group runs out of spins
+                    const bool withheld = a.fault != 0 && group == 0 && member == a.G - 1 && pp >= npan / 2;
+                    // pub_agent: the documented form (sc1 store, MI355X_MICROARCH.md inter-workgroup visibility); else a plain
+                    // store that stays in the L2 the group shares (DESIGN.md 4.7 has the measured difference)
+                    if (withheld) { }
+                    else if (a.pub_agent) __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+            // gather, scalar updates
+            SW_STAMP(1);
+            const int pa = it - LAGT;
+            if (pa >= 0 && pa < npan) {
+                const unsigned tag = a.tagbase + (unsigned)pa + 1u;
+                const unsigned long long *g = gbase + (size_t)(pa % SW_RING) * nq;
+                float vsum = 0.0f;
+                unsigned pend = 0;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    if (lane + 64 * i < nq) {
+                        if ((unsigned)(xg[i] >> 32) == tag) vsum += __uint_as_float((unsigned)xg[i]);
+                        else pend |= 1u << i;
+                    }
+                }
+                int spins = 0;
+                if (SW_DBG(a) & 1) pend = 0;
+#ifdef SW_PROFILE
+                if (!__all(pend == 0u)) {
+                    if (group == 0 && member == 0 && nmiss < 40) {
+                        const unsigned long long bal = __ballot(pend != 0u);
+                        if (lane == 0) { a.census[24 + 3 * nmiss] = (unsigned)pa; a.census[25 + 3 * nmiss] = (unsigned)bal; a.census[26 + 3 * nmiss] = (unsigned)(bal >> 32); }
+                    }
+                    ++nmiss;
+                }
+#endif
+                while (!dead && !__all(pend == 0u)) {
+#pragma unroll
+                    for (int i = 0; i < NL; ++i)
+                        if ((pend >> i) & 1u) xg[i] = __hip_atomic_load(g + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int i = 0; i < NL; ++i)
+                        if (((pend >> i) & 1u) && (unsigned)(xg[i] >> 32) == tag) {
+                            vsum += __uint_as_float((unsigned)xg[i]);
+                            pend &= ~(1u << i);
+                        }
+                    ++spins;
+#ifdef SW_PROFILE
+                    ++npoll;
+#endif
+                    if (spins > a.spin_max || ((spins & 255) == 0 && __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        if (lane == 0) atomicExch(errflag, 3u);
+                        dead = true;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (spins > 0) { polls_total += (unsigned)spins; polls_max = max(polls_max, (unsigned)spins); }
+                SW_STAMP(2);
+                // lane l holds members l / 2W + 32 i / W .. of quantity l % 2W: sum over the lanes of equal l % 2W
+                float sum = vsum;
+#pragma unroll
+                for (int o = 2 * W; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
+                float gT = sum;                                         // lanes 0 .. W-1: column's dot with v
+                float g3 = __shfl(sum, (lane + W) & 63, 64);            // ... and with x_y
+                if (lane < W) {
+                    const int j = c0 + pa * W + lane;
+                    const bool real = j < c1 && !dead;
+                    const int cs = pa % SW_CR;
+                    const float isc = ELEM == 2 ? cold[cs][8][lane] : 1.0f;      // stored column = true column x scale
+                    if constexpr (ELEM == 2) { gT *= isc; g3 *= isc; }
+                    const float cj = cold[cs][0][lane], Suj = cold[cs][1][lane], Txj = cold[cs][2][lane];
+                    const float uj = cold[cs][3][lane], xxj = cold[cs][5][lane], gPj = cold[cs][7][lane];
+                    float kuj = cold[cs][4][lane], kxj = cold[cs][6][lane];
+                    float u_new = uj;
+                    if (!a.first) {
+                        const float g2 = gPj - 2.0f * g3;
+                        u_new = sw_comp_add(uj, Suj * (-g2 - cj * rtau), comp_u, kuj);
+                    }
+                    const float x_new = sw_comp_add(xxj, Txj * (gT + cj * kappa), comp_x, kxj);
+                    scal[pa & 1][lane] = real ? u_new * isc : 0.0f;
+                    scal[pa & 1][W + lane] = real ? x_new * isc : 0.0f;
+                    if (real && member == pa % a.G) {
+                        if (!a.first) { a.u[j] = u_new; if (comp_u) a.ku[j] = kuj; }
+                        a.xx_out[j] = x_new;
+                        if (comp_x) a.kx_out[j] = kxj;
+                        a.gP[j] = g3;
+                        const float dj = conv ? fmaf(rt, g3, cj) : g3;      // solver.rs:596-597 / 634
+                        sdd = fmaf(dj, dj, sdd);
+                        scx = fmaf(cj, xxj, scx);
+                        scu = fmaf(cj, u_new, scu);
+                        scrx = fmaf(cj, xxj - 2.0f * x_new, scrx);
+                    }
+                }
+            }
+            // the loads of two intervals ahead, last and unconditional: the granules of panel pa + 2 (published
+            // LAGL - DLAG - 3 intervals ago) and the per-column data of panel it - LAGL + PF + 1 (read before this
+            // workgroup publishes that panel, two intervals from now)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SW_STAMP(3);
+            {
+                int pn = pa + 2;
+                pn = pn < 0 ? 0 : pn;
+                const unsigned long long *gn = gbase + (size_t)(pn % SW_RING) * nq;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    const int gi = min(lane + 64 * i, nq - 1);
+                    xg[i] = __hip_atomic_load(gn + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                int pc = it - LAGL + PF + 1;
+                pc = pc < 0 ? 0 : pc;
+                const int j = min(c0 + pc * W + cq, jlast);
+                cv = __hip_atomic_load(fp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            SW_STAMP(4);
+            sw_barrier_dbg(SW_DBG(a));
+            SW_STAMP(5);
+        };
+        int it = 0;
+        for (; it + 1 < total; it += 2) { interval(it, xgA, cvA); interval(it + 1, xgB, cvB); }
+        if (it < total) interval(it, xgA, cvA);
+        // what the hand-off through the group's L2 costs in polls (a visibility stall would show here long before a time-out)
+        if (polls_total != 0u && lane == 0) { atomicAdd(a.census + 18, polls_total); atomicMax(a.census + 19, polls_max); }
+        if (a.pn != nullptr) {
+            if constexpr (W == 2) {
+                sdd += __shfl_xor(sdd, 1, 64); scx += __shfl_xor(scx, 1, 64);
+                scu += __shfl_xor(scu, 1, 64); scrx += __shfl_xor(scrx, 1, 64);
+            }
+            if (lane == 0) {
+                float *o = a.pn + blockIdx.x;
+                o[0] = sdd; o[a.pn_stride] = scx; o[2 * a.pn_stride] = scu; o[3 * a.pn_stride] = scrx;
+            }
+        }
+#ifdef SW_PROFILE
+        if (group == 0 && member == 0 && lane == 0)
+        {
+            for (int i = 0; i < 6; ++i) a.census[10 + i] = (unsigned)tacc[i];
+            a.census[16] = nmiss; a.census[17] = npoll;
+        }
+#endif
+#undef SW_STAMP
+    }
+}
+
+template <int NSLOT, int W, int L, int D, int LS, int ELEM = 0>
+static inline int sweep_go(hipStream_t st, const SweepArgs &a)
+{
+    const size_t lds = (size_t)LS * W * NSLOT * SW_CT * sizeof(f32x4);
+    static bool attr_set = false;
+    if (lds > 0 && !attr_set) {
+        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_k<NSLOT, W, L, D, LS, ELEM>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sweep_k<NSLOT, W, L, D, LS, ELEM>), dim3(256), dim3(SW_THREADS), lds, st, a);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+
+}  // namespace thip
