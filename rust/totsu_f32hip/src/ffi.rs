@@ -30,7 +30,8 @@ pub struct thip_sweep_test {
     pub xx_in: *const f32, pub kx_in: *const f32,
     pub xx_out: *mut f32, pub kx_out: *mut f32, pub gp: *mut f32, pub hn: *mut f32, pub h3: *mut f32,
     pub kappa: f32, pub rtau: f32, pub first: i32, pub reps: i32,
-    pub force_members: i32, pub pub_agent: i32, pub variant: i32, pub reserved: i32,
+    pub force_members: i32, pub pub_agent: i32, pub variant: i32, pub elem: i32,
+    pub inv_s: *const f32,
 }
 
 pub enum thip_solver {}

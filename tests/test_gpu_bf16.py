@@ -134,17 +134,19 @@ def _socp(T, n, cones, seed):
                       _mb(T, T.MatType.General(0, n)), _mb(T, T.MatType.General(0, 1)))
 
 
-@pytest.mark.parametrize("schedule", ["reference", "fused", "carried"])
+@pytest.mark.parametrize("schedule", ["reference", "fused", "carried", "sweep"])
 def test_iterates_with_bf16_storage_follow_the_oracle_on_the_rounded_matrix(T, schedule):
-    dense = _socp(T, 30, [5, 1, 0, 17, 99, 3], seed=2).dense()
+    # (the one-pass kernel wants >= 80 columns for its two-column panels of a 16-bit matrix: a larger instance for it)
+    dense = (_socp(T, 100, [5, 1, 0, 17, 99, 3, 32], seed=2) if schedule == "sweep" else _socp(T, 30, [5, 1, 0, 17, 99, 3], seed=2)).dense()
     iters, tols = [0, 1, 9, 99], [2e-5, 2e-5, 1e-4, 2e-3]
     dr = _rounded(dense)
     ro = O.solve_matop_cones(O.param(max_iter=max(iters) + 2, eps_acc=1e-30), dr.vec_c, dr.mat_a, dr.vec_b, dr.seg_type,
                              dr.seg_len, snap_iters=iters, trace_cap=max(iters) + 3, use_ql=True)
     p = T.SolverParam()
     p.eps_acc = 1e-30
-    fs = T.FusedSolver.from_dense(dense, p, schedule, a_storage="bf16")      # the UNROUNDED matrix goes in
-    assert fs.passes()[1] == dense.n * dense.m * 2
+    fs = T.FusedSolver.from_dense(dense, p, schedule, a_storage="bf16", sweep_min_bytes=0)      # the UNROUNDED matrix goes in
+    assert fs.passes()[1] == dense.n * dense.m * 2 and fs.schedule_in_use() == schedule
+    assert fs.passes()[0] == {"reference": 6, "fused": 3, "carried": 2, "sweep": 1}[schedule]
     N = dense.n + 2 * dense.m + 1
     done = 0
     for q, (it, tol) in enumerate(zip(iters, tols)):
@@ -170,18 +172,20 @@ def test_bf16_passes_then_f32_passes_finish_on_the_exact_matrix(T, n, cones, see
     gap = lambda x: abs(float(np.dot(dense.vec_c, x)) - obj) / abs(obj)
     p = T.SolverParam()
     p.max_iter, p.eps_acc = 2_000_000, 1e-4
-    for sched in ("fused", "carried"):
-        fs = T.FusedSolver.from_dense(dense, p, sched)
+    for sched in ("fused", "carried") + (("sweep",) if n >= 80 else ()):
+        fs = T.FusedSolver.from_dense(dense, p, sched, sweep_min_bytes=0)
+        assert fs.schedule_in_use() == sched
         r0 = fs.run(-1, poll_every=64)
         assert r0.state == 0 and gap(fs.solution()[0]) < 1e-4
         fs.destroy()
-        fs = T.FusedSolver.from_dense(dense, p, sched, a_storage="bf16")
+        fs = T.FusedSolver.from_dense(dense, p, sched, a_storage="bf16", sweep_min_bytes=0)
+        assert fs.schedule_in_use() == sched
         r1 = fs.run(-1, poll_every=64)
         assert r1.state == 0
         gap16 = gap(fs.solution()[0])
         assert 1e-5 < gap16 < 3e-3, gap16                     # a nearby problem, not the same one
         fs.set_a_storage("f32")
-        assert fs.passes()[1] == dense.n * dense.m * 4
+        assert fs.passes()[1] == dense.n * dense.m * 4 and fs.schedule_in_use() == sched
         fs.resume()
         r2 = fs.run(-1, poll_every=64)
         assert r2.state == 0
@@ -330,10 +334,10 @@ def test_gemv_f16_equals_products_of_the_dequantised_matrix(T, shape):
     assert np.all(np.abs(dw.to_host() - want) <= 4e-6 * scale + 1e-30)
 
 
-@pytest.mark.parametrize("schedule", ["reference", "fused", "carried"])
+@pytest.mark.parametrize("schedule", ["reference", "fused", "carried", "sweep"])
 def test_iterates_with_f16_storage_follow_the_oracle_on_the_dequantised_matrix(T, schedule):
     import copy
-    dense = _socp(T, 30, [5, 1, 0, 17, 99, 3], seed=2).dense()
+    dense = (_socp(T, 100, [5, 1, 0, 17, 99, 3, 32], seed=2) if schedule == "sweep" else _socp(T, 30, [5, 1, 0, 17, 99, 3], seed=2)).dense()
     iters, tols = [0, 1, 9, 99], [2e-5, 2e-5, 1e-4, 2e-3]
     dr = copy.copy(dense)
     A = np.asarray(dense.mat_a, np.float32).reshape((dense.n, dense.m)).T
@@ -342,8 +346,8 @@ def test_iterates_with_f16_storage_follow_the_oracle_on_the_dequantised_matrix(T
                              dr.seg_len, snap_iters=iters, trace_cap=max(iters) + 3, use_ql=True)
     p = T.SolverParam()
     p.eps_acc = 1e-30
-    fs = T.FusedSolver.from_dense(dense, p, schedule, a_storage="f16")
-    assert fs.passes()[1] == dense.n * dense.m * 2
+    fs = T.FusedSolver.from_dense(dense, p, schedule, a_storage="f16", sweep_min_bytes=0)
+    assert fs.passes()[1] == dense.n * dense.m * 2 and fs.schedule_in_use() == schedule
     N = dense.n + 2 * dense.m + 1
     done = 0
     for q, (it, tol) in enumerate(zip(iters, tols)):
@@ -400,3 +404,56 @@ def test_caller_built_f16_matrix_equals_the_library_conversion(T):
         fs.destroy()
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
     conv.free(); direct.free(); inst.free()
+
+
+# ---- the one-pass kernel on a 16-bit-stored A (thip_sweep16.hip) -------------------------------------------------------
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("m,n,members,w", [(4096, 3000, 0, 2), (20000, 2500, 0, 2), (3584, 2400, 0, 1), (100_000, 800, 0, 2), (12504, 1000, 0, 4),
+                                           (1000, 2500, 0, 1), (248, 120, 0, 1), (28_672, 5200, 4, 2), (28_672, 5200, 2, 1), (21_504, 10_400, 2, 2),
+                                           (57_344, 5200, 8, 4)])
+def test_sweep_kernel_on_a_16_bit_matrix_vs_numpy(T, kind, m, n, members, w):
+    """sweep_k<..., ELEM = bf16 / f16> alone (thip_test_sweep) against numpy f64 on the ROUNDED matrix: one, two and four columns
+    per panel, 1 .. 4 eight-row slots per thread, every group size, the u update on and off"""
+    import ctypes as C
+    from totsu_amd import _lib
+    D = T.DeviceBuffer
+    rng = np.random.default_rng(m + 7 * n)
+    A = (rng.standard_normal((m, n)) * np.exp(rng.uniform(-3, 3, n))[None, :] / np.sqrt(n)).astype(np.float32)      # columns of different scales
+    mat = T.Bf16Matrix.from_f32(np.asfortranarray(A).ravel(order="F"), m, n, kind)
+    Ar = (bf16_round(A) if kind == "bf16" else f16_quantize(A)[2]).astype(np.float64)
+    host = dict(v=rng.standard_normal(m), xy=rng.standard_normal(m), c=rng.standard_normal(n), su=rng.random(n) + 0.5,
+                tx=rng.random(n) + 0.5, u=rng.standard_normal(n), xx=rng.standard_normal(n), gp=rng.standard_normal(n))
+    host = {k: np.asarray(a, np.float32) for k, a in host.items()}
+    for first in (0, 1):
+        bufs = {k: D.from_host(a) for k, a in host.items()}
+        outs = {k: D(sz, zero=True) for k, sz in dict(xx_out=n, hn=m + 8, h3=m + 8).items()}
+        t = _lib.SweepTest()
+        t.m, t.n, t.lda = (m + 7) // 8 * 8, n, mat.ld16          # the library-made copy has zero rows up to a multiple of 8
+        t.mat_a, t.v, t.xy, t.c, t.su, t.tx = mat.ptr, bufs["v"].ptr, bufs["xy"].ptr, bufs["c"].ptr, bufs["su"].ptr, bufs["tx"].ptr
+        t.u, t.ku, t.xx_in, t.kx_in, t.xx_out, t.kx_out = bufs["u"].ptr, None, bufs["xx"].ptr, None, outs["xx_out"].ptr, None
+        t.gp, t.hn, t.h3 = bufs["gp"].ptr, outs["hn"].ptr, outs["h3"].ptr
+        t.kappa, t.rtau, t.first, t.reps, t.force_members = -0.37, 0.81, first, 1, members
+        t.elem, t.inv_s, t.variant = (1 if kind == "bf16" else 2), mat.inv_ptr, w      # (16-bit: `variant` = columns per panel)
+        ms, info = (C.c_float * 2)(), (C.c_int * 8)()
+        if m % 8:
+            # v / x_y behind row m must read as zero (the solver's arena guarantees it): longer buffers here
+            for k in ("v", "xy"):
+                bufs[k].free()
+                bufs[k] = D.from_host(np.concatenate([host[k], np.zeros(8, np.float32)]))
+            t.v, t.xy = bufs["v"].ptr, bufs["xy"].ptr
+        _lib.lib.thip_test_sweep(C.byref(t), ms, info)
+        assert info[0] == 0, list(info)
+        g3 = Ar.T @ host["xy"].astype(np.float64)
+        gT = Ar.T @ host["v"].astype(np.float64)
+        u_ref = host["u"].astype(np.float64) if first else host["u"] + host["su"] * (-(host["gp"] - 2 * g3) - host["c"] * 0.81)
+        x_ref = host["xx"] + host["tx"] * (gT + host["c"] * (-0.37))
+        got = {"u": bufs["u"].to_host(), "x": outs["xx_out"].to_host(), "gp": bufs["gp"].to_host(),
+               "hn": outs["hn"].to_host()[:m], "h3": outs["h3"].to_host()[:m]}
+        ref = {"u": u_ref, "x": x_ref, "gp": g3, "hn": Ar @ u_ref, "h3": Ar @ x_ref}
+        for k in ref:
+            err = np.abs(got[k] - ref[k]).max() / (np.abs(ref[k]).max() + 1e-30)
+            assert err < 1e-5, (kind, m, n, members, w, first, k, err, list(info))
+        for b in list(bufs.values()) + list(outs.values()):
+            b.free()
+    mat.free()

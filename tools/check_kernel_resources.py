@@ -11,8 +11,10 @@ usage: check_kernel_resources.py <remarks file> [--report]"""
 import re
 import sys
 
-# instances that are experiment variants only (THIP_SWEEP_VARIANT=1): reported, not enforced
-VARIANTS = {(7, 1, 3, 1, 2), (4, 1, 8, 3, 3), (2, 2, 8, 3, 0), (1, 2, 8, 3, 0)} | {(n, 1, 2, 1, k) for n in range(1, 8) for k in (2, 3)} - {(7, 1, 2, 1, 3)}
+# <slots, columns per panel, LAGL, DLAG, LS, element kind (0 f32, 1 bf16, 2 f16)>
+# instances that are experiment variants only (thip_sweep_test.variant): reported, not enforced
+VARIANTS = ({(7, 1, 3, 1, 2, 0), (4, 1, 8, 3, 3, 0), (2, 2, 8, 3, 0, 0), (1, 2, 8, 3, 0, 0)}
+            | {(n, 1, 2, 1, k, 0) for n in range(1, 8) for k in (2, 3)}) - {(7, 1, 2, 1, 3, 0), (6, 1, 2, 1, 3, 0), (5, 1, 2, 1, 3, 0)}
 MAX_SCRATCH, MIN_OCC = 16, 2
 
 
@@ -40,7 +42,7 @@ def main():
     res = parse(txt)
     bad, seen = [], 0
     for name, r in sorted(res.items()):
-        m = re.search(r"sweep_kILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        m = re.search(r"sweep_kILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
         if not m or "scratch" not in r:
             continue
         inst = tuple(int(v) for v in m.groups())

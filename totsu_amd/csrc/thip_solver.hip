@@ -1438,7 +1438,7 @@ int sweep_prepare(thip_solver *s)
 {
     if (s->schedule != THIP_SCHED_SWEEP) return 0;
     if ((s->allreduce != nullptr) != s->col_shard) return 0;      // row shards run the carried schedule; column shards need the hook
-    if (s->sparse || s->is16() || s->m == 0 || s->n == 0) return 0;      // not now (may change)
+    if (s->sparse || s->m == 0 || s->n == 0) return 0;      // not now (may change)
     if (s->sweep_state != 0) return 0;
     s->sweep_state = -1;
     // a (re-)plan restarts the schedule from the consistent iterate: the timing sweeps below rewrite the groups' shares and
@@ -1447,14 +1447,17 @@ int sweep_prepare(thip_solver *s)
     static const int env_off = getenv("THIP_SWEEP_OFF") ? atoi(getenv("THIP_SWEEP_OFF")) : 0;
     if (env_off) return 0;
     size_t m_eff = s->m;
+    const int elem = s->a_kind;                   // THIP_A_F32, or the 16-bit form the iteration streams now
+    const size_t esize = elem ? 2 : 4;
     // a library-owned padded copy has zero rows behind row m, and every m-vector of the arena has zeros behind entry m
-    if (m_eff % 4 != 0 && s->Apad != nullptr && s->ldpad >= (m_eff + 3) / 4 * 4) m_eff = (m_eff + 3) / 4 * 4;
-    if (!s->col_shard && s->m * s->n * sizeof(float) < s->sweep_min_bytes) return 0;
+    if (!elem && m_eff % 4 != 0 && s->Apad != nullptr && s->ldpad >= (m_eff + 3) / 4 * 4) m_eff = (m_eff + 3) / 4 * 4;
+    if (elem && m_eff % 8 != 0 && s->A16_owned && s->ld16 >= (m_eff + 7) / 8 * 8) m_eff = (m_eff + 7) / 8 * 8;
+    if (!s->col_shard && s->m * s->n * esize < s->sweep_min_bytes) return 0;
     // the geometries the kernel offers for this matrix (group size, columns per panel); THIP_SWEEP_CLASS pins one
     SweepGeom cand[6];
     int nc = 0;
-    if (getenv("THIP_SWEEP_CLASS")) { if (sweep_plan(m_eff, s->n, s->alda(), s->amat(), &cand[0]) == 0) nc = 1; }
-    else nc = sweep_candidates(m_eff, s->n, s->alda(), s->amat(), cand, 6);
+    if (getenv("THIP_SWEEP_CLASS")) { if (sweep_plan(m_eff, s->n, s->alda(), s->amat(), &cand[0], elem) == 0) nc = 1; }
+    else nc = sweep_candidates(m_eff, s->n, s->alda(), s->amat(), cand, 6, elem);
     if (nc == 0) return 0;
     hipStream_t st = ctx().stream;
     if (!s->sw_census) {
@@ -1539,10 +1542,11 @@ int sweep_prepare(thip_solver *s)
         // "whenever the kernel can take the shape" (sweep_min_bytes = 0).  The two passes are priced at the dual GEMV's
         // usual 6.2 TB/s first, and when that is anywhere near, with the carried plan's own MEASURED pass
         if (!s->col_shard && s->sweep_min_bytes != 0) {
-            double carried_ms = 2.0 * (double)s->m * (double)s->n * sizeof(float) / 6.2e12 * 1e3 + 0.03;
+            double carried_ms = 2.0 * (double)s->m * (double)s->n * esize / 6.2e12 * 1e3 + 0.03;
             if ((double)s->sw_plan_ms > 0.75 * carried_ms) {
                 THIP_RC(autotune_gemv(s));
-                if (s->tuned && s->tuned_ms > 0.0f) carried_ms = 2.0 * (double)s->tuned_ms + 0.03;
+                const float pass_ms = elem ? (s->tuned16 ? s->tuned16_ms : 0.0f) : (s->tuned ? s->tuned_ms : 0.0f);
+                if (pass_ms > 0.0f) carried_ms = 2.0 * (double)pass_ms + 0.03;
             }
             if ((double)s->sw_plan_ms > carried_ms) return 0;
         }
@@ -1565,9 +1569,10 @@ int sweep_prepare(thip_solver *s)
 bool sweep_active(const thip_solver *s)
 {
     if (!(s->schedule == THIP_SCHED_SWEEP && s->sweep_state == 1 && (s->allreduce != nullptr) == s->col_shard && !s->sparse
-          && !s->is16())) return false;
-    // planned on the padded copy (m not a multiple of 4): only while that copy is the matrix in use
-    return (size_t)s->sgeom.m_eff == s->m || (s->Apad != nullptr && s->ldpad >= (size_t)s->sgeom.m_eff);
+          && s->sgeom.elem == s->a_kind)) return false;       // (planned for the stored form of A in use now)
+    // planned on the padded copy (m not a multiple of the rows per slot): only while that copy is the matrix in use
+    if ((size_t)s->sgeom.m_eff == s->m) return true;
+    return s->is16() ? (s->A16_owned && s->ld16 >= (size_t)s->sgeom.m_eff) : (s->Apad != nullptr && s->ldpad >= (size_t)s->sgeom.m_eff);
 }
 
 int sweep_pass(thip_solver *s, int first, int np_m)
@@ -1576,6 +1581,7 @@ int sweep_pass(thip_solver *s, int first, int np_m)
     const SweepGeom &g = s->sgeom;
     SweepArgs a;
     a.A = reinterpret_cast<const float *>(s->amat()); a.lda = s->alda(); a.m = g.m_eff; a.n = (int)s->n;
+    a.inv_s = s->ainv();
     a.G = g.G; a.rows_per_member = g.rows_per_member; a.cols_per_group = g.cols_per_group;
     a.v = s->v; a.xy = s->xy; a.c = s->c; a.Su = s->Su; a.Tx = s->Tx;
     a.u = s->u; a.ku = s->comp() ? s->ku : nullptr;
@@ -2240,6 +2246,7 @@ int thip_solver_set_a_storage(thip_solver *s, int a_kind)
     }
     const bool changed = s->a_kind != a_kind;
     s->a_kind = a_kind;
+    if (changed) s->sweep_state = 0;           // the one-pass schedule is planned per stored form (another kernel instance)
     if (s->inited && a_kind == THIP_A_F32) THIP_RC(ensure_apad(s, false));      // first f32 pass of this solve
     if (s->inited) {
         THIP_RC(autotune_gemv(s));      // a switch inside a running solve: tune the other kernel once

@@ -205,10 +205,15 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     THIP_NEED_INIT();
     if (!t) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
     SweepGeom g;
-    if ((t->force_members > 0 ? sweep_plan_one(t->m, t->n, t->lda, t->mat_a, 1, 1, &g, t->force_members)
-                              : sweep_plan(t->m, t->n, t->lda, t->mat_a, &g)) != 0)
+    if (t->elem < 0 || t->elem > THIP_A_F16 || (t->elem == THIP_A_F16 && !t->inv_s))
+        return fail(THIP_E_INVALID, "bad element kind", __FILE__, __LINE__);
+    // 16-bit: `variant` = columns per panel (1, 2 or 4; else the planner's preference)
+    const int w16 = (t->variant == 1 || t->variant == 2 || t->variant == 4) ? t->variant : 0;
+    if ((t->elem && w16) ? sweep_plan_one(t->m, t->n, t->lda, t->mat_a, w16, 1, &g, t->force_members, t->elem) != 0
+        : (t->force_members > 0 ? sweep_plan_one(t->m, t->n, t->lda, t->mat_a, t->elem ? 2 : 1, 1, &g, t->force_members, t->elem)
+                                : sweep_plan(t->m, t->n, t->lda, t->mat_a, &g, t->elem)) != 0)
         return fail(THIP_E_INVALID, "the one-pass kernel cannot take this shape", __FILE__, __LINE__);
-    if (t->variant > 0) g.variant = t->variant;
+    if (t->variant > 0 && !t->elem) g.variant = t->variant;
     hipStream_t st = ctx().stream;
     unsigned long long *gran = nullptr;
     unsigned *census = nullptr;
@@ -223,7 +228,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     const float hs[4] = { 0.0f, t->kappa, t->rtau, 1.0f };       // [0] doubles as the stop flag (int 0)
     THIP_TRY(hipMemcpyAsync(scal, hs, sizeof(hs), hipMemcpyHostToDevice, st));
     SweepArgs a;
-    a.A = t->mat_a; a.lda = t->lda; a.m = (int)t->m; a.n = (int)t->n;
+    a.A = t->mat_a; a.lda = t->lda; a.m = (int)t->m; a.n = (int)t->n; a.inv_s = t->inv_s;
     a.G = g.G; a.rows_per_member = g.rows_per_member; a.cols_per_group = g.cols_per_group;
     a.v = t->v; a.xy = t->xy; a.c = t->c; a.Su = t->su; a.Tx = t->tx; a.u = t->u; a.ku = t->ku;
     a.xx_in = t->xx_in; a.kx_in = t->kx_in; a.xx_out = t->xx_out; a.kx_out = t->kx_out; a.gP = t->gp;

@@ -40,7 +40,8 @@ __device__ __forceinline__ void sw_unpack(const f32x4 &raw, float (&e)[SwElem<EL
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const h2 h = __builtin_bit_cast(h2, raw[k]);
+            const float f = raw[k];                     // (by value: __builtin_bit_cast of the element lvalue reads element 0)
+            const h2 h = __builtin_bit_cast(h2, f);
             e[2 * k] = (float)h[0];
             e[2 * k + 1] = (float)h[1];
         }
