@@ -171,6 +171,7 @@ int thip_free(float *p)
     THIP_NEED_INIT();
     if (!p) return 0;
     THIP_TRY(hipStreamSynchronize(ctx().stream));
+    lazy_forget();                  // learnt call plans / read-ahead plans hold raw device addresses (thip_lazy.hip)
     THIP_TRY(hipFree(p));
     return 0;
 }

@@ -1187,6 +1187,21 @@ int lazy_flush()
     return flush_locked();
 }
 
+// thip_free: every learnt plan holds raw device addresses (the scalar reads of a pass; the operands of a replayed segment).
+// Once a buffer has been released the addresses may be unmapped -- or, worse, mapped to something else -- and a first read
+// that happens to match a plan's head would launch read_batch_k over all of them.  Forget what was learnt (it is learnt
+// again within one pass of the next solve).
+void lazy_forget()
+{
+    std::lock_guard<std::mutex> lock(Q.mu);
+    if (Q.rd_plans.empty() && !Q.rd_open && Q.rd_learn.empty() && Q.plans.empty()) return;
+    drop_all_plans();
+    drop_read_cache();
+    Q.rd_open = false; Q.rd_learn.clear();
+    for (ReadPlan *p : Q.rd_plans) free_read_plan(p);
+    Q.rd_plans.clear();
+}
+
 void lazy_release()
 {
     std::lock_guard<std::mutex> lock(Q.mu);

@@ -344,6 +344,35 @@ __global__ __launch_bounds__(256) void stream_read_chunks_k(const f32x4 *__restr
     const float s = acc[0] + acc[1] + acc[2] + acc[3];
     if (s == 123.456f) out[0] = s;
 }
+// the access pattern of the one-pass kernel itself, without its arithmetic: 256 persistent workgroups of 512 threads, 56 KB
+// contiguous per workgroup and step, three steps (21 loads per lane) in flight
+__global__ __launch_bounds__(512) void stream_read_persistent_k(const f32x4 *__restrict__ p, size_t n4, float *out)
+{
+    constexpr size_t CH = 512 * 7;
+    const size_t nch = n4 / CH;
+    f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+    f32x4 v[3][7];
+    size_t c = blockIdx.x;
+    const size_t step = gridDim.x;
+#define SRP_LOAD(S, C_) do { const f32x4 *q = p + (C_) * CH + threadIdx.x; _Pragma("unroll") for (int u = 0; u < 7; ++u) v[S][u] = __builtin_nontemporal_load(q + u * 512); } while (0)
+#define SRP_USE(S) do { _Pragma("unroll") for (int u = 0; u < 7; ++u) acc += v[S][u]; } while (0)
+    if (c < nch) SRP_LOAD(0, c);
+    if (c + step < nch) SRP_LOAD(1, c + step);
+    for (; c + 4 * step < nch; c += 3 * step) {
+        SRP_LOAD(2, c + 2 * step); SRP_USE(0);
+        SRP_LOAD(0, c + 3 * step); SRP_USE(1);
+        SRP_LOAD(1, c + 4 * step); SRP_USE(2);
+    }
+    // tail: at most four chunks of this workgroup are left, two of them loaded
+    if (c < nch) SRP_USE(0);
+    if (c + step < nch) SRP_USE(1);
+    for (size_t d = c + 2 * step; d < nch; d += step) { SRP_LOAD(2, d); SRP_USE(2); }
+#undef SRP_LOAD
+#undef SRP_USE
+    for (size_t i = nch * CH + (size_t)blockIdx.x * 512 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 512) acc += __builtin_nontemporal_load(p + i);
+    const float s_ = acc[0] + acc[1] + acc[2] + acc[3];
+    if (s_ == 123.456f) out[0] = s_;
+}
 }  // namespace
 
 extern "C" int thip_stream_probe(const void *dev_ptr, size_t bytes, int reps, float *host_best_ms, float *host_avg_ms)
@@ -356,18 +385,21 @@ extern "C" int thip_stream_probe(const void *dev_ptr, size_t bytes, int reps, fl
     THIP_TRY(hipEventCreate(&e0)); THIP_TRY(hipEventCreate(&e1));
     if (reps < 1) reps = 1;
     float best = 1e30f, best_avg = 1e30f;
-    // grid-stride form at the grids tools/stream_probe.hip found within 2 % of each other at 0.4 - 20 GB, and the chunked form
-    // at 8 and 16 resident workgroups per CU; one warm-up each; the best form's best and average launch
-    const unsigned grids[5] = { 4096u, 8192u, 16384u, 2048u, 4096u };
-    for (int f = 0; f < 5; ++f) {
+    // grid-stride form at the grids tools/stream_probe.hip found within 2 % of each other at 0.4 - 20 GB, the chunked form at 8
+    // and 16 resident workgroups per CU, the persistent form at one and two workgroups per CU; one warm-up each; the best
+    // form's best and average launch
+    const unsigned grids[7] = { 4096u, 8192u, 16384u, 2048u, 4096u, 256u, 512u };
+    for (int f = 0; f < 7; ++f) {
         const unsigned blocks = grids[f];
-        const bool chunks = f >= 3;
+        const int form = f < 3 ? 0 : (f < 5 ? 1 : 2);        // grid-stride / 32 KB chunks / persistent 56 KB chunks, 3 in flight
         if ((size_t)blocks * 256 * 8 > n4 && f != 0) continue;
         float tot = 0.0f, mn = 1e30f;
         for (int r = 0; r <= reps; ++r) {
             THIP_TRY(hipEventRecord(e0, st));
-            if (chunks) hipLaunchKernelGGL(stream_read_chunks_k, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(dev_ptr), n4, ctx().dev_scalar);
-            else hipLaunchKernelGGL(stream_read_k, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4 *>(dev_ptr), n4, ctx().dev_scalar);
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(dev_ptr);
+            if (form == 2) hipLaunchKernelGGL(stream_read_persistent_k, dim3(blocks), dim3(512), 0, st, src, n4, ctx().dev_scalar);
+            else if (form == 1) hipLaunchKernelGGL(stream_read_chunks_k, dim3(blocks), dim3(256), 0, st, src, n4, ctx().dev_scalar);
+            else hipLaunchKernelGGL(stream_read_k, dim3(blocks), dim3(256), 0, st, src, n4, ctx().dev_scalar);
             THIP_TRY(hipEventRecord(e1, st));
             THIP_TRY(hipEventSynchronize(e1));
             float ms = 0.0f;
