@@ -430,10 +430,11 @@ typedef struct thip_sweep_test {
     float kappa, rtau;
     int32_t first, reps;
     int32_t force_members, pub_agent;
-    int32_t variant, elem;          /* variant: 0 = the library's ring depth; 1 - 3 = experiment forms (thip_sweep.hip sweep_launch); with a
-                                     * 16-bit elem: columns per panel (1, 2, 4; 0 = the planner's preference);
-                                     * elem: THIP_A_F32, or THIP_A_BF16 / THIP_A_F16: mat_a then points at 16-bit entries, lda in entries */
+    int32_t variant, elem;          /* variant: columns per panel -- f32: 0 = one, 12 = two; 16-bit elem: 1, 2, 4 (0 = the planner's
+                                     * preference).  elem: THIP_A_F32, or THIP_A_BF16 / THIP_A_F16: mat_a then points at 16-bit entries, lda in entries */
     const float *inv_s;             /* THIP_A_F16: 1 / scale per column (thip_to_f16), else NULL */
+    float *host_sums;               /* optional, 4 floats on the HOST: the sums over n the sweep leaves for the criteria and the scalar
+                                     * updates (tau taken as 1): ||c + A^T xy||^2, c.xx_in, c.u, c.(xx_in - 2 xx_out) */
 } thip_sweep_test;
 int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *host_info);
 

@@ -32,6 +32,7 @@ pub struct thip_sweep_test {
     pub kappa: f32, pub rtau: f32, pub first: i32, pub reps: i32,
     pub force_members: i32, pub pub_agent: i32, pub variant: i32, pub elem: i32,
     pub inv_s: *const f32,
+    pub host_sums: *mut f32,
 }
 
 pub enum thip_solver {}

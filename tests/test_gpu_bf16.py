@@ -436,6 +436,8 @@ def test_sweep_kernel_on_a_16_bit_matrix_vs_numpy(T, kind, m, n, members, w):
         t.kappa, t.rtau, t.first, t.reps, t.force_members = -0.37, 0.81, first, 1, members
         t.elem, t.inv_s, t.variant = (1 if kind == "bf16" else 2), mat.inv_ptr, w      # (16-bit: `variant` = columns per panel)
         ms, info = (C.c_float * 2)(), (C.c_int * 8)()
+        sums = (C.c_float * 4)()
+        t.host_sums = sums
         if m % 8:
             # v / x_y behind row m must read as zero (the solver's arena guarantees it): longer buffers here
             for k in ("v", "xy"):
@@ -454,6 +456,11 @@ def test_sweep_kernel_on_a_16_bit_matrix_vs_numpy(T, kind, m, n, members, w):
         for k in ref:
             err = np.abs(got[k] - ref[k]).max() / (np.abs(ref[k]).max() + 1e-30)
             assert err < 1e-5, (kind, m, n, members, w, first, k, err, list(info))
+        c64, xx64 = host["c"].astype(np.float64), host["xx"].astype(np.float64)
+        want = [((c64 + g3) ** 2).sum(), c64 @ xx64, c64 @ u_ref, c64 @ (xx64 - 2 * x_ref)]
+        scale = [want[0], np.abs(c64) @ np.abs(xx64), np.abs(c64) @ np.abs(u_ref), np.abs(c64) @ (np.abs(xx64) + 2 * np.abs(x_ref))]
+        for q in range(4):
+            assert abs(sums[q] - want[q]) <= 3e-5 * scale[q], (kind, m, n, members, w, first, q, sums[q], want[q])
         for b in list(bufs.values()) + list(outs.values()):
             b.free()
     mat.free()

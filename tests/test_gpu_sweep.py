@@ -22,7 +22,7 @@ def T():
     return totsu_amd
 
 
-def _sweep_case(m, n, first, comp, seed, lda=None):
+def _sweep_case(m, n, first, comp, seed, lda=None, variant=0, members=0):
     from totsu_amd import _lib
     from totsu_amd.fused import DeviceBuffer
     lib = _lib.lib
@@ -47,8 +47,11 @@ def _sweep_case(m, n, first, comp, seed, lda=None):
     t.xx_out, t.kx_out = outs["xx_out"].ptr, (outs["kx_out"].ptr if comp else None)
     t.gp, t.hn, t.h3 = bufs["gp"].ptr, outs["hn"].ptr, outs["h3"].ptr
     t.kappa, t.rtau, t.first, t.reps = kappa, rtau, int(first), 1
+    t.variant, t.force_members = variant, members
     ms = (C.c_float * 2)()
     info = (C.c_int * 8)()
+    sums = (C.c_float * 4)()
+    t.host_sums = sums
     lib.thip_test_sweep(C.byref(t), ms, info)
     assert info[0] == 0, "the kernel raised its error word: %d" % info[0]
     Ad = A[:, :m].astype(np.float64)
@@ -63,6 +66,12 @@ def _sweep_case(m, n, first, comp, seed, lda=None):
     for k in ref:
         err = np.abs(got[k] - ref[k]).max() / (np.abs(ref[k]).max() + 1e-30)
         assert err < 5e-6, (m, n, first, comp, k, err)
+    # the sums over n the kernel leaves for the criteria and the scalar updates (tau = 1 in this entry point)
+    c64, xx64 = c.astype(np.float64), xx.astype(np.float64)
+    want = [((c64 + g3) ** 2).sum(), c64 @ xx64, c64 @ u_ref, c64 @ (xx64 - 2 * x_ref)]
+    scale = [((c64 + g3) ** 2).sum(), np.abs(c64) @ np.abs(xx64), np.abs(c64) @ np.abs(u_ref), np.abs(c64) @ (np.abs(xx64) + 2 * np.abs(x_ref))]
+    for q in range(4):
+        assert abs(sums[q] - want[q]) <= 2e-5 * scale[q], (m, n, first, comp, q, sums[q], want[q])
     if comp:
         # the Kahan term carries what the f32 sum dropped: (x + inc) - stored = -k (to f32 round-off of k itself)
         kxo = outs["kx_out"].to_host().astype(np.float64)
@@ -80,6 +89,15 @@ def test_sweep_kernel_vs_numpy(T, m, n):
     for first in (0, 1):
         for comp in (0, 1):
             _sweep_case(m, n, first, comp, seed=m + 3 * n + first + 2 * comp)
+
+
+@pytest.mark.parametrize("m,n,members", [(20000, 10000, 0), (5376, 21000, 1), (7000, 6000, 0), (1792, 20000, 0)])
+def test_sweep_kernel_two_columns_per_panel(T, m, n, members):
+    """the f32 instances with two columns per panel (1, 2, 3 slots per thread): half the column groups of the one-column
+    geometry at the same bytes per panel -- what the plan autotune may pick for short matrices"""
+    for first in (0, 1):
+        G, groups, _ = _sweep_case(m, n, first, 1, seed=m + n + first, variant=12, members=members)
+        assert G * groups == 256
 
 
 def test_sweep_kernel_padded_leading_dimension(T):

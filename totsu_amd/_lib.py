@@ -47,7 +47,8 @@ class SweepTest(C.Structure):
                [(k, C.c_void_p) for k in ("mat_a", "v", "xy", "c", "su", "tx", "u", "ku", "xx_in", "kx_in", "xx_out",
                                           "kx_out", "gp", "hn", "h3")] + \
                [("kappa", C.c_float), ("rtau", C.c_float), ("first", C.c_int32), ("reps", C.c_int32),
-                ("force_members", C.c_int32), ("pub_agent", C.c_int32), ("variant", C.c_int32), ("elem", C.c_int32), ("inv_s", C.c_void_p)]
+                ("force_members", C.c_int32), ("pub_agent", C.c_int32), ("variant", C.c_int32), ("elem", C.c_int32), ("inv_s", C.c_void_p),
+                ("host_sums", C.POINTER(C.c_float))]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)

@@ -59,11 +59,6 @@ int sweep_class()
     static const int v = getenv("THIP_SWEEP_CLASS") ? atoi(getenv("THIP_SWEEP_CLASS")) : 2;
     return v >= 0 && v < 3 ? v : 0;
 }
-int sweep_variant()
-{
-    static const int v = getenv("THIP_SWEEP_VARIANT") ? atoi(getenv("THIP_SWEEP_VARIANT")) : 0;
-    return v >= 0 && v < 4 ? v : 0;
-}
 }  // namespace
 
 // One candidate geometry: W columns per panel (1 or 2: the two families of kernel instances), the smallest group size
@@ -77,7 +72,7 @@ static int sweep_plan_one(size_t m, size_t n, size_t lda, const void *mat, int W
     const size_t slot_rows = (size_t)SW_CT * epv;
     // slots per streaming thread a kernel instance exists for: f32 1 .. 7 (one column per panel) / 1 .. 2 (two); 16-bit
     // storage keeps twice the rows per slot in registers (v, x_y, two accumulators: 32 VGPRs per slot): 1 .. 4 / 3 / 2
-    const int max_slots = elem ? (W == 1 ? 4 : (W == 2 ? 3 : 2)) : (W == 1 ? 7 : 2);
+    const int max_slots = elem ? (W == 1 ? 4 : (W == 2 ? 3 : 2)) : (W == 1 ? 7 : 3);
     if (W == 4 && !elem) return 1;
     const size_t cap = slot_rows * max_slots;
     auto rows_of = [&](int G_) { return ((m + G_ - 1) / G_ + epv - 1) / epv * epv; };
@@ -100,9 +95,9 @@ static int sweep_plan_one(size_t m, size_t n, size_t lda, const void *mat, int W
     g->G = G; g->ngroups = ngroups; g->rows_per_member = (int)rpm; g->cols_per_group = (int)cpg;
     // 16-byte slots per streaming thread: what the member's rows need (round 3 offered 4 or 7 only: the 10 000 rows per member
     // of the n = 10 000 LP ran 7 slots at 80 % of their lanes, the 7 829 of the k = 500 SDP at 62 %)
-    g->nslot = (W == 2 && !elem) ? (need <= 1 ? 1 : 2) : need;
+    g->nslot = need;
     g->mpad = (m + 63) / 64 * 64;
-    g->w = W; g->variant = sweep_variant();
+    g->w = W; g->variant = 0;
     g->npan = (int)(cpg / W);
     g->m_eff = (int)m;
     g->elem = elem;
@@ -154,33 +149,29 @@ int sweep_census_dry_run(hipStream_t st, unsigned *census, unsigned seq)
 int sweep_launch(hipStream_t st, const SweepGeom &g, const SweepArgs &a)
 {
     if (g.elem != 0) return sweep_launch16(st, g, a);
+    // <slots, columns per panel, LAGL, DLAG, LS>: 3 register stages + 3 LDS panels for every slot count.  Round 3's deeper
+    // rings for few slots (9 stages + 5 .. 8 panels) and the 4 + 3 / 4 + 4 forms for 5 / 6 slots were timed against it
+    // (profiles/r04_sweep_ring_depth_and_publish_scope.txt, r04_sweep_small_slot_ring_depth.txt): a launch runs
+    // npan + LAGL + LS intervals and the last LAGL + LS load nothing -- 5 - 10 us per launch in favour of the shallow ring at
+    // every slot count, nothing lost on long sweeps; one panel less (3 + 2) makes every gather poll once.
     if (g.w == 2) {
-        if (g.nslot == 2) return g.variant == 1 ? sweep_go<2, 2, 8, 3, 0>(st, a) : sweep_go<2, 2, 8, 3, 5>(st, a);
-        return g.variant == 1 ? sweep_go<1, 2, 8, 3, 0>(st, a) : sweep_go<1, 2, 8, 3, 5>(st, a);
+        // two columns per panel: half the column groups of the one-column geometry with the same bytes per panel (the m-tail
+        // reads every group's share of the two N products: 20 MB at the n = 10 000 LP with 128 groups)
+        switch (g.nslot) {
+        case 1: return sweep_go<1, 2, 2, 1, 3>(st, a);
+        case 2: return sweep_go<2, 2, 2, 1, 3>(st, a);
+        default: return sweep_go<3, 2, 2, 1, 3>(st, a);
+        }
     }
-    // <slots, columns per panel, LAGL, DLAG, LS>: register stages + LDS panels sized to the 512 VGPRs / 160 KB of a CU.
-    // variant 2 / 3 (experiments, thip_sweep_test.variant): shallower rings -- a launch runs npan + LAGL + LS intervals, and the
-    // last LAGL + LS of them load nothing
-#define SW_CASE(N, L0, D0, S0)                                                          \
-    case N:                                                                             \
-        if (g.variant == 2) return sweep_go<N, 1, 2, 1, 3>(st, a);                      \
-        if (g.variant == 3) return sweep_go<N, 1, 2, 1, 2>(st, a);                      \
-        return sweep_go<N, 1, L0, D0, S0>(st, a);
     switch (g.nslot) {
-    SW_CASE(1, 8, 3, 8)
-    SW_CASE(2, 8, 3, 8)
-    SW_CASE(3, 8, 3, 6)
-    case 4:
-        if (g.variant == 2) return sweep_go<4, 1, 2, 1, 3>(st, a);
-        if (g.variant == 3) return sweep_go<4, 1, 2, 1, 2>(st, a);
-        return g.variant == 1 ? sweep_go<4, 1, 8, 3, 3>(st, a) : sweep_go<4, 1, 8, 3, 5>(st, a);
-    SW_CASE(5, 2, 1, 3)      // (3 register stages + 3 LDS panels measured 2 - 5 % ahead of 4 + 3 / 4 + 4 on short sweeps: fewer
-    SW_CASE(6, 2, 1, 3)      //  intervals that load nothing at the end of a launch)
-    default:
-        if (g.variant == 3) return sweep_go<7, 1, 2, 1, 2>(st, a);
-        return g.variant == 1 ? sweep_go<7, 1, 3, 1, 2>(st, a) : sweep_go<7, 1, 2, 1, 3>(st, a);
+    case 1: return sweep_go<1, 1, 2, 1, 3>(st, a);
+    case 2: return sweep_go<2, 1, 2, 1, 3>(st, a);
+    case 3: return sweep_go<3, 1, 2, 1, 3>(st, a);
+    case 4: return sweep_go<4, 1, 2, 1, 3>(st, a);
+    case 5: return sweep_go<5, 1, 2, 1, 3>(st, a);
+    case 6: return sweep_go<6, 1, 2, 1, 3>(st, a);
+    default: return sweep_go<7, 1, 2, 1, 3>(st, a);
     }
-#undef SW_CASE
 }
 
 }  // namespace thip
@@ -208,20 +199,22 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     if (t->elem < 0 || t->elem > THIP_A_F16 || (t->elem == THIP_A_F16 && !t->inv_s))
         return fail(THIP_E_INVALID, "bad element kind", __FILE__, __LINE__);
     // 16-bit: `variant` = columns per panel (1, 2 or 4; else the planner's preference)
-    const int w16 = (t->variant == 1 || t->variant == 2 || t->variant == 4) ? t->variant : 0;
-    if ((t->elem && w16) ? sweep_plan_one(t->m, t->n, t->lda, t->mat_a, w16, 1, &g, t->force_members, t->elem) != 0
+    // (f32: variant 12 = two columns per panel)
+    const int w16 = t->elem ? ((t->variant == 1 || t->variant == 2 || t->variant == 4) ? t->variant : 0) : (t->variant == 12 ? 2 : 0);
+    if (w16 ? sweep_plan_one(t->m, t->n, t->lda, t->mat_a, w16, 1, &g, t->force_members, t->elem) != 0
         : (t->force_members > 0 ? sweep_plan_one(t->m, t->n, t->lda, t->mat_a, t->elem ? 2 : 1, 1, &g, t->force_members, t->elem)
                                 : sweep_plan(t->m, t->n, t->lda, t->mat_a, &g, t->elem)) != 0)
         return fail(THIP_E_INVALID, "the one-pass kernel cannot take this shape", __FILE__, __LINE__);
-    if (t->variant > 0 && !t->elem) g.variant = t->variant;
     hipStream_t st = ctx().stream;
     unsigned long long *gran = nullptr;
     unsigned *census = nullptr;
-    float *partH = nullptr, *scal = nullptr;
+    float *partH = nullptr, *scal = nullptr, *pnbuf = nullptr;
     THIP_TRY(hipMalloc((void **)&gran, sweep_gran_words(g) * sizeof(unsigned long long)));
     THIP_TRY(hipMalloc((void **)&census, 160 * sizeof(unsigned)));
     THIP_TRY(hipMalloc((void **)&partH, (size_t)g.ngroups * 2 * g.mpad * sizeof(float)));
     THIP_TRY(hipMalloc((void **)&scal, 4 * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&pnbuf, 4 * 256 * sizeof(float)));
+    THIP_TRY(hipMemsetAsync(pnbuf, 0, 4 * 256 * sizeof(float), st));
     THIP_TRY(hipMemsetAsync(gran, 0, sweep_gran_words(g) * sizeof(unsigned long long), st));
     THIP_TRY(hipMemsetAsync(census, 0, 160 * sizeof(unsigned), st));
     THIP_TRY(hipMemsetAsync(partH, 0, (size_t)g.ngroups * 2 * g.mpad * sizeof(float), st));
@@ -234,7 +227,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     a.xx_in = t->xx_in; a.kx_in = t->kx_in; a.xx_out = t->xx_out; a.kx_out = t->kx_out; a.gP = t->gp;
     a.partH = partH; a.mpad = g.mpad; a.gran = gran; a.census = census;
     a.first = t->first;
-    a.pn = nullptr; a.pn_stride = 0; a.tau_p = scal + 3; a.eps_zero = 1e-12f;
+    a.pn = pnbuf; a.pn_stride = 256; a.tau_p = scal + 3; a.eps_zero = 1e-12f;          // tau = 1: d = c + A^T x_y
     a.kappa_out = nullptr; a.skappa_p = nullptr; a.pm_brx = nullptr; a.np_m = 0; a.pn_count = 0;
     a.pn_in = nullptr; a.pn_in_stride = 0; a.spin_max = SW_SPIN_MAX; a.fault = 0; a.pub_agent = t->pub_agent != 0;
     a.dbg = getenv("THIP_SWEEP_DBG") ? atoi(getenv("THIP_SWEEP_DBG")) : 0;
@@ -258,8 +251,18 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     hipLaunchKernelGGL(sw_test_reduce_k, dim3(256), dim3(256), 0, st, (int)t->m, g.ngroups, g.mpad, partH, t->hn, t->h3);
     THIP_LAUNCH_CHECK();
     unsigned hc[160];
+    float hpn[4 * 256];
     THIP_TRY(hipMemcpyAsync(hc, census, sizeof(hc), hipMemcpyDeviceToHost, st));
+    THIP_TRY(hipMemcpyAsync(hpn, pnbuf, sizeof(hpn), hipMemcpyDeviceToHost, st));
     THIP_TRY(hipStreamSynchronize(st));
+    if (t->host_sums) {
+        // the workgroups' partial sums over n of the last launch, added up: ||d||^2, c.x_x, c.u, c.(x_x - 2 x_x')
+        for (int q = 0; q < 4; ++q) {
+            double acc = 0.0;
+            for (int k = 0; k < 256; ++k) acc += (double)hpn[q * 256 + k];
+            t->host_sums[q] = (float)acc;
+        }
+    }
     if (host_ms) { host_ms[0] = best; host_ms[1] = tot / reps; }
     if (host_info) {
         host_info[0] = (int)hc[9]; host_info[1] = g.G; host_info[2] = g.ngroups; host_info[3] = g.npan; host_info[4] = g.nslot;
@@ -274,7 +277,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
             hc[150] * 0.01, hc[151] * 0.01, hc[152] * 0.01, hc[153] * 0.01, hc[154] * 0.01, hc[155] * 0.01);
 #endif
     hipEventDestroy(e0); hipEventDestroy(e1);
-    hipFree(gran); hipFree(census); hipFree(partH); hipFree(scal);
+    hipFree(gran); hipFree(census); hipFree(partH); hipFree(scal); hipFree(pnbuf);
     return 0;
 }
 

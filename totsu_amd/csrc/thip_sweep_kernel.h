@@ -567,9 +567,11 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         // what the hand-off through the group's L2 costs in polls (a visibility stall would show here long before a time-out)
         if (polls_total != 0u && lane == 0) { atomicAdd(a.census + 18, polls_total); atomicMax(a.census + 19, polls_max); }
         if (a.pn != nullptr) {
-            if constexpr (W == 2) {
-                sdd += __shfl_xor(sdd, 1, 64); scx += __shfl_xor(scx, 1, 64);
-                scu += __shfl_xor(scu, 1, 64); scrx += __shfl_xor(scrx, 1, 64);
+            // lanes 0 .. W - 1 hold the sums of their columns
+#pragma unroll
+            for (int o = 1; o < W; o <<= 1) {
+                sdd += __shfl_xor(sdd, o, 64); scx += __shfl_xor(scx, o, 64);
+                scu += __shfl_xor(scu, o, 64); scrx += __shfl_xor(scrx, o, 64);
             }
             if (lane == 0) {
                 float *o = a.pn + blockIdx.x;
