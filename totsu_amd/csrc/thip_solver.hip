@@ -457,6 +457,18 @@ __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, 
         float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
         if (i < (size_t)m) {
             int g = kq;
+            // (sixteen loads in flight, added in the order of the plain loop below: the shares were written by workgroups on
+            // other XCDs, so every one of them is a trip to the Infinity Cache)
+            for (; g + 28 < ngroups; g += 32) {
+                float t[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float *q = partH + (size_t)(g + 8 * j) * 2 * mpad + i;
+                    t[4 * j] = q[0]; t[4 * j + 1] = q[mpad]; t[4 * j + 2] = q[8 * mpad]; t[4 * j + 3] = q[9 * mpad];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sa0 += t[4 * j]; sb0 += t[4 * j + 1]; sa1 += t[4 * j + 2]; sb1 += t[4 * j + 3]; }
+            }
             for (; g + 4 < ngroups; g += 8) {
                 const float *q = partH + (size_t)g * 2 * mpad + i;
                 sa0 += q[0]; sb0 += q[mpad]; sa1 += q[8 * mpad]; sb1 += q[9 * mpad];

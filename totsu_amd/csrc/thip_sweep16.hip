@@ -25,7 +25,7 @@ static int sweep_launch16_t(hipStream_t st, const SweepGeom &g, const SweepArgs 
         switch (g.nslot) {
         case 1: return sweep_go<1, 2, 2, 1, 3, ELEM>(st, a);
         case 2: return sweep_go<2, 2, 2, 1, 3, ELEM>(st, a);
-        default: return sweep_go<3, 2, 2, 1, 3, ELEM>(st, a);
+        default: return sweep_go<3, 2, 2, 1, 3, ELEM>(st, a);      // (4 slots x 2 columns: 8 / 71 VGPRs spilled for bf16 / f16 -- the build guard refuses it)
         }
     }
     if (g.nslot == 1) return sweep_go<1, 4, 2, 1, 3, ELEM>(st, a);

@@ -382,15 +382,17 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         // ahead and waited with vmcnt(0), every interval paid an L2 round trip: 1.59 us per panel instead of ~1.)
         float kappa = *a.kappa_p;
         const float rtau = *a.rtau_p;
-        if (a.kappa_out != nullptr && !a.first) {
-            // c.rx_x of the previous sweep (its workgroups' partials) + b.rx_y of the m-tail, in f64 like the other single-block sums
-            double dc = 0.0, db = 0.0;
-            for (int k = lane; k < a.pn_count; k += 64) dc += (double)a.pn_in[3 * a.pn_in_stride + k];
-            for (int k = lane; k < a.np_m; k += 64) db += (double)a.pm_brx[k];
+        // the kappa update (solver.rs:566-567) needs c.rx_x of the previous sweep (its workgroups' partials) and b.rx_y of the
+        // m-tail: up to 2 x 512 partials.  Their loads are issued HERE and summed only after the ring's first intervals
+        // (finish_kappa below): the first gather that uses kappa is LAGT intervals away, and the streaming waves' first barrier
+        // would otherwise wait for this round trip and the f64 sums (~2.5 us per launch)
+        const bool kupd = a.kappa_out != nullptr && !a.first;
+        float kc[8], kb[8];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { dc += __shfl_xor(dc, o, 64); db += __shfl_xor(db, o, 64); }
-            kappa = fminf(kappa + *a.skappa_p * ((float)dc + (float)db), 0.0f);
-            if (group == 0 && member == 0 && lane == 0) *a.kappa_out = kappa;
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            kc[j] = (kupd && k < a.pn_count) ? a.pn_in[3 * a.pn_in_stride + k] : 0.0f;
+            kb[j] = (kupd && k < a.np_m) ? a.pm_brx[k] : 0.0f;
         }
         const float tau = *a.tau_p;
         const bool conv = tau > a.eps_zero;
@@ -428,9 +430,10 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 #else
 #define SW_STAMP(i) do { } while (0)
 #endif
-        auto interval = [&](const int it, unsigned long long (&xg)[NL], float &cv) {
+        auto interval = [&](const int it, unsigned long long (&xg)[NL], float &cv, const bool nowait) {
             if (SW_DBG(a) & 8) { sw_barrier_dbg(SW_DBG(a)); return; }
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL + 1) : "memory");
+            // (intervals 0 and 1 use nothing that was fetched: no wait -- the kappa loads above are still in flight then)
+            if (!nowait) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL + 1) : "memory");
             SW_STAMP(0);
             // per-column data fetched two intervals ago: panel it - 2 - (LAGL - PF - 1)
             {
@@ -562,8 +565,20 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             SW_STAMP(5);
         };
         int it = 0;
-        for (; it + 1 < total; it += 2) { interval(it, xgA, cvA); interval(it + 1, xgB, cvB); }
-        if (it < total) interval(it, xgA, cvA);
+        const int pre = min(LAGT & ~1, total & ~1);
+        for (; it < pre; it += 2) { interval(it, xgA, cvA, it < 2); interval(it + 1, xgB, cvB, it < 2); }
+        if (kupd) {
+            // in f64, in the order of the single-block sums elsewhere (per lane ascending, then the butterfly)
+            double dc = 0.0, db = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dc += (double)kc[j]; db += (double)kb[j]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { dc += __shfl_xor(dc, o, 64); db += __shfl_xor(db, o, 64); }
+            kappa = fminf(kappa + *a.skappa_p * ((float)dc + (float)db), 0.0f);
+            if (group == 0 && member == 0 && lane == 0) *a.kappa_out = kappa;
+        }
+        for (; it + 1 < total; it += 2) { interval(it, xgA, cvA, false); interval(it + 1, xgB, cvB, false); }
+        if (it < total) interval(it, xgA, cvA, false);
         // what the hand-off through the group's L2 costs in polls (a visibility stall would show here long before a time-out)
         if (polls_total != 0u && lane == 0) { atomicAdd(a.census + 18, polls_total); atomicMax(a.census + 19, polls_max); }
         if (a.pn != nullptr) {
