@@ -310,6 +310,15 @@ public:
     void set_column_shard(bool on) { chk(thip_solver_set_column_shard(h_, on ? 1 : 0)); }
     // the schedule the next run() executes: THIP_SCHED_CARRIED when THIP_SCHED_SWEEP cannot take the problem
     int schedule_in_use() { int v = 0; chk(thip_solver_schedule_in_use(h_, &v)); return v; }
+    // recoveries from a one-pass kernel that gave up (the run restored its snapshot and went on with the 2-pass schedule)
+    int sweep_faults(int *last_word = nullptr, int64_t *restored_iter = nullptr)
+    {
+        int k = 0, w = 0; int64_t it = -1;
+        chk(thip_solver_sweep_faults(h_, &k, &w, &it));
+        if (last_word) *last_word = w;
+        if (restored_iter) *restored_iter = it;
+        return k;
+    }
     thip_solver *handle() { return h_; }
     void init() { chk(thip_solver_init(h_)); inited_ = true; }
     // runs until termination (max_steps < 0) or for max_steps iterations; returns the reference's SolverError

@@ -127,6 +127,14 @@ impl FusedSolver {
         chk(unsafe { thip_solver_schedule_in_use(self.h, &mut v) });
         v
     }
+    /// recoveries from a one-pass kernel that gave up (thip_solver_sweep_faults): how many in this solve, the kernel's error
+    /// word of the last one, the iteration of the snapshot the run went back to (-1: none).  The answer of `solve` is valid
+    /// either way: the run restored its snapshot and went on with the 2-pass schedule.
+    pub fn sweep_faults(&mut self) -> (c_int, c_int, i64) {
+        let (mut k, mut w, mut it): (c_int, c_int, i64) = (0, 0, -1);
+        chk(unsafe { thip_solver_sweep_faults(self.h, &mut k, &mut w, &mut it) });
+        (k, w, it)
+    }
     /// runs to termination; Ok((x, y)) or the reference's SolverError (solver_error.rs:3-17)
     pub fn solve(&mut self) -> Result<(Vec<f32>, Vec<f32>), SolverError> {
         let mut st: thip_status = unsafe { std::mem::zeroed() };
