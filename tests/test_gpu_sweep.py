@@ -714,6 +714,38 @@ def test_stream_probe_reports_a_plausible_rate(T):
     buf.free()
 
 
+def test_cone_wave_m_kernel_is_the_three_launch_form(T):
+    """every row in a second-order cone of at most 129 rows (the shape of BASELINE configs[2]): the step's m-tail -- the
+    shares summed and x_y / x_s, the projection of both blocks, v and the sums over m -- is ONE launch, a wave per cone
+    (sw_cone_k).  Against the three-launch form (test hook), ragged cones incl. one without rows and one of 129"""
+    socp = _socp(T, 150, [15, 40, 0, 3, 66, 128, 1, 99], seed=23)
+    d = socp.dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    a = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    b = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    b.inject_sweep_fault(3)                    # three launches
+    for steps in (1, 1, 8, 90):
+        a.run(steps, poll_every=16)
+        b.run(steps, poll_every=16)
+        for u_, v_ in zip(a.iterate(), b.iterate()):
+            assert np.abs(u_ - v_).max() <= 2e-6 * max(np.abs(v_).max(), 1e-6)
+        assert np.allclose(a.status().cri, b.status().cri, rtol=1e-4, atol=1e-7)
+    a.destroy()
+    b.destroy()
+    # a cone of 130 rows is beyond a wave's two slots + head: the three-launch form by itself, same answer as the carried run
+    socp2 = _socp(T, 150, [15, 129, 40], seed=24)
+    d2 = socp2.dense()
+    f1 = T.FusedSolver.from_dense(d2, p, "sweep", sweep_min_bytes=0)
+    f2 = T.FusedSolver.from_dense(d2, p, "carried")
+    f1.run(40, poll_every=8)
+    f2.run(40, poll_every=8)
+    for u_, v_ in zip(f1.iterate(), f2.iterate()):
+        assert np.abs(u_ - v_).max() <= 2e-5 * max(np.abs(v_).max(), 1e-6)
+    f1.destroy()
+    f2.destroy()
+
+
 def test_merged_m_kernel_is_the_two_launch_form(T):
     """an LP has element-wise cones only: the step's two m-kernels (x_y / x_s and cones; v and the sums over m) run as ONE
     launch.  Every per-row value has the arithmetic of the two-launch form (what SOCPs / SDPs take); only the block

@@ -526,6 +526,128 @@ __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, 
     }
 }
 
+// the groups' shares of the two N products of row i, added in sw_xm_k's order (four interleaved lanes of two accumulators
+// each, then (l0 + l1) + (l2 + l3)): the same bits whichever kernel forms the row
+__device__ __forceinline__ void sw_sum_shares(const float *__restrict__ partH, size_t mpad, int ngroups, size_t i, float &hN, float &hx)
+{
+    float sa[4], sb[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+        float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
+        int g = kq;
+        for (; g + 28 < ngroups; g += 32) {
+            float t[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float *q = partH + (size_t)(g + 8 * j) * 2 * mpad + i;
+                t[4 * j] = q[0]; t[4 * j + 1] = q[mpad]; t[4 * j + 2] = q[8 * mpad]; t[4 * j + 3] = q[9 * mpad];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sa0 += t[4 * j]; sb0 += t[4 * j + 1]; sa1 += t[4 * j + 2]; sb1 += t[4 * j + 3]; }
+        }
+        for (; g + 4 < ngroups; g += 8) {
+            const float *q = partH + (size_t)g * 2 * mpad + i;
+            sa0 += q[0]; sb0 += q[mpad]; sa1 += q[8 * mpad]; sb1 += q[9 * mpad];
+        }
+        if (g < ngroups) { sa0 += partH[((size_t)g * 2 + 0) * mpad + i]; sb0 += partH[((size_t)g * 2 + 1) * mpad + i]; }
+        sa[kq] = sa0 + sa1; sb[kq] = sb0 + sb1;
+    }
+    hN = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    hx = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+}
+
+// Every row in a second-order cone of at most 129 rows (BASELINE configs[2]: 1000 cones of 100): the WHOLE m-tail of a step
+// as one launch, one wave per cone -- sw_xm_k's row (the shares summed, x_y / x_s), soc_k's projection of both blocks
+// (cone_soc.rs:38-65; the same lane <-> row mapping and f64 sum of squares), sw_vm_k's row (v, the sums over m).  Lane l holds
+// rows beg + 1 + l and beg + 65 + l, lane 0 also the cone's first row.  Every per-row value has the arithmetic of the
+// three-launch form; only the block partials of the four sums over m are grouped differently.
+__global__ __launch_bounds__(BLK) void sw_cone_k(int n_cones, const int64_t *__restrict__ begs, const int64_t *__restrict__ ends,
+                                                int ngroups, size_t mpad, const float *__restrict__ partH,
+                                                const float *__restrict__ b, float *__restrict__ v, const float *__restrict__ Ty,
+                                                const float *__restrict__ Ts, float *__restrict__ xy, float *__restrict__ xs,
+                                                float *__restrict__ rxy, float *__restrict__ rxs, DevStatus *st,
+                                                float *__restrict__ ky, float *__restrict__ ks, float *__restrict__ hP,
+                                                const float *__restrict__ Sv, float *__restrict__ kv, float eps_zero,
+                                                float *__restrict__ part)
+{
+    if (st->stop != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float kappa = st->kappa;
+    const float tau = st->tau_next, rtau = st->r_tau_next;
+    const bool conv = tau > eps_zero;
+    const float rt = conv ? 1.0f / tau : 1.0f;
+    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+    for (int cone = blockIdx.x * 4 + wave; cone < n_cones; cone += gridDim.x * 4) {
+        const int64_t beg = begs[cone], end = ends[cone];
+        if (end <= beg) continue;
+        // slot 0 / 1: rows beg + 1 + lane (+ 64); slot 2: the first row (lane 0)
+        size_t idx[3] = { (size_t)(beg + 1 + lane), (size_t)(beg + 65 + lane), (size_t)beg };
+        bool ok[3] = { beg + 1 + lane < end, beg + 65 + lane < end, lane == 0 };
+        float oy[3], os[3], ny[3], ns[3], hxs[3], bi[3], vi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            oy[k] = os[k] = ny[k] = ns[k] = hxs[k] = bi[k] = vi[k] = 0.0f;
+            if (!ok[k]) continue;
+            const size_t i = idx[k];
+            float hN, hx;
+            sw_sum_shares(partH, mpad, ngroups, i, hN, hx);
+            hxs[k] = hx;
+            oy[k] = xy[i]; os[k] = xs[i]; bi[k] = b[i]; vi[k] = v[i];
+            ny[k] = comp_add(oy[k], Ty[i] * (bi[k] * kappa - hN), ky, i);
+            ns[k] = comp_add(os[k], Ts[i] * vi[k], ks, i);
+        }
+        // the projection of the x_y block and of the x_s block (soc_k, not rotated)
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float *x = which ? ns : ny;
+            const float s0 = __shfl(x[2], 0, 64);
+            double acc = 0.0;
+            if (ok[0]) acc += (double)x[0] * (double)x[0];
+            if (ok[1]) acc += (double)x[1] * (double)x[1];
+            const float norm_v = (float)sqrt(wave_sum_d(acc));
+            float f, s_new;
+            if (norm_v <= -s0) { f = 0.0f; s_new = 0.0f; }
+            else if (norm_v <= s0) { f = 1.0f; s_new = s0; }
+            else { f = (1.0f + s0 / norm_v) / 2.0f; s_new = (norm_v + s0) / 2.0f; }
+            x[2] = s_new;
+            if (f != 1.0f) { x[0] = f * x[0]; x[1] = f * x[1]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!ok[k]) continue;
+            const size_t i = idx[k];
+            xy[i] = ny[k];
+            xs[i] = ns[k];
+            const float ry = oy[k] - 2.0f * ny[k], rs = os[k] - 2.0f * ns[k];
+            rxy[i] = ry;
+            rxs[i] = rs;
+            const float hx = hxs[k];
+            const float h2 = hP[i] - 2.0f * hx;
+            hP[i] = hx;
+            const float vn = comp_add(vi[k], Sv[i] * (h2 + rs - bi[k] * rtau), kv, i);
+            v[i] = vn;
+            q0 = fmaf(bi[k], vn, q0);
+            q1 = fmaf(bi[k], ry, q1);
+            float p;
+            if (conv) { p = ns[k] * rt - bi[k]; p = fmaf(rt, hx, p); }
+            else p = ns[k] + hx;
+            q2 = fmaf(p, p, q2);
+            q3 = fmaf(bi[k], ny[k], q3);
+        }
+    }
+    __shared__ float sh[16];
+    q0 = block_sum(q0, sh); q1 = block_sum(q1, sh); q2 = block_sum(q2, sh); q3 = block_sum(q3, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = q0; part[gridDim.x + blockIdx.x] = q1;
+        part[2 * gridDim.x + blockIdx.x] = q2; part[3 * gridDim.x + blockIdx.x] = q3;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->tau = tau;
+        st->r_tau = rtau;
+        st->kappa_in = kappa;
+    }
+}
+
 // (re)start of the one-pass schedule: the tau update a regular step takes from the previous termination test
 __global__ __launch_bounds__(BLK) void sw_tau_k(DevStatus *st, const float *ps_cu, int np_cu, const float *ps_bv, int np_bv)
 {
@@ -891,6 +1013,7 @@ struct thip_solver {
     bool col_shard = false;
     float *cs_buf = nullptr; size_t cs_n = 0;
     size_t sweep_min_bytes = (size_t)128 << 20;     // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
+    bool all_soc_short = false;   // every row belongs to a plain second-order cone of <= 129 rows (sw_cone_k)
     bool no_merge = false;        // thip_test_sweep_fault(kind 3): the two m-kernels of a step as two launches also without block cones
     int pn_par = 0;               // which of the two buffers of sums over n (sw_part + par * 2 EG) the LAST sweep wrote
     int pub_agent = 0;            // thip_solver_set_sweep_publish
@@ -1669,8 +1792,11 @@ int one_iteration_sweep(thip_solver *s)
     };
     // no block cones (an LP: zero / nonneg rows only): the two m-kernels of a step are one launch
     const bool merge = s->n_soc == 0 && s->n_rot == 0 && s->psd.empty() && !s->no_merge;
+    // every row in a (plain) second-order cone of at most 129 rows: the three m-launches of a step are one, a wave per cone
+    const bool cone_merge = !merge && !s->no_merge && s->all_soc_short;
     const unsigned gx = merge ? grid_for(s->m, 64, EG) : grid_for(s->m, 64, 4096);      // (merged: its block partials fill gm slots)
-    const unsigned gmm = merge ? gx : gm;           // block partials per sum over m
+    const unsigned gc = grid_for(s->n_soc, 4, EG);
+    const unsigned gmm = merge ? gx : (cone_merge ? gc : gm);           // block partials per sum over m
     if (s->sw_first) {
         // from a consistent iterate (x_0, or wherever a run stopped): u is current, so the sweep leaves it alone
         THIP_RC(sweep_pass(s, 1, (int)gmm));
@@ -1682,6 +1808,10 @@ int one_iteration_sweep(thip_solver *s)
     if (merge) {
         hipLaunchKernelGGL(sw_xm_k<true>, dim3(gx), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
                            cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
+                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm);
+    } else if (cone_merge) {
+        hipLaunchKernelGGL(sw_cone_k, dim3(gc), dim3(BLK), 0, st, (int)s->n_soc, s->soc_beg, s->soc_end, cols ? 1 : s->sgeom.ngroups,
+                           s->sgeom.mpad, cols ? s->cs_buf : s->sw_partH, s->b, s->v, s->Ty, s->Ts, s->xy, s->xs, s->rxy, s->rxs,
                            s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm);
     } else {
         hipLaunchKernelGGL(sw_xm_k<false>, dim3(gx), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
@@ -1896,6 +2026,11 @@ static int solver_create_impl(const thip_problem *prob, const thip_param *par, i
         off += l;
     }
     s->n_soc = sb.size(); s->n_rot = rb.size(); s->n_grp = gb.size();
+    {
+        int64_t soc_rows = 0;
+        for (size_t i = 0; i < sb.size(); ++i) soc_rows += se[i] - sb[i];
+        s->all_soc_short = m > 0 && !sb.empty() && rb.empty() && (size_t)soc_rows == m && s->soc_max <= 129;
+    }
     auto up64 = [&](const std::vector<int64_t> &h, int64_t **d) -> int {
         *d = nullptr;
         if (h.empty()) return 0;
