@@ -526,41 +526,12 @@ __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, 
     }
 }
 
-// the groups' shares of the two N products of row i, added in sw_xm_k's order (four interleaved lanes of two accumulators
-// each, then (l0 + l1) + (l2 + l3)): the same bits whichever kernel forms the row
-__device__ __forceinline__ void sw_sum_shares(const float *__restrict__ partH, size_t mpad, int ngroups, size_t i, float &hN, float &hx)
-{
-    float sa[4], sb[4];
-#pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-        float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
-        int g = kq;
-        for (; g + 28 < ngroups; g += 32) {
-            float t[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float *q = partH + (size_t)(g + 8 * j) * 2 * mpad + i;
-                t[4 * j] = q[0]; t[4 * j + 1] = q[mpad]; t[4 * j + 2] = q[8 * mpad]; t[4 * j + 3] = q[9 * mpad];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { sa0 += t[4 * j]; sb0 += t[4 * j + 1]; sa1 += t[4 * j + 2]; sb1 += t[4 * j + 3]; }
-        }
-        for (; g + 4 < ngroups; g += 8) {
-            const float *q = partH + (size_t)g * 2 * mpad + i;
-            sa0 += q[0]; sb0 += q[mpad]; sa1 += q[8 * mpad]; sb1 += q[9 * mpad];
-        }
-        if (g < ngroups) { sa0 += partH[((size_t)g * 2 + 0) * mpad + i]; sb0 += partH[((size_t)g * 2 + 1) * mpad + i]; }
-        sa[kq] = sa0 + sa1; sb[kq] = sb0 + sb1;
-    }
-    hN = (sa[0] + sa[1]) + (sa[2] + sa[3]);
-    hx = (sb[0] + sb[1]) + (sb[2] + sb[3]);
-}
-
 // Every row in a second-order cone of at most 129 rows (BASELINE configs[2]: 1000 cones of 100): the WHOLE m-tail of a step
-// as one launch, one wave per cone -- sw_xm_k's row (the shares summed, x_y / x_s), soc_k's projection of both blocks
-// (cone_soc.rs:38-65; the same lane <-> row mapping and f64 sum of squares), sw_vm_k's row (v, the sums over m).  Lane l holds
-// rows beg + 1 + l and beg + 65 + l, lane 0 also the cone's first row.  Every per-row value has the arithmetic of the
-// three-launch form; only the block partials of the four sums over m are grouped differently.
+// as one launch, one workgroup per cone (looping when there are more than EG cones) -- sw_xm_k's row: the groups' shares
+// summed by four lanes per row exactly as there, x_y / x_s; then on the workgroup's first wave soc_k's projection of both
+// blocks (cone_soc.rs:38-65; the same lane <-> row mapping and f64 sum of squares) and sw_vm_k's row (v, the sums over m).
+// Lane l of that wave holds rows beg + 1 + l and beg + 65 + l, lane 0 also the cone's first row.  Every per-row value has
+// the arithmetic of the three-launch form; only the block partials of the four sums over m are grouped differently.
 __global__ __launch_bounds__(BLK) void sw_cone_k(int n_cones, const int64_t *__restrict__ begs, const int64_t *__restrict__ ends,
                                                 int ngroups, size_t mpad, const float *__restrict__ partH,
                                                 const float *__restrict__ b, float *__restrict__ v, const float *__restrict__ Ty,
@@ -571,30 +542,72 @@ __global__ __launch_bounds__(BLK) void sw_cone_k(int n_cones, const int64_t *__r
                                                 float *__restrict__ part)
 {
     if (st->stop != 0) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const float kappa = st->kappa;
     const float tau = st->tau_next, rtau = st->r_tau_next;
     const bool conv = tau > eps_zero;
     const float rt = conv ? 1.0f / tau : 1.0f;
+    __shared__ float comb[3][2][3][64];           // [row slot][product][lane quarter - 1][row lane]
     float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
-    for (int cone = blockIdx.x * 4 + wave; cone < n_cones; cone += gridDim.x * 4) {
+    for (int cone = blockIdx.x; cone < n_cones; cone += gridDim.x) {
         const int64_t beg = begs[cone], end = ends[cone];
-        if (end <= beg) continue;
-        // slot 0 / 1: rows beg + 1 + lane (+ 64); slot 2: the first row (lane 0)
-        size_t idx[3] = { (size_t)(beg + 1 + lane), (size_t)(beg + 65 + lane), (size_t)beg };
-        bool ok[3] = { beg + 1 + lane < end, beg + 65 + lane < end, lane == 0 };
-        float oy[3], os[3], ny[3], ns[3], hxs[3], bi[3], vi[3];
+        if (end <= beg) continue;                  // (uniform over the workgroup)
+        // slot 0 / 1: rows beg + 1 + e (+ 64); slot 2: the first row (lane 0)
+        const size_t idx[3] = { (size_t)(beg + 1 + e), (size_t)(beg + 65 + e), (size_t)beg };
+        const bool ok[3] = { beg + 1 + e < end, beg + 65 + e < end, e == 0 };
+        // the first wave's row data: requested before the shares, used after the barrier (one round trip for everything)
+        float oy[3], os[3], bi[3], vi[3], tyv[3], tsv[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            oy[k] = os[k] = ny[k] = ns[k] = hxs[k] = bi[k] = vi[k] = 0.0f;
+            oy[k] = os[k] = bi[k] = vi[k] = tyv[k] = tsv[k] = 0.0f;
+            if (kq == 0 && ok[k]) { const size_t i = idx[k]; oy[k] = xy[i]; os[k] = xs[i]; bi[k] = b[i]; vi[k] = v[i]; tyv[k] = Ty[i]; tsv[k] = Ts[i]; }
+        }
+        float sas[3], sbs[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            // the shares of row idx[k]: this thread's quarter of the groups, in sw_xm_k's order
+            float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
+            if (ok[k]) {
+                const size_t i = idx[k];
+                int g = kq;
+                for (; g + 28 < ngroups; g += 32) {
+                    float t[16];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float *q = partH + (size_t)(g + 8 * j) * 2 * mpad + i;
+                        t[4 * j] = q[0]; t[4 * j + 1] = q[mpad]; t[4 * j + 2] = q[8 * mpad]; t[4 * j + 3] = q[9 * mpad];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { sa0 += t[4 * j]; sb0 += t[4 * j + 1]; sa1 += t[4 * j + 2]; sb1 += t[4 * j + 3]; }
+                }
+                for (; g + 4 < ngroups; g += 8) {
+                    const float *q = partH + (size_t)g * 2 * mpad + i;
+                    sa0 += q[0]; sb0 += q[mpad]; sa1 += q[8 * mpad]; sb1 += q[9 * mpad];
+                }
+                if (g < ngroups) { sa0 += partH[((size_t)g * 2 + 0) * mpad + i]; sb0 += partH[((size_t)g * 2 + 1) * mpad + i]; }
+            }
+            sas[k] = sa0 + sa1; sbs[k] = sb0 + sb1;
+            if (kq > 0) { comb[k][0][kq - 1][e] = sas[k]; comb[k][1][kq - 1][e] = sbs[k]; }
+        }
+        __syncthreads();
+        float hNs[3] = { 0.0f, 0.0f, 0.0f }, hxs[3] = { 0.0f, 0.0f, 0.0f };
+        if (kq == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                hNs[k] = (sas[k] + comb[k][0][0][e]) + (comb[k][0][1][e] + comb[k][0][2][e]);
+                hxs[k] = (sbs[k] + comb[k][1][0][e]) + (comb[k][1][1][e] + comb[k][1][2][e]);
+            }
+        }
+        __syncthreads();                           // (the next cone's shares may overwrite comb)
+        if (kq != 0) continue;                     // the cone itself is the first wave's (no barrier below)
+        float ny[3], ns[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ny[k] = ns[k] = 0.0f;
             if (!ok[k]) continue;
             const size_t i = idx[k];
-            float hN, hx;
-            sw_sum_shares(partH, mpad, ngroups, i, hN, hx);
-            hxs[k] = hx;
-            oy[k] = xy[i]; os[k] = xs[i]; bi[k] = b[i]; vi[k] = v[i];
-            ny[k] = comp_add(oy[k], Ty[i] * (bi[k] * kappa - hN), ky, i);
-            ns[k] = comp_add(os[k], Ts[i] * vi[k], ks, i);
+            ny[k] = comp_add(oy[k], tyv[k] * (bi[k] * kappa - hNs[k]), ky, i);
+            ns[k] = comp_add(os[k], tsv[k] * vi[k], ks, i);
         }
         // the projection of the x_y block and of the x_s block (soc_k, not rotated)
 #pragma unroll
@@ -635,16 +648,17 @@ __global__ __launch_bounds__(BLK) void sw_cone_k(int n_cones, const int64_t *__r
             q3 = fmaf(bi[k], ny[k], q3);
         }
     }
-    __shared__ float sh[16];
-    q0 = block_sum(q0, sh); q1 = block_sum(q1, sh); q2 = block_sum(q2, sh); q3 = block_sum(q3, sh);
-    if (threadIdx.x == 0) {
-        part[blockIdx.x] = q0; part[gridDim.x + blockIdx.x] = q1;
-        part[2 * gridDim.x + blockIdx.x] = q2; part[3 * gridDim.x + blockIdx.x] = q3;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->tau = tau;
-        st->r_tau = rtau;
-        st->kappa_in = kappa;
+    if (kq == 0) {
+        q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2); q3 = wave_sum(q3);
+        if (e == 0) {
+            part[blockIdx.x] = q0; part[gridDim.x + blockIdx.x] = q1;
+            part[2 * gridDim.x + blockIdx.x] = q2; part[3 * gridDim.x + blockIdx.x] = q3;
+            if (blockIdx.x == 0) {
+                st->tau = tau;
+                st->r_tau = rtau;
+                st->kappa_in = kappa;
+            }
+        }
     }
 }
 
@@ -1795,7 +1809,7 @@ int one_iteration_sweep(thip_solver *s)
     // every row in a (plain) second-order cone of at most 129 rows: the three m-launches of a step are one, a wave per cone
     const bool cone_merge = !merge && !s->no_merge && s->all_soc_short;
     const unsigned gx = merge ? grid_for(s->m, 64, EG) : grid_for(s->m, 64, 4096);      // (merged: its block partials fill gm slots)
-    const unsigned gc = grid_for(s->n_soc, 4, EG);
+    const unsigned gc = grid_for(s->n_soc, 1, EG);       // a workgroup per cone
     const unsigned gmm = merge ? gx : (cone_merge ? gc : gm);           // block partials per sum over m
     if (s->sw_first) {
         // from a consistent iterate (x_0, or wherever a run stopped): u is current, so the sweep leaves it alone
