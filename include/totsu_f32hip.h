@@ -407,7 +407,9 @@ int thip_solver_sweep_faults(thip_solver *s, int *host_faults, int *host_last_wo
  * workgroup of the after_sweeps-th regular sweep from now withholds its partial dots; spin_max > 0 shortens the
  * bound of the gathers' polling loops (default ~2 s) so that a test does not wait for it.  kind 0 clears.
  * kind 3 / 4 (no fault): run the two m-kernels of a step as two launches also where the cones are all element-wise
- * (the form problems with block cones always take) / merged again -- lets a test compare the two forms. */
+ * (the form problems with block cones always take) / merged again -- lets a test compare the two forms.
+ * kind 5 / 6 (no fault): launch the termination test after every sweep / fold it into the next step's m-kernel again
+ * (the default where the m-tail is one of the merged forms: it is launched only when the host is about to look). */
 int thip_test_sweep_fault(thip_solver *s, int kind, int64_t after_sweeps, int spin_max);
 /* partial dots published with agent-scope (sc1) stores (1) or with plain stores that stay in the group's L2 (0, default);
  * between thip_solver_run calls */

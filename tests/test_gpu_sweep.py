@@ -850,3 +850,38 @@ def test_column_shard_exposes_its_one_collective_once_per_iteration(T):
     inst.free()
     for L in (30, 60):
         assert 0.6 * L <= t[L] - t[0] <= L + 10, t
+
+
+@pytest.mark.parametrize("kind", ["lp", "socp"])
+def test_folded_termination_test_is_the_launch_of_its_own(T, kind):
+    """with a merged m-tail the termination test of iterate k has no launch of its own inside a polling batch: every block of
+    the next step's m-kernel evaluates it at its head (same sums, same arithmetic).  Against the form that launches status_k
+    every iteration (test hook 5): bitwise the same iterates, the same stop iteration for convergence and for max_iter in the
+    middle of a batch, the same returned iterate"""
+    d = (_lp(T, 150, 7)[0] if kind == "lp" else _socp(T, 120, [15, 40, 3, 66], seed=9)).dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    a = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    b = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    b.inject_sweep_fault(5)                    # status_k every iteration
+    for steps, poll in ((1, 1), (7, 7), (50, 16), (33, 100)):
+        ra = a.run(steps, poll_every=poll)
+        rb = b.run(steps, poll_every=poll)
+        assert ra.iters == rb.iters and ra.cri == rb.cri and ra.tau == rb.tau and ra.kappa == rb.kappa
+        assert all(np.array_equal(u_, v_) for u_, v_ in zip(a.iterate(), b.iterate()))
+    a.destroy()
+    b.destroy()
+    # a stop decided by the folded head: max_iter inside a batch, and convergence
+    for par in (dict(max_iter=57, eps_acc=1e-30), dict(max_iter=400_000, eps_acc=1e-3)):
+        res = []
+        for hook in (None, 5):
+            q = T.SolverParam()
+            q.max_iter, q.eps_acc = par["max_iter"], par["eps_acc"]
+            f = T.FusedSolver.from_dense(d, q, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+            if hook:
+                f.inject_sweep_fault(hook)
+            r = f.run(-1, poll_every=100)
+            res.append((r.state, r.iters, r.cri, f.iterate()))
+            f.destroy()
+        assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][2] == res[1][2], (res[0][:3], res[1][:3])
+        assert all(np.array_equal(u_, v_) for u_, v_ in zip(res[0][3], res[1][3]))

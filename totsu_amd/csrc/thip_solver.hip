@@ -52,6 +52,9 @@ struct DevStatus {
     float     kappa_in;          // sweep schedule: kappa_{k-1} as sw_vm_k left it for the sweep that forms kappa_k
     float     tau_next, r_tau_next;   // sweep schedule: tau_{k+1} and rx_tau as the termination test of iterate k left them for the
                                  // next step's m-kernel (which commits them): no block of that kernel reads what another writes
+    float     tau_r[2]; long long iter_r[2];   // sweep schedule with the termination test folded into the next step's m-kernel: tau
+                                 // and the iteration index in two copies by step parity -- every block of that kernel reads one
+                                 // copy, its block 0 writes the other (and tau / iter themselves, which no block of it reads)
     int       fault;             // column-sharded sweep: some rank's one-pass kernel gave up (seen by every rank in the same
                                  // all-reduce, thip_solver_run restores the snapshot on all of them together)
 };
@@ -337,33 +340,34 @@ __global__ __launch_bounds__(BLK) void ycrit_k(int n, int m, int doy, int carrie
 }
 
 // the termination test, solver.rs:381-451 + the tails of criteria_conv / criteria_inf (solver.rs:599-611,
-// 636-655).  One block: sums the np block partials of ||d||^2 and c.x_x, then thread 0 decides.
-// ps_pp / ps_by: post_k's block partials of ||p||^2 and b.x_y (all-reduced block partials when sharded).
-__global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict__ part,
-                                               float eps_acc, float eps_inf, float eps_zero, long long max_iter,
-                                               DevStatus *st, const float *ps_pp, const float *ps_by, int npsum, int xbuf,
-                                               const float *fault_flag, const float *ps_cu = nullptr, int np_cu = 0,
-                                               const float *ps_bv = nullptr, int np_bv = 0)
+// 636-655).  status_eval is run by a whole block of 256 threads: six sums of block partials (f64 accumulation), each by ONE
+// wave, two per wave, all loads in flight together and one barrier; every thread then holds the verdict.  status_k -- one
+// block -- commits it; the merged m-kernels of the one-pass schedule evaluate it at their head in EVERY block (same inputs,
+// same arithmetic, same verdict) so that the test of iterate k needs no launch of its own between sweep k and step k + 1.
+struct StatArgs {
+    int np; const float *part;                       // sums over n: ||d||^2 = part[0 .. np), c.x_x = part[np .. 2 np)
+    const float *ps_pp, *ps_by; int npsum;           // sums over m: ||p||^2, b.x_y (post_k's / the m-kernel's block partials)
+    const float *ps_cu; int np_cu; const float *ps_bv; int np_bv;      // sweep schedule: c.u, b.v -> the next tau; else NULL
+    const float *fault_flag;                         // column-sharded sweep: the all-reduced "a kernel gave up" flag, else NULL
+    float eps_acc, eps_inf, eps_zero; long long max_iter; int xbuf;
+};
+struct StatOut { int state, kind; float cri[3]; float tau_next, r_tau_next; };      // state: THIP_ST_*, or -2: a peer's fault
+
+__device__ __forceinline__ StatOut status_eval(const StatArgs &a, float tau, long long i, float norm_b, float norm_c, float t_tau,
+                                               double *sums /* 8 doubles of LDS */)
 {
-    if (st->stop != 0) return;
-    if (fault_flag != nullptr && *fault_flag > 0.0f) {
-        // column-sharded: the sum over ranks of "my one-pass kernel gave up" came back non-zero -- on every rank, in this
-        // iteration: nothing after this sweep is to be trusted; stop here (state stays RUNNING) and let the host restore
-        if (threadIdx.x == 0) { st->fault = 1; st->stop = 1; }
-        return;
-    }
-    // six sums of block partials (f64 accumulation), each by ONE wave, two per wave, all loads in flight together and one
-    // barrier -- done one after the other by the whole block (round 3) this launch took 7 us, a tenth of it arithmetic
-    __shared__ double sums[8];
+    StatOut o;
+    o.state = THIP_ST_RUNNING; o.kind = 0; o.cri[0] = o.cri[1] = o.cri[2] = 0.0f; o.tau_next = tau; o.r_tau_next = 0.0f;
+    if (a.fault_flag != nullptr && *a.fault_flag > 0.0f) { o.state = -2; return o; }      // (uniform: every thread reads the same word)
     {
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         const float *src[2] = { nullptr, nullptr };
         int cnt[2] = { 0, 0 };
         switch (w) {
-        case 0: src[0] = ps_pp; cnt[0] = npsum; src[1] = ps_cu; cnt[1] = ps_cu ? np_cu : 0; break;
-        case 1: src[0] = ps_by; cnt[0] = npsum; src[1] = ps_bv; cnt[1] = ps_bv ? np_bv : 0; break;
-        case 2: src[0] = part; cnt[0] = np; break;
-        default: src[0] = part + np; cnt[0] = np; break;
+        case 0: src[0] = a.ps_pp; cnt[0] = a.npsum; src[1] = a.ps_cu; cnt[1] = a.ps_cu ? a.np_cu : 0; break;
+        case 1: src[0] = a.ps_by; cnt[0] = a.npsum; src[1] = a.ps_bv; cnt[1] = a.ps_bv ? a.np_bv : 0; break;
+        case 2: src[0] = a.part; cnt[0] = a.np; break;
+        default: src[0] = a.part + a.np; cnt[0] = a.np; break;
         }
         double acc[2] = { 0.0, 0.0 };
 #pragma unroll
@@ -375,47 +379,64 @@ __global__ __launch_bounds__(BLK) void status_k(int np, const float *__restrict_
     }
     __syncthreads();
     const float pp = (float)sums[0], by = (float)sums[1];
-    const double a0 = sums[2], a1 = sums[3];
+    const float dd = (float)sums[2], cx = (float)sums[3];
     const float dcu = (float)sums[4], dbv = (float)sums[5];
-    if (threadIdx.x != 0) return;
-    const float dd = (float)a0, cx = (float)a1;
-    const long long i = st->iter;
-    const bool excess_iter = (max_iter >= 0) ? (i + 1 >= max_iter) : false;
-    const float tau = st->tau;
+    const bool excess_iter = (a.max_iter >= 0) ? (i + 1 >= a.max_iter) : false;
     const float norm_p = sqrtf(pp), norm_d = sqrtf(dd);
     int state = THIP_ST_RUNNING;
-    if (tau > eps_zero) {
+    if (tau > a.eps_zero) {
         const float rt = 1.0f / tau;
         const float g_x = rt * cx;
         const float g_y = rt * by;
         const float g = g_x + g_y;
-        const float cri_pri = norm_p / (1.0f + st->norm_b);
-        const float cri_dual = norm_d / (1.0f + st->norm_c);
+        const float cri_pri = norm_p / (1.0f + norm_b);
+        const float cri_dual = norm_d / (1.0f + norm_c);
         const float cri_gap = fabsf(g) / (1.0f + fabsf(g_x) + fabsf(g_y));
-        st->kind = 0; st->cri[0] = cri_pri; st->cri[1] = cri_dual; st->cri[2] = cri_gap;
-        const bool term_conv = (cri_pri <= eps_acc) && (cri_dual <= eps_acc) && (cri_gap <= eps_acc);
+        o.kind = 0; o.cri[0] = cri_pri; o.cri[1] = cri_dual; o.cri[2] = cri_gap;
+        const bool term_conv = (cri_pri <= a.eps_acc) && (cri_dual <= a.eps_acc) && (cri_gap <= a.eps_acc);
         if (term_conv) state = THIP_ST_OK;
         else if (excess_iter) state = THIP_ST_EXCESS_ITER;
     } else {
         const float m_cx = -cx;
         const float m_by = -by;
-        const float cri_unbdd = (m_cx > eps_zero) ? norm_p * st->norm_c / m_cx : __builtin_inff();
-        const float cri_infeas = (m_by > eps_zero) ? norm_d * st->norm_b / m_by : __builtin_inff();
-        st->kind = 1; st->cri[0] = cri_unbdd; st->cri[1] = cri_infeas; st->cri[2] = 0.0f;
-        const bool term_unbdd = cri_unbdd <= eps_inf, term_infeas = cri_infeas <= eps_inf;
+        const float cri_unbdd = (m_cx > a.eps_zero) ? norm_p * norm_c / m_cx : __builtin_inff();
+        const float cri_infeas = (m_by > a.eps_zero) ? norm_d * norm_b / m_by : __builtin_inff();
+        o.kind = 1; o.cri[0] = cri_unbdd; o.cri[1] = cri_infeas; o.cri[2] = 0.0f;
+        const bool term_unbdd = cri_unbdd <= a.eps_inf, term_infeas = cri_infeas <= a.eps_inf;
         if (term_unbdd) state = THIP_ST_UNBOUNDED;
         else if (term_infeas) state = THIP_ST_INFEASIBLE;
         else if (excess_iter) state = THIP_ST_EXCESS_ITER;
     }
-    if (state == THIP_ST_RUNNING) {
-        st->iter = i + 1;
-        if (ps_cu != nullptr) {
-            const float t = fmaxf(tau + st->t_tau * (-dcu - dbv), 0.0f);
-            st->tau_next = t;
-            st->r_tau_next = tau - 2.0f * t;
-        }
+    o.state = state;
+    if (state == THIP_ST_RUNNING && a.ps_cu != nullptr) {
+        // sweep schedule: c.u_k and b.v_k are complete here too -- the tau update of the NEXT step (solver.rs:551-552)
+        const float t = fmaxf(tau + t_tau * (-dcu - dbv), 0.0f);
+        o.tau_next = t;
+        o.r_tau_next = tau - 2.0f * t;
     }
-    else { st->state = state; st->xbuf = xbuf; st->stop = 1; }     // one block, last kernel of the iteration: later launches are no-ops
+    return o;
+}
+
+// what ONE thread writes for a verdict that ends the loop (or for a peer's fault); a RUNNING verdict is committed by its
+// caller (status_k here; the m-kernels at their end)
+__device__ __forceinline__ void status_commit_stop(DevStatus *st, const StatOut &o, int xbuf)
+{
+    if (o.state == -2) { st->fault = 1; st->stop = 1; return; }
+    st->kind = o.kind; st->cri[0] = o.cri[0]; st->cri[1] = o.cri[1]; st->cri[2] = o.cri[2];
+    st->state = o.state; st->xbuf = xbuf; st->stop = 1;      // later launches are no-ops
+}
+
+__global__ __launch_bounds__(BLK) void status_k(const StatArgs a, DevStatus *st)
+{
+    if (st->stop != 0) return;
+    __shared__ double sums[8];
+    const long long i = st->iter;
+    const StatOut o = status_eval(a, st->tau, i, st->norm_b, st->norm_c, st->t_tau, sums);
+    if (threadIdx.x != 0) return;
+    if (o.state != THIP_ST_RUNNING) { status_commit_stop(st, o, a.xbuf); return; }
+    st->kind = o.kind; st->cri[0] = o.cri[0]; st->cri[1] = o.cri[1]; st->cri[2] = o.cri[2];
+    st->iter = i + 1;
+    if (a.ps_cu != nullptr) { st->tau_next = o.tau_next; st->r_tau_next = o.r_tau_next; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -439,11 +460,27 @@ __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, 
                                               float *__restrict__ xy, float *__restrict__ xs, float *__restrict__ rxy,
                                               float *__restrict__ rxs, DevStatus *st, float *__restrict__ ky, float *__restrict__ ks,
                                               float *__restrict__ hP, const float *__restrict__ Sv, float *__restrict__ kv,
-                                              float eps_zero, float *__restrict__ part)
+                                              float eps_zero, float *__restrict__ part, const StatArgs sa, int fold, int par)
 {
     if (st->stop != 0) return;
+    // fold != 0 (MERGE only): the termination test of the PREVIOUS iterate has had no launch of its own -- every block
+    // evaluates it here, from the same sums, before anything is written; a verdict that ends the loop leaves the iterate alone
+    float tau, rtau;
+    StatOut so;
+    long long it0 = 0;
+    if (MERGE && fold) {
+        __shared__ double ssum[8];
+        it0 = st->iter_r[par];
+        so = status_eval(sa, st->tau_r[par], it0, st->norm_b, st->norm_c, st->t_tau, ssum);
+        if (so.state != THIP_ST_RUNNING) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) status_commit_stop(st, so, sa.xbuf);
+            return;
+        }
+        tau = so.tau_next; rtau = so.r_tau_next;
+    } else {
+        tau = st->tau_next; rtau = st->r_tau_next;      // tau_k, rx_tau as status_k / sw_tau_k left them (read-only here)
+    }
     const float kappa = st->kappa;
-    const float tau = st->tau_next, rtau = st->r_tau_next;       // tau_k, rx_tau (read-only here: block 0 commits them at its end)
     const bool conv = tau > eps_zero;
     const float rt = conv ? 1.0f / tau : 1.0f;
     float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
@@ -522,7 +559,16 @@ __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->tau = tau;
         st->r_tau = rtau;
-        if (MERGE) st->kappa_in = kappa;          // nobody writes kappa between here and the sweep
+        if (MERGE) {
+            st->kappa_in = kappa;          // nobody writes kappa between here and the sweep
+            st->tau_r[par ^ 1] = tau;
+            if (fold) {
+                st->kind = so.kind; st->cri[0] = so.cri[0]; st->cri[1] = so.cri[1]; st->cri[2] = so.cri[2];
+                st->iter = it0 + 1; st->iter_r[par ^ 1] = it0 + 1;
+            } else {
+                st->iter_r[par ^ 1] = st->iter;
+            }
+        }
     }
 }
 
@@ -539,12 +585,26 @@ __global__ __launch_bounds__(BLK) void sw_cone_k(int n_cones, const int64_t *__r
                                                 float *__restrict__ rxy, float *__restrict__ rxs, DevStatus *st,
                                                 float *__restrict__ ky, float *__restrict__ ks, float *__restrict__ hP,
                                                 const float *__restrict__ Sv, float *__restrict__ kv, float eps_zero,
-                                                float *__restrict__ part)
+                                                float *__restrict__ part, const StatArgs sa, int fold, int par)
 {
     if (st->stop != 0) return;
     const int e = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    float tau, rtau;                               // (the folded termination test: see sw_xm_k)
+    StatOut so;
+    long long it0 = 0;
+    if (fold) {
+        __shared__ double ssum[8];
+        it0 = st->iter_r[par];
+        so = status_eval(sa, st->tau_r[par], it0, st->norm_b, st->norm_c, st->t_tau, ssum);
+        if (so.state != THIP_ST_RUNNING) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) status_commit_stop(st, so, sa.xbuf);
+            return;
+        }
+        tau = so.tau_next; rtau = so.r_tau_next;
+    } else {
+        tau = st->tau_next; rtau = st->r_tau_next;
+    }
     const float kappa = st->kappa;
-    const float tau = st->tau_next, rtau = st->r_tau_next;
     const bool conv = tau > eps_zero;
     const float rt = conv ? 1.0f / tau : 1.0f;
     __shared__ float comb[3][2][3][64];           // [row slot][product][lane quarter - 1][row lane]
@@ -657,6 +717,13 @@ __global__ __launch_bounds__(BLK) void sw_cone_k(int n_cones, const int64_t *__r
                 st->tau = tau;
                 st->r_tau = rtau;
                 st->kappa_in = kappa;
+                st->tau_r[par ^ 1] = tau;
+                if (fold) {
+                    st->kind = so.kind; st->cri[0] = so.cri[0]; st->cri[1] = so.cri[1]; st->cri[2] = so.cri[2];
+                    st->iter = it0 + 1; st->iter_r[par ^ 1] = it0 + 1;
+                } else {
+                    st->iter_r[par ^ 1] = st->iter;
+                }
             }
         }
     }
@@ -1028,6 +1095,10 @@ struct thip_solver {
     float *cs_buf = nullptr; size_t cs_n = 0;
     size_t sweep_min_bytes = (size_t)128 << 20;     // thip_solver_set_sweep_min_bytes: smaller matrices run the carried schedule
     bool all_soc_short = false;   // every row belongs to a plain second-order cone of <= 129 rows (sw_cone_k)
+    bool no_fold = false;         // thip_test_sweep_fault(kind 5): the termination test as a launch of its own in every iteration
+    bool status_pending = false;  // the last enqueued iteration's termination test has not been evaluated yet (the next m-kernel's head does)
+    int step_par = 0;             // parity of the tau / iter copies the next m-kernel reads
+    int pm_par = 0;               // which of the two buffers of sums over m (sw_part + (4 + 4 par) EG) holds the latest
     bool no_merge = false;        // thip_test_sweep_fault(kind 3): the two m-kernels of a step as two launches also without block cones
     int pn_par = 0;               // which of the two buffers of sums over n (sw_part + par * 2 EG) the LAST sweep wrote
     int pub_agent = 0;            // thip_solver_set_sweep_publish
@@ -1273,8 +1344,11 @@ int one_iteration(thip_solver *s)
     THIP_RC(allreduce_begin(s, s->g3, arcount));
     if (split && carried) { ycrit(0, 1); THIP_RC(allreduce_end(s)); ycrit(1, 0); }
     else                  { THIP_RC(allreduce_end(s)); ycrit(1, 1); }
-    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, (int)g, part_y, s->par.eps_acc, s->par.eps_inf,
-                       ez, (long long)s->par.max_iter, s->dst, shp(s->g3) + 2 * gq, shp(s->g3) + 3 * gq, (int)gq, s->xbuf, (const float *)nullptr);
+    {
+        const StatArgs sa{ (int)g, part_y, shp(s->g3) + 2 * gq, shp(s->g3) + 3 * gq, (int)gq, nullptr, 0, nullptr, 0, nullptr,
+                           s->par.eps_acc, s->par.eps_inf, ez, (long long)s->par.max_iter, s->xbuf };
+        hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, sa, s->dst);
+    }
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1428,8 +1502,11 @@ int split_tail(thip_solver *s)
     const SplitCtx c = split_ctx(s);
     THIP_RC(ar_wait(s, 3));
     split_ycrit(c, 1, 0, 1);
-    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, c.st, 2 * (int)c.g, c.part_y, s->par.eps_acc, s->par.eps_inf, c.ez,
-                       (long long)s->par.max_iter, s->dst, s->g3 + s->n + 2 * NPS, s->g3 + s->n + 3 * NPS, (int)NPS, s->xbuf, (const float *)nullptr);
+    {
+        const StatArgs sa{ 2 * (int)c.g, c.part_y, s->g3 + s->n + 2 * NPS, s->g3 + s->n + 3 * NPS, (int)NPS, nullptr, 0, nullptr, 0, nullptr,
+                           s->par.eps_acc, s->par.eps_inf, c.ez, (long long)s->par.max_iter, s->xbuf };
+        hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, c.st, sa, s->dst);
+    }
     THIP_LAUNCH_CHECK();
     s->tail_pending = false;
     return 0;
@@ -1611,7 +1688,7 @@ int sweep_prepare(thip_solver *s)
     hipStream_t st = ctx().stream;
     if (!s->sw_census) {
         THIP_TRY(hipMalloc((void **)&s->sw_census, 64 * sizeof(unsigned)));
-        THIP_TRY(hipMalloc((void **)&s->sw_part, 8 * EG * sizeof(float)));
+        THIP_TRY(hipMalloc((void **)&s->sw_part, 12 * EG * sizeof(float)));
     }
     THIP_TRY(hipMemsetAsync(s->sw_census, 0, 64 * sizeof(unsigned), st));
     s->sw_seq = 0;
@@ -1753,7 +1830,7 @@ int sweep_pass(thip_solver *s, int first, int np_m)
         // the sweep of a regular step opens with the kappa update: c.rx_x from the previous sweep's partials, b.rx_y from sw_vm_k
         const unsigned gm_ = np_m > 0 ? (unsigned)np_m : egrid(s->m);      // block partials per sum over m (the m-kernel's grid)
         a.kappa_p = &s->dst->kappa_in; a.kappa_out = &s->dst->kappa;
-        a.pm_brx = s->sw_part + 4 * EG + gm_; a.np_m = (int)gm_;
+        a.pm_brx = s->sw_part + (size_t)(4 + 4 * s->pm_par) * EG + gm_; a.np_m = (int)gm_;
         a.pn_count = 256;
         if (s->col_shard) { a.pn_in = s->cs_buf + 2 * g.mpad; a.pn_in_stride = (int)EG; a.pn_count = (int)EG; }
     }
@@ -1779,7 +1856,8 @@ void sweep_swap(thip_solver *s)
 // the x_x buffer that is NOT the iterate: x_x_{k+1} after a sweep
 float *sweep_next(thip_solver *s) { return s->xbuf == 0 ? s->xx2 : s->xx_home; }
 
-int one_iteration_sweep(thip_solver *s)
+// last: the host looks at the status block after this iteration (end of a polling batch / of the run)
+int one_iteration_sweep(thip_solver *s, bool last)
 {
     hipStream_t st = ctx().stream;
     const int m = (int)s->m;
@@ -1792,7 +1870,9 @@ int one_iteration_sweep(thip_solver *s)
     // (the sweep itself writes 4 x 256 to one of two buffers by launch parity: pn_now(); sw_gsum_k moves them into the tail)
     auto pn_now = [&]() -> float * { return cols ? s->cs_buf + 2 * s->sgeom.mpad : s->sw_part + (size_t)s->pn_par * 2 * EG; };
     const int pns = cols ? (int)EG : 256;         // one slot per workgroup of the sweep (256), EG in the all-reduced buffer
-    float *const pm = s->sw_part + 4 * EG;        // sums over m: [0] b.v [1] b.rx_y [2] ||p||^2 [3] b.x_y, gm partials each
+    // sums over m: [0] b.v [1] b.rx_y [2] ||p||^2 [3] b.x_y, gmm block partials each -- two buffers: a merged m-kernel that
+    // evaluates the previous iterate's termination test at its head reads one (the previous step's) and writes the other
+    auto pm_cur = [&]() -> float * { return s->sw_part + (size_t)(4 + 4 * s->pm_par) * EG; };
     float *const ky = s->comp() ? s->ky : nullptr, *const ks = s->comp() ? s->ks : nullptr;
     float *const kv = s->comp() ? s->kv : nullptr;
     auto post = [&]() -> int {
@@ -1815,22 +1895,37 @@ int one_iteration_sweep(thip_solver *s)
         // from a consistent iterate (x_0, or wherever a run stopped): u is current, so the sweep leaves it alone
         THIP_RC(sweep_pass(s, 1, (int)gmm));
         THIP_RC(post());
-        hipLaunchKernelGGL(sw_bv_k, dim3(gmm), dim3(BLK), 0, st, m, s->b, s->v, pm, s->dst);
-        hipLaunchKernelGGL(sw_tau_k, dim3(1), dim3(BLK), 0, st, s->dst, pn_now() + 2 * pns, pns, pm, (int)gmm);
+        hipLaunchKernelGGL(sw_bv_k, dim3(gmm), dim3(BLK), 0, st, m, s->b, s->v, pm_cur(), s->dst);
+        hipLaunchKernelGGL(sw_tau_k, dim3(1), dim3(BLK), 0, st, s->dst, pn_now() + 2 * pns, pns, pm_cur(), (int)gmm);
         s->sw_first = false;
+        s->status_pending = false;
     }
+    // the termination test of iterate k: by status_k after the sweep when the host is about to look (or the m-tail is not one
+    // of the merged forms), else by every block of the NEXT step's m-kernel at its head (two launches per iteration)
+    auto stat_args = [&](float *pmb) -> StatArgs {
+        return StatArgs{ pns, pn_now(), pmb + 2 * gmm, pmb + 3 * gmm, (int)gmm, pn_now() + 2 * pns, pns, pmb, (int)gmm,
+                         cols ? (const float *)(s->cs_buf + 2 * s->sgeom.mpad + 4 * EG) : (const float *)nullptr,
+                         s->par.eps_acc, s->par.eps_inf, ez, (long long)s->par.max_iter, s->xbuf };
+    };
+    const bool foldable = (merge || cone_merge) && !s->no_fold;
+    const int fold = (foldable && s->status_pending) ? 1 : 0;
+    const StatArgs sa_prev = stat_args(pm_cur());          // (read by the head only when fold != 0)
+    if (foldable) s->pm_par ^= 1;                          // the merged kernel writes the other buffer
+    float *const pm = pm_cur();
     if (merge) {
         hipLaunchKernelGGL(sw_xm_k<true>, dim3(gx), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
                            cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
-                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm);
+                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm, sa_prev, fold, s->step_par);
+        s->step_par ^= 1;
     } else if (cone_merge) {
         hipLaunchKernelGGL(sw_cone_k, dim3(gc), dim3(BLK), 0, st, (int)s->n_soc, s->soc_beg, s->soc_end, cols ? 1 : s->sgeom.ngroups,
                            s->sgeom.mpad, cols ? s->cs_buf : s->sw_partH, s->b, s->v, s->Ty, s->Ts, s->xy, s->xs, s->rxy, s->rxs,
-                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm);
+                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm, sa_prev, fold, s->step_par);
+        s->step_par ^= 1;
     } else {
         hipLaunchKernelGGL(sw_xm_k<false>, dim3(gx), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
                            cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
-                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm);
+                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm, sa_prev, 0, 0);
         THIP_RC(project_blocks(s));
         hipLaunchKernelGGL(sw_vm_k, dim3(gm), dim3(BLK), 0, st, m, s->h3, s->hP, s->b, s->rxs, s->rxy, s->Sv, s->v, kv, s->xs,
                            s->xy, ez, s->dst, pm);
@@ -1839,10 +1934,12 @@ int one_iteration_sweep(thip_solver *s)
     sweep_swap(s);                                // x_x_k (formed by the previous sweep) is now the iterate
     THIP_RC(sweep_pass(s, 0, (int)gmm));
     THIP_RC(post());
-    hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, pns, pn_now(), s->par.eps_acc, s->par.eps_inf, ez,
-                       (long long)s->par.max_iter, s->dst, pm + 2 * gmm, pm + 3 * gmm, (int)gmm, s->xbuf,
-                       cols ? (const float *)(s->cs_buf + 2 * s->sgeom.mpad + 4 * EG) : (const float *)nullptr,
-                       (const float *)(pn_now() + 2 * pns), pns, (const float *)pm, (int)gmm);
+    if (last || !foldable) {
+        hipLaunchKernelGGL(status_k, dim3(1), dim3(BLK), 0, st, stat_args(pm), s->dst);
+        s->status_pending = false;
+    } else {
+        s->status_pending = true;
+    }
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -1913,6 +2010,7 @@ int snapshot(thip_solver *s, bool restore)
     THIP_LAUNCH_CHECK();
     if (restore) {
         s->finalized = false;
+        s->status_pending = false;
         s->sw_first = true;             // the restored iterate is a consistent one: the next sweep step starts from it
         THIP_RC(poll(s, nullptr));      // host copy of the status block (state RUNNING again)
     } else {
@@ -2182,13 +2280,13 @@ int thip_solver_init(thip_solver *s)
     THIP_RC(ensure_gemv_scratch(s));
     if (!s->is16()) THIP_RC(ensure_apad(s, true));      // a fresh solve re-reads the caller's A (it may have changed in place)
     s->xx = s->xx_home; s->kx = s->kx_home; s->xbuf = 0;
-    s->sw_first = true; s->sweep_state = 0; s->pn_par = 0;
+    s->sw_first = true; s->sweep_state = 0; s->pn_par = 0; s->status_pending = false; s->step_par = 0; s->pm_par = 0;
     s->sweep_faults = 0; s->sweep_fault_word = 0; s->sweep_fault_iter = -1; s->snap_iter = -1;
     // init_vecs (solver.rs:483-494): x = 0, y = 0, tau = 1
     THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
     hipLaunchKernelGGL(init_status_k, dim3(1), dim3(1), 0, st, s->dst, 0.0f);
     THIP_RC(sweep_prepare(s));        // (its plan autotune runs idempotent sweeps: after the stop flag has been cleared)
-    if (s->sw_part) THIP_TRY(hipMemsetAsync(s->sw_part, 0, 8 * EG * sizeof(float), st));
+    if (s->sw_part) THIP_TRY(hipMemsetAsync(s->sw_part, 0, 12 * EG * sizeof(float), st));
     THIP_TRY(hipMemsetAsync(s->arena, 0, s->arena_n * sizeof(float), st));
 
     // calc_norms (solver.rs:460-481) + scalar parts of abssum (solver.rs:171-172)
@@ -2260,7 +2358,8 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
     while (s->hst->state == THIP_ST_RUNNING && (max_steps < 0 || done < max_steps)) {
         int64_t batch = poll_every;
         if (max_steps >= 0 && done + batch > max_steps) batch = max_steps - done;
-        for (int64_t k = 0; k < batch; ++k) THIP_RC(sweep ? one_iteration_sweep(s) : (split ? one_iteration_split(s) : one_iteration(s)));
+        for (int64_t k = 0; k < batch; ++k)
+            THIP_RC(sweep ? one_iteration_sweep(s, k + 1 == batch) : (split ? one_iteration_split(s) : one_iteration(s)));
         if (s->tail_pending) THIP_RC(split_tail(s));       // drain the pipeline before the host looks
         // every bounded device-side wait of the batch: did one run out?
         unsigned sw_err = 0, peer_fault = 0;
@@ -2496,7 +2595,8 @@ int thip_solver_sweep_faults(thip_solver *s, int *host_faults, int *host_last_wo
 
 int thip_test_sweep_fault(thip_solver *s, int kind, int64_t after_sweeps, int spin_max)
 {
-    if (!s || kind < 0 || kind > 4) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
+    if (!s || kind < 0 || kind > 6) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
+    if (kind == 5 || kind == 6) { s->no_fold = kind == 5; return 0; }      // 5 / 6: the termination test as its own launch / folded again
     if (kind >= 3) { s->no_merge = kind == 3; return 0; }       // 3 / 4: the step's m-kernels as two launches / merged again
     s->fault_kind = kind; s->fault_after = kind == 2 ? (long long)after_sweeps : -1;
     s->spin_max = spin_max > 0 ? spin_max : 0;
