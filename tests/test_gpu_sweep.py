@@ -852,17 +852,23 @@ def test_column_shard_exposes_its_one_collective_once_per_iteration(T):
         assert 0.6 * L <= t[L] - t[0] <= L + 10, t
 
 
-@pytest.mark.parametrize("kind", ["lp", "socp"])
+@pytest.mark.parametrize("kind", ["lp", "socp", "sdp"])
 def test_folded_termination_test_is_the_launch_of_its_own(T, kind):
     """with a merged m-tail the termination test of iterate k has no launch of its own inside a polling batch: every block of
     the next step's m-kernel evaluates it at its head (same sums, same arithmetic).  Against the form that launches status_k
     every iteration (test hook 5): bitwise the same iterates, the same stop iteration for convergence and for max_iter in the
     middle of a batch, the same returned iterate"""
-    d = (_lp(T, 150, 7)[0] if kind == "lp" else _socp(T, 120, [15, 40, 3, 66], seed=9)).dense()
+    if kind == "sdp":          # a PSD cone: the three-launch m-tail (its first kernel carries the folded test)
+        c_, syms = random_sdp(90, 12, seed=4)
+        d = T.ProbSDP(_mb(T, T.MatType.General(90, 1)).set_array(c_.reshape(-1, 1)), [_mb(T, T.MatType.SymPack(12)).set_array(s_) for s_ in syms],
+                      _mb(T, T.MatType.General(0, 90)), _mb(T, T.MatType.General(0, 1)), 1e-12).dense()
+    else:
+        d = (_lp(T, 150, 7)[0] if kind == "lp" else _socp(T, 120, [15, 40, 3, 66], seed=9)).dense()
     p = T.SolverParam()
     p.eps_acc = 1e-30
     a = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
     b = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    assert a.schedule_in_use() == "sweep"
     b.inject_sweep_fault(5)                    # status_k every iteration
     for steps, poll in ((1, 1), (7, 7), (50, 16), (33, 100)):
         ra = a.run(steps, poll_every=poll)

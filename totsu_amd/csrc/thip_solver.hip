@@ -463,12 +463,13 @@ __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, 
                                               float eps_zero, float *__restrict__ part, const StatArgs sa, int fold, int par)
 {
     if (st->stop != 0) return;
-    // fold != 0 (MERGE only): the termination test of the PREVIOUS iterate has had no launch of its own -- every block
-    // evaluates it here, from the same sums, before anything is written; a verdict that ends the loop leaves the iterate alone
+    // fold != 0: the termination test of the PREVIOUS iterate has had no launch of its own -- every block evaluates it here,
+    // from the same sums, before anything is written; a verdict that ends the loop leaves the iterate alone (the launches
+    // behind this one -- block cones, sw_vm_k, the sweep -- return at entry on the stop flag block 0 raises)
     float tau, rtau;
     StatOut so;
     long long it0 = 0;
-    if (MERGE && fold) {
+    if (fold) {
         __shared__ double ssum[8];
         it0 = st->iter_r[par];
         so = status_eval(sa, st->tau_r[par], it0, st->norm_b, st->norm_c, st->t_tau, ssum);
@@ -559,15 +560,13 @@ __global__ __launch_bounds__(BLK) void sw_xm_k(int m, int ngroups, size_t mpad, 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->tau = tau;
         st->r_tau = rtau;
-        if (MERGE) {
-            st->kappa_in = kappa;          // nobody writes kappa between here and the sweep
-            st->tau_r[par ^ 1] = tau;
-            if (fold) {
-                st->kind = so.kind; st->cri[0] = so.cri[0]; st->cri[1] = so.cri[1]; st->cri[2] = so.cri[2];
-                st->iter = it0 + 1; st->iter_r[par ^ 1] = it0 + 1;
-            } else {
-                st->iter_r[par ^ 1] = st->iter;
-            }
+        if (MERGE) st->kappa_in = kappa;          // nobody writes kappa between here and the sweep
+        st->tau_r[par ^ 1] = tau;
+        if (fold) {
+            st->kind = so.kind; st->cri[0] = so.cri[0]; st->cri[1] = so.cri[1]; st->cri[2] = so.cri[2];
+            st->iter = it0 + 1; st->iter_r[par ^ 1] = it0 + 1;
+        } else {
+            st->iter_r[par ^ 1] = st->iter;
         }
     }
 }
@@ -1900,17 +1899,19 @@ int one_iteration_sweep(thip_solver *s, bool last)
         s->sw_first = false;
         s->status_pending = false;
     }
-    // the termination test of iterate k: by status_k after the sweep when the host is about to look (or the m-tail is not one
-    // of the merged forms), else by every block of the NEXT step's m-kernel at its head (two launches per iteration)
+    // the termination test of iterate k: by status_k after the sweep when the host is about to look, else by every block of
+    // the NEXT step's (first) m-kernel at its head
     auto stat_args = [&](float *pmb) -> StatArgs {
         return StatArgs{ pns, pn_now(), pmb + 2 * gmm, pmb + 3 * gmm, (int)gmm, pn_now() + 2 * pns, pns, pmb, (int)gmm,
                          cols ? (const float *)(s->cs_buf + 2 * s->sgeom.mpad + 4 * EG) : (const float *)nullptr,
                          s->par.eps_acc, s->par.eps_inf, ez, (long long)s->par.max_iter, s->xbuf };
     };
-    const bool foldable = (merge || cone_merge) && !s->no_fold;
+    const bool foldable = !s->no_fold;
     const int fold = (foldable && s->status_pending) ? 1 : 0;
     const StatArgs sa_prev = stat_args(pm_cur());          // (read by the head only when fold != 0)
-    if (foldable) s->pm_par ^= 1;                          // the merged kernel writes the other buffer
+    // a merged kernel writes its sums over m while other blocks still read the previous step's at their head: the other buffer
+    // (the three-launch form writes them in sw_vm_k, a later launch: one buffer)
+    if (foldable && (merge || cone_merge)) s->pm_par ^= 1;
     float *const pm = pm_cur();
     if (merge) {
         hipLaunchKernelGGL(sw_xm_k<true>, dim3(gx), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
@@ -1925,7 +1926,8 @@ int one_iteration_sweep(thip_solver *s, bool last)
     } else {
         hipLaunchKernelGGL(sw_xm_k<false>, dim3(gx), dim3(BLK), 0, st, m, cols ? 1 : s->sgeom.ngroups, s->sgeom.mpad,
                            cols ? s->cs_buf : s->sw_partH, s->h3, s->b, s->v, s->Ty, s->Ts, s->cls, s->xy, s->xs, s->rxy, s->rxs,
-                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm, sa_prev, 0, 0);
+                           s->dst, ky, ks, s->hP, s->Sv, kv, ez, pm, sa_prev, fold, s->step_par);
+        s->step_par ^= 1;
         THIP_RC(project_blocks(s));
         hipLaunchKernelGGL(sw_vm_k, dim3(gm), dim3(BLK), 0, st, m, s->h3, s->hP, s->b, s->rxs, s->rxy, s->Sv, s->v, kv, s->xs,
                            s->xy, ez, s->dst, pm);
