@@ -615,12 +615,29 @@ __global__ __launch_bounds__(BLK) void sw_cone_k(int n_cones, const int64_t *__r
         const size_t idx[3] = { (size_t)(beg + 1 + e), (size_t)(beg + 65 + e), (size_t)beg };
         const bool ok[3] = { beg + 1 + e < end, beg + 65 + e < end, e == 0 };
         // the first wave's row data: requested before the shares, used after the barrier (one round trip for everything)
-        float oy[3], os[3], bi[3], vi[3], tyv[3], tsv[3];
+        // (the Kahan terms, hP and Sv too: the cone phase below is then arithmetic and stores only -- with them fetched where
+        // they are used it was three dependent round trips per cone, 20 us per launch at configs[2])
+        float oy[3], os[3], bi[3], vi[3], tyv[3], tsv[3], kyv[3], ksv[3], kvv[3], hPv[3], svv[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            oy[k] = os[k] = bi[k] = vi[k] = tyv[k] = tsv[k] = 0.0f;
-            if (kq == 0 && ok[k]) { const size_t i = idx[k]; oy[k] = xy[i]; os[k] = xs[i]; bi[k] = b[i]; vi[k] = v[i]; tyv[k] = Ty[i]; tsv[k] = Ts[i]; }
+            oy[k] = os[k] = bi[k] = vi[k] = tyv[k] = tsv[k] = kyv[k] = ksv[k] = kvv[k] = hPv[k] = svv[k] = 0.0f;
+            if (kq == 0 && ok[k]) {
+                const size_t i = idx[k];
+                oy[k] = xy[i]; os[k] = xs[i]; bi[k] = b[i]; vi[k] = v[i]; tyv[k] = Ty[i]; tsv[k] = Ts[i];
+                hPv[k] = hP[i]; svv[k] = Sv[i];
+                if (ky) kyv[k] = ky[i];
+                if (ks) ksv[k] = ks[i];
+                if (kv) kvv[k] = kv[i];
+            }
         }
+        // comp_add with the Kahan term already in a register
+        auto cadd = [](float x, float inc, float *__restrict__ kp, size_t i, float kval) -> float {
+            if (kp == nullptr) return x + inc;
+            const float y = inc - kval;
+            const float t = x + y;
+            kp[i] = (t - x) - y;
+            return t;
+        };
         float sas[3], sbs[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -665,8 +682,8 @@ __global__ __launch_bounds__(BLK) void sw_cone_k(int n_cones, const int64_t *__r
             ny[k] = ns[k] = 0.0f;
             if (!ok[k]) continue;
             const size_t i = idx[k];
-            ny[k] = comp_add(oy[k], tyv[k] * (bi[k] * kappa - hNs[k]), ky, i);
-            ns[k] = comp_add(os[k], tsv[k] * vi[k], ks, i);
+            ny[k] = cadd(oy[k], tyv[k] * (bi[k] * kappa - hNs[k]), ky, i, kyv[k]);
+            ns[k] = cadd(os[k], tsv[k] * vi[k], ks, i, ksv[k]);
         }
         // the projection of the x_y block and of the x_s block (soc_k, not rotated)
 #pragma unroll
@@ -694,9 +711,9 @@ __global__ __launch_bounds__(BLK) void sw_cone_k(int n_cones, const int64_t *__r
             rxy[i] = ry;
             rxs[i] = rs;
             const float hx = hxs[k];
-            const float h2 = hP[i] - 2.0f * hx;
+            const float h2 = hPv[k] - 2.0f * hx;
             hP[i] = hx;
-            const float vn = comp_add(vi[k], Sv[i] * (h2 + rs - bi[k] * rtau), kv, i);
+            const float vn = cadd(vi[k], svv[k] * (h2 + rs - bi[k] * rtau), kv, i, kvv[k]);
             v[i] = vn;
             q0 = fmaf(bi[k], vn, q0);
             q1 = fmaf(bi[k], ry, q1);
