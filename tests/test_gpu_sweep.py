@@ -296,7 +296,7 @@ def test_sweep_at_a_size_where_it_is_the_default(T):
 
 # ---- N > 1: column shards (thip_solver_set_column_shard) -----------------------------------------------------
 
-def _run_col_sharded(T, dense, cuts, param, max_steps, poll_every=16, fault=None, pre_steps=0):
+def _run_col_sharded(T, dense, cuts, param, max_steps, poll_every=16, fault=None, pre_steps=0, a_storage="f32"):
     """ranks emulated by threads in one process (the pattern of tests/test_gpu_sharded.py): each drives its own solver
     over its block of columns; the hook meets at a barrier and sums the device buffers on the shared stream"""
     import threading
@@ -329,7 +329,8 @@ def _run_col_sharded(T, dense, cuts, param, max_steps, poll_every=16, fault=None
         try:
             p = parts[rank]
             fs = T.FusedSolver(p["n"], m, p["mat_a"], dense.vec_b, p["vec_c"], dense.seg_type, dense.seg_len, param, "sweep",
-                               vec_b_rowabs=dense.vec_b_rowabs, allreduce=make_hook(rank), col_shard=True)
+                               vec_b_rowabs=dense.vec_b_rowabs, allreduce=make_hook(rank), col_shard=True, a_storage=a_storage,
+                               sweep_min_bytes=0)
             assert fs.schedule_in_use() == "sweep"
             if pre_steps:
                 fs.run(pre_steps, poll_every=poll_every)
@@ -891,3 +892,27 @@ def test_folded_termination_test_is_the_launch_of_its_own(T, kind):
             f.destroy()
         assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and res[0][2] == res[1][2], (res[0][:3], res[1][:3])
         assert all(np.array_equal(u_, v_) for u_, v_ in zip(res[0][3], res[1][3]))
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_column_sharded_sweep_on_a_16_bit_matrix(T, kind):
+    """column shards of a 16-bit-stored A take the same path as f32 ones (the rank's block is converted by the library): two
+    emulated ranks against the unsharded 16-bit one-pass run"""
+    socp = _socp(T, 260, [15, 40, 3, 66, 99, 21], seed=12)
+    d = socp.dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    cuts = [0, 100, 260]
+    one = T.FusedSolver.from_dense(d, p, "sweep", sweep_min_bytes=0, a_storage=kind)
+    assert one.schedule_in_use() == "sweep" and one.passes() == (1, 2 * d.n * d.m)
+    one.run(40, poll_every=8)
+    x1, y1 = one.iterate()
+    one.destroy()
+    out = _run_col_sharded(T, d, cuts, p, 40, poll_every=8, a_storage=kind)
+    xs = np.concatenate([o[1][0][:hi - lo] for o, lo, hi in zip(out, cuts[:-1], cuts[1:])])
+    us = np.concatenate([o[1][1][:hi - lo] for o, lo, hi in zip(out, cuts[:-1], cuts[1:])])
+    x = np.concatenate([xs, out[0][1][0][cuts[1]:]])
+    y = np.concatenate([us, out[0][1][1][cuts[1]:]])
+    assert all(o[0].iters == 40 for o in out)
+    assert np.abs(x - x1).max() <= 2e-4 * max(np.abs(x1).max(), 1e-6) and np.abs(y - y1).max() <= 2e-4 * max(np.abs(y1).max(), 1e-6)
+    assert np.array_equal(out[0][1][0][cuts[1]:], out[1][1][0][cuts[2] - cuts[1]:])      # the replicated m-part: bitwise the same on both ranks
