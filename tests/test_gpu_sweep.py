@@ -734,6 +734,18 @@ def test_cone_wave_m_kernel_is_the_three_launch_form(T):
         assert np.allclose(a.status().cri, b.status().cri, rtol=1e-4, atol=1e-7)
     a.destroy()
     b.destroy()
+    # more cones than the kernel has workgroups (512): every workgroup walks several
+    many = _socp(T, 100, [2] * 700, seed=25).dense()
+    a = T.FusedSolver.from_dense(many, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    b = T.FusedSolver.from_dense(many, p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+    b.inject_sweep_fault(3)
+    for steps in (1, 30):
+        a.run(steps, poll_every=8)
+        b.run(steps, poll_every=8)
+        for u_, v_ in zip(a.iterate(), b.iterate()):
+            assert np.abs(u_ - v_).max() <= 2e-6 * max(np.abs(v_).max(), 1e-6)
+    a.destroy()
+    b.destroy()
     # a cone of 130 rows is beyond a wave's two slots + head: the three-launch form by itself, same answer as the carried run
     socp2 = _socp(T, 150, [15, 129, 40], seed=24)
     d2 = socp2.dense()
