@@ -45,7 +45,7 @@ int  lazy_push_set(float *x, float value, int *deferred);              // SliceL
 // SYNC scalar reads: *served = 1 and the value when the read-ahead has it; else the record has been run and the caller reads
 int  lazy_read(int is_norm, const float *p, size_t n, float *value, int *served);
 void lazy_release();      // frees the queue's device memory (thip_shutdown)
-void lazy_forget();       // drops every learnt plan (thip_free: they hold raw device addresses)
+void lazy_forget(uintptr_t lo, uintptr_t hi);      // drops the learnt plans that hold an address in [lo, hi) (thip_free)
 int  fail(int code, const char *what, const char *file, int line);
 int  need_init();
 // returns a scratch buffer of at least n floats (grows with hipMalloc; not inside graph capture)

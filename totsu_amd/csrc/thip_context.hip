@@ -171,7 +171,14 @@ int thip_free(float *p)
     THIP_NEED_INIT();
     if (!p) return 0;
     THIP_TRY(hipStreamSynchronize(ctx().stream));
-    lazy_forget();                  // learnt call plans / read-ahead plans hold raw device addresses (thip_lazy.hip)
+    {
+        // learnt call plans / read-ahead plans hold raw device addresses (thip_lazy.hip): those inside this allocation go
+        hipDeviceptr_t base = nullptr; size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) == hipSuccess && size > 0)
+            lazy_forget((uintptr_t)base, (uintptr_t)base + size);
+        else
+            lazy_forget(0, ~(uintptr_t)0);
+    }
     THIP_TRY(hipFree(p));
     return 0;
 }

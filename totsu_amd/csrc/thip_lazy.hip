@@ -1189,17 +1189,35 @@ int lazy_flush()
 
 // thip_free: every learnt plan holds raw device addresses (the scalar reads of a pass; the operands of a replayed segment).
 // Once a buffer has been released the addresses may be unmapped -- or, worse, mapped to something else -- and a first read
-// that happens to match a plan's head would launch read_batch_k over all of them.  Forget what was learnt (it is learnt
-// again within one pass of the next solve).
-void lazy_forget()
+// that happens to match a plan's head would launch read_batch_k over all of them.  What touches the released range
+// [lo, hi) is forgotten: the read-ahead plans whose address hull meets it, and -- when any recorded call of any product /
+// projection plan has an operand in it -- the call plans (all of them: they are chained by prediction).  Plans on other
+// buffers survive, so a host that solves again on the same vectors does not learn its 4000 scalar reads a second time.
+void lazy_forget(uintptr_t lo, uintptr_t hi)
 {
     std::lock_guard<std::mutex> lock(Q.mu);
     if (Q.rd_plans.empty() && !Q.rd_open && Q.rd_learn.empty() && Q.plans.empty()) return;
-    drop_all_plans();
-    drop_read_cache();
-    Q.rd_open = false; Q.rd_learn.clear();
-    for (ReadPlan *p : Q.rd_plans) free_read_plan(p);
-    Q.rd_plans.clear();
+    auto in = [&](const void *p) { const uintptr_t a = (uintptr_t)p; return p != nullptr && a >= lo && a < hi; };
+    bool hit = false;
+    for (const Plan *p : Q.plans) {
+        if (in(p->base)) hit = true;
+        for (const Call &c : p->calls) if (in(c.A) || in(c.x) || in(c.y)) { hit = true; break; }
+        if (hit) break;
+    }
+    if (hit) drop_all_plans();
+    // read-ahead: the group being learnt and the cached one may hold the range too -- cheap to learn again
+    bool rd_hit = false;
+    for (const ReadReq &r : Q.rd_learn) if (overlap((uintptr_t)r.p, (uintptr_t)(r.p + (r.n ? r.n : 1)), lo, hi)) rd_hit = true;
+    if (rd_hit) { Q.rd_open = false; Q.rd_learn.clear(); }
+    for (size_t i = 0; i < Q.rd_plans.size();) {
+        ReadPlan *p = Q.rd_plans[i];
+        const bool meets = !p->suf_lo.empty() && overlap(p->suf_lo[0], p->suf_hi[0], lo, hi);
+        if (meets) {
+            if (Q.rd_cur == p) drop_read_cache();
+            free_read_plan(p);
+            Q.rd_plans.erase(Q.rd_plans.begin() + i);
+        } else ++i;
+    }
 }
 
 void lazy_release()
