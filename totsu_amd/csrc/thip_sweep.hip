@@ -137,7 +137,8 @@ int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom 
     return k;
 }
 
-size_t sweep_gran_words(const SweepGeom &g) { return (size_t)g.ngroups * SW_RING * g.G * (2 * g.w); }
+// the ring of every group + one spare 128-byte line per workgroup (the service wave's unconditional stores, thip_sweep_kernel.h)
+size_t sweep_gran_words(const SweepGeom &g) { return (size_t)g.ngroups * SW_RING * g.G * (2 * g.w) + 256 * 16; }
 
 int sweep_census_dry_run(hipStream_t st, unsigned *census, unsigned seq)
 {

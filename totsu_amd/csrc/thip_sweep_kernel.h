@@ -71,40 +71,30 @@ __device__ __forceinline__ float sw_comp_add(float x, float inc, bool comp, floa
     return t;
 }
 
-template <int K, int O>
-__device__ __forceinline__ void sw_halve(float *v, int lane)
+// x + (x of the lane a DPP control pairs this lane with): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141
+// (i <-> 7 - i), row_mirror = 0x140 (i <-> 15 - i).  A VALU operand modifier -- no trip through the LDS crossbar, which is what a
+// __shfl_xor (ds_bpermute) costs: ~120 cycles each, and the sums of an interval are a CHAIN of them.
+template <int CTRL>
+__device__ __forceinline__ float sw_dpp_add(float x)
 {
-    const bool hi = (lane & O) != 0;
-#pragma unroll
-    for (int i = 0; i < K / 2; ++i) {
-        const float send = hi ? v[i] : v[i + K / 2];
-        const float keep = hi ? v[i + K / 2] : v[i];
-        v[i] = keep + __shfl_xor(send, O, 64);
-    }
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true);
+    return x + __builtin_bit_cast(float, y);
 }
-
-// K per-lane values on 64 lanes -> the K wave sums; the lanes with (lane >> (6 - log2 K)) == c hold sum c
-template <int K>
-__device__ __forceinline__ float sw_reduce(float *v, int lane)
+// sum over the aligned block of N = 8 or 16 lanes this lane belongs to, left in every lane of the block (symmetric pairings:
+// the same bits in every lane)
+template <int N>
+__device__ __forceinline__ float sw_block_sum(float x)
 {
-    static_assert(K == 2 || K == 4 || K == 8, "1, 2 or 4 columns per panel");
-    if constexpr (K == 2) {
-        sw_halve<2, 32>(v, lane);
-        float r = v[0];
-        r += __shfl_xor(r, 16, 64); r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 4, 64);
-        r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
-        return r;
-    } else if constexpr (K == 8) {
-        sw_halve<8, 32>(v, lane); sw_halve<4, 16>(v, lane); sw_halve<2, 8>(v, lane);
-        float r = v[0];
-        r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
-        return r;
-    } else {
-        sw_halve<4, 32>(v, lane); sw_halve<2, 16>(v, lane);
-        float r = v[0];
-        r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
-        return r;
-    }
+    static_assert(N == 8 || N == 16, "half a DPP row or a whole one");
+    x = sw_dpp_add<0xB1>(x);
+    x = sw_dpp_add<0x4E>(x);
+    x = sw_dpp_add<0x141>(x);
+    if constexpr (N == 16) x = sw_dpp_add<0x140>(x);
+    return x;
+}
+__device__ __forceinline__ float sw_readlane(float x, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
 }
 
 // census.  Every workgroup counts itself on its XCD: the ticket it draws is its place (group, member) among the 32 of that
@@ -181,7 +171,8 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
     constexpr int NL = (2 * W * 32 + 63) / 64;        // granule loads per service lane (G = 32)
     static_assert(SW_RING > 2 * (LAGT - DLAG) - 1 && SW_CR > LAGT - DLAG, "ring depths");
     __shared__ int s_role[4];
-    __shared__ float dotbuf[2][SW_CW][2 * W];
+    // partial dots of a panel: [parity][quantity][4 wave + DPP row] -- 28 row sums per quantity (entries 28 .. 31 are never read)
+    __shared__ __attribute__((aligned(16))) float dotbuf[2][2 * W][32];
     __shared__ float scal[2][2 * W];
     __shared__ float cold[SW_CR][9][W];
     extern __shared__ f32x4 sw_lds[];                 // LS panels the streaming threads park between registers and axpy
@@ -265,11 +256,17 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                 }                                                                                              \
                 p_[q] = d1; p_[W + q] = d2;                                                                    \
             }                                                                                                  \
-            if (SW_DBG(a) & 2) { if (lane < 2 * W) dotbuf[(P) & 1][wave][lane] = p_[0]; }                          \
-            else {                                                                                             \
-            const float r_ = sw_reduce<2 * W>(p_, lane);                                                       \
-            if ((lane & (64 / (2 * W) - 1)) == 0) dotbuf[(P) & 1][wave][lane / (64 / (2 * W))] = r_;          \
+            /* sums over each row of 16 lanes by DPP; lane q of a row writes the row's sum of quantity q -- the service */ \
+            /* wave adds the 7 x 4 row sums (a full wave reduction by __shfl_xor was a chain of 6 .. 10 ds_bpermutes */   \
+            /* in front of every barrier: with the service wave idle it alone cost 16 % of a 16-bit sweep) */            \
+            float r_ = p_[0];                                                                                  \
+            if (!(SW_DBG(a) & 2)) {                                                                            \
+                _Pragma("unroll") for (int q = 0; q < 2 * W; ++q) {                                            \
+                    const float s_ = sw_block_sum<16>(p_[q]);                                                  \
+                    r_ = (lane & 15) == q ? s_ : r_;                                                           \
+                }                                                                                              \
             }                                                                                                  \
+            if ((lane & 15) < 2 * W) dotbuf[(P) & 1][lane & 15][4 * wave + (lane >> 4)] = r_;                  \
         } while (0)
 #define SW_AXPY(S, P)                                                                                          \
         do {                                                                                                   \
@@ -380,6 +377,8 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         // addresses clamped, no branches around them): the interval then opens with s_waitcnt vmcnt(NL + 1) -- "everything
         // but the loads of the previous interval has arrived" -- and never waits for a round trip.  (Issued one interval
         // ahead and waited with vmcnt(0), every interval paid an L2 round trip: 1.59 us per panel instead of ~1.)
+        // the interval's chain runs on a SIMD it shares with a streaming wave: it goes first
+        if (!(SW_DBG(a) & 256)) __builtin_amdgcn_s_setprio(3);
         float kappa = *a.kappa_p;
         const float rtau = *a.rtau_p;
         // the kappa update (solver.rs:566-567) needs c.rx_x of the previous sweep (its workgroups' partials) and b.rx_y of the
@@ -417,6 +416,27 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         const int jlast = max(c1 - 1, 0);
         bool dead = false;                            // a gather timed out (here or elsewhere): no more polling
         unsigned polls_total = 0u, polls_max = 0u;    // gathers that had to poll: how often, and the longest (census[18], [19])
+        // gather: the LPQ = 64 / 2W lanes [q LPQ, (q + 1) LPQ) hold quantity q (column q's dot with v for q < W, column q - W's
+        // with x_y otherwise), lane position p the members p, p + LPQ, ...: the sum over a quantity's members is then a sum over
+        // an aligned block of lanes -- DPP adds, no ds_bpermute
+        constexpr int LPQ = 64 / (2 * W);
+        static_assert(NL * LPQ == 32, "one granule load per LPQ members");
+        const int gq = lane / LPQ, gpos = lane % LPQ;
+        // publish: lane 8 q + j sums wave j's four row sums of quantity q (one ds_read_b128), the eight lanes are added by DPP
+        const int dq = lane >> 3, dj = lane & 7;
+        const bool dlane = dq < 2 * W && dj < SW_CW;
+        const int cl = lane < W ? lane : 0;
+        // Vector-memory instructions retire IN ORDER (vmcnt): the loads an interval issues for the interval after next sit behind
+        // the stores issued before them, and a wait for those loads is a wait for every older store's write acknowledgement
+        // (~1 us with the memory pipeline full).  Round 4 found every interval waiting for the acknowledgement of the granule
+        // it had just published -- vmcnt(0)s the compiler put into the arithmetic because branches around the poll loop's loads
+        // and around the granule store cost its wait-count analysis the thread: the floor under every 16-bit sweep (an interval
+        // there is ~1 us).  Now: ONE granule store per interval, unconditional (a lane or an interval with nothing to publish
+        // writes to the workgroup's spare line behind the granule ring), a poll loop without lane conditions around its loads,
+        // and the column stores (one interval in G) behind a branch of their own: the compiler's counts come out as "the loads
+        // of the interval before last have landed, the granule just published may still be on its way".
+        unsigned long long *const spare = a.gran + (size_t)256 * SW_RING * (2 * W) + (size_t)blockIdx.x * 16;
+        float *const sparef = reinterpret_cast<float *>(spare + 1);
         // register sets A / B alternate by interval parity
         unsigned long long xgA[NL], xgB[NL];
         float cvA = 0.0f, cvB = 0.0f;
@@ -430,11 +450,39 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 #else
 #define SW_STAMP(i) do { } while (0)
 #endif
+        // An interval of the service wave is a CHAIN (LDS reads -> sums -> per-column arithmetic -> LDS writes -> barrier) that the
+        // streaming waves wait for at the barrier: at two or four columns of 16-bit elements per panel an interval is ~1 us and the
+        // chain was the longest thing in it (round 4: with this wave idle a bf16 sweep ran 23 % faster).  Hence: every LDS read of
+        // the interval is issued first, the cross-lane sums are DPP adds, and nothing waits for a global round trip.
+        // the columns' new values: by the lanes of real columns of the member whose turn it is (a lane without one: spare line)
+        auto col_stores = [&](const bool wr, const int j, const float u_new, const float ku_new, const float x_new, const float kx_new,
+                              const float g3) {
+            *((wr && !a.first) ? a.u + j : sparef) = u_new;
+            *((wr && !a.first && comp_u) ? a.ku + j : sparef + 1) = ku_new;
+            *(wr ? a.xx_out + j : sparef + 2) = x_new;
+            *((wr && comp_x) ? a.kx_out + j : sparef + 3) = kx_new;
+            *(wr ? a.gP + j : sparef + 4) = g3;
+        };
         auto interval = [&](const int it, unsigned long long (&xg)[NL], float &cv, const bool nowait) {
             if (SW_DBG(a) & 8) { sw_barrier_dbg(SW_DBG(a)); return; }
             // (intervals 0 and 1 use nothing that was fetched: no wait -- the kappa loads above are still in flight then)
-            if (!nowait) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL + 1) : "memory");
+            if (!nowait) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 + NL + 1) : "memory");
             SW_STAMP(0);
+            const int pp = it - DLAG - 1;                 // panel whose partial dots this workgroup publishes
+            const int pa = it - LAGT;                     // panel gathered
+            const bool pub = pp >= 0 && pp < npan, gath = pa >= 0 && pa < npan;
+            const int pac = gath ? pa : 0;
+            const int cs = pac % SW_CR;
+            f32x4 dsum = { 0.0f, 0.0f, 0.0f, 0.0f };
+            if (pub && dlane) dsum = *reinterpret_cast<const f32x4 *>(&dotbuf[pp & 1][dq][4 * dj]);
+            // (no branch of an interval holds a vector-memory instruction -- the poll loop apart, which leaves nothing in flight:
+            // the compiler's own wait counts then come out exact; an interval that gathers nothing runs the same instructions on
+            // slot 0 and stores to the spare line)
+            const float cj = cold[cs][0][cl], Suj = cold[cs][1][cl], Txj = cold[cs][2][cl], uj = cold[cs][3][cl];
+            float kuj = cold[cs][4][cl], kxj = cold[cs][6][cl];
+            const float xxj = cold[cs][5][cl], gPj = cold[cs][7][cl];
+            float isc = 1.0f;
+            if constexpr (ELEM == 2) isc = cold[cs][8][cl];                     // stored column = true column x scale
             // per-column data fetched two intervals ago: panel it - 2 - (LAGL - PF - 1)
             {
                 const int pc = it - 2 - LAGL + PF + 1;
@@ -442,32 +490,29 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             }
             // publish the workgroup's partial dots
             {
-                const int pp = it - DLAG - 1;
-                if (pp >= 0 && pp < npan && lane < 2 * W) {
-                    float sum = dotbuf[pp & 1][0][lane];
-#pragma unroll
-                    for (int w = 1; w < SW_CW; ++w) sum += dotbuf[pp & 1][w][lane];
-                    unsigned long long *g = gbase + ((size_t)(pp % SW_RING) * a.G + member) * (2 * W) + lane;
-                    // TEST HOOK (thip_test_sweep_fault): one workgroup stops publishing half-way -- its group runs out of spins
-                    const bool withheld = a.fault != 0 && group == 0 && member == a.G - 1 && pp >= npan / 2;
-                    // pub_agent: the documented form (sc1 store, MI355X_MICROARCH.md inter-workgroup visibility); else a plain
-                    // store that stays in the L2 the group shares (DESIGN.md 4.7 has the measured difference)
-                    if (withheld) { }
-                    else if (a.pub_agent) __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else __hip_atomic_store(g, sw_pack(sum, a.tagbase + (unsigned)pp + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                }
+                float sum = ((dsum[0] + dsum[1]) + dsum[2]) + dsum[3];
+                sum = sw_block_sum<8>(sum);
+                // TEST HOOK (thip_test_sweep_fault): one workgroup stops publishing half-way -- its group runs out of spins
+                const bool withheld = a.fault != 0 && group == 0 && member == a.G - 1 && pp >= npan / 2;
+                const bool pw = pub && dj == 0 && dq < 2 * W && !withheld && !(SW_DBG(a) & 64);
+                unsigned long long *g = gbase + ((size_t)((pub ? pp : 0) % SW_RING) * a.G + member) * (2 * W) + dq;
+                // pub_agent: the documented form (sc1 store, MI355X_MICROARCH.md inter-workgroup visibility); else a plain
+                // store that stays in the L2 the group shares (DESIGN.md 4.7 has the measured difference).  The plain store is
+                // always issued (to the spare line when the other form is wanted): the default's instruction stream has no branch
+                const unsigned long long gv = sw_pack(sum, a.tagbase + (unsigned)pp + 1u);
+                __hip_atomic_store((pw && !a.pub_agent) ? g : spare, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (a.pub_agent) __hip_atomic_store(pw ? g : spare, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // gather, scalar updates
             SW_STAMP(1);
-            const int pa = it - LAGT;
-            if (pa >= 0 && pa < npan) {
+            {
                 const unsigned tag = a.tagbase + (unsigned)pa + 1u;
-                const unsigned long long *g = gbase + (size_t)(pa % SW_RING) * nq;
+                const unsigned long long *g = gbase + (size_t)(pac % SW_RING) * nq + gq;
                 float vsum = 0.0f;
                 unsigned pend = 0;
 #pragma unroll
                 for (int i = 0; i < NL; ++i) {
-                    if (lane + 64 * i < nq) {
+                    if (gath && gpos + LPQ * i < a.G) {
                         if ((unsigned)(xg[i] >> 32) == tag) vsum += __uint_as_float((unsigned)xg[i]);
                         else pend |= 1u << i;
                     }
@@ -484,15 +529,21 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                 }
 #endif
                 while (!dead && !__all(pend == 0u)) {
+                    // (no lane conditions around the loads: every lane re-reads its NL granules, clamped -- with branches around
+                    // them the compiler's wait-count analysis lost track and put vmcnt(0) into the arithmetic below, i.e. every
+                    // interval waited for the write acknowledgement of the granule it had just published)
+                    unsigned long long yg[NL];
 #pragma unroll
-                    for (int i = 0; i < NL; ++i)
-                        if ((pend >> i) & 1u) xg[i] = __hip_atomic_load(g + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int i = 0; i < NL; ++i) {
+                        const int mi = min(gpos + LPQ * i, a.G - 1);
+                        yg[i] = __hip_atomic_load(g + (size_t)mi * (2 * W), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
 #pragma unroll
-                    for (int i = 0; i < NL; ++i)
-                        if (((pend >> i) & 1u) && (unsigned)(xg[i] >> 32) == tag) {
-                            vsum += __uint_as_float((unsigned)xg[i]);
-                            pend &= ~(1u << i);
-                        }
+                    for (int i = 0; i < NL; ++i) {
+                        const bool hit = ((pend >> i) & 1u) != 0u && (unsigned)(yg[i] >> 32) == tag;
+                        vsum += hit ? __uint_as_float((unsigned)yg[i]) : 0.0f;
+                        pend = hit ? (pend & ~(1u << i)) : pend;
+                    }
                     ++spins;
 #ifdef SW_PROFILE
                     ++npoll;
@@ -505,40 +556,38 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                 }
                 if (spins > 0) { polls_total += (unsigned)spins; polls_max = max(polls_max, (unsigned)spins); }
                 SW_STAMP(2);
-                // lane l holds members l / 2W + 32 i / W .. of quantity l % 2W: sum over the lanes of equal l % 2W
-                float sum = vsum;
+                // every lane of a block: the block's sum; lane w < W takes its column's two
+                const float tot = sw_block_sum<(LPQ >= 16 ? 16 : 8)>(vsum);
+                float gT = 0.0f, g3 = 0.0f;
 #pragma unroll
-                for (int o = 2 * W; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);
-                float gT = sum;                                         // lanes 0 .. W-1: column's dot with v
-                float g3 = __shfl(sum, (lane + W) & 63, 64);            // ... and with x_y
-                if (lane < W) {
-                    const int j = c0 + pa * W + lane;
-                    const bool real = j < c1 && !dead;
-                    const int cs = pa % SW_CR;
-                    const float isc = ELEM == 2 ? cold[cs][8][lane] : 1.0f;      // stored column = true column x scale
-                    if constexpr (ELEM == 2) { gT *= isc; g3 *= isc; }
-                    const float cj = cold[cs][0][lane], Suj = cold[cs][1][lane], Txj = cold[cs][2][lane];
-                    const float uj = cold[cs][3][lane], xxj = cold[cs][5][lane], gPj = cold[cs][7][lane];
-                    float kuj = cold[cs][4][lane], kxj = cold[cs][6][lane];
-                    float u_new = uj;
-                    if (!a.first) {
-                        const float g2 = gPj - 2.0f * g3;
-                        u_new = sw_comp_add(uj, Suj * (-g2 - cj * rtau), comp_u, kuj);
-                    }
-                    const float x_new = sw_comp_add(xxj, Txj * (gT + cj * kappa), comp_x, kxj);
+                for (int w = 0; w < W; ++w) {
+                    float s1 = sw_readlane(tot, w * LPQ), s2 = sw_readlane(tot, (W + w) * LPQ);
+                    if constexpr (LPQ == 32) { s1 += sw_readlane(tot, w * LPQ + 16); s2 += sw_readlane(tot, (W + w) * LPQ + 16); }
+                    if (lane == w) { gT = s1; g3 = s2; }
+                }
+                // (every lane runs the arithmetic -- lanes >= W on column 0's data with zero dots -- and every lane stores: only
+                // the lanes of real columns of the member whose turn it is store to the vectors)
+                const int j = c0 + pac * W + cl;
+                const bool real = gath && lane < W && j < c1 && !dead;
+                if constexpr (ELEM == 2) { gT *= isc; g3 *= isc; }
+                float u_new = uj;
+                if (!a.first) {
+                    const float g2 = gPj - 2.0f * g3;
+                    u_new = sw_comp_add(uj, Suj * (-g2 - cj * rtau), comp_u, kuj);
+                }
+                const float x_new = sw_comp_add(xxj, Txj * (gT + cj * kappa), comp_x, kxj);
+                if (gath && lane < W) {
                     scal[pa & 1][lane] = real ? u_new * isc : 0.0f;
                     scal[pa & 1][W + lane] = real ? x_new * isc : 0.0f;
-                    if (real && member == pa % a.G) {
-                        if (!a.first) { a.u[j] = u_new; if (comp_u) a.ku[j] = kuj; }
-                        a.xx_out[j] = x_new;
-                        if (comp_x) a.kx_out[j] = kxj;
-                        a.gP[j] = g3;
-                        const float dj = conv ? fmaf(rt, g3, cj) : g3;      // solver.rs:596-597 / 634
-                        sdd = fmaf(dj, dj, sdd);
-                        scx = fmaf(cj, xxj, scx);
-                        scu = fmaf(cj, u_new, scu);
-                        scrx = fmaf(cj, xxj - 2.0f * x_new, scrx);
-                    }
+                }
+                const bool wr = real && member == pa % a.G && !(SW_DBG(a) & 32);
+                if (gath && member == pa % a.G) col_stores(wr, j, u_new, kuj, x_new, kxj, g3);
+                if (wr) {
+                    const float dj_ = conv ? fmaf(rt, g3, cj) : g3;      // solver.rs:596-597 / 634
+                    sdd = fmaf(dj_, dj_, sdd);
+                    scx = fmaf(cj, xxj, scx);
+                    scu = fmaf(cj, u_new, scu);
+                    scrx = fmaf(cj, xxj - 2.0f * x_new, scrx);
                 }
             }
             // the loads of two intervals ahead, last and unconditional: the granules of panel pa + 2 (published
@@ -549,11 +598,11 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             {
                 int pn = pa + 2;
                 pn = pn < 0 ? 0 : pn;
-                const unsigned long long *gn = gbase + (size_t)(pn % SW_RING) * nq;
+                const unsigned long long *gn = gbase + (size_t)(pn % SW_RING) * nq + gq;
 #pragma unroll
                 for (int i = 0; i < NL; ++i) {
-                    const int gi = min(lane + 64 * i, nq - 1);
-                    xg[i] = __hip_atomic_load(gn + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int mi = min(gpos + LPQ * i, a.G - 1);
+                    xg[i] = __hip_atomic_load(gn + (size_t)mi * (2 * W), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 int pc = it - LAGL + PF + 1;
                 pc = pc < 0 ? 0 : pc;
