@@ -29,6 +29,10 @@
 // stages per panel (W x rows x 4): fewer members per group (more rows each, one column per panel) buy longer intervals
 // for the service wave's dependent chain and fewer workgroups that can hold a group up -- 32 members with 2-column
 // panels ran at 0.65 of the HBM peak, 8 members with 1-column panels at 0.85 - 0.89 (DESIGN.md 4.7 has the steps).
+// An interval's cross-lane sums are DPP adds (streaming waves: per row of 16 lanes, the service wave adds the 7 x 4 row
+// sums; the gather: the members of a quantity sit in an aligned block of lanes), never ds_bpermute chains, and the service
+// wave runs at priority 3: at 16-bit storage an interval is ~1 us and that chain, not HBM, was what it waited for
+// (DESIGN.md 4.8).
 // Every spin is bounded; a workgroup that gives up raises the error word and the host reports a failed run.  A census at
 // kernel entry (XCC_ID + tickets) checks that exactly 32 workgroups sit on every XCD -- i.e. one per CU, all resident --
 // before anything is written; thip_solver.hip runs it once as a dry run and falls back to the carried schedule if the
