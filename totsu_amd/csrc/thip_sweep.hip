@@ -128,7 +128,8 @@ int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g, in
 int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *out, int max_out, int elem)
 {
     static const int cand32[6][2] = { { 1, 1 }, { 1, 2 }, { 1, 4 }, { 2, 1 }, { 2, 2 }, { 1, 8 } };
-    static const int cand16[6][2] = { { 2, 1 }, { 1, 1 }, { 4, 1 }, { 2, 2 }, { 4, 2 }, { 1, 2 } };
+    // (16-bit: one column per panel first since the interval's sums are DPP adds -- before, two columns were the safer default)
+    static const int cand16[6][2] = { { 1, 1 }, { 4, 1 }, { 2, 1 }, { 2, 2 }, { 4, 2 }, { 1, 2 } };
     const int (*cand)[2] = elem ? cand16 : cand32;
     int k = 0;
     for (int c = 0; c < 6 && k < max_out; ++c) {
