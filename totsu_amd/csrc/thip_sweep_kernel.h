@@ -374,10 +374,12 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         // ---------------- service wave ----------------
         // Its global loads (the granules of a panel, the per-column data of a panel) are issued TWO intervals before they
         // are used, as the last memory operations of an interval and always the same number of instructions (NL + 1,
-        // addresses clamped, no branches around them): the interval then opens with s_waitcnt vmcnt(NL + 1) -- "everything
-        // but the loads of the previous interval has arrived" -- and never waits for a round trip.  (Issued one interval
-        // ahead and waited with vmcnt(0), every interval paid an L2 round trip: 1.59 us per panel instead of ~1.)
-        // the interval's chain runs on a SIMD it shares with a streaming wave: it goes first
+        // addresses clamped, no branches around them): the interval then opens with s_waitcnt vmcnt(1 + NL + 1) -- "everything
+        // but the loads of the previous interval and the granule store in front of them has arrived" -- and never waits for a
+        // round trip.  (Issued one interval ahead and waited with vmcnt(0), every interval paid an L2 round trip: 1.59 us per
+        // panel instead of ~1.)  The explicit wait only states the intent: the compiler inserts its own, and what keeps THOSE
+        // from degenerating to vmcnt(0) is described at `spare` below.
+        // The interval's chain runs on a SIMD it shares with a streaming wave: it goes first.
         if (!(SW_DBG(a) & 256)) __builtin_amdgcn_s_setprio(3);
         float kappa = *a.kappa_p;
         const float rtau = *a.rtau_p;
