@@ -4,7 +4,7 @@ at a given shape (default BASELINE configs[2]: m = 100 000, n = 50 000).
     python tools/sweep_probe.py [--check] [--m M --n N --reps R]
 
 The geometry is sweep_plan()'s default (one column per panel, the fewest workgroups per column the rows allow);
-THIP_SWEEP_CLASS=0|1 and THIP_SWEEP_VARIANT=1 pick the other forms (totsu_amd/csrc/thip_sweep.hip), THIP_SWEEP_DBG the
+THIP_SWEEP_CLASS=0|1 picks the other forms (totsu_amd/csrc/thip_sweep.hip), THIP_SWEEP_DBG the
 experiment switches of a -DSW_DEBUG build, and a -DSW_PROFILE build prints the service wave's phase stamps."""
 import argparse
 import ctypes as C

@@ -153,8 +153,9 @@ __device__ __forceinline__ int sw_census(unsigned *census, unsigned seq, int G, 
 // panel q - 16 is free.  Per-column data of panel q is fetched in interval q + DLAG and has arrived before the member
 // publishes q in interval q + DLAG + 1; the writer of panel q's columns stores u / gP (in place) only after it has gathered
 // q, i.e. after every member holds its copy.
-// THIP_SWEEP_DBG (experiments of DESIGN.md 4.7: 1 no polling, 2 no wave reduction of the dots, 4 no barrier, 8 service wave
-// idle, 16 no arithmetic) exists only in a -DSW_DEBUG build; otherwise the switches fold away
+// THIP_SWEEP_DBG (experiments of DESIGN.md 4.7 / 4.8: 1 no polling, 2 no row sums of the dots, 4 no barrier, 8 service wave
+// idle, 16 no arithmetic, 32 column stores to the spare line, 64 nothing published (with 1), 256 service wave at priority 0)
+// exists only in a -DSW_DEBUG build; otherwise the switches fold away
 #ifdef SW_DEBUG
 #define SW_DBG(a) ((a).dbg)
 #else
