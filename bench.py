@@ -291,6 +291,88 @@ def kkt_f64(inst, x, y_local, allreduce_host, block_cones=50):
     }
 
 
+def kkt_f64_lp(inst, x, y_local, allreduce_host, block_rows=4000):
+    """kkt_f64 for the benchmark_lp construction (rows [r0, r1) of [-I ; U(0, 1)] on this rank, nonneg cone): the same
+    quantities, the cone tests being min(s) >= 0 and min(y) >= 0."""
+    import oracle as O
+    from totsu_amd import synth as S
+    n = inst.n
+    x64, y64 = x.astype(np.float64), y_local.astype(np.float64)
+    b64, c64 = inst.vec_b_host.astype(np.float64), inst.vec_c_host.astype(np.float64)
+    r = np.zeros(n)
+    viol_p = viol_d = 0.0
+    t0 = time.perf_counter()
+    for k0 in range(0, inst.m, block_rows):
+        mb = min(block_rows, inst.m - k0)
+        g0 = inst.r0 + k0                          # global index of the block's first row
+        At = np.asarray(O.gen_matrix(mb, n, inst.seed, S.STREAM_A, g0, 0, inst.m_total, 0, 1.0)).reshape(n, mb)
+        for i in range(max(0, min(mb, n - g0))):   # rows below n of the full matrix are -I
+            At[:, i] = 0.0
+            At[g0 + i, i] = -1.0
+        yb = y64[k0:k0 + mb]
+        sl = b64[k0:k0 + mb] - At.T @ x64
+        r += At @ yb
+        viol_p = max(viol_p, float(np.max(np.maximum(0.0, -sl))))
+        viol_d = max(viol_d, float(np.max(np.maximum(0.0, -yb))))
+    sums = allreduce_host(np.concatenate([r, [float(b64 @ y64), float(b64 @ b64)]]))
+    mx = allreduce_host(np.array([viol_p, viol_d]), op="max")
+    r = sums[:n] + c64
+    pobj, dobj = float(c64 @ x64), -float(sums[n])
+    return {
+        "primal_obj_f64": pobj, "dual_obj_f64": dobj,
+        "gap_rel": abs(pobj - dobj) / (1.0 + abs(pobj) + abs(dobj)),
+        "dual_residual_rel_f64": float(np.linalg.norm(r)) / (1.0 + float(np.linalg.norm(c64))),
+        "primal_cone_violation": float(mx[0]),
+        "primal_cone_violation_rel_to_norm_b": float(mx[0]) / (1.0 + math.sqrt(float(sums[n + 1]))),
+        "dual_cone_violation": float(mx[1]),
+        "f64_evaluation_seconds": time.perf_counter() - t0,
+        "what": "x, y of THIS run's time_to_eps solve re-evaluated in f64 against the regenerated A = [-I ; U] (solver.rs:573-612's "
+                "quantities; cone tests: s >= 0, y >= 0): approximate KKT, not a bracket",
+    }
+
+
+def kkt_f64_sdp(inst, x, y):
+    """kkt_f64 for the synthetic SDP (one PSD cone of order k, A = [svec(F_i)]): the cone tests are the most negative
+    eigenvalue of mat(s) and of mat(y) (numpy eigh in f64; svec scales the off-diagonal entries by sqrt 2)."""
+    import oracle as O
+    from totsu_amd import synth as S
+    n, k, sk = inst.n, inst.k, inst.m
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    b64, c64 = inst.vec_b_host.astype(np.float64), inst.vec_c_host.astype(np.float64)
+    t0 = time.perf_counter()
+    ax = np.zeros(sk)
+    r = np.zeros(n)
+    for j0 in range(0, n, 250):
+        nc = min(250, n - j0)
+        A = np.asarray(O.gen_matrix(sk, nc, inst.seed, S.STREAM_A, 0, j0, sk, 1, 1.0 / math.sqrt(k))).reshape(nc, sk)
+        ax += x64[j0:j0 + nc] @ A                 # row j of the reshaped block is column j of A
+        r[j0:j0 + nc] = A @ y64
+    r += c64
+
+    def lam_min(v):
+        mat = np.zeros((k, k))
+        iu = np.triu_indices(k)                   # packed upper by columns: entry c (c + 1) / 2 + r is (r, c), r <= c
+        order = np.lexsort((iu[0], iu[1]))
+        rr, cc = iu[0][order], iu[1][order]
+        mat[rr, cc] = v / np.where(rr == cc, 1.0, math.sqrt(2.0))
+        mat = mat + np.triu(mat, 1).T
+        return float(np.linalg.eigvalsh(mat)[0])
+    sl = b64 - ax
+    viol_p, viol_d = max(0.0, -lam_min(sl)), max(0.0, -lam_min(y64))
+    pobj, dobj = float(c64 @ x64), -float(b64 @ y64)
+    return {
+        "primal_obj_f64": pobj, "dual_obj_f64": dobj,
+        "gap_rel": abs(pobj - dobj) / (1.0 + abs(pobj) + abs(dobj)),
+        "dual_residual_rel_f64": float(np.linalg.norm(r)) / (1.0 + float(np.linalg.norm(c64))),
+        "primal_cone_violation": viol_p,
+        "primal_cone_violation_rel_to_norm_b": viol_p / (1.0 + float(np.linalg.norm(b64))),
+        "dual_cone_violation": viol_d,
+        "f64_evaluation_seconds": time.perf_counter() - t0,
+        "what": "x, y of THIS run's time_to_eps solve re-evaluated in f64 against the regenerated A (solver.rs:573-612's "
+                "quantities; cone tests: the most negative eigenvalue of mat(s) and of mat(y)): approximate KKT, not a bracket",
+    }
+
+
 def kkt_f64_cols(inst, x_local, y, allreduce_host, block_cols=500):
     """kkt_f64 for a COLUMN-sharded answer: this rank holds x over its columns [col0, col1) and the whole of y (replicated).
     A x adds up over the ranks (one all-reduce of an m-vector), the dual residual r = c + A^T y is this rank's block (its
@@ -504,7 +586,7 @@ def run(a):
         mm = a.cones * 100 if a.workload == "socp" else 2 * nn
         c0_, c1_ = synth.shard_cols(nn, emu or world, rank)
         ok_ = C_.c_int(0)
-        lib.thip_sweep_probe(mm, c1_ - c0_, mm, C_.byref(ok_))
+        lib.thip_sweep_probe(mm, c1_ - c0_, mm, {"f32": 0, "bf16": 1, "f16": 2}.get(a.a_storage, 0), C_.byref(ok_))
         from totsu_amd.parallel import agree_on_column_shards
         all_ok = agree_on_column_shards(ok_.value != 0, allreduce_host, world) if use_dist else ok_.value
         if not all_ok:
@@ -868,9 +950,14 @@ def run(a):
         else:
             dobj = float(allreduce_host(np.array([dloc], dtype=np.float32))[0]) if use_dist else dloc
         out["time_to_eps"].update({"primal_obj": pobj, "dual_obj": dobj})
-        if a.workload == "socp" and not a.no_gate:
+        if not a.no_gate and not (cols and a.workload != "socp") and not (a.bf16_direct or a.f16_direct):
             try:
-                gate = kkt_f64_cols(inst, x, y, allreduce_host) if cols else kkt_f64(inst, x, y, allreduce_host)
+                if a.workload == "lp":
+                    gate = kkt_f64_lp(inst, x, y, allreduce_host)
+                elif a.workload == "sdp":
+                    gate = kkt_f64_sdp(inst, x, y)
+                else:
+                    gate = kkt_f64_cols(inst, x, y, allreduce_host) if cols else kkt_f64(inst, x, y, allreduce_host)
                 gate.update({"eps_acc": a.to_eps, "gpu_criteria_f32": list(r2.cri), "state": r2.state})
                 out["objective_gate"]["this_run"] = gate
             except Exception as e:                      # the checker must never break the bench line

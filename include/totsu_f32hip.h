@@ -387,8 +387,12 @@ int thip_solver_sweep_plan(thip_solver *s, int *host_members, int *host_cols_per
 int thip_solver_set_column_shard(thip_solver *s, int on);
 /* Can the one-pass kernel run on this device for an m x n_local block (geometry + one placement census, no collective)?
  * A multi-rank host asks every rank and takes the minimum BEFORE building column-sharded solvers: a rank that found out
- * inside thip_solver_init would leave the others waiting in their first all-reduce. */
-int thip_sweep_probe(size_t m, size_t n_local, size_t lda, int *host_ok);
+ * inside thip_solver_init would leave the others waiting in their first all-reduce.  elem = the stored form of A the run
+ * will stream (THIP_A_F32 / THIP_A_BF16 / THIP_A_F16: a 16-bit plan has eight rows per slot and caps of its own).
+ * A rank whose plan still fails later (a re-plan inside thip_solver_run after thip_solver_set_a_storage /
+ * _set_sweep_min_bytes) takes part in the peers' collectives with its fault flag raised: every rank of the run returns
+ * THIP_E_TIMEOUT at the same batch. */
+int thip_sweep_probe(size_t m, size_t n_local, size_t lda, int elem, int *host_ok);
 
 /* What THIS device streams: a bare non-temporal read of `bytes` at dev_ptr (device memory, 16-byte aligned -- e.g. the
  * solver's own A), best and average of `reps` timed launches per grid (HIP events).  bench.py prints it beside the
@@ -451,6 +455,19 @@ int thip_test_gemm_sym(int n, int ld, float alpha, const float *A, const float *
  * 2: 32 x 64 blocks (what the library picks when a launch has more tiles than the device has CUs) */
 int thip_test_gemm_chain(int shape, int kernel, int n, int ld, int nb, float alpha, const float *X, const float *Y,
                          float beta, const float *D, float gamma, float *C);
+/* test entry point for the all-symmetric products of the round-5 chain: O_p = alpha_p * A * B_p + beta_p * B_p + gamma_p * I_n
+ * for A, B_p symmetric ld x ld (ld a multiple of 64 up to 512, nb items ld * ld apart), computed on the lower triangle of
+ * 32 x 32 tiles and mirrored; with dsym_p != 0 the diagonal tiles are averaged with their transpose.  coef = { alpha0, beta0,
+ * gamma0, dsym0, alpha1, beta1, gamma1, dsym1 }; B1 == NULL: one product.  kernel 0: the two-product kernel with the
+ * library's tiles-per-workgroup; 1..3: that number forced; 4 / 5: the one-tile / 32 x 64 block kernels (one product) */
+int thip_test_gemm_dual(int kernel, int n, int ld, int nb, const float *A, const float *B0, const float *B1, const float *coef,
+                        float *O0, float *O1);
+/* timing probe of the chain's launch shapes (tools/psd_chain_probe.py): `reps` dependent launches of ld x ld products,
+ * *host_us = microseconds per launch.  mode 0 / 1: 32 x 64 blocks, batch of two, symmetric / general result; 2: one tile
+ * per workgroup, symmetric, batch of two; 3: the same, one item; 4: mode 3 on two streams at once (per launch PAIR);
+ * 5: one tile per workgroup, general, one item; 6-8: the two-product kernel (two products / one with averaged diagonal tiles /
+ * one with the packed output); 9: mode 0 with averaged diagonal tiles */
+int thip_test_chain_probe(int mode, int ld, int reps, float *host_us);
 
 /* the GEMV tiling chosen by the create-time autotune (rows groups per lane, grid size, its measured ms); 0 = heuristic */
 int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, float *host_ms);
@@ -458,6 +475,9 @@ int thip_solver_gemv_plan(const thip_solver *s, int *host_nj, int *host_blocks, 
 /* per-launch timing of the GEMV kernels of the fused loop (HIP events on the launch stream): enable, run,
  * then read the number of timed launches and their summed duration.  Used by bench.py's roofline. */
 int thip_prof_enable(int on);
+/* the same for the PSD cones of the fused loop: one span per iteration around the projection chains of all its PSD blocks
+ * (x_y and x_s together): number of spans timed and their summed duration -- bench.py's roofline_eig */
+int thip_prof_read_psd(int64_t *host_spans, double *host_total_ms);
 int thip_prof_read(int64_t *host_launches, double *host_total_ms);     /* SYNC */
 
 /* ---------------------------------------------------------------------------------------------

@@ -152,7 +152,7 @@ extern "C" {
     pub fn thip_solver_schedule_in_use(s: *mut thip_solver, host_schedule: *mut c_int) -> c_int;
     pub fn thip_solver_set_sweep_min_bytes(s: *mut thip_solver, bytes: usize) -> c_int;
     pub fn thip_solver_set_column_shard(s: *mut thip_solver, on: c_int) -> c_int;
-    pub fn thip_sweep_probe(m: usize, n_local: usize, lda: usize, host_ok: *mut c_int) -> c_int;
+    pub fn thip_sweep_probe(m: usize, n_local: usize, lda: usize, elem: c_int, host_ok: *mut c_int) -> c_int;
     pub fn thip_solver_sweep_plan(s: *mut thip_solver, host_members: *mut c_int, host_cols_per_panel: *mut c_int, host_slots: *mut c_int, host_ms: *mut f32) -> c_int;
     pub fn thip_test_sweep(t: *const thip_sweep_test, host_ms: *mut f32, host_info: *mut c_int) -> c_int;
     pub fn thip_stream_probe(dev_ptr: *const c_void, bytes: usize, reps: c_int, host_best_ms: *mut f32, host_avg_ms: *mut f32) -> c_int;
@@ -183,10 +183,14 @@ extern "C" {
 
     pub fn thip_prof_enable(on: c_int) -> c_int;
     pub fn thip_prof_read(host_launches: *mut i64, host_total_ms: *mut f64) -> c_int;
+    pub fn thip_prof_read_psd(host_spans: *mut i64, host_total_ms: *mut f64) -> c_int;
     pub fn thip_test_gemm_sym(n: c_int, ld: c_int, alpha: f32, a: *const f32, b: *const f32, beta: f32, d: *const f32,
                               gamma: f32, c: *mut f32) -> c_int;
     pub fn thip_test_gemm_chain(shape: c_int, kernel: c_int, n: c_int, ld: c_int, nb: c_int, alpha: f32, x: *const f32,
                                 y: *const f32, beta: f32, d: *const f32, gamma: f32, c: *mut f32) -> c_int;
+    pub fn thip_test_chain_probe(mode: c_int, ld: c_int, reps: c_int, host_us: *mut f32) -> c_int;
+    pub fn thip_test_gemm_dual(kernel: c_int, n: c_int, ld: c_int, nb: c_int, a: *const f32, b0: *const f32, b1: *const f32,
+                               coef: *const f32, o0: *mut f32, o1: *mut f32) -> c_int;
 }
 
 pub const THIP_A_F32: c_int = 0;

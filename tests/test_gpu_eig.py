@@ -292,6 +292,83 @@ def test_mfma_gemm_both_kernels_every_k_split(L, ld, shape):
         d.free()
 
 
+@pytest.mark.parametrize("ld", [64, 192, 320, 448, 512])
+@pytest.mark.parametrize("nb", [1, 2])
+def test_all_symmetric_products_of_the_degree_7_chain(L, ld, nb):
+    """round 5: O_p = alpha_p A B_p + beta_p B_p + gamma_p I for symmetric A, B_p from the lower triangle of tiles, mirrored,
+    the diagonal tiles of an A != B_p product averaged with their transpose (thip_test_gemm_dual).  Against f64 numpy with
+    exactly that symmetrisation; every result bitwise symmetric; the two-product kernel with 1, 2, 3 tile-jobs per workgroup
+    bitwise the same (one order of every sum), and its one-product form bitwise the one-tile and the 32 x 64 block kernel's"""
+    from totsu_amd._lib import lib
+    from totsu_amd.fused import DeviceBuffer
+    n = ld - 13
+    rng = np.random.default_rng(77 * ld + nb)
+
+    def symm(shape):
+        M = rng.standard_normal(shape).astype(np.float32)
+        M = M + M.transpose(0, 2, 1)
+        M[:, n:, :] = 0
+        M[:, :, n:] = 0
+        return M
+    A, B0, B1 = symm((nb, ld, ld)), symm((nb, ld, ld)), symm((nb, ld, ld))
+    up = lambda M: DeviceBuffer.from_host(np.ascontiguousarray(M).ravel())
+    dA, dB0, dB1 = up(A), up(B0), up(B1)
+    eye = np.zeros((ld, ld))
+    eye[:n, :n] = np.eye(n)
+
+    def ref(Bm, alpha, beta, gamma, dsym):
+        E = A.astype(np.float64) @ Bm.astype(np.float64)
+        sc = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64)
+        out, scl = np.empty_like(E), np.empty_like(sc)
+        nt = ld // 32
+        for i in range(nt):
+            for j in range(i + 1):
+                I, J = slice(32 * i, 32 * i + 32), slice(32 * j, 32 * j + 32)
+                t, s_ = E[:, I, J], sc[:, I, J]
+                if i == j and dsym:
+                    t = 0.5 * (t + t.transpose(0, 2, 1))
+                    s_ = 0.5 * (s_ + s_.transpose(0, 2, 1))
+                out[:, I, J], scl[:, I, J] = t, s_
+                if i != j:
+                    out[:, J, I], scl[:, J, I] = t.transpose(0, 2, 1), s_.transpose(0, 2, 1)
+        return alpha * out + beta * Bm + gamma * eye, abs(alpha) * scl + abs(beta) * np.abs(Bm) + abs(gamma)
+
+    coef = np.array([0.5, -2.0, 3.0, 0.0, 1.5, 0.25, 0.0, 1.0], dtype=np.float32)
+    r0, s0 = ref(B0, 0.5, -2.0, 3.0, False)
+    r1, s1 = ref(B1, 1.5, 0.25, 0.0, True)
+    got = {}
+    for kernel in (0, 1, 2, 3):
+        d0, d1 = DeviceBuffer(nb * ld * ld), DeviceBuffer(nb * ld * ld)
+        assert lib.thip_test_gemm_dual(kernel, n, ld, nb, dA.ptr, dB0.ptr, dB1.ptr, coef.ctypes.data, d0.ptr, d1.ptr) == 0
+        g0, g1 = d0.to_host().reshape((nb, ld, ld)), d1.to_host().reshape((nb, ld, ld))
+        d0.free()
+        d1.free()
+        # (B_0 is not A: without dsym the diagonal tiles of product 0 need not be symmetric -- compare its lower tiles' image only)
+        assert np.all(np.abs(g1 - r1) <= 2e-6 * s1), kernel
+        assert np.array_equal(g1, g1.transpose(0, 2, 1)), kernel
+        lowr = np.tril(np.ones((ld // 32, ld // 32)), -1).repeat(32, 0).repeat(32, 1).astype(bool)
+        E0 = 0.5 * (A.astype(np.float64) @ B0.astype(np.float64)) - 2.0 * B0 + 3.0 * eye
+        assert np.all(np.abs(g0 - E0)[:, lowr] <= 2e-6 * s0[:, lowr]), kernel
+        got[kernel] = (g0, g1)
+    for kernel in (1, 2, 3):
+        assert np.array_equal(got[kernel][0], got[0][0]) and np.array_equal(got[kernel][1], got[0][1]), kernel
+    # one product with averaged diagonal tiles: the two-product kernel's one-product form, the one-tile and the block kernel
+    c1 = np.array([1.5, 0.0, 0.75, 1.0, 0, 0, 0, 0], dtype=np.float32)
+    rr, ss = ref(B1, 1.5, 0.0, 0.75, True)
+    outs = []
+    for kernel in (0, 4, 5):
+        d0 = DeviceBuffer(nb * ld * ld)
+        assert lib.thip_test_gemm_dual(kernel, n, ld, nb, dA.ptr, dB1.ptr, None, c1.ctypes.data, d0.ptr, None) == 0
+        g = d0.to_host().reshape((nb, ld, ld))
+        d0.free()
+        assert np.all(np.abs(g - rr) <= 2e-6 * ss), kernel
+        assert np.array_equal(g, g.transpose(0, 2, 1)), kernel
+        outs.append(g)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    for d in (dA, dB0, dB1):
+        d.free()
+
+
 @pytest.mark.parametrize("k", [500, 700, 1300])      # 64 / 32 / 16 rows of Z per workgroup in the rotation replay
 def test_general_eigen_engine_time_and_orthogonality(L, k):
     """the two-phase closure path (thip_eig_decompose -> host closure -> thip_eig_rebuild): eigenvalues against numpy,

@@ -591,10 +591,15 @@ def test_sweep_probe_and_plan_queries(T):
     from totsu_amd import _lib
     lib = _lib.lib
     ok = C.c_int(-1)
-    lib.thip_sweep_probe(100_000, 6250, 100_000, C.byref(ok))
+    lib.thip_sweep_probe(100_000, 6250, 100_000, 0, C.byref(ok))
     assert ok.value == 1                       # an MI355X: 8 XCDs x 32 CUs, one resident workgroup each
-    lib.thip_sweep_probe(100_000, 20, 100_000, C.byref(ok))
+    lib.thip_sweep_probe(100_000, 20, 100_000, 0, C.byref(ok))
     assert ok.value == 0                       # fewer than 40 columns: the kernel does not take the block
+    for elem in (1, 2):                        # the 16-bit plans (eight rows per slot) of the same column shard, and of a ragged m
+        lib.thip_sweep_probe(100_000, 6250, 100_000, elem, C.byref(ok))
+        assert ok.value == 1
+        lib.thip_sweep_probe(100_003, 6250, 100_003, elem, C.byref(ok))
+        assert ok.value == 1
     lp, _ = _lp(T, 120, 3)
     p = T.SolverParam()
     fs = T.FusedSolver.from_dense(lp.dense(), p, "sweep", sweep_min_bytes=0)
@@ -702,6 +707,68 @@ def test_column_sharded_fault_on_one_rank_is_seen_by_all_and_retried_together(T)
     # replicated m-vectors stay bitwise identical across the ranks through the recovery
     n0, n1 = 90, 170
     assert np.array_equal(hit[0][1][0][n0:], hit[1][1][0][n1:]) and np.array_equal(hit[0][1][1][n0:], hit[1][1][1][n1:])
+
+
+def test_column_shard_whose_replan_fails_on_one_rank_stops_every_rank_together(T):
+    """2 emulated ranks, 16 clean iterations; then every rank re-plans (thip_solver_set_sweep_min_bytes) and rank 1's plan fails
+    (test hook: its placement census says "not 8 x 32").  A column block has no 2-pass form: rank 1 takes part in its peer's
+    collectives with the fault flag raised, rank 0 retries from its snapshot three times, and BOTH return THIP_E_TIMEOUT --
+    nobody hangs in a collective, nobody iterates another schedule"""
+    import threading
+    from totsu_amd import _lib
+    lib = _lib.lib
+    socp = _socp(T, 260, [15, 40, 3, 66, 99, 21], seed=12)
+    d = socp.dense()
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+    cuts = [0, 90, 260]
+    n, m = d.n, d.m
+    A = np.asarray(d.mat_a).reshape((n, m))
+    barrier = threading.Barrier(2)
+    bufs, codes, calls, errs = [None, None], [None, None], [0, 0], []
+
+    def make_hook(rank):
+        def hook(ctx, ptr, cnt, stream):
+            try:
+                bufs[rank] = (ptr, cnt)
+                barrier.wait(timeout=60)
+                assert bufs[0][1] == bufs[1][1], bufs             # the same message length on both ranks, always
+                if rank == 0:
+                    lib.thip_add(cnt, 1.0, bufs[1][0], bufs[0][0])
+                    lib.thip_copy(cnt, bufs[0][0], bufs[1][0])
+                barrier.wait(timeout=60)
+                calls[rank] += 1
+                return 0
+            except Exception as e:      # noqa
+                errs.append(e)
+                return 1
+        return hook
+
+    def worker(rank):
+        try:
+            lo, hi = cuts[rank], cuts[rank + 1]
+            fs = T.FusedSolver(hi - lo, m, A[lo:hi].ravel().copy(), d.vec_b, np.asarray(d.vec_c)[lo:hi], d.seg_type, d.seg_len, p,
+                               "sweep", vec_b_rowabs=d.vec_b_rowabs, allreduce=make_hook(rank), col_shard=True, sweep_min_bytes=0)
+            fs.run(16, poll_every=8)
+            if rank == 1:
+                fs.inject_sweep_fault(1)                          # its next plan fails
+            fs.set_sweep_min_bytes(0)                             # every rank re-plans inside its next run
+            try:
+                fs.run(24, poll_every=8)
+                codes[rank] = 0
+            except _lib.ThipError as e:
+                codes[rank] = e.code
+            fs.destroy()
+        except Exception as e:          # noqa
+            errs.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    [t_.start() for t_ in th]
+    [t_.join() for t_ in th]
+    assert not errs, errs
+    assert codes == [_lib.E_TIMEOUT, _lib.E_TIMEOUT], codes
+    assert calls[0] == calls[1]
 
 
 def test_stream_probe_reports_a_plausible_rate(T):

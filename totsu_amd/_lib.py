@@ -147,7 +147,7 @@ PROTOTYPES = {
     "thip_solver_schedule_in_use": (_i, [_vp, C.POINTER(_i)]),
     "thip_solver_set_sweep_min_bytes": (_i, [_vp, _sz]),
     "thip_solver_set_column_shard": (_i, [_vp, _i]),
-    "thip_sweep_probe": (_i, [_sz, _sz, _sz, C.POINTER(_i)]),
+    "thip_sweep_probe": (_i, [_sz, _sz, _sz, _i, C.POINTER(_i)]),
     "thip_solver_sweep_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),
     "thip_test_sweep": (_i, [_vp, C.POINTER(_f), C.POINTER(_i)]),
     "thip_stream_probe": (_i, [_vp, _sz, _i, C.POINTER(_f), C.POINTER(_f)]),
@@ -156,9 +156,12 @@ PROTOTYPES = {
     "thip_solver_set_sweep_publish": (_i, [_vp, _i]),
     "thip_test_gemm_sym": (_i, [_i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_test_gemm_chain": (_i, [_i, _i, _i, _i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
+    "thip_test_chain_probe": (_i, [_i, _i, _i, C.POINTER(_f)]),
+    "thip_test_gemm_dual": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thip_solver_gemv_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),
     "thip_prof_enable": (_i, [_i]),
     "thip_prof_read": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "thip_prof_read_psd": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "thip_gen_vector": (_i, [_vp, _sz, _u64, _u64, _u64, _i, _f, _f]),
     "thip_gen_identity": (_i, [_vp, _sz, _sz, _sz, _u64, _f]),
     "thip_gen_matrix": (_i, [_vp, _sz, _sz, _sz, _u64, _u64, _u64, _u64, _u64, _i, _f, _f]),

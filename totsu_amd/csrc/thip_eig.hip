@@ -390,7 +390,7 @@ __global__ __launch_bounds__(GNW * 64) void gemm_k(int n, int ld, float alpha, c
 template <bool GEN, int KW, int NW, bool SYM>
 __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha, const float *__restrict__ X,
                                                       const float *__restrict__ Y, float beta, const float *D, float gamma,
-                                                      float *C, const int *__restrict__ stop, size_t ws, int pitch)
+                                                      float *C, const int *__restrict__ stop, size_t ws, int pitch, int dsym)
 {
     static_assert(!(GEN && SYM), "the symmetric shortcut is for X Y^T products");
     // the stop flag is fetched now and looked at just before the first store: tested here, every launch of the chain
@@ -467,10 +467,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
             const size_t o = (size_t)ti * pitch + tj;
             if (beta != 0.0f) v = fmaf(beta, D[o], v);
             if (ti == tj && ti < n) v += gamma;
-            C[o] = v;
+            if (!(SYM && dsym != 0 && bi == bj)) C[o] = v;
             vv[r] = v;
         }
         if constexpr (SYM) {
+            if (bi == bj && dsym != 0) {
+                // X != Y: the diagonal tile is stored as the average of itself and its transpose (see gemm_pre2_k)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tr[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = vv[r];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    C[(size_t)(i0 + tl) * pitch + j0 + (lane & 31)] = 0.5f * (vv[r] + tr[lane & 31][tl]);
+                }
+            }
             if (bi != bj) {
                 // the mirror tile: element (ti, tj) of this tile goes to Cmem[(j0 + tj) * ld + i0 + ti]; through LDS so
                 // that the 32 lanes of a store walk along ti
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
 template <bool GEN, int KW, bool SYM>
 __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, const float *__restrict__ X,
                                                    const float *__restrict__ Y, float beta, const float *D, float gamma,
-                                                   float *C, const int *__restrict__ stop, size_t ws, int pitch)
+                                                   float *C, const int *__restrict__ stop, size_t ws, int pitch, int dsym)
 {
     static_assert(!(GEN && SYM), "the symmetric shortcut is for X Y^T products");
     // the stop flag is fetched now and looked at just before the first store: tested here, every launch of the chain
@@ -573,6 +585,10 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
     // wave w finishes accumulator registers 4 w .. 4 w + 3 of both column sets: rows (r & 3) + 8 w + 4 h
     const int tj = j0 + 2 * li;                               // this lane's columns tj, tj + 1
     const bool colok = !SYM || tj < (bi + 1) * GT;
+    // dsym (SYM, X != Y: the product of two commuting symmetric matrices): inside the DIAGONAL tile element (r, c) and
+    // (c, r) are different sums -- the tile is stored as the average of itself and its transpose (a + b == b + a: bitwise
+    // symmetric), after the block has been staged in tr
+    const bool indiag = SYM && dsym != 0 && tj >= bi * GT && tj < (bi + 1) * GT;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int r = 4 * wave + rr;
@@ -591,7 +607,7 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
             if (ti == tj) ve += gamma;
             if (ti == tj + 1) vo += gamma;
         }
-        if (colok) {
+        if (colok && !indiag) {
             f32x2_t v2;
             v2[0] = ve; v2[1] = vo;
             *reinterpret_cast<f32x2_t *>(C + o) = v2;
@@ -602,6 +618,18 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
         // the mirror image of the tiles strictly below the diagonal: element (ti, tj) also goes to Cmem[tj * ld + ti];
         // through LDS so that the 32 lanes of a store walk along ti.  Wave w: rows j0 + 16 w .. + 15 of the image.
         __syncthreads();
+        if (indiag) {
+            const int cd = bi * GT - j0;                      // the diagonal tile's first column inside the strip
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int tl = rr + 8 * wave + 4 * h;
+                const int c0 = 2 * li - cd;                   // tile columns c0, c0 + 1
+                f32x2_t v2;
+                v2[0] = 0.5f * (tr[tl][2 * li] + tr[c0][cd + tl]);
+                v2[1] = 0.5f * (tr[tl][2 * li + 1] + tr[c0 + 1][cd + tl]);
+                *reinterpret_cast<f32x2_t *>(C + (size_t)(i0 + tl) * pitch + tj) = v2;
+            }
+        }
 #pragma unroll
         for (int sI = 0; sI < 8; ++sI) {
             const int jj = 16 * wave + 2 * sI + h;
@@ -610,10 +638,229 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Two symmetric products that SHARE their first factor, in one launch (round 5: the degree-7 polar step and the
+// merged Newton-Schulz / M sign(M) pair):  O_p = alpha_p * A * B_p + beta_p * B_p + gamma_p * I_n,  p < nprod <= 2,
+// A and B_p bitwise symmetric and commuting (polynomials of one symmetric matrix).  Only the lower triangle of tiles
+// is computed, every tile is stored with its mirror image, diagonal tiles of a product with dsym_p != 0 (A != B_p)
+// as the average of the tile and its transpose -- every result is bitwise symmetric again.
+// A workgroup owns tile row bi's panel of A and up to NT of that row's tile-jobs (tile column j, product p), taken
+// NT at a time from the list (j = 0, p = 0), (0, 1), (1, 0), ...: at ld = 512 the batch of two has 544 tile-jobs,
+// NT = 3 puts them on 192 workgroups -- one per CU, which is what the chain's kernels need (a second workgroup on a CU
+// halves both) -- of 3 x 64 MFMAs per wave.  Four waves split K four ways (KW each) and are combined
+// through LDS; operand loads run DEP slabs of 8 k ahead of the MFMAs, as in gemm_pre_k, whose order of sums per
+// element this kernel keeps.
+struct DualArgs {
+    int          n, ld, pitch, nprod;
+    const float *A;
+    const float *B[2];
+    float       *O[2];
+    float        alpha[2], beta[2], gamma[2];
+    int          dsym[2];
+    const int   *stop;
+    size_t       ws;
+    // pack != nullptr (nprod == 1): instead of O_0, the lower triangle of P = (M + O_0) / 2 leaves packed (diagonal /
+    // scale) -- the last product of the projection -- and rx <- rx - 2 P rides along when rx != nullptr
+    float       *pack;
+    const float *M;
+    float       *rx;
+    ptrdiff_t    ps, rps;
+    int          has_scale;
+    float        scale;
+};
+
+__host__ __device__ inline int dual_groups(int nt, int nprod, int NT)
+{
+    int g = 0;
+    for (int i = 0; i < nt; ++i) g += (nprod * (i + 1) + NT - 1) / NT;
+    return g;
+}
+
+template <int KW, int NT>
+__global__ __launch_bounds__(256) void polar_dual_k(const DualArgs a)
+{
+    const int halted = *a.stop;                 // looked at before the first store (see gemm_pre_k)
+    constexpr int NW = 4;
+    // blockIdx.x -> (tile row bi, group gl of NT jobs inside it)
+    int bi = 0, gl = blockIdx.x;
+    for (;;) {
+        const int gi = (a.nprod * (bi + 1) + NT - 1) / NT;
+        if (gl < gi) break;
+        gl -= gi; ++bi;
+    }
+    const int njobs = a.nprod * (bi + 1);
+    const size_t zo = blockIdx.z * a.ws;
+    __shared__ float red[NW][NT][16][64];
+    __shared__ float tr[NT][32][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // uniform: the panel bases below stay in SGPRs
+    const int h = lane >> 5, li = lane & 31;
+    const int i0 = bi * GT, kb = wave * KW;
+    const int pitch = a.pitch;
+    int bj[NT], pr[NT];
+    bool live[NT];
+    // every load is (uniform base of the panel row) + (this lane's 32-bit byte offset): one global_load with an SGPR base and
+    // no address arithmetic on the vector ALU, so that a load can issue in the shadow of the MFMA before it
+    const char *pb[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int t = NT * gl + u;
+        live[u] = t < njobs;
+        const int tt = live[u] ? t : NT * gl;                      // a job past the row's end repeats the group's first (not stored)
+        bj[u] = a.nprod == 2 ? tt >> 1 : tt;
+        pr[u] = a.nprod == 2 ? tt & 1 : 0;
+        pb[u] = reinterpret_cast<const char *>(a.B[pr[u]] + zo + (size_t)kb * pitch + bj[u] * GT);
+    }
+    const char *pa = reinterpret_cast<const char *>(a.A + zo + (size_t)kb * pitch + i0);
+    const unsigned lo = (unsigned)((4 * h * pitch + li) * (int)sizeof(float));
+    const unsigned rowb = (unsigned)pitch * (unsigned)sizeof(float);
+    constexpr int NQ = KW / 8;
+    constexpr int PER = 4 * (NT + 1);                              // load instructions per slab of 8 k
+    constexpr int DEP0 = 64 / PER < 1 ? 1 : 64 / PER;              // as many slabs ahead as fit the 64 loads a wave may have in flight
+    constexpr int DEP = DEP0 < NQ ? DEP0 : NQ;
+    float av[NQ][4], bv[NQ][NT][4];
+    // load number x of slab q: x < 4: A row 8 q + x; else panel (x - 4) / 4, row 8 q + (x - 4) % 4
+    auto load1 = [&](const int q, const int x) {
+        if (x < 4) av[q][x] = *reinterpret_cast<const float *>(pa + (size_t)((8 * q + x) * rowb) + lo);
+        else {
+            const int u = (x - 4) >> 2, t = (x - 4) & 3;
+            bv[q][u][t] = *reinterpret_cast<const float *>(pb[u] + (size_t)((8 * q + t) * rowb) + lo);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < DEP; ++q) {
+#pragma unroll
+        for (int x = 0; x < PER; ++x) load1(q, x);
+    }
+    // the beta * B_p term of the epilogue: this lane's four elements of every tile, fetched now instead of after the sums
+    float dv[NT][4];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            dv[u][rr] = a.B[pr[u]][zo + (size_t)(i0 + rr + 8 * wave + 4 * h) * pitch + bj[u] * GT + li];
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // slab q's 4 NT MFMAs with slab q + DEP's PER loads dealt out between them (an MFMA holds the pipe for 64 cycles: the
+    // loads issue in its shadow; in blocks after the MFMAs they cost the wave a quarter of the MFMAs' time again)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        int x = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][u][t], acc[u], 0, 0, 0);
+                if (q + DEP < NQ) {
+                    const int upto = ((t * NT + u + 1) * PER + 4 * NT - 1) / (4 * NT);
+                    for (; x < upto && x < PER; ++x) load1(q + DEP, x);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][u][r][lane] = acc[u][r];
+    }
+    __syncthreads();
+    if (halted != 0) return;
+    // wave w finishes accumulator registers 4 w .. 4 w + 3 of every tile: rows tl = rr + 8 w + 4 h, column li
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int p = pr[u], j0 = bj[u] * GT;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr, tl = rr + 8 * wave + 4 * h;
+            float v = red[0][u][r][lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += red[w][u][r][lane];
+            v *= a.alpha[p];
+            const int ti = i0 + tl, tj = j0 + li;
+            v = fmaf(a.beta[p], dv[u][rr], v);
+            if (ti == tj && ti < a.n) v += a.gamma[p];
+            tr[u][tl][li] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        if (!live[u]) continue;
+        const int p = pr[u], j0 = bj[u] * GT;
+        const bool diag = bj[u] == bi;
+        float *Om = a.O[p] + zo;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int tl = rr + 8 * wave + 4 * h;
+            float v = tr[u][tl][li];
+            if (diag && a.dsym[p] != 0) v = 0.5f * (v + tr[u][li][tl]);
+            if (a.pack == nullptr) {
+                Om[(size_t)(i0 + tl) * pitch + j0 + li] = v;
+                if (!diag) Om[(size_t)(j0 + tl) * pitch + i0 + li] = tr[u][li][tl];       // the mirror image, rows along j
+            } else {
+                // element (row r = j0 + li, column c = i0 + tl) of the upper triangle by columns: r <= c
+                const int rr_ = j0 + li, cc = i0 + tl;
+                if (rr_ <= cc && cc < a.n) {
+                    float pv = 0.5f * (a.M[zo + (size_t)cc * pitch + rr_] + v);
+                    if (rr_ == cc && a.has_scale) pv = pv / a.scale;
+                    const size_t o = (size_t)cc * (cc + 1) / 2 + rr_;
+                    a.pack[(ptrdiff_t)blockIdx.z * a.ps + o] = pv;
+                    if (a.rx != nullptr) {
+                        float *rx = a.rx + (ptrdiff_t)blockIdx.z * a.rps;
+                        rx[o] = rx[o] - 2.0f * pv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+static int launch_dual(hipStream_t st, const DualArgs &a, int nb)
+{
+    const int nt = a.ld / GT;
+    const dim3 g((unsigned)dual_groups(nt, a.nprod, NT), 1, (unsigned)nb);
+#define THIP_DUAL(KW) hipLaunchKernelGGL((polar_dual_k<KW, NT>), g, dim3(256), 0, st, a)
+    switch (a.ld / 4) {
+    case 16: THIP_DUAL(16); break;
+    case 32: THIP_DUAL(32); break;
+    case 48: THIP_DUAL(48); break;
+    case 64: THIP_DUAL(64); break;
+    case 80: THIP_DUAL(80); break;
+    case 96: THIP_DUAL(96); break;
+    case 112: THIP_DUAL(112); break;
+    default: THIP_DUAL(128); break;
+    }
+#undef THIP_DUAL
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+// the smallest NT whose grid fits one workgroup per CU
+static int dual(hipStream_t st, DualArgs a, int nb)
+{
+    if (a.ld > 512 || a.ld % 64 != 0) return fail(THIP_E_INVALID, "dual: ld <= 512", __FILE__, __LINE__);
+    if (a.stop == nullptr) a.stop = ctx().never_stop;
+    const int nt = a.ld / GT;
+    static const int force_nt = getenv("THIP_PSD_DUAL_NT") ? atoi(getenv("THIP_PSD_DUAL_NT")) : 0;
+    int NT = 1;
+    while (NT < 3 && dual_groups(nt, a.nprod, NT) * nb > ctx().num_cu) ++NT;
+    if (force_nt >= 1 && force_nt <= 3) NT = force_nt;
+    return NT == 1 ? launch_dual<1>(st, a, nb) : NT == 2 ? launch_dual<2>(st, a, nb) : launch_dual<3>(st, a, nb);
+}
+
 // S = M / ||M||_F; the exact zero matrix stays zero.  ||M||_F from unpack_k's block 2-norms (part, np of them), summed by
 // EVERY workgroup for itself (np <= 512 floats from L2: cheaper than a launch that does it once)
 __global__ __launch_bounds__(BLK) void scale_by_fro_k(size_t tot, const float *__restrict__ M, const float *__restrict__ part, int np,
-                                                     float *__restrict__ S, const int *__restrict__ stop, size_t ws)
+                                                     float *__restrict__ S, const int *__restrict__ stop, size_t ws, float mul)
 {
     if (stop != nullptr && *stop != 0) return;
     M += blockIdx.z * ws; part += blockIdx.z * ws; S += blockIdx.z * ws;
@@ -623,7 +870,7 @@ __global__ __launch_bounds__(BLK) void scale_by_fro_k(size_t tot, const float *_
     acc = block_sum_d(acc, shd);
     // a division per element: 1 / f overflows for a subnormal norm, and 0 * inf would poison the iterate
     const float f = (float)sqrt(acc);
-    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) S[i] = f > 0.0f ? M[i] / f : 0.0f;
+    for (size_t i = blockIdx.x * (size_t)BLK + threadIdx.x; i < tot; i += (size_t)gridDim.x * BLK) S[i] = f > 0.0f ? mul * (M[i] / f) : 0.0f;
 }
 
 // packed(r,c) = (M + MS)(r,c) / 2 symmetrised, diag / scale
@@ -762,8 +1009,10 @@ __global__ __launch_bounds__(256) void polar_small_k(int n, float *__restrict__ 
 
 static int g_force_kernel = 0;     // thip_test_gemm_chain: 1 = one tile per workgroup, 2 = 32 x 64 blocks, 0 = by tile count
 // gen == false: C = alpha X Y^T + beta D + gamma I (symmetric result); gen == true: C = alpha X Y + ... (X symmetric)
+// dsym (gen == false only): X != Y, both bitwise symmetric and commuting -- diagonal tiles are stored averaged with
+// their transpose, so that the result is bitwise symmetric like an X X^T product's
 int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, const float *Y, float beta, const float *D,
-         float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0, int pitch = 0)
+         float gamma, float *C, const int *stop, int nb = 1, size_t ws = 0, int pitch = 0, int dsym = 0)
 {
     if (pitch == 0) pitch = ld;                 // rows of the operands are `pitch` floats apart; ld = the extent of every index
     dim3 g(ld / GT, ld / GT, nb);
@@ -779,10 +1028,10 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
     for (int bi = 0; bi < nt; ++bi) npair += bi / 2 + 1;
 #define THIP_GEMM_PRE4(KW)                                                                                                  \
     do {                                                                                                                    \
-        if (pairs && gen) hipLaunchKernelGGL((gemm_pre2_k<true, KW, false>), dim3(nt, nt / 2, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch); \
-        else if (pairs)   hipLaunchKernelGGL((gemm_pre2_k<false, KW, true>), dim3(npair, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch); \
-        else if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false>), g, dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch);  \
-        else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, true>), dim3(nt * (nt + 1) / 2, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch); \
+        if (pairs && gen) hipLaunchKernelGGL((gemm_pre2_k<true, KW, false>), dim3(nt, nt / 2, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch, dsym); \
+        else if (pairs)   hipLaunchKernelGGL((gemm_pre2_k<false, KW, true>), dim3(npair, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch, dsym); \
+        else if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false>), g, dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch, dsym);  \
+        else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, true>), dim3(nt * (nt + 1) / 2, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch, dsym); \
     } while (0)
     if (mode >= 2 && ld <= 512) {
         switch (ld / 4) {
@@ -796,7 +1045,7 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
         default: THIP_GEMM_PRE4(128); break;
         }
     }
-    else if (pitch != ld) return fail(THIP_E_INVALID, "gemm: a padded pitch needs ld <= 512", __FILE__, __LINE__);
+    else if (pitch != ld || dsym != 0) return fail(THIP_E_INVALID, "gemm: a padded pitch / dsym needs ld <= 512", __FILE__, __LINE__);
     else if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
     else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
 #undef THIP_GEMM_PRE4
@@ -1886,7 +2135,7 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
     float *M = k.G, *S = k.S, *Y = k.Y, *Z = k.Z, *T = k.V;
     hipLaunchKernelGGL(unpack_k, dim3(g, 1, nb), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, M, (float *)nullptr,
                        k.part, stop, ws, ps, pitch);
-    hipLaunchKernelGGL(scale_by_fro_k, dim3(g, 1, nb), dim3(BLK), 0, st, tot, M, k.part, (int)g, S, stop, ws);
+    hipLaunchKernelGGL(scale_by_fro_k, dim3(g, 1, nb), dim3(BLK), 0, st, tot, M, k.part, (int)g, S, stop, ws, 1.0f);
     // sign(M) = the polar factor of S = M / ||M||_F by the polar iteration S <- p_k(S S^T) S with odd quintics
     // p_k(x) = a x + b x^3 + c x^5.  Three GEMMs per step, the polynomial folded into the second one's epilogue:
     //   Y = S S^T ;  T = c Y Y^T + b Y + a I ;  S <- T S
@@ -1930,6 +2179,64 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
     dim3 gp((unsigned)((n + BLK - 1) / BLK), (unsigned)n, nb);
     hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop, ws, ps, rx, rps, pitch);
     THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// Round 5: the same projection with every product SYMMETRIC and degree-7 steps -- 36 launches instead of 47.
+//   * S is kept bitwise symmetric: T S is computed like S S^T (lower triangle of tiles, mirrored; diagonal tiles averaged
+//     with their transpose, `dsym`), which turns the antisymmetric round-off of a step into a symmetric perturbation of
+//     the same size instead of carrying it along (measured, tools/psd_err_sweep.py and the numpy restatement in DESIGN.md:
+//     <= 3e-7 |X| on the spectra of tests/test_gpu_eig.py, 2-5e-8 at k = 500).  With S symmetric every operand of every
+//     product can be read as rows, and half the tiles of the 16 general products go away.
+//   * an odd polynomial of degree 7 is x q(x^2) with q cubic, and a real cubic always has a real root:
+//     p(S) = U V with U = q0 Y^2 + q1 Y + q2 I and V = (Y - r0 I) S, Y = S^2.  Y Y and Y S share their first factor and
+//     run as ONE launch (polar_dual_k), so a degree-7 step is three dependent launches like the quintic's -- and the
+//     chain is bound by its launches, not its flops.  Gain 5.64 per step instead of 3.94 on the band
+//     [0.15, 1.85] (tools/polar_coeffs.py: the polynomial accepts (0, 1.85] and returns [0.1525, 1.828]): 8 lifting
+//     steps bring relative eigenvalues >= 1e-7 into the band (5.644^8 = 1.03e6; S_0 = 1.85 M / ||M||_F), 3 minimax
+//     steps take the band to 1 +- 8e-7, and the Newton-Schulz step shares a launch with M S:
+//       {T = 1.5 I - 0.5 S S, R = M S}  ->  M sign(M) = T R, packed by the last launch itself.
+// THIP_PSD_CHAIN=5 keeps the round-4 chain (quintic steps, general T S products).
+int polar_project7(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop,
+                   int nb, size_t ws, ptrdiff_t ps, float *rx, ptrdiff_t rps)
+{
+    const int ni = (int)n, ld = (int)np_of(n), pitch = (int)pitch_of((size_t)ld);
+    const size_t tot = (size_t)pitch * ld;
+    const unsigned g = grid_for(tot, BLK, 512);
+    float *M = k.G, *S = k.S, *Y = k.Y, *U = k.Z, *V = k.V;
+    hipLaunchKernelGGL(unpack_k, dim3(g, 1, nb), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, M, (float *)nullptr,
+                       k.part, stop, ws, ps, pitch);
+    hipLaunchKernelGGL(scale_by_fro_k, dim3(g, 1, nb), dim3(BLK), 0, st, tot, M, k.part, (int)g, S, stop, ws, 1.85f);
+    // r0, q0, q1, q2 of q(y) = (y - r0)(q0 y^2 + q1 y + q2)      (tools/polar_coeffs.py)
+    static const float LIFT7[4] = { 3.446387665f, -0.824204593f, 2.299589116f, -1.666968041f };
+    static const float TAIL7[3][4] = {
+        { 3.563184240f, -0.454986096f, 1.283810123f, -1.135084021f },   // -> [0.58562779, 1.41437225]
+        { 2.790799048f, -0.331962123f, 0.657669174f, -0.874710814f },   // -> [0.98052265, 1.01947735]
+        { 2.503539308f, -0.323241073f, 0.536661220f, -0.878517037f },   // -> [0.99999922, 1.00000079]
+    };
+    DualArgs d;
+    memset(&d, 0, sizeof(d));
+    d.n = ni; d.ld = ld; d.pitch = pitch; d.stop = stop; d.ws = ws;
+    for (int it = 0; it < 11; ++it) {
+        const float *c = it < 8 ? LIFT7 : TAIL7[it - 8];
+        THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop, nb, ws, pitch));        // Y = S S
+        d.nprod = 2; d.A = Y;
+        d.B[0] = Y; d.O[0] = U; d.alpha[0] = c[1]; d.beta[0] = c[2]; d.gamma[0] = c[3]; d.dsym[0] = 0;    // U = q0 Y Y + q1 Y + q2 I
+        d.B[1] = S; d.O[1] = V; d.alpha[1] = 1.0f; d.beta[1] = -c[0]; d.gamma[1] = 0.0f; d.dsym[1] = 1;   // V = Y S - r0 S
+        THIP_RC(dual(st, d, nb));
+        THIP_RC(gemm(st, false, ni, ld, 1.0f, U, V, 0.0f, nullptr, 0.0f, S, stop, nb, ws, pitch, 1));     // S <- U V
+    }
+    // Newton-Schulz x (3 - x^2) / 2 and M sign(M), merged:  T = 1.5 I - 0.5 S S (into Y),  R = S M (into U);  T R -> packed
+    d.nprod = 2; d.A = S;
+    d.B[0] = S; d.O[0] = Y; d.alpha[0] = -0.5f; d.beta[0] = 0.0f; d.gamma[0] = 1.5f; d.dsym[0] = 0;
+    d.B[1] = M; d.O[1] = U; d.alpha[1] = 1.0f; d.beta[1] = 0.0f; d.gamma[1] = 0.0f; d.dsym[1] = 1;
+    THIP_RC(dual(st, d, nb));
+    d.nprod = 1; d.A = Y;
+    d.B[0] = U; d.O[0] = nullptr; d.alpha[0] = 1.0f; d.beta[0] = 0.0f; d.gamma[0] = 0.0f; d.dsym[0] = 1;
+    d.B[1] = nullptr; d.O[1] = nullptr;
+    d.pack = packed; d.M = M; d.rx = rx; d.ps = ps; d.rps = rps; d.has_scale = has_scale; d.scale = scale;
+    THIP_RC(dual(st, d, nb));
     return 0;
 }
 
@@ -1986,6 +2293,10 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
         return eig_psd_project_small(st, n, packed, nullptr, 1, has_scale, scale_diag, stop, nbatch, pstride, rx, rx_stride);
     }
     if (map_kind == 0 && n > POLAR_MIN_N) {
+        // orders up to 512 (ld <= 512): the all-symmetric degree-7 chain; above, or THIP_PSD_CHAIN=5: the round-4 quintic chain
+        static const int chain = getenv("THIP_PSD_CHAIN") ? atoi(getenv("THIP_PSD_CHAIN")) : 7;
+        if (chain == 7 && np_of(n) <= 512)
+            return polar_project7(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride, rx, rx_stride);
         return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride, rx, rx_stride);
     }
     for (int z = 0; z < nbatch; ++z) {          // the Jacobi engine works on one matrix at a time
@@ -2016,6 +2327,108 @@ int thip_test_gemm_chain(int shape, int kernel, int n, int ld, int nb, float alp
     g_force_kernel = kernel;
     const int rc = gemm(ctx().stream, shape == 1, n, ld, alpha, X, Y, beta, D, gamma, C, nullptr, nb, (size_t)ld * ld);
     g_force_kernel = 0;
+    return rc;
+}
+
+
+// timing probe (tools/psd_chain_probe.py): `reps` DEPENDENT launches of one product shape, microseconds per launch.
+//   mode 0 / 1: the 32 x 64 block kernel on a batch of two (symmetric / general result) -- the round-4 chain's launches;
+//   mode 2: one tile per workgroup, symmetric, batch of two (272 workgroups at ld = 512); mode 3: the same, one item;
+//   mode 4: mode 3 on TWO streams at once (one item each; us per launch PAIR); mode 5: one tile, general, one item
+// test entry point for the round-5 kernels of the chain: O_p = alpha_p A B_p + beta_p B_p + gamma_p I_n from the lower triangle
+// of tiles (mirrored; diagonal tiles of a product with dsym_p averaged with their transpose), nb items ld * ld apart.
+// coef = { alpha0, beta0, gamma0, dsym0, alpha1, beta1, gamma1, dsym1 }; B1 == nullptr: one product.  kernel 0: polar_dual_k with
+// the library's NT; 1 .. 3: NT forced; 4 / 5: the one-tile / 32 x 64 block kernel of gemm() (one product, beta = 0)
+int thip_test_gemm_dual(int kernel, int n, int ld, int nb, const float *A, const float *B0, const float *B1, const float *coef,
+                        float *O0, float *O1)
+{
+    THIP_NEED_INIT();
+    if (ld <= 0 || ld % 64 != 0 || ld > 512 || n < 0 || n > ld || nb < 1 || kernel < 0 || kernel > 5 || !A || !B0 || !coef || !O0)
+        return fail(THIP_E_INVALID, "thip_test_gemm_dual", __FILE__, __LINE__);
+    const size_t ws = (size_t)ld * ld;
+    if (kernel >= 4) {
+        if (B1 != nullptr || coef[1] != 0.0f) return fail(THIP_E_INVALID, "thip_test_gemm_dual: kernels 4, 5 take one product, beta = 0", __FILE__, __LINE__);
+        g_force_kernel = kernel == 4 ? 1 : 2;
+        const int rc = gemm(ctx().stream, false, n, ld, coef[0], A, B0, 0.0f, nullptr, coef[2], O0, nullptr, nb, ws, ld, coef[3] != 0.0f);
+        g_force_kernel = 0;
+        return rc;
+    }
+    DualArgs d;
+    memset(&d, 0, sizeof(d));
+    d.n = n; d.ld = ld; d.pitch = ld; d.ws = ws; d.A = A; d.stop = ctx().never_stop;
+    d.nprod = B1 ? 2 : 1;
+    d.B[0] = B0; d.O[0] = O0; d.alpha[0] = coef[0]; d.beta[0] = coef[1]; d.gamma[0] = coef[2]; d.dsym[0] = coef[3] != 0.0f;
+    if (B1) { d.B[1] = B1; d.O[1] = O1; d.alpha[1] = coef[4]; d.beta[1] = coef[5]; d.gamma[1] = coef[6]; d.dsym[1] = coef[7] != 0.0f; }
+    if (kernel == 0) return dual(ctx().stream, d, nb);
+    return kernel == 1 ? launch_dual<1>(ctx().stream, d, nb) : kernel == 2 ? launch_dual<2>(ctx().stream, d, nb) : launch_dual<3>(ctx().stream, d, nb);
+}
+
+__global__ void probe_delay_k(long long cycles)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+}
+
+int thip_test_chain_probe(int mode, int ld, int reps, float *host_us)
+{
+    THIP_NEED_INIT();
+    if (ld <= 0 || ld % 64 != 0 || ld > 512 || reps < 1 || mode < 0 || mode > 9)
+        return fail(THIP_E_INVALID, "thip_test_chain_probe", __FILE__, __LINE__);
+    Ctx &c = ctx();
+    const size_t ws = (size_t)ld * ld;
+    float *buf = nullptr;
+    THIP_TRY(hipMalloc(&buf, sizeof(float) * ws * 6));
+    THIP_TRY(hipMemsetAsync(buf, 0, sizeof(float) * ws * 6, c.stream));
+    if (c.eig_side == nullptr) THIP_TRY(hipStreamCreateWithFlags(&c.eig_side, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k)
+        if (c.eig_ev[k] == nullptr) THIP_TRY(hipEventCreateWithFlags(&c.eig_ev[k], hipEventDisableTiming));
+    hipEvent_t e0, e1;
+    THIP_TRY(hipEventCreate(&e0));
+    THIP_TRY(hipEventCreate(&e1));
+    const bool gen = mode == 1 || mode == 5;
+    const int nb = (mode <= 2 || mode >= 6) ? 2 : 1;
+    float *pk = nullptr;
+    if (mode == 8) { THIP_TRY(hipMalloc(&pk, sizeof(float) * ws * 4)); THIP_TRY(hipMemsetAsync(pk, 0, sizeof(float) * ws * 4, c.stream)); }
+    int rc = 0;
+    for (int pass = 0; pass < 2 && rc == 0; ++pass) {          // pass 0 warms up
+        // the host enqueues behind a 100 MHz-clock delay so that the chain's time is the device's, not the launch rate's
+        hipLaunchKernelGGL(probe_delay_k, dim3(1), dim3(64), 0, c.stream, (long long)(100 * (12 * reps + 500)));
+        hipEventRecord(e0, c.stream);
+        if (mode == 4) { hipEventRecord(c.eig_ev[0], c.stream); hipStreamWaitEvent(c.eig_side, c.eig_ev[0], 0); }
+        for (int r = 0; r < reps && rc == 0; ++r) {
+            // items 0 and 1 live 3 ws apart; a launch reads buffer r % 3 and writes (r + 1) % 3 of its item(s)
+            float *X = buf + (size_t)(r % 3) * ws, *C = buf + (size_t)((r + 1) % 3) * ws;
+            if (mode >= 6) {
+                // 6: the degree-7 step's middle launch (two products sharing A); 7: one product, diagonal tiles averaged;
+                // 8: the last launch (one product, packed output + rx); 9: mode 7 through the 32 x 64 block kernel
+                DualArgs d;
+                memset(&d, 0, sizeof(d));
+                d.n = ld; d.ld = ld; d.pitch = ld; d.ws = 3 * ws; d.A = X;
+                d.B[0] = X; d.O[0] = C; d.alpha[0] = 0.5f; d.beta[0] = mode == 6 ? 0.1f : 0.0f; d.gamma[0] = 0.25f;
+                d.nprod = mode == 6 ? 2 : 1;
+                if (mode == 6) { d.B[1] = buf + (size_t)((r + 2) % 3) * ws; d.O[1] = d.B[1] == X ? C : const_cast<float *>(d.B[1]); d.alpha[1] = 0.5f; d.beta[1] = 0.1f; d.dsym[1] = 1; }
+                if (mode == 7) d.dsym[0] = 1;
+                if (mode == 8) { d.dsym[0] = 1; d.pack = pk; d.M = X; d.rx = pk + 2 * ws; d.ps = (ptrdiff_t)ws; d.rps = (ptrdiff_t)ws; d.has_scale = 1; d.scale = 1.414f; }
+                if (mode == 9) rc = gemm(c.stream, false, ld, ld, 0.5f, X, X, 0.0f, nullptr, 0.25f, C, nullptr, nb, 3 * ws, ld, 1);
+                else rc = dual(c.stream, d, nb);
+                continue;
+            }
+            g_force_kernel = mode <= 1 ? 2 : 1;
+            rc = gemm(c.stream, gen, ld, ld, 0.5f, X, X, 0.0f, nullptr, 0.25f, C, nullptr, nb, 3 * ws);
+            if (mode == 4 && rc == 0)
+                rc = gemm(c.eig_side, gen, ld, ld, 0.5f, X + 3 * ws, X + 3 * ws, 0.0f, nullptr, 0.25f, C + 3 * ws, nullptr, 1, 3 * ws);
+            g_force_kernel = 0;
+        }
+        if (mode == 4) { hipEventRecord(c.eig_ev[1], c.eig_side); hipStreamWaitEvent(c.stream, c.eig_ev[1], 0); }
+        hipEventRecord(e1, c.stream);
+        THIP_TRY(hipEventSynchronize(e1));
+    }
+    float ms = 0.0f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *host_us = 1e3f * ms / (float)reps;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(buf);
+    if (pk) hipFree(pk);
     return rc;
 }
 

@@ -1144,30 +1144,32 @@ struct Prof {
     size_t used = 0;
     double total_ms = 0.0;
     long long launches = 0;
-} g_prof;
+} g_prof, g_prof_psd;      // the pass over A; the PSD cones' projection chains of an iteration (bench.py's roofline_eig)
 
-void prof_begin(hipStream_t st)
+void prof_begin(hipStream_t st, Prof &p = g_prof)
 {
-    if (!g_prof.on) return;
-    if (g_prof.used + 2 > g_prof.ev.size()) {
-        for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); g_prof.ev.push_back(e); }
+    if (!p.on) return;
+    if (p.used + 2 > p.ev.size()) {
+        for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); p.ev.push_back(e); }
     }
-    hipEventRecord(g_prof.ev[g_prof.used], st);
+    hipEventRecord(p.ev[p.used], st);
 }
-void prof_end(hipStream_t st)
+void prof_end(hipStream_t st, Prof &p = g_prof)
 {
-    if (!g_prof.on) return;
-    hipEventRecord(g_prof.ev[g_prof.used + 1], st);
-    g_prof.used += 2;
+    if (!p.on) return;
+    hipEventRecord(p.ev[p.used + 1], st);
+    p.used += 2;
 }
 
 }  // namespace
 namespace thip {
 void prof_release()
 {
-    for (hipEvent_t e : g_prof.ev) hipEventDestroy(e);
-    g_prof.ev.clear();
-    g_prof.used = 0; g_prof.on = false;
+    for (Prof *p : { &g_prof, &g_prof_psd }) {
+        for (hipEvent_t e : p->ev) hipEventDestroy(e);
+        p->ev.clear();
+        p->used = 0; p->on = false;
+    }
 }
 }  // namespace thip
 namespace {
@@ -1268,6 +1270,7 @@ int project_blocks(thip_solver *s)
             const size_t k = (size_t)((std::sqrt((double)(8 * pr.second + 1)) - 1.0) / 2.0 + 0.5);
             fold = fold && psd_project_takes_rx(k);
         }
+        prof_begin(st, g_prof_psd);
         for (auto &g : s->psd_groups)
             THIP_RC(eig_psd_project_small(st, g.k, s->xy, g.dev_offs, g.count, 1, std::sqrt(2.0f), stop, 2, s->xs - s->xy,
                                           fold ? s->rxy : nullptr, s->rxs - s->rxy));
@@ -1279,6 +1282,7 @@ int project_blocks(thip_solver *s)
                                     s->psd_worklen, 0, stop, 2, s->xs - s->xy, fold ? s->rxy + pr.first : nullptr,
                                     s->rxs - s->rxy));
         }
+        prof_end(st, g_prof_psd);
         if (fold) return 0;
         hipLaunchKernelGGL(rx_psd_k, dim3(egrid(s->m)), dim3(BLK), 0, st, (int)s->m, s->cls, s->xy, s->xs, s->rxy, s->rxs, s->dst);
     }
@@ -2359,6 +2363,42 @@ int thip_solver_init(thip_solver *s)
     return 0;
 }
 
+// A column shard whose (re-)plan of the one-pass kernel failed on THIS rank (thip_solver_set_a_storage / _set_sweep_min_bytes
+// re-plan inside run(); the 16-bit plan rejecting the shape, a timing sweep raising the error word, a placement census that
+// changed): there is no 2-pass form over a column block, and the peers are already sweeping -- their next batch holds one
+// all-reduce per iteration (+ one when it starts from a consistent iterate).  This rank takes part in exactly those
+// collectives with its fault flag raised (the tail slot every rank's termination test reads), for the three attempts the
+// peers make from their snapshot, so that every rank of the run returns THIP_E_TIMEOUT at the same batch instead of one
+// rank iterating a row-sharded schedule on a column block while the others wait in a collective of another size.
+static int col_shard_abort(thip_solver *s, int64_t max_steps, int64_t poll_every)
+{
+    hipStream_t st = ctx().stream;
+    const size_t mpad = pad64(s->m);                  // SweepGeom::mpad of every plan of this m (rows round to 4 or 8, mpad to 64)
+    const size_t need = 2 * mpad + 4 * EG + 64;
+    if (s->cs_n != need) {
+        if (s->cs_buf) { THIP_TRY(hipStreamSynchronize(st)); THIP_TRY(hipFree(s->cs_buf)); s->cs_buf = nullptr; }
+        THIP_TRY(hipMalloc((void **)&s->cs_buf, need * sizeof(float)));
+        s->cs_n = need;
+    }
+    int64_t batch = poll_every;
+    if (max_steps >= 0 && batch > max_steps) batch = max_steps;
+    const float one = 1.0f;
+    bool first = s->sw_first;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        const int64_t calls = batch + (first ? 1 : 0);
+        for (int64_t k = 0; k < calls; ++k) {
+            THIP_TRY(hipMemsetAsync(s->cs_buf, 0, need * sizeof(float), st));
+            THIP_TRY(hipMemcpyAsync(s->cs_buf + 2 * mpad + 4 * EG, &one, sizeof(float), hipMemcpyHostToDevice, st));
+            THIP_RC(do_allreduce(s, s->cs_buf, s->cs_n));
+        }
+        THIP_TRY(hipStreamSynchronize(st));
+        first = true;                                 // the peers restore their snapshot: a consistent iterate
+    }
+    s->sweep_faults += 1;
+    s->sweep_fault_word = 5u;                         // 5: this rank could not plan the kernel at all
+    return fail(THIP_E_TIMEOUT, "the one-pass kernel could not be planned on this rank of a column-sharded run: every rank stops", __FILE__, __LINE__);
+}
+
 int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_status *host_status)
 {
     THIP_NEED_INIT();
@@ -2369,6 +2409,10 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
     if (s->carried_stale && s->hst->state == THIP_ST_RUNNING) THIP_RC(rebuild_carried(s));
     THIP_RC(sweep_prepare(s));
     bool sweep = sweep_active(s);
+    if (s->col_shard && !sweep) {
+        if (s->hst->state != THIP_ST_RUNNING || max_steps == 0) return 0;      // nothing would run on any rank
+        return col_shard_abort(s, max_steps, poll_every);
+    }
     THIP_RC(prepare_split(s));
     bool split = split_active(s);
     if (!sweep) s->sw_first = true;         // whatever runs instead leaves a consistent iterate and gP / hP of it
@@ -2702,25 +2746,38 @@ int thip_solver_sweep_plan(thip_solver *s, int *host_members, int *host_cols_per
 int thip_prof_enable(int on)
 {
     THIP_NEED_INIT();
-    g_prof.on = on != 0;
-    g_prof.used = 0; g_prof.total_ms = 0.0; g_prof.launches = 0;
+    for (Prof *p : { &g_prof, &g_prof_psd }) {
+        p->on = on != 0;
+        p->used = 0; p->total_ms = 0.0; p->launches = 0;
+    }
     return 0;
+}
+
+static int prof_collect(Prof &p, int64_t *host_count, double *host_total_ms)
+{
+    THIP_TRY(hipStreamSynchronize(ctx().stream));
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        float ms = 0.0f;
+        THIP_TRY(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        p.total_ms += ms;
+        p.launches += 1;
+    }
+    p.used = 0;
+    if (host_count) *host_count = p.launches;
+    if (host_total_ms) *host_total_ms = p.total_ms;
+    return 0;
+}
+
+int thip_prof_read_psd(int64_t *host_spans, double *host_total_ms)
+{
+    THIP_NEED_INIT();
+    return prof_collect(g_prof_psd, host_spans, host_total_ms);
 }
 
 int thip_prof_read(int64_t *host_launches, double *host_total_ms)
 {
     THIP_NEED_INIT();
-    THIP_TRY(hipStreamSynchronize(ctx().stream));
-    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-        float ms = 0.0f;
-        THIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
-        g_prof.total_ms += ms;
-        g_prof.launches += 1;
-    }
-    g_prof.used = 0;
-    if (host_launches) *host_launches = g_prof.launches;
-    if (host_total_ms) *host_total_ms = g_prof.total_ms;
-    return 0;
+    return prof_collect(g_prof, host_launches, host_total_ms);
 }
 
 int thip_solver_destroy(thip_solver *s)

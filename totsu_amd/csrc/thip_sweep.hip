@@ -290,14 +290,16 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
 // Can the one-pass kernel run on THIS device for an m x n_local block (leading dimension lda)?  Geometry + one placement
 // census, no collective: a multi-rank host asks every rank and takes the minimum BEFORE it builds column-sharded solvers
 // (a rank that found out inside thip_solver_init would leave the others waiting in their first all-reduce).
-extern "C" int thip_sweep_probe(size_t m, size_t n_local, size_t lda, int *host_ok)
+// elem = the stored form the run will stream (THIP_A_F32 / _BF16 / _F16): a 16-bit plan has 8 rows per slot and its own caps.
+extern "C" int thip_sweep_probe(size_t m, size_t n_local, size_t lda, int elem, int *host_ok)
 {
     THIP_NEED_INIT();
-    if (!host_ok) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    if (!host_ok || elem < 0 || elem > 2) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
     *host_ok = 0;
     SweepGeom g;
+    const size_t epv = elem ? 8 : 4;              // rows per 16-byte vector: the library's own copy pads rows and pitch to it
     // (the matrix itself is not needed: any 16-byte aligned address stands for it)
-    if (sweep_plan((m + 3) / 4 * 4, n_local, (lda + 3) / 4 * 4, reinterpret_cast<const void *>((uintptr_t)4096), &g) != 0) return 0;
+    if (sweep_plan((m + epv - 1) / epv * epv, n_local, (lda + epv - 1) / epv * epv, reinterpret_cast<const void *>((uintptr_t)4096), &g, elem) != 0) return 0;
     unsigned *census = nullptr;
     THIP_TRY(hipMalloc((void **)&census, 16 * sizeof(unsigned)));
     hipStream_t st = ctx().stream;

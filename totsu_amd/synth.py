@@ -159,7 +159,7 @@ class LpInstanceCols:
 
     def __init__(self, n, seed=0, rank=0, world=1):
         _lib.ensure_init()
-        self.n = n
+        self.n, self.seed = n, seed
         m = self.m = self.m_total = 2 * n
         self.col0, self.col1 = shard_cols(n, world, rank)
         nl = self.n_local = self.col1 - self.col0
@@ -190,7 +190,7 @@ class LpInstance:
         block_cols columns (identical entries, rounded); the f32 shard is never allocated -- for shards that only fit
         HBM at 16 bits per entry."""
         _lib.ensure_init()
-        self.n = n
+        self.n, self.seed = n, seed
         self.m_total = 2 * n
         base, rem = divmod(self.m_total, world)
         r0 = rank * base + min(rank, rem)
@@ -240,7 +240,7 @@ class SdpInstance:
 
     def __init__(self, n, k, seed=0):
         _lib.ensure_init()
-        self.n, self.k = n, k
+        self.n, self.k, self.seed = n, k, seed
         sk = k * (k + 1) // 2
         self.m = self.m_total = sk
         self.mat_a = DeviceBuffer(sk * n)
