@@ -1,7 +1,10 @@
 """One-off measurement for SURVEY.md 8d ("final objective within 1e-4 relative of the f64 CPU result on the same
 instance") at a size the CPU oracle still finishes: the synthetic SOCP of bench.py at n = 5000, 100 cones, solved to
-the same eps_acc by the GPU (f32, carried schedule; optionally bf16 -> f32) and by the C oracle (f64, OpenMP) on the
-host.  Prints one JSON line.  Usage: python tests/measure_objective_gap.py [n] [cones] [eps]"""
+the same eps_acc by the GPU (f32, and f16-stored passes then f32, through --schedule) and by the C oracle (f64, OpenMP) on the
+host.  Prints one JSON line.
+Usage: python tests/measure_objective_gap.py [n] [cones] [eps] [--schedule carried|sweep|fused] [--force-sweep]
+  --schedule     the GPU schedule of both legs (round 5: the line bench.py cites is the one whose schedule matches the run's)
+  --force-sweep  sweep_min_bytes = 0: the one-pass kernel also below the size where it is the default (128 MiB of A)"""
 import json
 import os
 import sys
@@ -17,19 +20,28 @@ from totsu_amd import _lib, synth      # noqa: E402
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-    cones = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    eps = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-3
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("n", nargs="?", type=int, default=2000)
+    ap.add_argument("cones", nargs="?", type=int, default=40)
+    ap.add_argument("eps", nargs="?", type=float, default=1e-3)
+    ap.add_argument("--schedule", default="carried", choices=["carried", "sweep", "fused"])
+    ap.add_argument("--force-sweep", action="store_true")
+    ar = ap.parse_args()
+    n, cones, eps = ar.n, ar.cones, ar.eps
     _lib.init()
     inst = synth.SocpInstance(n, cones, 99, seed=0)
     a = inst.mat_a.to_host()[:inst.m * inst.n].astype(np.float64)
     b, c = inst.vec_b_host.astype(np.float64), inst.vec_c_host.astype(np.float64)
-    out = {"instance": "synthetic SOCP n=%d, %d cones of 1+99 rows (m=%d), seed 0" % (n, cones, inst.m), "eps_acc": eps}
+    out = {"instance": "synthetic SOCP n=%d, %d cones of 1+99 rows (m=%d), seed 0" % (n, cones, inst.m), "eps_acc": eps,
+           "schedule": ar.schedule, "sweep_forced_below_its_default_size": bool(ar.force_sweep)}
+    kw = {"sweep_min_bytes": 0} if ar.force_sweep else {}
     p = T.SolverParam()
     p.eps_acc, p.max_iter = eps, None
     for mode in ("f32", "mixed"):
-        fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, "carried",
-                           a_storage="f32" if mode == "f32" else "bf16")
+        fs = T.FusedSolver(inst.n, inst.m, inst.mat_a, inst.vec_b, inst.vec_c, inst.seg_type, inst.seg_len, p, ar.schedule,
+                           a_storage="f32" if mode == "f32" else "f16", **kw)
+        sched1 = fs.schedule_in_use()
         t0 = time.perf_counter()
         r = fs.run(-1, poll_every=64)
         if mode == "mixed":
@@ -39,6 +51,7 @@ def main():
         dt = time.perf_counter() - t0
         x, y = fs.solution()
         out["gpu_" + mode] = {"state": r.state, "iterations": r.iters + 1, "seconds": dt, "cri": list(r.cri),
+                              "schedule_in_use": [sched1, fs.schedule_in_use()], "sweep_faults": fs.sweep_faults(),
                               "primal_obj": float(c @ x.astype(np.float64)), "dual_obj": -float(b @ y.astype(np.float64))}
         fs.destroy()
         sys.stderr.write(json.dumps(out) + "\n")       # the CPU leg below can take very long: keep what is known

@@ -157,3 +157,67 @@ def test_kernel_resource_guard_fails_a_build_that_spills(tmp_path):
     built = os.path.join(os.path.dirname(HERE), "totsu_amd", "csrc", "thip_sweep.remarks.txt")
     if os.path.exists(built):
         assert subprocess.run([sys.executable, tool, built], capture_output=True).returncode == 0
+
+
+def _bench_dry(args, env_extra=None, timeout=600):
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run"] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    return r, lines
+
+
+def test_bench_gpus_8_control_path_at_the_real_shapes_without_a_gpu():
+    """`python bench.py --gpus 8` -- the driver's command on a node nobody has had yet -- up to its first kernel, with real
+    processes and real collectives (gloo): the ranks are spawned by bench.py itself, agree on column shards, plan their shards
+    at the REAL configs[2] shape (100 000 x 50 000 over 8 column blocks + the row-sharded extra leg), assert the plan against
+    288 GB, bracket a timed region with barriers and a max over ranks, and rank 0 prints ONE line carrying the keys of a real
+    one.  --dry-run replaces the HIP library (no GPU here), nothing else."""
+    r, lines = _bench_dry(["--gpus", "8", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["value"] is None
+    for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "rccl_ranks", "row_sharded", "time_to_eps", "objective_gate"):
+        assert key in d, key
+    plans = d["config"]["hbm_plan"]
+    assert [p["rank"] for p in plans] == list(range(8))
+    assert all(p["partition"] == "columns" and p["rows"] == 100_000 and p["cols"] == 6250 for p in plans)
+    assert all(p["A_bytes"] == 4 * 100_000 * 6250 and p["row_leg_rows"] == 12_500 for p in plans)
+    # the row leg's shard has columns of 50 000 B: the library's padded copy (12 512 rows) is in the plan
+    assert all(p["row_leg_bytes"] == 4 * 12_500 * 50_000 + 4 * 12_512 * 50_000 for p in plans)
+    assert all(p["fits"] and p["total_bytes"] < 0.1 * p["hbm_bytes"] for p in plans)
+    assert d["row_sharded"]["rows_per_gpu"] == 12_500
+    assert "bench.py: --gpus 8 without a launcher" in r.stderr
+
+
+def test_bench_gpus_8_configs4_budget_and_a_rank_that_cannot_sweep():
+    """configs[4] (LP n = 200 000, m = 400 000) over 8 ranks: a 40 GB column shard + the row leg's 40 GB shard per rank, inside
+    288 GB; and when ONE rank's probe says no (rank 5), every rank plans row shards and the carried schedule"""
+    r, lines = _bench_dry(["--gpus", "8", "--workload", "lp", "--size", "200000", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(lines[0])
+    plans = d["config"]["hbm_plan"]
+    assert all(p["partition"] == "columns" and p["rows"] == 400_000 and p["cols"] == 25_000 for p in plans)
+    assert all(p["A_bytes"] == 40_000_000_000 and p["row_leg_bytes"] == 40_000_000_000 for p in plans)      # 50 000 rows: no padded copy
+    assert all(p["fits"] and 80e9 < p["total_bytes"] < 0.94 * 288e9 for p in plans)
+    r, lines = _bench_dry(["--gpus", "8", "--workload", "lp", "--size", "200000", "--steps", "2", "--warmup", "1"],
+                          env_extra={"THIP_DRY_PROBE_NO": "5"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(lines[0])
+    plans = d["config"]["hbm_plan"]
+    assert all(p["partition"] == "rows" and p["rows"] == 50_000 and p["cols"] == 200_000 and p["row_leg_bytes"] == 0 for p in plans)
+    assert d["config"]["schedule"] == "carried" and d["row_sharded"] is None
+    assert "row shards, carried schedule" in r.stderr
+
+
+def test_bench_plan_that_does_not_fit_stops_every_rank_before_allocating():
+    """a shard that cannot fit 288 GB (LP n = 400 000 over 2 ranks: 640 GB each): every rank leaves with the plan in the
+    message -- no rank is left in a collective, nothing was allocated"""
+    r, lines = _bench_dry(["--gpus", "2", "--workload", "lp", "--size", "400000", "--steps", "2"], timeout=300)
+    assert r.returncode != 0 and not lines
+    assert "does not fit" in r.stderr

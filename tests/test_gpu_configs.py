@@ -207,10 +207,12 @@ def test_c4_full_size_sdp_iterates_vs_oracle(T, schedule):
 
 # ---- configs[2] at the full n ---------------------------------------------------------------------------------------
 
-def _c3_vs_oracle(T, schedule, sub, want_members=None):
+def _c3_vs_oracle(T, schedule, sub, want_members=None, iters=(0, 1, 2)):
     """the standalone problem made of the first `sub` of the 1000 cones of BASELINE configs[2] at its full n = 50 000 (sub =
-    1000: the headline instance itself): preconditioner (solver.rs:496-524), iterates after iterations 0, 1, 2
-    (solver.rs:526-571) and the criteria triple (solver.rs:573-612) against the f64 oracle on the SAME inputs"""
+    1000: the headline instance itself): preconditioner (solver.rs:496-524), iterates after iterations `iters`
+    (solver.rs:526-571) and the criteria triple (solver.rs:573-612) against the f64 oracle on the SAME inputs.  The
+    tolerance grows with the iteration like the toy-size snapshots' (tests/test_gpu_sweep.py::_check_sweep_iterates):
+    f32 round-off of the iterate accumulates over the steps, the oracle's f64 does not"""
     import math
     import os
     from totsu_amd import synth
@@ -231,9 +233,9 @@ def _c3_vs_oracle(T, schedule, sub, want_members=None):
             assert np.array_equal(col.to_host()[:m].astype(np.float64), np.asarray(a)[cc * m:(cc + 1) * m]), cc
         col.free()
         b, c = inst.vec_b_host.astype(np.float64), inst.vec_c_host.astype(np.float64)
-        iters = [0, 1, 2]
-        ro = O.solve_matop_cones(O.param(max_iter=5, eps_acc=1e-30), c, a, b, [O.CONE_SOC] * sub, [rows] * sub,
-                                 snap_iters=iters, trace_cap=8)
+        iters = list(iters)
+        ro = O.solve_matop_cones(O.param(max_iter=iters[-1] + 3, eps_acc=1e-30), c, a, b, [O.CONE_SOC] * sub, [rows] * sub,
+                                 snap_iters=iters, trace_cap=iters[-1] + 4)
     finally:
         O.set_num_threads(k)
     del a
@@ -257,12 +259,21 @@ def _c3_vs_oracle(T, schedule, sub, want_members=None):
         x, y = fs.iterate()
         rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
         sx, sy = max(np.abs(rx).max(), 1e-6), max(np.abs(ry).max(), 1e-6)
-        assert np.abs(x - rx).max() <= 1e-4 * sx, (it, np.abs(x - rx).max() / sx)
-        assert np.abs(y - ry).max() <= 1e-4 * sy, (it, np.abs(y - ry).max() / sy)
+        tol = 1e-4 if it < 9 else (3e-4 if it < 99 else 2e-3)
+        assert np.abs(x - rx).max() <= tol * sx, (it, np.abs(x - rx).max() / sx)
+        assert np.abs(y - ry).max() <= tol * sy, (it, np.abs(y - ry).max() / sy)
         tr = ro.trace[it]
-        assert np.allclose(fs.status().cri, tr[2:], rtol=5e-3, atol=1e-5), (it, fs.status().cri, tr)
+        assert np.allclose(fs.status().cri, tr[2:], rtol=max(5e-3, 50 * tol), atol=1e-5), (it, fs.status().cri, tr)
     fs.destroy()
     inst.free()
+
+
+def test_c3_first_328_cones_at_full_n_through_sweep_to_iteration_99(T):
+    """the chain of evidence of the headline schedule at the headline's column count: the one-pass schedule's iterates 0, 1, 2,
+    9 and 99 of the 328-cone sub-instance (A_sub 32 800 x 50 000) against the f64 oracle's -- the toy-size snapshots of
+    tests/test_gpu_sweep.py at n = 50 000 (the oracle needs ~ 100 iterations of 6 products over 13 GB of f64: minutes on
+    the GPU box's cores)"""
+    _c3_vs_oracle(T, "sweep", 328, iters=(0, 1, 2, 9, 99))
 
 
 @pytest.mark.parametrize("schedule", ["fused", "carried", "sweep"])

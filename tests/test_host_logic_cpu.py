@@ -313,3 +313,66 @@ def test_invalid_op_and_work_shortage():
         Solver(La).solve((op_c, op_a, op_b, ConeRPos(La), np.zeros(47)))
     assert e.value.kind == SolverError.WorkShortage
     assert O.lib().oc_query_worklen(3, 2) == Solver.query_worklen((3, 2)) == 48
+
+
+def test_bench_f64_gates_for_lp_and_sdp_lines_on_oracle_solutions():
+    """bench.py's objective_gate.this_run for LP and SDP lines (kkt_f64_lp / kkt_f64_sdp: round 5): fed the f64 oracle's own
+    converged (x, y) of a small instance of the bench's construction -- built here from the counter-based generator the
+    way synth.LpInstance / SdpInstance build it on the device -- the gate must report the stopping test's quantities:
+    dual residual at eps, no cone violation, objectives that bracket"""
+    import math
+    import sys
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from totsu_amd import synth as S
+    ident = lambda v, op="sum": v
+    # ---- LP: c = -U, G = [-I ; U], h = [0 ; U] (benchmark_lp), two row blocks as two ranks would hold them
+    n, seed = 40, 3
+    m = 2 * n
+    A = np.asarray(O.gen_matrix(m, n, seed, S.STREAM_A, 0, 0, m, 0, 1.0)).reshape(n, m).T.copy()      # (m, n)
+    A[:n, :] = -np.eye(n)
+    h = O.gen_vector(m, seed, S.STREAM_H, 0, 0)
+    h[:n] = 0.0
+    c = -O.gen_vector(n, seed, S.STREAM_C, 0, 0)
+    ro = O.solve_matop_cones(O.param(max_iter=400000, eps_acc=1e-6), c, np.asfortranarray(A).ravel(order="F"), h, [O.CONE_RPOS], [m])
+    assert ro.status == O.OK
+    inst = types.SimpleNamespace(n=n, seed=seed, r0=0, r1=m, m=m, m_total=m, vec_b_host=h.astype(np.float32),
+                                 vec_c_host=c.astype(np.float32))
+    g = bench.kkt_f64_lp(inst, ro.x.astype(np.float32), ro.y.astype(np.float32), ident, block_rows=23)
+    assert g["dual_residual_rel_f64"] <= 5e-6 and g["gap_rel"] <= 1e-5, g
+    assert g["primal_cone_violation"] <= 1e-5 and g["dual_cone_violation"] <= 1e-6, g
+    assert abs(g["primal_obj_f64"] - float(c @ ro.x)) <= 1e-5 * (1 + abs(float(c @ ro.x)))
+    # the same answer seen as two row shards: the sums over the ranks reproduce the one-rank evaluation
+    parts = []
+    for r0, r1 in ((0, 33), (33, m)):
+        ip = types.SimpleNamespace(n=n, seed=seed, r0=r0, r1=r1, m=r1 - r0, m_total=m, vec_b_host=h[r0:r1].astype(np.float32),
+                                   vec_c_host=c.astype(np.float32))
+        box = {}
+        bench.kkt_f64_lp(ip, ro.x.astype(np.float32), ro.y[r0:r1].astype(np.float32),
+                         lambda v, op="sum", box=box: box.setdefault(op + str(len(v)), v.copy()), block_rows=17)
+        parts.append(box)
+    rsum = parts[0]["sum%d" % (n + 2)] + parts[1]["sum%d" % (n + 2)]
+    r_full = rsum[:n] + c.astype(np.float32).astype(np.float64)
+    assert abs(np.linalg.norm(r_full) / (1 + np.linalg.norm(c)) - g["dual_residual_rel_f64"]) <= 1e-9
+    # ---- SDP: one PSD cone of order k, A = [svec(F_i)], b = svec(I) + A x0, c = -A^T svec(Y)
+    k, n2, seed = 8, 6, 5
+    sk = k * (k + 1) // 2
+    A2 = np.asarray(O.gen_matrix(sk, n2, seed, S.STREAM_A, 0, 0, sk, 1, 1.0 / math.sqrt(k)))              # column-major sk x n2
+    Am = A2.reshape(n2, sk).T
+    diag = np.array([cc * (cc + 1) // 2 + cc for cc in range(k)])
+    x0 = O.gen_vector(n2, seed, S.STREAM_X0, 0, 1, 1.0 / math.sqrt(n2))
+    b2 = Am @ x0
+    b2[diag] += 1.0
+    yv = 0.1 / math.sqrt(k) * O.gen_vector(sk, seed, S.STREAM_W, 0, 1)
+    yv[diag] += 1.0
+    c2 = -(Am.T @ yv)
+    ro = O.solve_matop_cones(O.param(max_iter=400000, eps_acc=1e-6), c2, A2, b2, [O.CONE_PSD], [sk], use_ql=True)
+    assert ro.status == O.OK
+    inst = types.SimpleNamespace(n=n2, k=k, m=sk, seed=seed, vec_b_host=b2.astype(np.float32), vec_c_host=c2.astype(np.float32))
+    g = bench.kkt_f64_sdp(inst, ro.x.astype(np.float32), ro.y.astype(np.float32))
+    assert g["dual_residual_rel_f64"] <= 5e-6 and g["gap_rel"] <= 1e-5, g
+    assert g["primal_cone_violation"] <= 1e-5 and g["dual_cone_violation"] <= 1e-5, g
+    # and it does tell a wrong answer: y = 0 is feasible for the cone but leaves the residual at ||c||
+    g0 = bench.kkt_f64_sdp(inst, ro.x.astype(np.float32), np.zeros(sk, dtype=np.float32))
+    assert g0["dual_residual_rel_f64"] > 0.1

@@ -190,16 +190,21 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 #endif
 
     if (tid == 0) {
+        // ONE thread decides for the workgroup whether this launch runs: were every wave to read the stop flag and the error
+        // word for itself, a peer raising the error word between two waves' loads would send some waves home and leave the
+        // others streaming (axpys with a stale `scal`, or granules published from an unwritten dotbuf)
         int g = 0, mbr = 0;
-        s_role[2] = sw_ticket(a.census, a.seq, a.G, &g, &mbr);
+        int go = sw_ticket(a.census, a.seq, a.G, &g, &mbr);
         s_role[0] = g; s_role[1] = mbr;
+        if (*a.stop != 0 || __hip_atomic_load(a.census + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) go = 0;
+        s_role[2] = go;
     }
     __syncthreads();
     // the ticket comes first even when the loop has stopped: the host numbers the launches, and one that left before
     // counting itself would leave every later launch's tickets off by one
     // (a raised error word -- this launch's census, or an earlier sweep of the batch that gave up -- ends every later sweep
     // at entry: the host restores its snapshot of the iterate, thip_solver.hip sweep_recover)
-    if (s_role[2] == 0 || *a.stop != 0 || __hip_atomic_load(a.census + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    if (s_role[2] == 0) return;
     const int group = s_role[0], member = s_role[1];
     SW_PHASE(0);
 
