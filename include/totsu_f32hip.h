@@ -415,9 +415,16 @@ int thip_solver_sweep_faults(thip_solver *s, int *host_faults, int *host_last_wo
  * kind 5 / 6 (no fault): launch the termination test after every sweep / fold it into the next step's m-kernel again
  * (the default where the m-tail is one of the merged forms: it is launched only when the host is about to look). */
 int thip_test_sweep_fault(thip_solver *s, int kind, int64_t after_sweeps, int spin_max);
-/* partial dots published with agent-scope (sc1) stores (1) or with plain stores that stay in the group's L2 (0, default);
- * between thip_solver_run calls */
+/* partial dots published with agent-scope (sc1) stores (1), with plain stores that stay in the group's L2 (0), or by the
+ * verdict of the process's publish-scope self-test (-1, the default); between thip_solver_run calls */
 int thip_solver_set_sweep_publish(thip_solver *s, int agent_scope);
+/* The publish-scope self-test: once per process, before the first plan of the one-pass kernel, 200 sweeps of a scratch matrix
+ * with 32 members per group, a short polling bound and the kernel's poll counters decide whether plain-store publishing is
+ * visible to the gatherers on this driver / firmware (0) or every solver publishes at agent scope (1).  mode 0: the cached
+ * verdict (run now if need be); 1: run again; 2: run again and count it as failed (test hook).  host_info (4 ints): the
+ * kernel's error word, polls summed over all gathers, the most polls any one gather needed, sweeps run.
+ * THIP_SWEEP_PUBLISH=0 / 1 in the environment pins the verdict without a test. */
+int thip_sweep_publish_selftest(int mode, int *host_agent_scope, int *host_info);
 
 /* test entry point of the one-pass kernel (thip_sweep.hip): one sweep over the m x n matrix A (device, column-major),
  *   gT = A^T v ; g3 = A^T xy ; u <- u + Su o (-(gP - 2 g3) - c rtau) unless `first` ; gP <- g3 ;

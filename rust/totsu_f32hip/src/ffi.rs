@@ -159,6 +159,7 @@ extern "C" {
     pub fn thip_solver_sweep_faults(s: *mut thip_solver, host_faults: *mut c_int, host_last_word: *mut c_int, host_restored_iter: *mut i64) -> c_int;
     pub fn thip_test_sweep_fault(s: *mut thip_solver, kind: c_int, after_sweeps: i64, spin_max: c_int) -> c_int;
     pub fn thip_solver_set_sweep_publish(s: *mut thip_solver, agent_scope: c_int) -> c_int;
+    pub fn thip_sweep_publish_selftest(mode: c_int, host_agent_scope: *mut c_int, host_info: *mut c_int) -> c_int;
     pub fn thip_solver_gemv_plan(s: *const thip_solver, host_nj: *mut c_int, host_blocks: *mut c_int, host_ms: *mut f32) -> c_int;
 
     pub fn thip_comm_unique_id(host_id128: *mut u8) -> c_int;

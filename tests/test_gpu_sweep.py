@@ -771,6 +771,38 @@ def test_column_shard_whose_replan_fails_on_one_rank_stops_every_rank_together(T
     assert calls[0] == calls[1]
 
 
+def test_publish_scope_self_test_and_its_fallback(T):
+    """the once-per-process self-test of the plain-store publish (thip_sweep_publish_selftest): passes on this device with
+    gathers that hardly ever poll; counted as failed (test hook) every solver publishes at agent scope -- the documented
+    form -- and iterates exactly as before (the scope changes where a granule is visible, not its value)"""
+    from totsu_amd import _lib
+    lib = _lib.lib
+    agent, info = C.c_int(-1), (C.c_int * 4)()
+    lib.thip_sweep_publish_selftest(1, C.byref(agent), info)
+    assert agent.value == 0, list(info)
+    assert info[0] == 0 and info[3] == 200 and info[2] <= 4096, list(info)
+    lp, _ = _lp(T, 120, 3)
+    p = T.SolverParam()
+    p.eps_acc = 1e-30
+
+    def run():
+        fs = T.FusedSolver.from_dense(lp.dense(), p, "sweep", sweep_min_bytes=0, gemv_autotune=False)
+        fs.run(40, poll_every=8)
+        out = fs.iterate()
+        faults = fs.sweep_faults()["faults"]
+        fs.destroy()
+        return out, faults
+    (x0, y0), f0 = run()
+    try:
+        lib.thip_sweep_publish_selftest(2, C.byref(agent), info)       # "the hand-off did not show": agent scope from here on
+        assert agent.value == 1
+        (x1, y1), f1 = run()
+    finally:
+        lib.thip_sweep_publish_selftest(1, C.byref(agent), info)
+    assert agent.value == 0 and f0 == 0 and f1 == 0
+    assert np.array_equal(x0, x1) and np.array_equal(y0, y1)
+
+
 def test_stream_probe_reports_a_plausible_rate(T):
     import ctypes as C
     from totsu_amd import _lib

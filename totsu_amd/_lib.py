@@ -154,6 +154,7 @@ PROTOTYPES = {
     "thip_solver_sweep_faults": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int64)]),
     "thip_test_sweep_fault": (_i, [_vp, _i, C.c_int64, _i]),
     "thip_solver_set_sweep_publish": (_i, [_vp, _i]),
+    "thip_sweep_publish_selftest": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "thip_test_gemm_sym": (_i, [_i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_test_gemm_chain": (_i, [_i, _i, _i, _i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_test_chain_probe": (_i, [_i, _i, _i, C.POINTER(_f)]),

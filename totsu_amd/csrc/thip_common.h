@@ -258,6 +258,9 @@ struct SweepArgs {
     // order, same value) and one of them stores it; *kappa_p is then the copy sw_vm_k left of kappa_{k-1}
     float *kappa_out; const float *skappa_p; const float *pm_brx; int np_m, pn_count;
 };
+// how the groups' partial dots are published by default in this process: 0 plain stores (the publish-scope self-test of
+// thip_sweep.hip passed), 1 agent scope.  Runs the self-test on first use (allocates and synchronises: plan time only)
+int sweep_publish_default();
 int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g, int elem = 0);
 int sweep_candidates(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *out, int max_out, int elem = 0);
 int sweep_launch16(hipStream_t st, const SweepGeom &g, const SweepArgs &a);       // thip_sweep16.hip

@@ -1117,7 +1117,7 @@ struct thip_solver {
     int pm_par = 0;               // which of the two buffers of sums over m (sw_part + (4 + 4 par) EG) holds the latest
     bool no_merge = false;        // thip_test_sweep_fault(kind 3): the two m-kernels of a step as two launches also without block cones
     int pn_par = 0;               // which of the two buffers of sums over n (sw_part + par * 2 EG) the LAST sweep wrote
-    int pub_agent = 0;            // thip_solver_set_sweep_publish
+    int pub_agent = -1;           // thip_solver_set_sweep_publish: 0 plain stores, 1 agent scope, -1 what the process's self-test said
     // recovery when the persistent kernel gives up (thip_solver_run): a device copy of the consistent iterate of the last
     // completed batch -- x_x, u, (x_y x_s v), their Kahan terms, the status block
     float *snap = nullptr; DevStatus *snap_st = nullptr; long long snap_iter = -1;
@@ -1856,7 +1856,7 @@ int sweep_pass(thip_solver *s, int first, int np_m)
     }
     s->pn_par = par;
     a.spin_max = s->spin_max > 0 ? s->spin_max : SW_SPIN_MAX;
-    a.pub_agent = s->pub_agent;
+    a.pub_agent = s->pub_agent >= 0 ? s->pub_agent : sweep_publish_default();
     a.fault = 0;
     if (!first && s->fault_kind == 2 && s->fault_after >= 0 && s->fault_after-- == 0) { a.fault = 1; s->fault_kind = 0; }
     prof_begin(st);
@@ -2669,7 +2669,7 @@ int thip_test_sweep_fault(thip_solver *s, int kind, int64_t after_sweeps, int sp
 int thip_solver_set_sweep_publish(thip_solver *s, int agent_scope)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
-    s->pub_agent = agent_scope != 0;
+    s->pub_agent = agent_scope < 0 ? -1 : (agent_scope != 0);
     return 0;
 }
 

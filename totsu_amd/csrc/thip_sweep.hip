@@ -41,6 +41,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 using namespace thip;
 
@@ -197,9 +198,8 @@ __global__ void sw_test_reduce_k(int m, int ngroups, size_t mpad, const float *_
 }
 }  // namespace
 
-extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *host_info)
+static int run_test_sweep(const thip_sweep_test *t, int spin_max, float *host_ms, int *host_info)
 {
-    THIP_NEED_INIT();
     if (!t) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
     SweepGeom g;
     if (t->elem < 0 || t->elem > THIP_A_F16 || (t->elem == THIP_A_F16 && !t->inv_s))
@@ -235,7 +235,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
     a.first = t->first;
     a.pn = pnbuf; a.pn_stride = 256; a.tau_p = scal + 3; a.eps_zero = 1e-12f;          // tau = 1: d = c + A^T x_y
     a.kappa_out = nullptr; a.skappa_p = nullptr; a.pm_brx = nullptr; a.np_m = 0; a.pn_count = 0;
-    a.pn_in = nullptr; a.pn_in_stride = 0; a.spin_max = SW_SPIN_MAX; a.fault = 0; a.pub_agent = t->pub_agent != 0;
+    a.pn_in = nullptr; a.pn_in_stride = 0; a.spin_max = spin_max; a.fault = 0; a.pub_agent = t->pub_agent != 0;
     a.dbg = getenv("THIP_SWEEP_DBG") ? atoi(getenv("THIP_SWEEP_DBG")) : 0;
     a.stop = reinterpret_cast<const int *>(scal); a.kappa_p = scal + 1; a.rtau_p = scal + 2;
     unsigned seq = 0, tagbase = 0;
@@ -284,6 +284,88 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
 #endif
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(gran); hipFree(census); hipFree(partH); hipFree(scal); hipFree(pnbuf);
+    return 0;
+}
+
+extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *host_info)
+{
+    THIP_NEED_INIT();
+    return run_test_sweep(t, SW_SPIN_MAX, host_ms, host_info);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The publish-scope self-test (round 5).  The groups' partial dots travel through granules that the publisher stores at
+// WAVEFRONT scope (a plain store that stays in the XCD's L2, which all members of a group share) and the gatherers read
+// with agent-scope loads: outside the memory model's guarantees, kept because it measured 3-5 % faster than the documented
+// sc1 form and has never failed.  What would make it fail is a change of the L2's write policy under it (driver, firmware):
+// the store would sit in a place the gatherers' loads do not look, every gather would poll until its bound, and a solve
+// would limp from time-out to time-out.  So, once per process, before the first plan: SELFTEST_SWEEPS idempotent sweeps of
+// a scratch 65 536 x 1024 matrix with 32 members per group (256 intervals each: ~1.6 million granule hand-offs, ~15 ms),
+// a short polling bound, and the kernel's own poll counters.  A hand-off that is merely late polls a few times; one that is
+// not visible polls to the bound.  Error word raised, or any gather needing more than SELFTEST_MAX_POLLS: every solver of
+// this process publishes at agent scope (slower, inside the model) -- thip_solver_set_sweep_publish overrides either way.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr int SELFTEST_SWEEPS = 200, SELFTEST_SPIN = 50000, SELFTEST_MAX_POLLS = 4096;
+int g_pub_state = -1;              // -1 not run, 0 wavefront-scope publish passed, 1 agent scope (failed, or no 8 x 32 device)
+int g_pub_info[4] = { 0, 0, 0, 0 };   // error word, polls summed, most polls of one gather, sweeps run
+int g_pub_force_fail = 0;
+
+int publish_selftest_run()
+{
+    const size_t m = 65536, n = 1024;
+    float *A = nullptr, *vec = nullptr;
+    g_pub_info[0] = g_pub_info[1] = g_pub_info[2] = g_pub_info[3] = 0;
+    if (hipMalloc((void **)&A, m * n * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); g_pub_state = 1; return 0; }
+    const size_t nv = 6 * m + 12 * n;
+    if (hipMalloc((void **)&vec, nv * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); hipFree(A); g_pub_state = 1; return 0; }
+    hipStream_t st = ctx().stream;
+    THIP_TRY(hipMemsetAsync(A, 0, m * n * sizeof(float), st));
+    THIP_TRY(hipMemsetAsync(vec, 0, nv * sizeof(float), st));
+    thip_sweep_test t;
+    memset(&t, 0, sizeof(t));
+    float *p = vec;
+    auto take = [&](size_t k) { float *q = p; p += k; return q; };
+    t.m = m; t.n = n; t.lda = m; t.mat_a = A;
+    t.v = take(m); t.xy = take(m); t.hn = take(m); t.h3 = take(m); p += 2 * m;
+    t.c = take(n); t.su = take(n); t.tx = take(n); t.u = take(n); t.ku = take(n); t.xx_in = take(n); t.kx_in = take(n);
+    t.xx_out = take(n); t.kx_out = take(n); t.gp = take(n);
+    t.kappa = 0.0f; t.rtau = 1.0f; t.first = 1; t.reps = SELFTEST_SWEEPS; t.force_members = 32; t.pub_agent = 0;
+    int info[8] = { 0 };
+    float ms[2];
+    const int rc = run_test_sweep(&t, SELFTEST_SPIN, ms, info);
+    THIP_TRY(hipStreamSynchronize(st));
+    hipFree(A); hipFree(vec);
+    if (rc != 0) { g_pub_state = 1; g_pub_info[0] = -1; return 0; }      // no 8 x 32 placement, or the shape was refused: the documented form
+    g_pub_info[0] = info[0]; g_pub_info[1] = info[5]; g_pub_info[2] = info[6]; g_pub_info[3] = SELFTEST_SWEEPS;
+    const bool ok = info[0] == 0 && info[6] <= SELFTEST_MAX_POLLS && !g_pub_force_fail;
+    g_pub_state = ok ? 0 : 1;
+    return 0;
+}
+}  // namespace
+
+namespace thip {
+// 0: partial dots published with plain stores (the self-test passed), 1: at agent scope
+int sweep_publish_default()
+{
+    if (g_pub_state < 0) {
+        static const int env = getenv("THIP_SWEEP_PUBLISH") ? atoi(getenv("THIP_SWEEP_PUBLISH")) : -1;      // 0 / 1: no self-test
+        if (env == 0 || env == 1) g_pub_state = env;
+        else if (publish_selftest_run() != 0) g_pub_state = 1;
+    }
+    return g_pub_state;
+}
+}  // namespace thip
+
+extern "C" int thip_sweep_publish_selftest(int mode, int *host_agent_scope, int *host_info)
+{
+    THIP_NEED_INIT();
+    // mode 0: the cached verdict (run now if it has not been); 1: run again; 2: run again and treat it as FAILED (test hook)
+    if (mode < 0 || mode > 2) return fail(THIP_E_INVALID, "thip_sweep_publish_selftest: mode 0, 1 or 2", __FILE__, __LINE__);
+    if (mode != 0) { g_pub_force_fail = mode == 2; THIP_RC(publish_selftest_run()); g_pub_force_fail = 0; }
+    const int v = sweep_publish_default();
+    if (host_agent_scope) *host_agent_scope = v;
+    if (host_info) for (int i = 0; i < 4; ++i) host_info[i] = g_pub_info[i];
     return 0;
 }
 
