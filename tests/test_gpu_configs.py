@@ -101,6 +101,42 @@ def test_c5_shard_iteration_schedules_agree(T):
     inst.free()
 
 
+def test_c5_column_shard_through_the_full_loop(T):
+    """rank 0's COLUMN shard of configs[4] (400 000 x 25 000 f32 = 40 GB; LP n = 200 000 over 8 GPUs) through the WHOLE device
+    loop -- plan, preconditioner, 55 iterations of sweep + m-tail + termination test -- with a stand-in collective of 30 us
+    (bench.py --emulate-world 8: the sum over one rank is the identity; the hook's placement, the message and the fault flag
+    in its tail are the sharded code path).  Twice: the rate is the shard's, not an accident of one run.  The line goes to
+    gpurun_out/ for profiles/r05_c5_column_shard_full_loop.json"""
+    import json
+    import os
+    import subprocess
+    import sys
+    import psutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = []
+    for rep in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "lp", "--size", str(N5), "--emulate-world",
+                            str(WORLD5), "--emulate-latency", "30", "--steps", "50", "--warmup", "5"], capture_output=True, text=True,
+                           timeout=1200, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(out) == 1
+        lines.append(json.loads(out[0]))
+    d = lines[0]
+    cfg = d["config"]
+    assert cfg["schedule"] == "sweep" and cfg["passes_over_A_per_iter"] == 1 and cfg["emulated_world"] == WORLD5
+    assert cfg["rows_per_gpu"] == 2 * N5 and cfg["cols_per_gpu"] == N5 // WORLD5
+    assert cfg["hbm_plan"]["A_bytes"] == 4 * 2 * N5 * (N5 // WORLD5) and cfg["hbm_plan"]["fits"]
+    assert d["sweep_faults"]["faults"] == 0
+    assert d["roofline"]["passes_over_A_per_iter"] == 1 and d["roofline"]["frac"] > 0.70, d["roofline"]
+    assert d["roofline"]["launches_timed"] == 50
+    # one iteration = one sweep of 40 GB + the m-tail + the 30 us stand-in: well under 8 ms, well over the bare sweep
+    assert 5.0 < d["ms_per_step"] < 8.0, d["ms_per_step"]
+    assert abs(lines[1]["ms_per_step"] / d["ms_per_step"] - 1) < 0.05
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    json.dump(d, open(os.path.join(root, "gpurun_out", "c5_column_shard_full_loop.json"), "w"))
+
+
 def test_c5_aspect_eight_emulated_ranks_vs_oracle(T):
     """the benchmark_lp construction at n = 96 split over EIGHT emulated ranks (shards of 24 x 96: C5's 1 : 4 aspect
     ratio; ranks 0-3 hold -I rows, ranks 4-7 dense rows, as at full size) against the oracle's solve"""

@@ -844,6 +844,246 @@ static int launch_dual(hipStream_t st, const DualArgs &a, int nb)
     return 0;
 }
 
+
+// polar_dual_k with the operands staged through LDS by the DMA path (global_load_lds_dwordx4: 1 KB per wave-instruction,
+// no VGPR destination).  What bounded polar_dual_k and gemm_pre2_k was not the MFMAs but Little's law on load INSTRUCTIONS:
+// a wave may have 64 vector loads in flight, a dword load carries 256 bytes, an operand round trip under this load is
+// ~1.8 us, so four waves pull ~64 KB per round trip into a CU and the 256 KB of a three-tile workgroup need four of them
+// (7 us for 5.4 us of MFMAs).  A DMA piece carries four times the bytes per slot in flight: the same 256 KB are two round
+// trips with a ring of 8 slabs, and the launch is bound by its MFMAs again.
+// Each wave stages ITS OWN K range (the waves split K four ways as before) into its own ring of R slabs of 8 k; a slab is
+// NT + 1 pieces of 1 KB -- 8 rows k of 32 floats, the layout the lanes' source addresses give it (lane l: row l / 8, floats
+// 4 (l % 8) ..), which is the layout the MFMA operands are read back in: lane (h, li) of MFMA t takes row 4 h + t, float li.
+// Only the issuing wave reads what it staged, so its own counted vmcnt orders the reads (no barrier in the loop); a slot is
+// refilled after the MFMAs that consumed its operands have been issued.  Per element every sum keeps gemm_pre_k's order.
+typedef __attribute__((address_space(3))) void thip_lds_void;
+typedef const __attribute__((address_space(1))) void thip_gbl_void;
+
+template <int KW, int NT>
+struct LdsGeom {
+    static constexpr int NP = NT + 1, NQ = KW / 8;
+    static constexpr int R0 = NT == 3 ? 8 : (NT == 2 ? 10 : 14);
+    static constexpr int R = R0 < NQ ? R0 : NQ;
+    static constexpr size_t ring_bytes = (size_t)4 * R * NP * 1024;
+    static constexpr size_t epi_bytes = (size_t)4 * NT * 16 * 64 * 4 + (size_t)NT * 32 * 33 * 4;
+    static constexpr size_t lds_bytes = ring_bytes > epi_bytes ? ring_bytes : epi_bytes;
+};
+
+// wait until at most n of this wave's vector-memory operations are outstanding (the other counters untouched)
+#define THIP_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt((((n) & 0xF) | (((n) >> 4) << 14) | 0x0F70))
+
+template <int KW, int NT>
+__global__ __launch_bounds__(256) void polar_lds_k(const DualArgs a)
+{
+    using G = LdsGeom<KW, NT>;
+    constexpr int NW = 4, NP = G::NP, NQ = G::NQ, R = G::R;
+    const int halted = *a.stop;
+    extern __shared__ __attribute__((aligned(16))) char polar_smem[];
+    int bi = 0, gl = blockIdx.x;
+    for (;;) {
+        const int gi = (a.nprod * (bi + 1) + NT - 1) / NT;
+        if (gl < gi) break;
+        gl -= gi; ++bi;
+    }
+    const int njobs = a.nprod * (bi + 1);
+    const size_t zo = blockIdx.z * a.ws;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, li = lane & 31;
+    const int i0 = bi * GT, kb = wave * KW;
+    const int pitch = a.pitch;
+    int bj[NT], pr[NT];
+    bool live[NT];
+    const int rk = lane >> 3, c4 = (lane & 7) * 4;              // this lane's row and floats of a DMA piece
+    const float *srcB[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int t = NT * gl + u;
+        live[u] = t < njobs;
+        const int tt = live[u] ? t : NT * gl;
+        bj[u] = a.nprod == 2 ? tt >> 1 : tt;
+        pr[u] = a.nprod == 2 ? tt & 1 : 0;
+        srcB[u] = a.B[pr[u]] + zo + (size_t)(kb + rk) * pitch + bj[u] * GT + c4;
+    }
+    const float *srcA = a.A + zo + (size_t)(kb + rk) * pitch + i0 + c4;
+    char *const ring = polar_smem + (size_t)wave * (R * NP * 1024);
+    auto issue = [&](const int q) {
+        char *dst = ring + (size_t)(q % R) * (NP * 1024);
+        const size_t go = (size_t)(8 * q) * pitch;
+        __builtin_amdgcn_global_load_lds((thip_gbl_void *)(srcA + go), (thip_lds_void *)dst, 16, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+            __builtin_amdgcn_global_load_lds((thip_gbl_void *)(srcB[u] + go), (thip_lds_void *)(dst + (1 + u) * 1024), 16, 0, 0);
+    };
+    // the beta * B_p term of the epilogue: ordinary loads, issued FIRST (the oldest of the wave's vector-memory operations: the
+    // counted waits below then cover them by themselves) and used after the loop
+    float dv[NT][4];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            dv[u][rr] = a.B[pr[u]][zo + (size_t)(i0 + rr + 8 * wave + 4 * h) * pitch + bj[u] * GT + li];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < R; ++q) issue(q);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
+    }
+    // operands of a slab: lane (h, li), MFMA t: row 4 h + t of the piece, float li
+    const float *rd = reinterpret_cast<const float *>(ring) + (4 * h) * 32 + li;
+    float av[2][4], bv[2][NT][4];
+    auto fetch = [&](const int q, const int s_) {
+        const float *b = rd + (size_t)(q % R) * (NP * 256);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            av[s_][t] = b[t * 32];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) bv[s_][u][t] = b[(1 + u) * 256 + t * 32];
+        }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    THIP_WAIT_VMCNT((R - 1) * NP);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + 1 < NQ) {
+            // slabs issued so far: 0 .. min(q - 1 + R, NQ - 1); the pieces of those behind slab q + 1 may still be in flight
+            const int last = (q - 1 + R < NQ - 1) ? q - 1 + R : NQ - 1;
+            const int behind = (last - (q + 1)) * NP;
+            __builtin_amdgcn_sched_barrier(0);
+            switch (behind < 0 ? 0 : behind) {           // (compile-time after unrolling; the builtin wants a constant)
+#define THIP_VW(n) case n: THIP_WAIT_VMCNT(n); break;
+            THIP_VW(0) THIP_VW(1) THIP_VW(2) THIP_VW(3) THIP_VW(4) THIP_VW(5) THIP_VW(6) THIP_VW(7) THIP_VW(8) THIP_VW(9) THIP_VW(10)
+            THIP_VW(11) THIP_VW(12) THIP_VW(13) THIP_VW(14) THIP_VW(15) THIP_VW(16) THIP_VW(17) THIP_VW(18) THIP_VW(19) THIP_VW(20)
+            THIP_VW(21) THIP_VW(22) THIP_VW(23) THIP_VW(24) THIP_VW(25) THIP_VW(26) THIP_VW(27) THIP_VW(28) THIP_VW(29) THIP_VW(30)
+            THIP_VW(31) THIP_VW(32) THIP_VW(33) THIP_VW(34) THIP_VW(35) THIP_VW(36) THIP_VW(37) THIP_VW(38) THIP_VW(39) THIP_VW(40)
+            THIP_VW(41) THIP_VW(42) THIP_VW(43) THIP_VW(44) THIP_VW(45) THIP_VW(46) THIP_VW(47) THIP_VW(48)
+#undef THIP_VW
+            default: THIP_WAIT_VMCNT(0); break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(q + 1, (q + 1) & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][t], bv[q & 1][u][t], acc[u], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + R < NQ) {
+            // slab q's slot: its operands were fetched an iteration ago and the MFMAs above have consumed them
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): no LDS read of this wave is still on its way
+            issue(q + R);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the rings become the epilogue's buffers: every wave must be through with its own first
+    __syncthreads();
+    float (*red)[NT][16][64] = reinterpret_cast<float (*)[NT][16][64]>(polar_smem);
+    float (*tr)[32][33] = reinterpret_cast<float (*)[32][33]>(polar_smem + (size_t)NW * NT * 16 * 64 * 4);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][u][r][lane] = acc[u][r];
+    }
+    __syncthreads();
+    if (halted != 0) return;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int p = pr[u], j0 = bj[u] * GT;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr, tl = rr + 8 * wave + 4 * h;
+            float v = red[0][u][r][lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += red[w][u][r][lane];
+            v *= a.alpha[p];
+            const int ti = i0 + tl, tj = j0 + li;
+            v = fmaf(a.beta[p], dv[u][rr], v);
+            if (ti == tj && ti < a.n) v += a.gamma[p];
+            tr[u][tl][li] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        if (!live[u]) continue;
+        const int p = pr[u], j0 = bj[u] * GT;
+        const bool diag = bj[u] == bi;
+        float *Om = a.O[p] + zo;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int tl = rr + 8 * wave + 4 * h;
+            float v = tr[u][tl][li];
+            if (diag && a.dsym[p] != 0) v = 0.5f * (v + tr[u][li][tl]);
+            if (a.pack == nullptr) {
+                Om[(size_t)(i0 + tl) * pitch + j0 + li] = v;
+                if (!diag) Om[(size_t)(j0 + tl) * pitch + i0 + li] = tr[u][li][tl];
+            } else {
+                const int rr_ = j0 + li, cc = i0 + tl;
+                if (rr_ <= cc && cc < a.n) {
+                    float pv = 0.5f * (a.M[zo + (size_t)cc * pitch + rr_] + v);
+                    if (rr_ == cc && a.has_scale) pv = pv / a.scale;
+                    const size_t o = (size_t)cc * (cc + 1) / 2 + rr_;
+                    a.pack[(ptrdiff_t)blockIdx.z * a.ps + o] = pv;
+                    if (a.rx != nullptr) {
+                        float *rx = a.rx + (ptrdiff_t)blockIdx.z * a.rps;
+                        rx[o] = rx[o] - 2.0f * pv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KW, int NT>
+static int launch_lds_one(hipStream_t st, const DualArgs &a, const dim3 &g)
+{
+    using G = LdsGeom<KW, NT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&polar_lds_k<KW, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)G::lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((polar_lds_k<KW, NT>), g, dim3(256), G::lds_bytes, st, a);
+    return 0;
+}
+
+template <int NT>
+static int launch_lds(hipStream_t st, const DualArgs &a, int nb)
+{
+    const int nt = a.ld / GT;
+    const dim3 g((unsigned)dual_groups(nt, a.nprod, NT), 1, (unsigned)nb);
+    switch (a.ld / 4) {
+    case 16: THIP_RC((launch_lds_one<16, NT>(st, a, g))); break;
+    case 32: THIP_RC((launch_lds_one<32, NT>(st, a, g))); break;
+    case 48: THIP_RC((launch_lds_one<48, NT>(st, a, g))); break;
+    case 64: THIP_RC((launch_lds_one<64, NT>(st, a, g))); break;
+    case 80: THIP_RC((launch_lds_one<80, NT>(st, a, g))); break;
+    case 96: THIP_RC((launch_lds_one<96, NT>(st, a, g))); break;
+    case 112: THIP_RC((launch_lds_one<112, NT>(st, a, g))); break;
+    default: THIP_RC((launch_lds_one<128, NT>(st, a, g))); break;
+    }
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+static int g_dual_force_regs = 0;      // thip_test_gemm_dual: 1 = polar_dual_k whatever THIP_PSD_LDS says
+// THIP_PSD_LDS=0: the chain's operands through VGPRs (gemm_pre2_k / polar_dual_k, the first half of round 5); default: through
+// LDS by the DMA path (polar_lds_k for every product of the chain)
+static bool psd_use_lds()
+{
+    static const int v = getenv("THIP_PSD_LDS") ? atoi(getenv("THIP_PSD_LDS")) : 1;
+    return v != 0;
+}
 // the smallest NT whose grid fits one workgroup per CU
 static int dual(hipStream_t st, DualArgs a, int nb)
 {
@@ -854,6 +1094,8 @@ static int dual(hipStream_t st, DualArgs a, int nb)
     int NT = 1;
     while (NT < 3 && dual_groups(nt, a.nprod, NT) * nb > ctx().num_cu) ++NT;
     if (force_nt >= 1 && force_nt <= 3) NT = force_nt;
+    if (psd_use_lds() && g_dual_force_regs == 0)
+        return NT == 1 ? launch_lds<1>(st, a, nb) : NT == 2 ? launch_lds<2>(st, a, nb) : launch_lds<3>(st, a, nb);
     return NT == 1 ? launch_dual<1>(st, a, nb) : NT == 2 ? launch_dual<2>(st, a, nb) : launch_dual<3>(st, a, nb);
 }
 
@@ -2218,14 +2460,22 @@ int polar_project7(hipStream_t st, size_t n, float *packed, int has_scale, float
     DualArgs d;
     memset(&d, 0, sizeof(d));
     d.n = ni; d.ld = ld; d.pitch = pitch; d.stop = stop; d.ws = ws;
+    // one symmetric product O = A B (dsym: A != B)
+    auto prod1 = [&](const float *A_, const float *B_, float *O_, int dsym) -> int {
+        if (!psd_use_lds()) return gemm(st, false, ni, ld, 1.0f, A_, B_, 0.0f, nullptr, 0.0f, O_, stop, nb, ws, pitch, dsym);
+        DualArgs e = d;
+        e.nprod = 1; e.A = A_; e.B[0] = B_; e.O[0] = O_; e.alpha[0] = 1.0f; e.beta[0] = 0.0f; e.gamma[0] = 0.0f; e.dsym[0] = dsym;
+        e.B[1] = nullptr; e.O[1] = nullptr;
+        return dual(st, e, nb);
+    };
     for (int it = 0; it < 11; ++it) {
         const float *c = it < 8 ? LIFT7 : TAIL7[it - 8];
-        THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop, nb, ws, pitch));        // Y = S S
+        THIP_RC(prod1(S, S, Y, 0));                                                                        // Y = S S
         d.nprod = 2; d.A = Y;
         d.B[0] = Y; d.O[0] = U; d.alpha[0] = c[1]; d.beta[0] = c[2]; d.gamma[0] = c[3]; d.dsym[0] = 0;    // U = q0 Y Y + q1 Y + q2 I
         d.B[1] = S; d.O[1] = V; d.alpha[1] = 1.0f; d.beta[1] = -c[0]; d.gamma[1] = 0.0f; d.dsym[1] = 1;   // V = Y S - r0 S
         THIP_RC(dual(st, d, nb));
-        THIP_RC(gemm(st, false, ni, ld, 1.0f, U, V, 0.0f, nullptr, 0.0f, S, stop, nb, ws, pitch, 1));     // S <- U V
+        THIP_RC(prod1(U, V, S, 1));                                                                        // S <- U V
     }
     // Newton-Schulz x (3 - x^2) / 2 and M sign(M), merged:  T = 1.5 I - 0.5 S S (into Y),  R = S M (into U);  T R -> packed
     d.nprod = 2; d.A = S;
@@ -2337,13 +2587,14 @@ int thip_test_gemm_chain(int shape, int kernel, int n, int ld, int nb, float alp
 //   mode 4: mode 3 on TWO streams at once (one item each; us per launch PAIR); mode 5: one tile, general, one item
 // test entry point for the round-5 kernels of the chain: O_p = alpha_p A B_p + beta_p B_p + gamma_p I_n from the lower triangle
 // of tiles (mirrored; diagonal tiles of a product with dsym_p averaged with their transpose), nb items ld * ld apart.
-// coef = { alpha0, beta0, gamma0, dsym0, alpha1, beta1, gamma1, dsym1 }; B1 == nullptr: one product.  kernel 0: polar_dual_k with
-// the library's NT; 1 .. 3: NT forced; 4 / 5: the one-tile / 32 x 64 block kernel of gemm() (one product, beta = 0)
+// coef = { alpha0, beta0, gamma0, dsym0, alpha1, beta1, gamma1, dsym1 }; B1 == nullptr: one product.  kernel 0: the library's choice
+// (polar_lds_k with its NT); 1 .. 3: polar_lds_k with NT forced; 6 .. 8: polar_dual_k (operands through VGPRs) with NT = 1 .. 3;
+// 4 / 5: the one-tile / 32 x 64 block kernel of gemm() (one product, beta = 0)
 int thip_test_gemm_dual(int kernel, int n, int ld, int nb, const float *A, const float *B0, const float *B1, const float *coef,
                         float *O0, float *O1)
 {
     THIP_NEED_INIT();
-    if (ld <= 0 || ld % 64 != 0 || ld > 512 || n < 0 || n > ld || nb < 1 || kernel < 0 || kernel > 5 || !A || !B0 || !coef || !O0)
+    if (ld <= 0 || ld % 64 != 0 || ld > 512 || n < 0 || n > ld || nb < 1 || kernel < 0 || kernel > 8 || !A || !B0 || !coef || !O0)
         return fail(THIP_E_INVALID, "thip_test_gemm_dual", __FILE__, __LINE__);
     const size_t ws = (size_t)ld * ld;
     if (kernel >= 4) {
@@ -2360,7 +2611,8 @@ int thip_test_gemm_dual(int kernel, int n, int ld, int nb, const float *A, const
     d.B[0] = B0; d.O[0] = O0; d.alpha[0] = coef[0]; d.beta[0] = coef[1]; d.gamma[0] = coef[2]; d.dsym[0] = coef[3] != 0.0f;
     if (B1) { d.B[1] = B1; d.O[1] = O1; d.alpha[1] = coef[4]; d.beta[1] = coef[5]; d.gamma[1] = coef[6]; d.dsym[1] = coef[7] != 0.0f; }
     if (kernel == 0) return dual(ctx().stream, d, nb);
-    return kernel == 1 ? launch_dual<1>(ctx().stream, d, nb) : kernel == 2 ? launch_dual<2>(ctx().stream, d, nb) : launch_dual<3>(ctx().stream, d, nb);
+    if (kernel >= 6) return kernel == 6 ? launch_dual<1>(ctx().stream, d, nb) : kernel == 7 ? launch_dual<2>(ctx().stream, d, nb) : launch_dual<3>(ctx().stream, d, nb);
+    return kernel == 1 ? launch_lds<1>(ctx().stream, d, nb) : kernel == 2 ? launch_lds<2>(ctx().stream, d, nb) : launch_lds<3>(ctx().stream, d, nb);
 }
 
 __global__ void probe_delay_k(long long cycles)
