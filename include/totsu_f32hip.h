@@ -465,9 +465,8 @@ int thip_test_gemm_chain(int shape, int kernel, int n, int ld, int nb, float alp
 /* test entry point for the all-symmetric products of the round-5 chain: O_p = alpha_p * A * B_p + beta_p * B_p + gamma_p * I_n
  * for A, B_p symmetric ld x ld (ld a multiple of 64 up to 512, nb items ld * ld apart), computed on the lower triangle of
  * 32 x 32 tiles and mirrored; with dsym_p != 0 the diagonal tiles are averaged with their transpose.  coef = { alpha0, beta0,
- * gamma0, dsym0, alpha1, beta1, gamma1, dsym1 }; B1 == NULL: one product.  kernel 0: the library's choice (operands staged
- * through LDS by global_load_lds, its tiles-per-workgroup); 1..3: that kernel with 1..3 tiles per workgroup; 6..8: the same
- * products with the operands loaded to registers; 4 / 5: the one-tile / 32 x 64 block kernels (one product) */
+ * gamma0, dsym0, alpha1, beta1, gamma1, dsym1 }; B1 == NULL: one product.  kernel 0: the two-product kernel with the
+ * library's tiles-per-workgroup; 1..3: that number forced; 4 / 5: the one-tile / 32 x 64 block kernels (one product) */
 int thip_test_gemm_dual(int kernel, int n, int ld, int nb, const float *A, const float *B0, const float *B1, const float *coef,
                         float *O0, float *O1);
 /* timing probe of the chain's launch shapes (tools/psd_chain_probe.py): `reps` dependent launches of ld x ld products,

@@ -297,9 +297,8 @@ def test_mfma_gemm_both_kernels_every_k_split(L, ld, shape):
 def test_all_symmetric_products_of_the_degree_7_chain(L, ld, nb):
     """round 5: O_p = alpha_p A B_p + beta_p B_p + gamma_p I for symmetric A, B_p from the lower triangle of tiles, mirrored,
     the diagonal tiles of an A != B_p product averaged with their transpose (thip_test_gemm_dual).  Against f64 numpy with
-    exactly that symmetrisation; every result bitwise symmetric; the two-product kernel with 1, 2, 3 tile-jobs per workgroup,
-    operands staged through LDS by the DMA path or loaded to registers, bitwise the same (one order of every sum), and its
-    one-product form bitwise the one-tile and the 32 x 64 block kernel's"""
+    exactly that symmetrisation; every result bitwise symmetric; the two-product kernel with 1, 2, 3 tile-jobs per workgroup
+    bitwise the same (one order of every sum), and its one-product form bitwise the one-tile and the 32 x 64 block kernel's"""
     from totsu_amd._lib import lib
     from totsu_amd.fused import DeviceBuffer
     n = ld - 13
@@ -338,7 +337,7 @@ def test_all_symmetric_products_of_the_degree_7_chain(L, ld, nb):
     r0, s0 = ref(B0, 0.5, -2.0, 3.0, False)
     r1, s1 = ref(B1, 1.5, 0.25, 0.0, True)
     got = {}
-    for kernel in (0, 1, 2, 3, 6, 7, 8):        # LDS-staged operands (1-3 tiles per workgroup), register operands (1-3)
+    for kernel in (0, 1, 2, 3):
         d0, d1 = DeviceBuffer(nb * ld * ld), DeviceBuffer(nb * ld * ld)
         assert lib.thip_test_gemm_dual(kernel, n, ld, nb, dA.ptr, dB0.ptr, dB1.ptr, coef.ctypes.data, d0.ptr, d1.ptr) == 0
         g0, g1 = d0.to_host().reshape((nb, ld, ld)), d1.to_host().reshape((nb, ld, ld))
@@ -351,13 +350,13 @@ def test_all_symmetric_products_of_the_degree_7_chain(L, ld, nb):
         E0 = 0.5 * (A.astype(np.float64) @ B0.astype(np.float64)) - 2.0 * B0 + 3.0 * eye
         assert np.all(np.abs(g0 - E0)[:, lowr] <= 2e-6 * s0[:, lowr]), kernel
         got[kernel] = (g0, g1)
-    for kernel in (1, 2, 3, 6, 7, 8):
+    for kernel in (1, 2, 3):
         assert np.array_equal(got[kernel][0], got[0][0]) and np.array_equal(got[kernel][1], got[0][1]), kernel
     # one product with averaged diagonal tiles: the two-product kernel's one-product form, the one-tile and the block kernel
     c1 = np.array([1.5, 0.0, 0.75, 1.0, 0, 0, 0, 0], dtype=np.float32)
     rr, ss = ref(B1, 1.5, 0.0, 0.75, True)
     outs = []
-    for kernel in (0, 7, 4, 5):
+    for kernel in (0, 2, 4, 5):
         d0 = DeviceBuffer(nb * ld * ld)
         assert lib.thip_test_gemm_dual(kernel, n, ld, nb, dA.ptr, dB1.ptr, None, c1.ctypes.data, d0.ptr, None) == 0
         g = d0.to_host().reshape((nb, ld, ld))

@@ -526,8 +526,10 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
     const int halted = *stop;                   // never null: gemm() passes ctx().never_stop
     constexpr int NW = 4;
     int bi, bj;
+    const int item = blockIdx.z;
     if constexpr (SYM) {
         // blockIdx.x runs over the blocks of the lower triangle: tile row bi holds bi / 2 + 1 of them
+        // (dealing the items out to the XCDs as polar_dual_k does measured 9.25 against 9.09 us here: not taken)
         int t = blockIdx.x;
         bi = 0;
         while (t >= bi / 2 + 1) { t -= bi / 2 + 1; ++bi; }
@@ -536,8 +538,8 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
         bi = blockIdx.x;
         bj = 2 * blockIdx.y;
     }
-    X += blockIdx.z * ws; Y += blockIdx.z * ws; C += blockIdx.z * ws;
-    if (D) D += blockIdx.z * ws;
+    X += item * ws; Y += item * ws; C += item * ws;
+    if (D) D += item * ws;
     __shared__ float red[NW][2][16][64];
     __shared__ float tr[SYM ? 32 : 1][65];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -668,6 +670,12 @@ struct DualArgs {
     ptrdiff_t    ps, rps;
     int          has_scale;
     float        scale;
+    // workgroup -> (item, group of tile-jobs).  xpi > 0: a 1-D grid of 8 * spx blocks; block b runs on XCD b % 8 (observed,
+    // not promised: only the speed depends on it); the XCDs are dealt out xpi per item and each takes a CONTIGUOUS chunk of
+    // spx of its item's gp groups, i.e. a range of tile rows -- an XCD then pulls ONE item's operands through the fabric, and
+    // of those mostly the panels of its rows (every operand of a launch was written by the previous launch on other XCDs:
+    // the chain is bound by that traffic, NOTEBOOK 9.1b).  xpi == 0: blockIdx.x = group, blockIdx.z = item.
+    int          xpi, gp, spx;
 };
 
 __host__ __device__ inline int dual_groups(int nt, int nprod, int NT)
@@ -683,14 +691,20 @@ __global__ __launch_bounds__(256) void polar_dual_k(const DualArgs a)
     const int halted = *a.stop;                 // looked at before the first store (see gemm_pre_k)
     constexpr int NW = 4;
     // blockIdx.x -> (tile row bi, group gl of NT jobs inside it)
-    int bi = 0, gl = blockIdx.x;
+    int bi = 0, gl = blockIdx.x, item = blockIdx.z;
+    if (a.xpi > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        item = xcd / a.xpi;
+        gl = (xcd % a.xpi) * a.spx + slot;
+        if (gl >= a.gp) return;                         // (the last chunk of an item may be short)
+    }
     for (;;) {
         const int gi = (a.nprod * (bi + 1) + NT - 1) / NT;
         if (gl < gi) break;
         gl -= gi; ++bi;
     }
     const int njobs = a.nprod * (bi + 1);
-    const size_t zo = blockIdx.z * a.ws;
+    const size_t zo = item * a.ws;
     __shared__ float red[NW][NT][16][64];
     __shared__ float tr[NT][32][33];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -791,30 +805,46 @@ __global__ __launch_bounds__(256) void polar_dual_k(const DualArgs a)
         }
     }
     __syncthreads();
+    if (a.pack == nullptr) {
+        // the tile and its mirror image leave as 16-byte stores: thread t owns floats 4 (t % 8) .. of row t / 8 of either
+        // (8 store instructions per tile per thread as dwords cost 1.5 us per tile of the launch: the stores' issue)
+        typedef float f32x4s __attribute__((ext_vector_type(4)));
+        const int er = tid >> 3, ec = (tid & 7) * 4;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            if (!live[u]) continue;
+            const int p = pr[u], j0 = bj[u] * GT;
+            const bool diag = bj[u] == bi;
+            float *Om = a.O[p] + zo;
+            f32x4s v, w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = tr[u][er][ec + k]; w[k] = tr[u][ec + k][er]; }
+            if (diag && a.dsym[p] != 0) v = 0.5f * (v + w);
+            *reinterpret_cast<f32x4s *>(Om + (size_t)(i0 + er) * pitch + j0 + ec) = v;
+            if (!diag) *reinterpret_cast<f32x4s *>(Om + (size_t)(j0 + er) * pitch + i0 + ec) = w;
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         if (!live[u]) continue;
         const int p = pr[u], j0 = bj[u] * GT;
         const bool diag = bj[u] == bi;
-        float *Om = a.O[p] + zo;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int tl = rr + 8 * wave + 4 * h;
             float v = tr[u][tl][li];
             if (diag && a.dsym[p] != 0) v = 0.5f * (v + tr[u][li][tl]);
-            if (a.pack == nullptr) {
-                Om[(size_t)(i0 + tl) * pitch + j0 + li] = v;
-                if (!diag) Om[(size_t)(j0 + tl) * pitch + i0 + li] = tr[u][li][tl];       // the mirror image, rows along j
-            } else {
+            {
                 // element (row r = j0 + li, column c = i0 + tl) of the upper triangle by columns: r <= c
                 const int rr_ = j0 + li, cc = i0 + tl;
                 if (rr_ <= cc && cc < a.n) {
                     float pv = 0.5f * (a.M[zo + (size_t)cc * pitch + rr_] + v);
                     if (rr_ == cc && a.has_scale) pv = pv / a.scale;
                     const size_t o = (size_t)cc * (cc + 1) / 2 + rr_;
-                    a.pack[(ptrdiff_t)blockIdx.z * a.ps + o] = pv;
+                    a.pack[(ptrdiff_t)item * a.ps + o] = pv;
                     if (a.rx != nullptr) {
-                        float *rx = a.rx + (ptrdiff_t)blockIdx.z * a.rps;
+                        float *rx = a.rx + (ptrdiff_t)item * a.rps;
                         rx[o] = rx[o] - 2.0f * pv;
                     }
                 }
@@ -823,11 +853,26 @@ __global__ __launch_bounds__(256) void polar_dual_k(const DualArgs a)
     }
 }
 
-template <int NT>
-static int launch_dual(hipStream_t st, const DualArgs &a, int nb)
+// the grid of a launch and its workgroup -> (item, group) mapping (DualArgs::xpi)
+static dim3 dual_grid(DualArgs &a, int nt, int NT, int nb)
 {
-    const int nt = a.ld / GT;
-    const dim3 g((unsigned)dual_groups(nt, a.nprod, NT), 1, (unsigned)nb);
+    static const int xcd_map = getenv("THIP_PSD_XCD_MAP") ? atoi(getenv("THIP_PSD_XCD_MAP")) : 1;
+    const int gp = dual_groups(nt, a.nprod, NT);
+    a.gp = gp; a.xpi = 0; a.spx = 0;
+    if (xcd_map && (nb == 1 || nb == 2 || nb == 4 || nb == 8)) {
+        a.xpi = 8 / nb;
+        a.spx = (gp + a.xpi - 1) / a.xpi;
+        return dim3((unsigned)(8 * a.spx), 1, 1);
+    }
+    return dim3((unsigned)gp, 1, (unsigned)nb);
+}
+
+template <int NT>
+static int launch_dual(hipStream_t st, const DualArgs &a_in, int nb)
+{
+    const int nt = a_in.ld / GT;
+    DualArgs a = a_in;
+    const dim3 g = dual_grid(a, nt, NT, nb);
 #define THIP_DUAL(KW) hipLaunchKernelGGL((polar_dual_k<KW, NT>), g, dim3(256), 0, st, a)
     switch (a.ld / 4) {
     case 16: THIP_DUAL(16); break;
@@ -845,245 +890,11 @@ static int launch_dual(hipStream_t st, const DualArgs &a, int nb)
 }
 
 
-// polar_dual_k with the operands staged through LDS by the DMA path (global_load_lds_dwordx4: 1 KB per wave-instruction,
-// no VGPR destination).  What bounded polar_dual_k and gemm_pre2_k was not the MFMAs but Little's law on load INSTRUCTIONS:
-// a wave may have 64 vector loads in flight, a dword load carries 256 bytes, an operand round trip under this load is
-// ~1.8 us, so four waves pull ~64 KB per round trip into a CU and the 256 KB of a three-tile workgroup need four of them
-// (7 us for 5.4 us of MFMAs).  A DMA piece carries four times the bytes per slot in flight: the same 256 KB are two round
-// trips with a ring of 8 slabs, and the launch is bound by its MFMAs again.
-// Each wave stages ITS OWN K range (the waves split K four ways as before) into its own ring of R slabs of 8 k; a slab is
-// NT + 1 pieces of 1 KB -- 8 rows k of 32 floats, the layout the lanes' source addresses give it (lane l: row l / 8, floats
-// 4 (l % 8) ..), which is the layout the MFMA operands are read back in: lane (h, li) of MFMA t takes row 4 h + t, float li.
-// Only the issuing wave reads what it staged, so its own counted vmcnt orders the reads (no barrier in the loop); a slot is
-// refilled after the MFMAs that consumed its operands have been issued.  Per element every sum keeps gemm_pre_k's order.
-typedef __attribute__((address_space(3))) void thip_lds_void;
-typedef const __attribute__((address_space(1))) void thip_gbl_void;
-
-template <int KW, int NT>
-struct LdsGeom {
-    static constexpr int NP = NT + 1, NQ = KW / 8;
-    static constexpr int R0 = NT == 3 ? 8 : (NT == 2 ? 10 : 14);
-    static constexpr int R = R0 < NQ ? R0 : NQ;
-    static constexpr size_t ring_bytes = (size_t)4 * R * NP * 1024;
-    static constexpr size_t epi_bytes = (size_t)4 * NT * 16 * 64 * 4 + (size_t)NT * 32 * 33 * 4;
-    static constexpr size_t lds_bytes = ring_bytes > epi_bytes ? ring_bytes : epi_bytes;
-};
-
-// wait until at most n of this wave's vector-memory operations are outstanding (the other counters untouched)
-#define THIP_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt((((n) & 0xF) | (((n) >> 4) << 14) | 0x0F70))
-
-template <int KW, int NT>
-__global__ __launch_bounds__(256) void polar_lds_k(const DualArgs a)
-{
-    using G = LdsGeom<KW, NT>;
-    constexpr int NW = 4, NP = G::NP, NQ = G::NQ, R = G::R;
-    const int halted = *a.stop;
-    extern __shared__ __attribute__((aligned(16))) char polar_smem[];
-    int bi = 0, gl = blockIdx.x;
-    for (;;) {
-        const int gi = (a.nprod * (bi + 1) + NT - 1) / NT;
-        if (gl < gi) break;
-        gl -= gi; ++bi;
-    }
-    const int njobs = a.nprod * (bi + 1);
-    const size_t zo = blockIdx.z * a.ws;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, li = lane & 31;
-    const int i0 = bi * GT, kb = wave * KW;
-    const int pitch = a.pitch;
-    int bj[NT], pr[NT];
-    bool live[NT];
-    const int rk = lane >> 3, c4 = (lane & 7) * 4;              // this lane's row and floats of a DMA piece
-    const float *srcB[NT];
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        const int t = NT * gl + u;
-        live[u] = t < njobs;
-        const int tt = live[u] ? t : NT * gl;
-        bj[u] = a.nprod == 2 ? tt >> 1 : tt;
-        pr[u] = a.nprod == 2 ? tt & 1 : 0;
-        srcB[u] = a.B[pr[u]] + zo + (size_t)(kb + rk) * pitch + bj[u] * GT + c4;
-    }
-    const float *srcA = a.A + zo + (size_t)(kb + rk) * pitch + i0 + c4;
-    char *const ring = polar_smem + (size_t)wave * (R * NP * 1024);
-    auto issue = [&](const int q) {
-        char *dst = ring + (size_t)(q % R) * (NP * 1024);
-        const size_t go = (size_t)(8 * q) * pitch;
-        __builtin_amdgcn_global_load_lds((thip_gbl_void *)(srcA + go), (thip_lds_void *)dst, 16, 0, 0);
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-            __builtin_amdgcn_global_load_lds((thip_gbl_void *)(srcB[u] + go), (thip_lds_void *)(dst + (1 + u) * 1024), 16, 0, 0);
-    };
-    // the beta * B_p term of the epilogue: ordinary loads, issued FIRST (the oldest of the wave's vector-memory operations: the
-    // counted waits below then cover them by themselves) and used after the loop
-    float dv[NT][4];
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-            dv[u][rr] = a.B[pr[u]][zo + (size_t)(i0 + rr + 8 * wave + 4 * h) * pitch + bj[u] * GT + li];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < R; ++q) issue(q);
-    f32x16 acc[NT];
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
-    }
-    // operands of a slab: lane (h, li), MFMA t: row 4 h + t of the piece, float li
-    const float *rd = reinterpret_cast<const float *>(ring) + (4 * h) * 32 + li;
-    float av[2][4], bv[2][NT][4];
-    auto fetch = [&](const int q, const int s_) {
-        const float *b = rd + (size_t)(q % R) * (NP * 256);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            av[s_][t] = b[t * 32];
-#pragma unroll
-            for (int u = 0; u < NT; ++u) bv[s_][u][t] = b[(1 + u) * 256 + t * 32];
-        }
-    };
-    __builtin_amdgcn_sched_barrier(0);
-    THIP_WAIT_VMCNT((R - 1) * NP);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (q + 1 < NQ) {
-            // slabs issued so far: 0 .. min(q - 1 + R, NQ - 1); the pieces of those behind slab q + 1 may still be in flight
-            const int last = (q - 1 + R < NQ - 1) ? q - 1 + R : NQ - 1;
-            const int behind = (last - (q + 1)) * NP;
-            __builtin_amdgcn_sched_barrier(0);
-            switch (behind < 0 ? 0 : behind) {           // (compile-time after unrolling; the builtin wants a constant)
-#define THIP_VW(n) case n: THIP_WAIT_VMCNT(n); break;
-            THIP_VW(0) THIP_VW(1) THIP_VW(2) THIP_VW(3) THIP_VW(4) THIP_VW(5) THIP_VW(6) THIP_VW(7) THIP_VW(8) THIP_VW(9) THIP_VW(10)
-            THIP_VW(11) THIP_VW(12) THIP_VW(13) THIP_VW(14) THIP_VW(15) THIP_VW(16) THIP_VW(17) THIP_VW(18) THIP_VW(19) THIP_VW(20)
-            THIP_VW(21) THIP_VW(22) THIP_VW(23) THIP_VW(24) THIP_VW(25) THIP_VW(26) THIP_VW(27) THIP_VW(28) THIP_VW(29) THIP_VW(30)
-            THIP_VW(31) THIP_VW(32) THIP_VW(33) THIP_VW(34) THIP_VW(35) THIP_VW(36) THIP_VW(37) THIP_VW(38) THIP_VW(39) THIP_VW(40)
-            THIP_VW(41) THIP_VW(42) THIP_VW(43) THIP_VW(44) THIP_VW(45) THIP_VW(46) THIP_VW(47) THIP_VW(48)
-#undef THIP_VW
-            default: THIP_WAIT_VMCNT(0); break;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(q + 1, (q + 1) & 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q & 1][t], bv[q & 1][u][t], acc[u], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (q + R < NQ) {
-            // slab q's slot: its operands were fetched an iteration ago and the MFMAs above have consumed them
-            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): no LDS read of this wave is still on its way
-            issue(q + R);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // the rings become the epilogue's buffers: every wave must be through with its own first
-    __syncthreads();
-    float (*red)[NT][16][64] = reinterpret_cast<float (*)[NT][16][64]>(polar_smem);
-    float (*tr)[32][33] = reinterpret_cast<float (*)[32][33]>(polar_smem + (size_t)NW * NT * 16 * 64 * 4);
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave][u][r][lane] = acc[u][r];
-    }
-    __syncthreads();
-    if (halted != 0) return;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        const int p = pr[u], j0 = bj[u] * GT;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = 4 * wave + rr, tl = rr + 8 * wave + 4 * h;
-            float v = red[0][u][r][lane];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) v += red[w][u][r][lane];
-            v *= a.alpha[p];
-            const int ti = i0 + tl, tj = j0 + li;
-            v = fmaf(a.beta[p], dv[u][rr], v);
-            if (ti == tj && ti < a.n) v += a.gamma[p];
-            tr[u][tl][li] = v;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        if (!live[u]) continue;
-        const int p = pr[u], j0 = bj[u] * GT;
-        const bool diag = bj[u] == bi;
-        float *Om = a.O[p] + zo;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int tl = rr + 8 * wave + 4 * h;
-            float v = tr[u][tl][li];
-            if (diag && a.dsym[p] != 0) v = 0.5f * (v + tr[u][li][tl]);
-            if (a.pack == nullptr) {
-                Om[(size_t)(i0 + tl) * pitch + j0 + li] = v;
-                if (!diag) Om[(size_t)(j0 + tl) * pitch + i0 + li] = tr[u][li][tl];
-            } else {
-                const int rr_ = j0 + li, cc = i0 + tl;
-                if (rr_ <= cc && cc < a.n) {
-                    float pv = 0.5f * (a.M[zo + (size_t)cc * pitch + rr_] + v);
-                    if (rr_ == cc && a.has_scale) pv = pv / a.scale;
-                    const size_t o = (size_t)cc * (cc + 1) / 2 + rr_;
-                    a.pack[(ptrdiff_t)blockIdx.z * a.ps + o] = pv;
-                    if (a.rx != nullptr) {
-                        float *rx = a.rx + (ptrdiff_t)blockIdx.z * a.rps;
-                        rx[o] = rx[o] - 2.0f * pv;
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int KW, int NT>
-static int launch_lds_one(hipStream_t st, const DualArgs &a, const dim3 &g)
-{
-    using G = LdsGeom<KW, NT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&polar_lds_k<KW, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)G::lds_bytes));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((polar_lds_k<KW, NT>), g, dim3(256), G::lds_bytes, st, a);
-    return 0;
-}
-
-template <int NT>
-static int launch_lds(hipStream_t st, const DualArgs &a, int nb)
-{
-    const int nt = a.ld / GT;
-    const dim3 g((unsigned)dual_groups(nt, a.nprod, NT), 1, (unsigned)nb);
-    switch (a.ld / 4) {
-    case 16: THIP_RC((launch_lds_one<16, NT>(st, a, g))); break;
-    case 32: THIP_RC((launch_lds_one<32, NT>(st, a, g))); break;
-    case 48: THIP_RC((launch_lds_one<48, NT>(st, a, g))); break;
-    case 64: THIP_RC((launch_lds_one<64, NT>(st, a, g))); break;
-    case 80: THIP_RC((launch_lds_one<80, NT>(st, a, g))); break;
-    case 96: THIP_RC((launch_lds_one<96, NT>(st, a, g))); break;
-    case 112: THIP_RC((launch_lds_one<112, NT>(st, a, g))); break;
-    default: THIP_RC((launch_lds_one<128, NT>(st, a, g))); break;
-    }
-    THIP_LAUNCH_CHECK();
-    return 0;
-}
-
-static int g_dual_force_regs = 0;      // thip_test_gemm_dual: 1 = polar_dual_k whatever THIP_PSD_LDS says
-// THIP_PSD_LDS=0: the chain's operands through VGPRs (gemm_pre2_k / polar_dual_k, the first half of round 5); default: through
-// LDS by the DMA path (polar_lds_k for every product of the chain)
-static bool psd_use_lds()
-{
-    static const int v = getenv("THIP_PSD_LDS") ? atoi(getenv("THIP_PSD_LDS")) : 1;
-    return v != 0;
-}
+// (a variant of this kernel with the operands staged through LDS by global_load_lds_dwordx4 -- a ring of 8 slabs per wave, counted
+// vmcnt waits, no barrier in the loop -- was built, passed the same bitwise tests and measured the same: 12.4 vs 12.3 us for
+// three tile-jobs, 9.8 vs 9.5 for two.  Compile-time variants of it located the time: operand traffic 1.1 us, MFMAs 4.3 us,
+// and 3-4 us that disappear when the launch stores nothing -- because then the NEXT launch finds its operands in its XCD's
+// L2 instead of pulling them through the fabric.  Removed; NOTEBOOK 9.1b has the table.)
 // the smallest NT whose grid fits one workgroup per CU
 static int dual(hipStream_t st, DualArgs a, int nb)
 {
@@ -1092,10 +903,15 @@ static int dual(hipStream_t st, DualArgs a, int nb)
     const int nt = a.ld / GT;
     static const int force_nt = getenv("THIP_PSD_DUAL_NT") ? atoi(getenv("THIP_PSD_DUAL_NT")) : 0;
     int NT = 1;
-    while (NT < 3 && dual_groups(nt, a.nprod, NT) * nb > ctx().num_cu) ++NT;
+    // (one workgroup per CU: in all, and -- with the items dealt out to the XCDs, dual_grid -- on every XCD)
+    auto too_many = [&](int NT_) {
+        const int gp = dual_groups(nt, a.nprod, NT_);
+        if (gp * nb > ctx().num_cu) return true;
+        if (nb == 1 || nb == 2 || nb == 4 || nb == 8) return (gp + 8 / nb - 1) / (8 / nb) > ctx().num_cu / 8;
+        return false;
+    };
+    while (NT < 3 && too_many(NT)) ++NT;
     if (force_nt >= 1 && force_nt <= 3) NT = force_nt;
-    if (psd_use_lds() && g_dual_force_regs == 0)
-        return NT == 1 ? launch_lds<1>(st, a, nb) : NT == 2 ? launch_lds<2>(st, a, nb) : launch_lds<3>(st, a, nb);
     return NT == 1 ? launch_dual<1>(st, a, nb) : NT == 2 ? launch_dual<2>(st, a, nb) : launch_dual<3>(st, a, nb);
 }
 
@@ -2460,13 +2276,10 @@ int polar_project7(hipStream_t st, size_t n, float *packed, int has_scale, float
     DualArgs d;
     memset(&d, 0, sizeof(d));
     d.n = ni; d.ld = ld; d.pitch = pitch; d.stop = stop; d.ws = ws;
-    // one symmetric product O = A B (dsym: A != B)
+    // one symmetric product O = A B (dsym: A != B): the 32 x 64 block kernel, whose second operand is one dwordx2 per lane
+    // (8.8-9.0 us per batched launch at k = 500; the two-product kernel's one-product form: 9.5)
     auto prod1 = [&](const float *A_, const float *B_, float *O_, int dsym) -> int {
-        if (!psd_use_lds()) return gemm(st, false, ni, ld, 1.0f, A_, B_, 0.0f, nullptr, 0.0f, O_, stop, nb, ws, pitch, dsym);
-        DualArgs e = d;
-        e.nprod = 1; e.A = A_; e.B[0] = B_; e.O[0] = O_; e.alpha[0] = 1.0f; e.beta[0] = 0.0f; e.gamma[0] = 0.0f; e.dsym[0] = dsym;
-        e.B[1] = nullptr; e.O[1] = nullptr;
-        return dual(st, e, nb);
+        return gemm(st, false, ni, ld, 1.0f, A_, B_, 0.0f, nullptr, 0.0f, O_, stop, nb, ws, pitch, dsym);
     };
     for (int it = 0; it < 11; ++it) {
         const float *c = it < 8 ? LIFT7 : TAIL7[it - 8];
@@ -2545,7 +2358,7 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
     if (map_kind == 0 && n > POLAR_MIN_N) {
         // orders up to 512 (ld <= 512): the all-symmetric degree-7 chain; above, or THIP_PSD_CHAIN=5: the round-4 quintic chain
         static const int chain = getenv("THIP_PSD_CHAIN") ? atoi(getenv("THIP_PSD_CHAIN")) : 7;
-        if (chain == 7 && np_of(n) <= 512)
+        if (chain == 7 && np_of(n) <= 512 && pitch_of(np_of(n)) % 4 == 0)
             return polar_project7(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride, rx, rx_stride);
         return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride, rx, rx_stride);
     }
@@ -2587,17 +2400,16 @@ int thip_test_gemm_chain(int shape, int kernel, int n, int ld, int nb, float alp
 //   mode 4: mode 3 on TWO streams at once (one item each; us per launch PAIR); mode 5: one tile, general, one item
 // test entry point for the round-5 kernels of the chain: O_p = alpha_p A B_p + beta_p B_p + gamma_p I_n from the lower triangle
 // of tiles (mirrored; diagonal tiles of a product with dsym_p averaged with their transpose), nb items ld * ld apart.
-// coef = { alpha0, beta0, gamma0, dsym0, alpha1, beta1, gamma1, dsym1 }; B1 == nullptr: one product.  kernel 0: the library's choice
-// (polar_lds_k with its NT); 1 .. 3: polar_lds_k with NT forced; 6 .. 8: polar_dual_k (operands through VGPRs) with NT = 1 .. 3;
-// 4 / 5: the one-tile / 32 x 64 block kernel of gemm() (one product, beta = 0)
+// coef = { alpha0, beta0, gamma0, dsym0, alpha1, beta1, gamma1, dsym1 }; B1 == nullptr: one product.  kernel 0: polar_dual_k with
+// the library's NT; 1 .. 3: NT forced; 4 / 5: the one-tile / 32 x 64 block kernel of gemm() (one product, beta = 0)
 int thip_test_gemm_dual(int kernel, int n, int ld, int nb, const float *A, const float *B0, const float *B1, const float *coef,
                         float *O0, float *O1)
 {
     THIP_NEED_INIT();
-    if (ld <= 0 || ld % 64 != 0 || ld > 512 || n < 0 || n > ld || nb < 1 || kernel < 0 || kernel > 8 || !A || !B0 || !coef || !O0)
+    if (ld <= 0 || ld % 64 != 0 || ld > 512 || n < 0 || n > ld || nb < 1 || kernel < 0 || kernel > 5 || !A || !B0 || !coef || !O0)
         return fail(THIP_E_INVALID, "thip_test_gemm_dual", __FILE__, __LINE__);
     const size_t ws = (size_t)ld * ld;
-    if (kernel >= 4) {
+    if (kernel == 4 || kernel == 5) {
         if (B1 != nullptr || coef[1] != 0.0f) return fail(THIP_E_INVALID, "thip_test_gemm_dual: kernels 4, 5 take one product, beta = 0", __FILE__, __LINE__);
         g_force_kernel = kernel == 4 ? 1 : 2;
         const int rc = gemm(ctx().stream, false, n, ld, coef[0], A, B0, 0.0f, nullptr, coef[2], O0, nullptr, nb, ws, ld, coef[3] != 0.0f);
@@ -2611,8 +2423,7 @@ int thip_test_gemm_dual(int kernel, int n, int ld, int nb, const float *A, const
     d.B[0] = B0; d.O[0] = O0; d.alpha[0] = coef[0]; d.beta[0] = coef[1]; d.gamma[0] = coef[2]; d.dsym[0] = coef[3] != 0.0f;
     if (B1) { d.B[1] = B1; d.O[1] = O1; d.alpha[1] = coef[4]; d.beta[1] = coef[5]; d.gamma[1] = coef[6]; d.dsym[1] = coef[7] != 0.0f; }
     if (kernel == 0) return dual(ctx().stream, d, nb);
-    if (kernel >= 6) return kernel == 6 ? launch_dual<1>(ctx().stream, d, nb) : kernel == 7 ? launch_dual<2>(ctx().stream, d, nb) : launch_dual<3>(ctx().stream, d, nb);
-    return kernel == 1 ? launch_lds<1>(ctx().stream, d, nb) : kernel == 2 ? launch_lds<2>(ctx().stream, d, nb) : launch_lds<3>(ctx().stream, d, nb);
+    return kernel == 1 ? launch_dual<1>(ctx().stream, d, nb) : kernel == 2 ? launch_dual<2>(ctx().stream, d, nb) : launch_dual<3>(ctx().stream, d, nb);
 }
 
 __global__ void probe_delay_k(long long cycles)
