@@ -401,14 +401,17 @@ int thip_stream_probe(const void *dev_ptr, size_t bytes, int reps, float *host_b
 
 /* The one-pass kernel is persistent and every wait in it is bounded.  When a workgroup gives up (placement changed under
  * it, a peer workgroup was withheld), thip_solver_run restores the iterate of the last completed batch from a device
- * snapshot and goes on with the 2-pass carried schedule (thip_solver_schedule_in_use then says THIP_SCHED_CARRIED); a
+ * snapshot, re-arms the kernel's census and tries the batch once more; a second failure in a row hands the rest of the
+ * solve to the 2-pass carried schedule (thip_solver_schedule_in_use then says THIP_SCHED_CARRIED); a
  * column-sharded run, which has no 2-pass form, raises the fault through its all-reduce so that every rank restores the
  * same iterate and retries together, and fails with THIP_E_TIMEOUT on every rank at once after two retries.
  * host_faults = recoveries so far in this solve, host_last_word = the kernel's error word of the last one (1, 2 census,
  * 3 a gather ran out of spins), host_restored_iter = the iteration the restored snapshot held (-1: none). */
 int thip_solver_sweep_faults(thip_solver *s, int *host_faults, int *host_last_word, int64_t *host_restored_iter);
 /* TEST HOOK: kind 1 = the placement census of the next plan (thip_solver_init) reports a bad placement; kind 2 = one
- * workgroup of the after_sweeps-th regular sweep from now withholds its partial dots; spin_max > 0 shortens the
+ * workgroup of the after_sweeps-th regular sweep from now withholds its partial dots (once: a transient -- thip_solver_run
+ * restores, re-arms and goes on with the one-pass schedule); kind 7 = the same in EVERY sweep from then on (a placement that
+ * stays wrong: the second failure hands over to the 2-pass schedule); spin_max > 0 shortens the
  * bound of the gathers' polling loops (default ~2 s) so that a test does not wait for it.  kind 0 clears.
  * kind 3 / 4 (no fault): run the two m-kernels of a step as two launches also where the cones are all element-wise
  * (the form problems with block cones always take) / merged again -- lets a test compare the two forms.

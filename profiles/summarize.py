@@ -3,6 +3,7 @@
   python profiles/summarize.py stats gpurun_out/prof_r01/bench_results.db > profiles/r01_socp_carried_kernel_stats.txt
   python profiles/summarize.py pmc gpurun_out/pmc_fetch/f_results.db gpurun_out/pmc_write/w_results.db KEY
   python profiles/summarize.py counters gpurun_out/pmc_a/x_results.db [more.db ...]
+  python profiles/summarize.py mfma <MfmaUtil.db> <raw counters.db> 500 profiles/r05_sdp_k500_mfma_util.json
 
 `pmc` prints per-kernel averages of FETCH_SIZE / WRITE_SIZE (KiB as rocprofv3 reports them) and updates
 profiles/hbm_traffic.json[KEY] with the corrected HBM bytes per launch of the dominant kernel: on gfx950
@@ -39,6 +40,39 @@ def counters(*dbs):
             if calls < 20:
                 continue
             print("%-30s %-44s launches %-6d avg %-12.5g avg_us %.2f" % (cname, short, calls, val, dur / 1e3))
+
+
+def mfma(util_db, raw_db, order, out_json):
+    """profiles/r05_sdp_k500_mfma_util.json (bench.py's roofline_eig.MfmaUtil_stored): MfmaUtil per chain kernel from one --pmc
+    pass, and from a second pass the raw counters behind it (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) with the busy fraction
+    over the kernel's OWN duration (busy cycles / (SIMDs x duration x 2.4 GHz)): the derived counter divides by the profiler's
+    window around the dispatch, about twice a 10 us kernel (NOTEBOOK.md 9.2)"""
+    out = {"order": int(order), "source": "rocprofv3 --kernel-trace --pmc MfmaUtil / --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE "
+                                          "-- python bench.py --workload sdp --no-cpu --no-to-eps --steps 6 --warmup 2",
+           "files": [util_db, raw_db], "kernels": {}}
+    cur = sqlite3.connect(util_db).cursor()
+    q = ("select kernel_name, count(*), avg(value), avg(duration) from counters_collection where counter_name = 'MfmaUtil' "
+         "group by kernel_name order by sum(duration) desc")
+    for name, calls, val, dur in cur.execute(q):
+        if calls < 20 or not ("gemm_pre" in name or "polar_" in name):
+            continue
+        out["kernels"][_short(name)] = {"launches": calls, "MfmaUtil_percent": val, "avg_us_under_pmc": dur / 1e3}
+    if raw_db and os.path.exists(raw_db):
+        cur = sqlite3.connect(raw_db).cursor()
+        q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
+             "group by kernel_name, counter_name")
+        for name, cname, calls, val, dur in cur.execute(q):
+            k = _short(name)
+            if k in out["kernels"]:
+                out["kernels"][k][cname] = val
+                out["kernels"][k]["avg_us_raw_pass"] = dur / 1e3
+        for k, r in out["kernels"].items():
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in r:
+                r["busy_fraction_over_kernel_duration"] = r["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * r["avg_us_raw_pass"] * 1e-6 * 2.4e9)
+                if r.get("GRBM_GUI_ACTIVE"):
+                    r["window_us_at_2.4GHz"] = r["GRBM_GUI_ACTIVE"] / 2.4e3
+    json.dump(out, open(out_json, "w"), indent=1)
+    print(json.dumps(out, indent=1))
 
 
 def _short(name):
@@ -94,5 +128,7 @@ if __name__ == "__main__":
         stats(sys.argv[2])
     elif sys.argv[1] == "counters":
         counters(*sys.argv[2:])
+    elif sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])

@@ -1859,6 +1859,7 @@ int sweep_pass(thip_solver *s, int first, int np_m)
     a.pub_agent = s->pub_agent >= 0 ? s->pub_agent : sweep_publish_default();
     a.fault = 0;
     if (!first && s->fault_kind == 2 && s->fault_after >= 0 && s->fault_after-- == 0) { a.fault = 1; s->fault_kind = 0; }
+    if (!first && s->fault_kind == 7 && (s->fault_after < 0 || s->fault_after-- <= 0)) { a.fault = 1; s->fault_after = -1; }      // every sweep from then on
     prof_begin(st);
     THIP_RC(sweep_launch(st, g, a));
     prof_end(st);
@@ -2439,6 +2440,11 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
                 if (++retries > 2)
                     return fail(THIP_E_TIMEOUT, "the one-pass kernel gave up on some rank of a column-sharded run (3 attempts from the same iterate)", __FILE__, __LINE__);
                 THIP_RC(sweep_rearm(s));
+            } else if (++retries <= 1) {
+                // one GPU: a transient (another process on the device for a moment) should not halve the rate of the 100 000
+                // iterations that may follow -- clean census, ring and error word and give the one-pass schedule ONE more batch
+                // from the restored iterate before giving it up
+                THIP_RC(sweep_rearm(s));
             } else {
                 s->sweep_state = -1;                               // for the rest of this solve: the 2-pass schedule
                 THIP_RC(prepare_split(s));                         // (tunes the GEMV plan if that has not happened yet)
@@ -2658,10 +2664,10 @@ int thip_solver_sweep_faults(thip_solver *s, int *host_faults, int *host_last_wo
 
 int thip_test_sweep_fault(thip_solver *s, int kind, int64_t after_sweeps, int spin_max)
 {
-    if (!s || kind < 0 || kind > 6) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
+    if (!s || kind < 0 || kind > 7) return fail(THIP_E_INVALID, "bad argument", __FILE__, __LINE__);
     if (kind == 5 || kind == 6) { s->no_fold = kind == 5; return 0; }      // 5 / 6: the termination test as its own launch / folded again
-    if (kind >= 3) { s->no_merge = kind == 3; return 0; }       // 3 / 4: the step's m-kernels as two launches / merged again
-    s->fault_kind = kind; s->fault_after = kind == 2 ? (long long)after_sweeps : -1;
+    if (kind >= 3 && kind <= 4) { s->no_merge = kind == 3; return 0; }       // 3 / 4: the step's m-kernels as two launches / merged again
+    s->fault_kind = kind; s->fault_after = (kind == 2 || kind == 7) ? (long long)after_sweeps : -1;
     s->spin_max = spin_max > 0 ? spin_max : 0;
     return 0;
 }

@@ -302,7 +302,8 @@ class FusedSolver:
         return {"faults": k.value, "last_word": w.value, "restored_iter": it.value}
 
     def inject_sweep_fault(self, kind, after_sweeps=0, spin_max=0):
-        """TEST HOOK (thip_test_sweep_fault): kind 1 = the next plan's placement census fails; 2 = one workgroup of the
+        """TEST HOOK (thip_test_sweep_fault): kind 1 = the next plan's placement census fails; 7 = kind 2 in every sweep from then on;
+        2 = one workgroup of the
         after_sweeps-th regular sweep from now withholds its partial dots; spin_max shortens the polling bound"""
         lib.thip_test_sweep_fault(self.h, int(kind), int(after_sweeps), int(spin_max))
 
