@@ -70,7 +70,9 @@ def mfma(util_db, raw_db, order, out_json):
             if "SQ_VALU_MFMA_BUSY_CYCLES" in r:
                 r["busy_fraction_over_kernel_duration"] = r["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * r["avg_us_raw_pass"] * 1e-6 * 2.4e9)
                 if r.get("GRBM_GUI_ACTIVE"):
-                    r["window_us_at_2.4GHz"] = r["GRBM_GUI_ACTIVE"] / 2.4e3
+                    # (the database holds the SUM over the 8 XCDs' instances; the derived counter takes their max)
+                    r["window_us_at_2.4GHz"] = r["GRBM_GUI_ACTIVE"] / 8.0 / 2.4e3
+                    r["MfmaUtil_recomputed_percent"] = 100.0 * r["SQ_VALU_MFMA_BUSY_CYCLES"] / (r["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     json.dump(out, open(out_json, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
@@ -81,14 +83,15 @@ def _short(name):
 
 def pmc(fetch_db, write_db, key):
     """FETCH_SIZE and WRITE_SIZE of ONE kernel instance: the matching instance (sweep_k<...> / dual_gemv_k<.., DO_N, DO_T, ..>)
-    with the most launches in the FETCH pass -- the loop's kernel, not a geometry the plan autotune timed -- and the SAME
+    with the most TIME in the FETCH pass (launches x duration) -- the loop's kernel, not a geometry the plan autotune timed nor
+    the 200 short sweeps of the publish-scope self-test -- and the SAME
     instance's row of the WRITE pass (round 3 paired the first row of each pass: two different instances when the two runs'
     autotunes disagreed)."""
     rows = {}
     for label, db in (("FETCH_SIZE", fetch_db), ("WRITE_SIZE", write_db)):
         cur = sqlite3.connect(db).cursor()
         q = ("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
-             "where counter_name = ? group by kernel_name order by avg(value) * count(*) desc")
+             "where counter_name = ? group by kernel_name order by sum(duration) desc")
         print("# rocprofv3 --pmc %s   source: %s" % (label, db))
         print("%-6s %-16s %-12s %s" % ("calls", "avg_KiB", "avg_us", "kernel"))
         rows[label] = {}
@@ -102,7 +105,7 @@ def pmc(fetch_db, write_db, key):
         if key.endswith("_sweep"):
             return "sweep_k<" in short
         return short.startswith("dual_gemv_k<") and ", true, true, false" in short and ("unsigned short" in short) == key.endswith("_bf16")
-    cand = [(v[0], k) for k, v in rows["FETCH_SIZE"].items() if wanted(k)]
+    cand = [(v[0] * v[2], k) for k, v in rows["FETCH_SIZE"].items() if wanted(k)]
     if not cand:
         print("# %s: no matching kernel in the FETCH pass" % key)
         return

@@ -300,7 +300,7 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
 // sc1 form and has never failed.  What would make it fail is a change of the L2's write policy under it (driver, firmware):
 // the store would sit in a place the gatherers' loads do not look, every gather would poll until its bound, and a solve
 // would limp from time-out to time-out.  So, once per process, before the first plan: SELFTEST_SWEEPS idempotent sweeps of
-// a scratch 65 536 x 1024 matrix with 32 members per group (256 intervals each: ~1.6 million granule hand-offs, ~15 ms),
+// a scratch 32 768 x 512 matrix (64 MB) with 32 members per group (64 intervals each: ~400 000 granule hand-offs, ~10 ms),
 // a short polling bound, and the kernel's own poll counters.  A hand-off that is merely late polls a few times; one that is
 // not visible polls to the bound.  Error word raised, or any gather needing more than SELFTEST_MAX_POLLS: every solver of
 // this process publishes at agent scope (slower, inside the model) -- thip_solver_set_sweep_publish overrides either way.
@@ -313,7 +313,7 @@ int g_pub_force_fail = 0;
 
 int publish_selftest_run()
 {
-    const size_t m = 65536, n = 1024;
+    const size_t m = 32768, n = 512;
     float *A = nullptr, *vec = nullptr;
     g_pub_info[0] = g_pub_info[1] = g_pub_info[2] = g_pub_info[3] = 0;
     if (hipMalloc((void **)&A, m * n * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); g_pub_state = 1; return 0; }
