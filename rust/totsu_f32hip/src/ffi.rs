@@ -83,7 +83,6 @@ extern "C" {
     pub fn thip_eig_rebuild(n: usize, mat: *mut f32, has_scale: c_int, scale_diag: f32, work: *mut f32,
                             worklen: usize, host_e: *const f32, host_keep: *const u8) -> c_int;
     pub fn thip_eig_engine_info(host_engine: *mut c_int, host_polish: *mut c_int, host_cert: *mut f32) -> c_int;
-    pub fn thip_test_eig_force(engine: c_int) -> c_int;
 
     pub fn thip_absadd_cols(n_row: usize, n_col: usize, mat: *const f32, tau: *mut f32) -> c_int;
     pub fn thip_absadd_rows(n_row: usize, n_col: usize, mat: *const f32, sigma: *mut f32) -> c_int;
@@ -107,7 +106,6 @@ extern "C" {
     pub fn thip_solver_set_overlap(s: *mut thip_solver, mode: c_int) -> c_int;
     pub fn thip_solver_overlap_info(s: *mut thip_solver, host_mode: *mut c_int, host_launches_per_pass: *mut c_int,
                                     host_split_col: *mut usize) -> c_int;
-    pub fn thip_test_spin_allreduce(s: *mut thip_solver, latency_us: c_int) -> c_int;
     pub fn thip_solver_init(s: *mut thip_solver) -> c_int;
     pub fn thip_solver_run(s: *mut thip_solver, max_steps: i64, poll_every: i64, host_status: *mut thip_status) -> c_int;
     pub fn thip_solver_solution(s: *mut thip_solver, host_x: *mut f32, host_y: *mut f32) -> c_int;
@@ -154,10 +152,8 @@ extern "C" {
     pub fn thip_solver_set_column_shard(s: *mut thip_solver, on: c_int) -> c_int;
     pub fn thip_sweep_probe(m: usize, n_local: usize, lda: usize, elem: c_int, host_ok: *mut c_int) -> c_int;
     pub fn thip_solver_sweep_plan(s: *mut thip_solver, host_members: *mut c_int, host_cols_per_panel: *mut c_int, host_slots: *mut c_int, host_ms: *mut f32) -> c_int;
-    pub fn thip_test_sweep(t: *const thip_sweep_test, host_ms: *mut f32, host_info: *mut c_int) -> c_int;
     pub fn thip_stream_probe(dev_ptr: *const c_void, bytes: usize, reps: c_int, host_best_ms: *mut f32, host_avg_ms: *mut f32) -> c_int;
     pub fn thip_solver_sweep_faults(s: *mut thip_solver, host_faults: *mut c_int, host_last_word: *mut c_int, host_restored_iter: *mut i64) -> c_int;
-    pub fn thip_test_sweep_fault(s: *mut thip_solver, kind: c_int, after_sweeps: i64, spin_max: c_int) -> c_int;
     pub fn thip_solver_set_sweep_publish(s: *mut thip_solver, agent_scope: c_int) -> c_int;
     pub fn thip_sweep_publish_selftest(mode: c_int, host_agent_scope: *mut c_int, host_info: *mut c_int) -> c_int;
     pub fn thip_solver_gemv_plan(s: *const thip_solver, host_nj: *mut c_int, host_blocks: *mut c_int, host_ms: *mut f32) -> c_int;
@@ -185,6 +181,16 @@ extern "C" {
     pub fn thip_prof_enable(on: c_int) -> c_int;
     pub fn thip_prof_read(host_launches: *mut i64, host_total_ms: *mut f64) -> c_int;
     pub fn thip_prof_read_psd(host_spans: *mut i64, host_total_ms: *mut f64) -> c_int;
+}
+
+/// Test hooks and timing probes (include/totsu_f32hip_test.h): exported by the same library, not part of the interface
+/// this crate wraps -- declared only for the crate's own device tests.
+#[cfg(feature = "test-hooks")]
+extern "C" {
+    pub fn thip_test_eig_force(engine: c_int) -> c_int;
+    pub fn thip_test_spin_allreduce(s: *mut thip_solver, latency_us: c_int) -> c_int;
+    pub fn thip_test_sweep(t: *const thip_sweep_test, host_ms: *mut f32, host_info: *mut c_int) -> c_int;
+    pub fn thip_test_sweep_fault(s: *mut thip_solver, kind: c_int, after_sweeps: i64, spin_max: c_int) -> c_int;
     pub fn thip_test_gemm_sym(n: c_int, ld: c_int, alpha: f32, a: *const f32, b: *const f32, beta: f32, d: *const f32,
                               gamma: f32, c: *mut f32) -> c_int;
     pub fn thip_test_gemm_chain(shape: c_int, kernel: c_int, n: c_int, ld: c_int, nb: c_int, alpha: f32, x: *const f32,

@@ -8,8 +8,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _headers():
+    # the interface (totsu_f32hip.h) and the test hooks / probes the same library exports (totsu_f32hip_test.h)
+    return "\n".join(open(os.path.join(ROOT, "include", f)).read() for f in ("totsu_f32hip.h", "totsu_f32hip_test.h"))
+
+
 def _declared():
-    txt = open(os.path.join(ROOT, "include", "totsu_f32hip.h")).read()
+    txt = _headers()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = set(re.findall(r"\b(thip_[a-z0-9_]+)\s*\(", txt))
     names -= {"thip_allreduce_fn"}
@@ -52,6 +57,20 @@ def test_product_never_imports_oracle():
                 assert "libtotsu_oracle" not in src, f
 
 
+def test_test_hooks_are_not_in_the_interface_header():
+    # thip_test_* (fault injection, engine switches, single-kernel entry points) live in totsu_f32hip_test.h only
+    main = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "totsu_f32hip.h")).read(), flags=re.S)
+    assert not re.findall(r"\bthip_test_[a-z0-9_]+\s*\(", main)
+    hooks = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "totsu_f32hip_test.h")).read(), flags=re.S)
+    assert len(set(re.findall(r"\b(thip_test_[a-z0-9_]+)\s*\(", hooks))) >= 8
+    # and no host built on the interface (examples/, the C++ mirrors) needs them
+    for d, files in (("include", ["totsu_f32hip.hpp", "totsu_f32hip_prob.hpp"]), ("examples", os.listdir(os.path.join(ROOT, "examples")))):
+        for f in files:
+            p = os.path.join(ROOT, d, f)
+            if os.path.isfile(p) and f.endswith((".c", ".cpp", ".hpp", ".h")):
+                assert "thip_test_" not in open(p).read(), p
+
+
 def test_authored_rust_binding_declares_every_symbol():
     # rust/totsu_f32hip cannot be compiled here (no cargo); at least its extern block stays one-to-one with the header
     src = open(os.path.join(ROOT, "rust", "totsu_f32hip", "src", "ffi.rs")).read()
@@ -61,7 +80,7 @@ def test_authored_rust_binding_declares_every_symbol():
 
 def test_authored_rust_binding_has_the_header_arities():
     # second line of defence for the uncompiled crate: every extern declaration takes as many arguments as the header says
-    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "totsu_f32hip.h")).read(), flags=re.S)
+    hdr = re.sub(r"/\*.*?\*/", "", _headers(), flags=re.S)
     arity = {}
     for m in re.finditer(r"\b(thip_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
         args = m.group(2).strip()

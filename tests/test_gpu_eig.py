@@ -36,7 +36,8 @@ def _rand_sym(k, seed, rank_def=False):
     return s
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 5, 6, 9, 20, 21, 32, 33, 48, 63, 64, 65, 100, 200, 500])
+# (<= 64: one workgroup; 65 .. 512: the all-symmetric degree-7 chain; 600: the round-4 chain, which serves orders above 512)
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 6, 9, 20, 21, 32, 33, 48, 63, 64, 65, 100, 200, 500, 512, 600])
 @pytest.mark.parametrize("rank_def", [False, True])
 def test_psd_projection(L, k, rank_def):
     from totsu_amd import ConePSD

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "totsu_f32hip.h"
+#include "totsu_f32hip_test.h"
 
 namespace thip {
 

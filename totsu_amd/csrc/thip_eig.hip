@@ -2241,7 +2241,7 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
 }
 
 
-// Round 5: the same projection with every product SYMMETRIC and degree-7 steps -- 36 launches instead of 47.
+// Round 5: the same projection with every product SYMMETRIC and degree-7 steps -- 37 launches instead of 48.
 //   * S is kept bitwise symmetric: T S is computed like S S^T (lower triangle of tiles, mirrored; diagonal tiles averaged
 //     with their transpose, `dsym`), which turns the antisymmetric round-off of a step into a symmetric perturbation of
 //     the same size instead of carrying it along (measured, tools/psd_err_sweep.py and the numpy restatement in DESIGN.md:
