@@ -440,3 +440,41 @@ def test_c2_full_size_lp_iterates_vs_oracle(T, schedule):
         assert np.allclose(fs.status().cri, tr[2:], rtol=5e-3, atol=1e-5), (it, fs.status().cri, tr)
     fs.destroy()
     inst.free()
+
+
+def test_bench_lines_of_the_lp_and_sdp_workloads_carry_their_gates_and_the_eig_record():
+    """round 5: `bench.py --workload lp|sdp --to-eps …` lines carry objective_gate.this_run (the answer of the run re-evaluated
+    in f64 against the regenerated A: kkt_f64_lp / kkt_f64_sdp), the SDP line the second roofline record `roofline_eig` (the PSD
+    chain timed by HIP events, its flops, the fraction of the f32 matrix peak), and a `--mixed-leg` run its second time-to-eps
+    record -- at sizes that take seconds"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def line(args):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu", "--steps", "20", "--warmup", "5"] + args,
+                           capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(out) == 1
+        return json.loads(out[0])
+    d = line(["--workload", "sdp", "--k", "96", "--size", "300", "--to-eps", "1e-3"])
+    e = d["roofline_eig"]
+    assert e["bound"] == "mfma" and e["order"] == 96 and e["launches_per_projection_pair"] == 37 and e["spans_timed"] == 20
+    assert 0.05 < e["ms_per_projection_pair"] < 1.0 and 0 < e["frac"] < 1 and 0 < e["share_of_iteration"] < 1
+    g = d["objective_gate"]["this_run"]
+    assert d["time_to_eps"]["state"] == 0 and "error" not in g, g
+    assert g["dual_residual_rel_f64"] <= 1.1e-3 and g["gap_rel"] <= 1.1e-3 and g["primal_cone_violation_rel_to_norm_b"] <= 1e-4, g
+    assert g["dual_cone_violation"] <= 1e-4
+    assert d["config"]["hbm_plan"]["fits"] and d["config"]["hbm_plan"]["A_bytes"] == 4 * (96 * 97 // 2) * 300
+    d = line(["--workload", "lp", "--size", "1500", "--to-eps", "1e-3", "--mixed-leg"])
+    g = d["objective_gate"]["this_run"]
+    assert d["time_to_eps"]["state"] == 0 and "error" not in g, g
+    assert g["dual_residual_rel_f64"] <= 1.1e-3 and g["gap_rel"] <= 1.1e-3 and g["dual_cone_violation"] <= 1e-5, g
+    assert d["roofline_eig"] is None
+    mx = d["time_to_eps_mixed"]
+    assert mx["state"] == 0 and mx["a_storage"] == "mixed" and "f16_phase" in mx
+    assert mx["vs_f32_leg"]["primal_obj_rel_diff"] <= 1e-3
+    assert "error" not in mx["objective_gate_this_run"]
