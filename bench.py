@@ -1186,12 +1186,15 @@ def run(a):
             # BASELINE's metric has two halves; the second one has a lever the f32 headline does not use: the same solve with
             # the first phase streamed from an f16-stored copy of A (half the bytes per iteration), finished on the exact f32
             # matrix to the SAME stopping test.  Reported beside the f32 leg, never instead of it.
-            rec, gate = to_eps_leg("mixed")
-            rec["objective_gate_this_run"] = gate
-            rec["vs_f32_leg"] = {"seconds_ratio": rec["seconds"] / out["time_to_eps"]["seconds"],
-                                 "primal_obj_rel_diff": abs(rec["primal_obj"] - out["time_to_eps"]["primal_obj"])
-                                 / (1.0 + abs(out["time_to_eps"]["primal_obj"]))}
-            out["time_to_eps_mixed"] = rec
+            try:
+                rec, gate = to_eps_leg("mixed")
+                rec["objective_gate_this_run"] = gate
+                rec["vs_f32_leg"] = {"seconds_ratio": rec["seconds"] / out["time_to_eps"]["seconds"],
+                                     "primal_obj_rel_diff": abs(rec["primal_obj"] - out["time_to_eps"]["primal_obj"])
+                                     / (1.0 + abs(out["time_to_eps"]["primal_obj"]))}
+                out["time_to_eps_mixed"] = rec
+            except Exception as e:          # the extra leg must never cost the line (single GPU: no peer is left waiting)
+                out["time_to_eps_mixed"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not a.no_cpu and a.workload == "socp":
         import oracle as O
