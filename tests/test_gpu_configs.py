@@ -129,7 +129,7 @@ def test_c5_column_shard_through_the_full_loop(T):
     assert cfg["hbm_plan"]["A_bytes"] == 4 * 2 * N5 * (N5 // WORLD5) and cfg["hbm_plan"]["fits"]
     assert d["sweep_faults"]["faults"] == 0
     assert d["roofline"]["passes_over_A_per_iter"] == 1 and d["roofline"]["frac"] > 0.70, d["roofline"]
-    assert d["roofline"]["launches_timed"] == 50
+    assert d["roofline"]["launches_timed"] == 50          # (50 steps: every launch is timed)
     # one iteration = one sweep of 40 GB + the m-tail + the 30 us stand-in: well under 8 ms, well over the bare sweep
     assert 5.0 < d["ms_per_step"] < 8.0, d["ms_per_step"]
     assert abs(lines[1]["ms_per_step"] / d["ms_per_step"] - 1) < 0.05

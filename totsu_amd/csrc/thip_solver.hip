@@ -1140,6 +1140,9 @@ size_t pad64(size_t v) { return (v + 63) / 64 * 64; }
 // launch stream around every GEMV kernel of products()
 struct Prof {
     bool on = false;
+    int period = 1;                 // every period-th span is timed (an event pair costs the stream 3-5 us: 9 % of a 0.14 ms iteration)
+    long long seen = 0;             // spans begun since thip_prof_enable
+    bool open = false;              // the current span is one of the timed ones
     std::vector<hipEvent_t> ev;     // pairs
     size_t used = 0;
     double total_ms = 0.0;
@@ -1149,6 +1152,8 @@ struct Prof {
 void prof_begin(hipStream_t st, Prof &p = g_prof)
 {
     if (!p.on) return;
+    p.open = (p.seen++ % p.period) == 0;
+    if (!p.open) return;
     if (p.used + 2 > p.ev.size()) {
         for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); p.ev.push_back(e); }
     }
@@ -1156,9 +1161,10 @@ void prof_begin(hipStream_t st, Prof &p = g_prof)
 }
 void prof_end(hipStream_t st, Prof &p = g_prof)
 {
-    if (!p.on) return;
+    if (!p.on || !p.open) return;
     hipEventRecord(p.ev[p.used + 1], st);
     p.used += 2;
+    p.open = false;
 }
 
 }  // namespace
@@ -2752,8 +2758,11 @@ int thip_solver_sweep_plan(thip_solver *s, int *host_members, int *host_cols_per
 int thip_prof_enable(int on)
 {
     THIP_NEED_INIT();
+    // on = 0: off; on = N >= 1: every N-th span of each kind is timed (1: all of them)
     for (Prof *p : { &g_prof, &g_prof_psd }) {
-        p->on = on != 0;
+        p->on = on > 0;
+        p->period = on > 0 ? on : 1;
+        p->seen = 0; p->open = false;
         p->used = 0; p->total_ms = 0.0; p->launches = 0;
     }
     return 0;
