@@ -675,7 +675,8 @@ struct DualArgs {
     // spx of its item's gp groups, i.e. a range of tile rows -- an XCD then pulls ONE item's operands through the fabric, and
     // of those mostly the panels of its rows (every operand of a launch was written by the previous launch on other XCDs:
     // the chain is bound by that traffic, NOTEBOOK 9.1b).  xpi == 0: blockIdx.x = group, blockIdx.z = item.
-    int          xpi, gp, spx;
+    // half > 0 (with xpi == 4): the item's four XCDs take two-dimensional blocks of the tile triangle instead (polar_dual_k)
+    int          xpi, gp, spx, half;
 };
 
 __host__ __device__ inline int dual_groups(int nt, int nprod, int NT)
@@ -692,18 +693,43 @@ __global__ __launch_bounds__(256) void polar_dual_k(const DualArgs a)
     constexpr int NW = 4;
     // blockIdx.x -> (tile row bi, group gl of NT jobs inside it)
     int bi = 0, gl = blockIdx.x, item = blockIdx.z;
-    if (a.xpi > 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        item = xcd / a.xpi;
-        gl = (xcd % a.xpi) * a.spx + slot;
-        if (gl >= a.gp) return;                         // (the last chunk of an item may be short)
+    int c0 = 0, njobs;                                  // first tile column of the row's jobs here, and how many jobs it has
+    if (a.xpi == 4 && a.half > 0) {
+        // TWO-DIMENSIONAL blocks (batch of two: four XCDs per item).  The lower triangle of the nt x nt tile grid, hf = nt / 2:
+        //   block 0: rows [0, hf), columns <= row            block 3: rows [hf, nt), columns [hf, row]
+        //   block 1: rows [hf, hf + hf / 2), columns [0, hf)    block 2: rows [hf + hf / 2, nt), columns [0, hf)
+        // -- 36 / 32 / 32 / 36 tiles at nt = 16, and an XCD needs the panels of its rows and of its columns only: 8 or 12 of
+        // the 16 of each operand instead of all of them on the XCD that holds the last rows of a row-wise deal
+        const int xcd = blockIdx.x & 7;
+        int slot = blockIdx.x >> 3;
+        item = xcd >> 2;
+        const int blk = xcd & 3, hf = a.half, nt = 2 * hf;
+        const bool tri = blk == 0 || blk == 3;
+        const int r0 = blk == 0 ? 0 : (blk == 2 ? hf + hf / 2 : hf), r1 = blk == 0 ? hf : (blk == 1 ? hf + hf / 2 : nt);
+        c0 = blk == 3 ? hf : 0;
+        bi = r0;
+        for (;;) {
+            if (bi >= r1) return;                           // (a block with fewer groups than the largest one)
+            njobs = a.nprod * (tri ? bi - c0 + 1 : hf);
+            const int gi = (njobs + NT - 1) / NT;
+            if (slot < gi) break;
+            slot -= gi; ++bi;
+        }
+        gl = slot;
+    } else {
+        if (a.xpi > 0) {
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+            item = xcd / a.xpi;
+            gl = (xcd % a.xpi) * a.spx + slot;
+            if (gl >= a.gp) return;                         // (the last chunk of an item may be short)
+        }
+        for (;;) {
+            const int gi = (a.nprod * (bi + 1) + NT - 1) / NT;
+            if (gl < gi) break;
+            gl -= gi; ++bi;
+        }
+        njobs = a.nprod * (bi + 1);
     }
-    for (;;) {
-        const int gi = (a.nprod * (bi + 1) + NT - 1) / NT;
-        if (gl < gi) break;
-        gl -= gi; ++bi;
-    }
-    const int njobs = a.nprod * (bi + 1);
     const size_t zo = item * a.ws;
     __shared__ float red[NW][NT][16][64];
     __shared__ float tr[NT][32][33];
@@ -722,7 +748,7 @@ __global__ __launch_bounds__(256) void polar_dual_k(const DualArgs a)
         const int t = NT * gl + u;
         live[u] = t < njobs;
         const int tt = live[u] ? t : NT * gl;                      // a job past the row's end repeats the group's first (not stored)
-        bj[u] = a.nprod == 2 ? tt >> 1 : tt;
+        bj[u] = c0 + (a.nprod == 2 ? tt >> 1 : tt);
         pr[u] = a.nprod == 2 ? tt & 1 : 0;
         pb[u] = reinterpret_cast<const char *>(a.B[pr[u]] + zo + (size_t)kb * pitch + bj[u] * GT);
     }
@@ -856,9 +882,18 @@ __global__ __launch_bounds__(256) void polar_dual_k(const DualArgs a)
 // the grid of a launch and its workgroup -> (item, group) mapping (DualArgs::xpi)
 static dim3 dual_grid(DualArgs &a, int nt, int NT, int nb)
 {
-    static const int xcd_map = getenv("THIP_PSD_XCD_MAP") ? atoi(getenv("THIP_PSD_XCD_MAP")) : 1;
+    static const int xcd_map = getenv("THIP_PSD_XCD_MAP") ? atoi(getenv("THIP_PSD_XCD_MAP")) : 2;
     const int gp = dual_groups(nt, a.nprod, NT);
-    a.gp = gp; a.xpi = 0; a.spx = 0;
+    a.gp = gp; a.xpi = 0; a.spx = 0; a.half = 0;
+    if (xcd_map >= 2 && nb == 2 && nt % 4 == 0) {
+        // two-dimensional blocks: slots per XCD = the groups of the largest of the four blocks
+        const int hf = nt / 2;
+        int gtri = 0;
+        for (int r = 0; r < hf; ++r) gtri += (a.nprod * (r + 1) + NT - 1) / NT;
+        const int grect = (hf / 2) * ((a.nprod * hf + NT - 1) / NT);
+        a.xpi = 4; a.half = hf; a.spx = gtri > grect ? gtri : grect;
+        return dim3((unsigned)(8 * a.spx), 1, 1);
+    }
     if (xcd_map && (nb == 1 || nb == 2 || nb == 4 || nb == 8)) {
         a.xpi = 8 / nb;
         a.spx = (gp + a.xpi - 1) / a.xpi;
@@ -907,6 +942,13 @@ static int dual(hipStream_t st, DualArgs a, int nb)
     auto too_many = [&](int NT_) {
         const int gp = dual_groups(nt, a.nprod, NT_);
         if (gp * nb > ctx().num_cu) return true;
+        if (nb == 2 && nt % 4 == 0) {                  // (the two-dimensional blocks of dual_grid: the largest block's groups)
+            const int hf = nt / 2;
+            int gtri = 0;
+            for (int r = 0; r < hf; ++r) gtri += (a.nprod * (r + 1) + NT_ - 1) / NT_;
+            const int grect = (hf / 2) * ((a.nprod * hf + NT_ - 1) / NT_);
+            return (gtri > grect ? gtri : grect) > ctx().num_cu / 8;
+        }
         if (nb == 1 || nb == 2 || nb == 4 || nb == 8) return (gp + 8 / nb - 1) / (8 / nb) > ctx().num_cu / 8;
         return false;
     };
