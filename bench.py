@@ -1061,14 +1061,21 @@ def run(a):
                 else:
                     inst_r = synth.LpInstance(n, seed=0, rank=rank, world=world)
                 lib.thip_sync()
-                fs_r = T.FusedSolver(n, inst_r.m, inst_r.mat_a, inst_r.vec_b, inst_r.vec_c, inst_r.seg_type, inst_r.seg_len, p,
-                                     "carried", allreduce=hook, overlap=None)
             except Exception as e:
                 err_r = e
                 if a.workload == "socp" and inst_r is None:
                     allreduce_host(np.zeros(n, dtype=np.float32))      # the sum the healthy ranks are in
+            # (the solver's init holds a collective of its own -- the |A| column sums: entered only when every rank has its shard)
             if not all_ranks_ok(err_r is None):
-                raise RuntimeError("the row-sharded leg could not be built on every rank (this rank: %r)" % (err_r,))
+                raise RuntimeError("the row-sharded leg's shard could not be built on every rank (this rank: %r)" % (err_r,))
+            stage = "init"
+            try:
+                fs_r = T.FusedSolver(n, inst_r.m, inst_r.mat_a, inst_r.vec_b, inst_r.vec_c, inst_r.seg_type, inst_r.seg_len, p,
+                                     "carried", allreduce=hook, overlap=None)
+            except Exception as e:
+                err_r = e
+            if not all_ranks_ok(err_r is None):
+                raise RuntimeError("the row-sharded leg's solver could not be set up on every rank (this rank: %r)" % (err_r,))
             stage = "run"
             pick_r, times_r, _ = tune_overlap(fs_r) if a.collective != "gloo" else (None, None, 0)
             fs_r.run(a.warmup, poll_every=max(a.warmup, 1))
