@@ -91,6 +91,9 @@ def parse():
                     help="stop the time-to-eps leg after this many seconds and report the criteria reached (state -1)")
     ap.add_argument("--state", default="compensated", choices=["compensated", "plain"],
                     help="thip_param.state_arith: compensated (Kahan) or plain f32 iterate updates")
+    ap.add_argument("--watchdog", type=float, default=1500.0,
+                    help="N > 1: seconds after which rank 0 prints the line as far as it has got and every rank leaves (a leg behind "
+                         "the timed region that hangs in a collective must not cost the line); 0 = off")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no HIP library: run the control path only -- rank spawn, process group (gloo), the column-shard "
                          "agreement, the shard plan with its HBM budget, the barrier / max-over-ranks timing bracket, the ONE JSON line")
@@ -601,6 +604,10 @@ def dry_run(a, rank, world, dist, allreduce_host, cols, emu, mixed_leg):
     def barrier():
         if world > 1:
             dist.barrier()
+    if os.environ.get("THIP_DRY_HANG_RANK") == str(rank):      # (test hook: this rank never reaches the barrier)
+        time.sleep(3600)
+    _PARTIAL["out"] = {"metric": "DRY RUN (no GPU, no kernels): control path only", "dry_run": True, "value": None, "n_gpus": world,
+                       "config": {"hbm_plan": plans}}
     barrier()
     t0 = time.perf_counter()
     time.sleep(0.001 * a.steps)
@@ -644,6 +651,29 @@ def spawn_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
+# the line as far as it has got (rank 0): what the watchdog prints when a later leg of a multi-rank run never comes back
+_PARTIAL = {"out": None, "fd": None, "timer": None}
+
+
+def _watchdog():
+    """N > 1 only: the legs behind the timed region (the row-sharded leg, time-to-eps) each hold collectives, and a first run on
+    a node nobody has had may hang in one.  After --watchdog seconds rank 0 prints the line with whatever it holds (the timed
+    region's value is complete by then or the line says it is not) and leaves; the launcher then takes the other ranks down.
+    A timer THREAD, not SIGALRM: a Python signal handler does not run while the main thread sits inside a collective's C call."""
+    out = _PARTIAL["out"]
+    rank = int(os.environ.get("RANK", "0"))
+    sys.stderr.write("bench.py: watchdog on rank %d: a leg did not come back; %s\n"
+                     % (rank, "printing the line as far as it got" if (rank == 0 and out) else "leaving"))
+    sys.stderr.flush()
+    if rank == 0 and out is not None and _PARTIAL["fd"] is not None:
+        out["watchdog"] = "a leg behind the timed region did not return within the watchdog's time: this line is partial"
+        try:
+            os.write(_PARTIAL["fd"], (json.dumps(out, default=repr) + "\n").encode())
+        except Exception:
+            pass
+    os._exit(3 if out is None else 0)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -652,6 +682,12 @@ def main():
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and a.watchdog > 0:
+        import threading
+        _PARTIAL["fd"] = saved_stdout
+        _PARTIAL["timer"] = threading.Timer(a.watchdog, _watchdog)
+        _PARTIAL["timer"].daemon = True
+        _PARTIAL["timer"].start()
     try:
         out, rank, cleanup = run(a)
     finally:
@@ -663,6 +699,9 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        if _PARTIAL["timer"] is not None:
+            _PARTIAL["timer"].cancel()
+            _PARTIAL["fd"] = None
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     if rank == 0:
@@ -1038,6 +1077,7 @@ def run(a):
                                                 % fs.schedule_in_use()},
         "sweep_faults": fs.sweep_faults(),
     }
+    _PARTIAL["out"] = out          # (the legs below add to it in place)
 
     if cols and use_dist and a.workload in ("socp", "lp") and not a.no_row_leg:
         # north_star / configs[4] name ROW blocks with the A^T y all-reduce overlapped on a side stream; the default at N > 1

@@ -221,3 +221,17 @@ def test_bench_plan_that_does_not_fit_stops_every_rank_before_allocating():
     r, lines = _bench_dry(["--gpus", "2", "--workload", "lp", "--size", "400000", "--steps", "2"], timeout=300)
     assert r.returncode != 0 and not lines
     assert "does not fit" in r.stderr
+
+
+def test_bench_watchdog_prints_the_partial_line_when_a_rank_never_comes_back():
+    """N > 1: a leg that hangs in a collective must not cost the line.  Rank 1 never reaches the barrier (test hook); after
+    --watchdog seconds rank 0's timer thread -- the main thread sits inside the barrier's C call -- prints the line as far as it
+    got, marked partial, and the launcher takes every rank down: the run ends instead of waiting for the driver's kill"""
+    import time
+    t0 = time.time()
+    r, lines = _bench_dry(["--gpus", "2", "--steps", "2", "--watchdog", "6"], env_extra={"THIP_DRY_HANG_RANK": "1"}, timeout=240)
+    assert time.time() - t0 < 200
+    assert len(lines) == 1, (lines, r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and "watchdog" in d and d["n_gpus"] == 2
+    assert "watchdog on rank 0" in r.stderr
