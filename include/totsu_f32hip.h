@@ -151,6 +151,23 @@ int thip_eig_engine_info(int *host_engine, int *host_polish, float *host_cert);
 int thip_spmv_csr(size_t n_row, size_t n_col, size_t nnz, const int64_t *dev_rowptr, const int32_t *dev_colidx,
                   const float *vals, float alpha, const float *x, float beta, float *y, int abs_mode);
 
+/* A sparse operator held ONCE on the device and serving both products (round 6): built from the caller's HOST arrays in
+ * compressed-sparse-column form (int64 column pointers, int32 row indices, f32 values -- what a MatBuild<General> with its zeros
+ * dropped holds, matbuild/mod.rs:22-41) into 4096 x 4096 tiles of {value, local row | local column << 16} entries; both A x and
+ * A^T y stream the same 8 bytes per entry with 16-byte loads and scatter into LDS accumulators -- no second copy of the values,
+ * no global atomics (thip_sptile.hip has the measurements behind the format).  Sums are not bitwise reproducible from run to run
+ * (LDS atomics).  thip_sptile_mv is `Operator::op / trans_op` (operator.rs:40-75) for such an operator: y = alpha A x + beta y,
+ * transpose != 0: A^T; abs_mode != 0: |A| and x = 1 (absadd_rows / absadd_cols, operator.rs:82-154).  x, y on the device. */
+typedef struct thip_sptile thip_sptile;
+int thip_sptile_create(size_t n_row, size_t n_col, size_t nnz, const int64_t *host_colptr, const int32_t *host_rowidx,
+                       const float *host_vals, thip_sptile **out);
+int thip_sptile_destroy(thip_sptile *mat);
+int thip_sptile_mv(thip_sptile *mat, int transpose, float alpha, const float *x, float beta, float *y, int abs_mode);
+/* stored entries (tiles padded to whole 16-byte quads), tiles, work items and slices (partial sums per block) of the two
+ * products, bytes on the device */
+int thip_sptile_info(const thip_sptile *mat, size_t *host_nnz_stored, int *host_tiles, int *host_items_n, int *host_items_t,
+                     int *host_slices_n, int *host_slices_t, size_t *host_bytes);
+
 /* ---------------------------------------------------------------------------------------------
  * Device-resident variants used by the fused path (no host round trip).  They replace host loops
  * in totsu_core that a generic backend cannot intercept ("hard parts").
@@ -287,6 +304,11 @@ int thip_solver_create(const thip_problem *prob, const thip_param *par, int sche
 int thip_solver_set_csr(thip_solver *s, size_t nnz,
                         const int64_t *dev_rowptr, const int32_t *dev_colidx, const float *dev_vals,
                         const int64_t *dev_t_rowptr, const int32_t *dev_t_colidx, const float *dev_t_vals);
+/* Sparse A for the fused loop, ONE copy (before thip_solver_init; prob->mat_a may be NULL; `mat` must outlive the solver).
+ * Every schedule runs on it; THIP_SCHED_SWEEP is the one-pass recurrence in three launches -- A^T [v x_y], the per-column
+ * updates, A [u x_x'] -- 16 bytes per stored entry and iteration (thip_solver_set_csr's two copies under the carried schedule:
+ * 32).  Replaces SolverCore's op / trans_op calls on a user's sparse Operator (solver.rs:109-157). */
+int thip_solver_set_sptile(thip_solver *s, thip_sptile *mat);
 int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *ctx);
 /* Row-sharded runs: where the all-reduce of a stage's A^T y runs relative to the other work (solver.rs:146 vs 149,
  * 122 vs 125 are the independences used).  May be switched between thip_solver_run calls.

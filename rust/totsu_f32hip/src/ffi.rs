@@ -36,6 +36,7 @@ pub struct thip_sweep_test {
 }
 
 pub enum thip_solver {}
+pub enum thip_sptile {}
 pub type thip_allreduce_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, dev_buf: *mut f32, n: usize, stream: *mut c_void) -> c_int>;
 
 pub const THIP_CONE_ZERO: i32 = 0;
@@ -125,6 +126,14 @@ extern "C" {
     pub fn thip_absadd_sympack(n: usize, mat: *const f32, y: *mut f32) -> c_int;
     pub fn thip_spmv_csr(n_row: usize, n_col: usize, nnz: usize, dev_rowptr: *const i64, dev_colidx: *const i32,
                          vals: *const f32, alpha: f32, x: *const f32, beta: f32, y: *mut f32, abs_mode: c_int) -> c_int;
+    pub fn thip_sptile_create(n_row: usize, n_col: usize, nnz: usize, host_colptr: *const i64, host_rowidx: *const i32,
+                              host_vals: *const f32, out: *mut *mut thip_sptile) -> c_int;
+    pub fn thip_sptile_destroy(mat: *mut thip_sptile) -> c_int;
+    pub fn thip_sptile_mv(mat: *mut thip_sptile, transpose: c_int, alpha: f32, x: *const f32, beta: f32, y: *mut f32,
+                          abs_mode: c_int) -> c_int;
+    pub fn thip_sptile_info(mat: *const thip_sptile, host_nnz_stored: *mut usize, host_tiles: *mut c_int,
+                            host_items_n: *mut c_int, host_items_t: *mut c_int, host_slices_n: *mut c_int,
+                            host_slices_t: *mut c_int, host_bytes: *mut usize) -> c_int;
     pub fn thip_to_bf16(n_row: usize, n_col: usize, mat: *const f32, mat16: *mut u16, ld16: usize) -> c_int;
     pub fn thip_transform_ge_bf16(transpose: c_int, n_row: usize, n_col: usize, alpha: f32, mat16: *const u16,
                                   ld16: usize, x: *const f32, beta: f32, y: *mut f32) -> c_int;
@@ -135,6 +144,7 @@ extern "C" {
     pub fn thip_solver_set_csr(s: *mut thip_solver, nnz: usize, dev_rowptr: *const i64, dev_colidx: *const i32,
                                dev_vals: *const f32, dev_t_rowptr: *const i64, dev_t_colidx: *const i32,
                                dev_t_vals: *const f32) -> c_int;
+    pub fn thip_solver_set_sptile(s: *mut thip_solver, mat: *mut thip_sptile) -> c_int;
     pub fn thip_solver_set_a_storage(s: *mut thip_solver, a_kind: c_int) -> c_int;
     pub fn thip_solver_set_a_bf16(s: *mut thip_solver, mat16: *const u16, ld16: usize) -> c_int;
     pub fn thip_solver_set_a_f16(s: *mut thip_solver, mat16: *const u16, ld16: usize, inv_scale: *const f32) -> c_int;

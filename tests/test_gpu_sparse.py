@@ -24,15 +24,21 @@ def _sl(L, a):
     return L.Sl.new_mut(np.ascontiguousarray(a, dtype=np.float32))
 
 
+@pytest.mark.parametrize("two_copies", [False, True])
 @pytest.mark.parametrize("shape,density", [((1, 1), 1.0), ((50, 30), 0.1), ((300, 1000), 0.01), ((5000, 4000), 0.002),
-                                           ((64, 64), 0.9), ((7, 2000), 0.5), ((2000, 3), 0.4)])
-def test_sparse_operator_contract(T, shape, density):
+                                           ((64, 64), 0.9), ((7, 2000), 0.5), ((2000, 3), 0.4),
+                                           # several 4096 x 4096 tiles; tall dense columns (a wave's entries share a column);
+                                           # an empty row block in the middle; a visit below the LDS-staging threshold
+                                           ((9000, 5000), 0.01), ((13000, 70), 0.9), ((300, 20000), 0.02), ((12500, 4097), 0.0008)])
+def test_sparse_operator_contract(T, shape, density, two_copies):
     from totsu_amd.sparse import SparseMatOp
     L = T.F32HIP
     rng = np.random.default_rng(shape[0] + shape[1])
     a = sp.random(shape[0], shape[1], density=density, format="csr", random_state=rng, dtype=np.float64)
     a.data = rng.standard_normal(a.nnz)
-    op = SparseMatOp(L, a)
+    if shape == (12500, 4097):
+        a = a.tolil(); a[4096:8192, :] = 0.0; a = a.tocsr(); a.eliminate_zeros()
+    op = SparseMatOp(L, a, two_copies=two_copies)
     d = a.toarray()
     x = rng.standard_normal(shape[1]).astype(np.float32)
     y0 = rng.standard_normal(shape[0]).astype(np.float32)
@@ -83,16 +89,20 @@ def test_sparse_l1reg_lp_solve_matches_dense_oracle(T):
     op_a.drop()
 
 
-@pytest.mark.parametrize("schedule", ["reference", "fused", "carried"])
-def test_fused_loop_on_csr_matches_dense(T, schedule):
-    # the device-resident loop with A given as scipy.sparse: same iterates as with the dense matrix
+@pytest.mark.parametrize("schedule,two_copies", [("reference", True), ("fused", True), ("carried", True), ("reference", False),
+                                                 ("fused", False), ("carried", False), ("sweep", False)])
+def test_fused_loop_on_csr_matches_dense(T, schedule, two_copies):
+    # the device-resident loop with A given as scipy.sparse (one tiled copy, or round 5's two CSR copies): same iterates as
+    # with the dense matrix
     c, G, h = l1reg_lp(20, seed=1)
     n, m = c.size, h.size
     p = T.SolverParam()
     p.eps_acc = 1e-3
-    dense = T.FusedSolver(n, m, np.asfortranarray(G).ravel(order="F").astype(np.float32), h, c, [1], [m], p, schedule)
+    dense = T.FusedSolver(n, m, np.asfortranarray(G).ravel(order="F").astype(np.float32), h, c, [1], [m], p,
+                          "carried" if schedule == "sweep" else schedule)
     xd, yd = dense.solve()
-    sparse = T.FusedSolver(n, m, sp.csr_matrix(G.astype(np.float32)), h, c, [1], [m], p, schedule)
+    sparse = T.FusedSolver(n, m, sp.csr_matrix(G.astype(np.float32)), h, c, [1], [m], p, schedule, sparse_two_copies=two_copies)
+    assert sparse.schedule_in_use() == schedule
     xs, ys = sparse.solve()
     assert abs(dense.status().iters - sparse.status().iters) <= max(3, 0.02 * dense.status().iters)
     ro = O.solve_lp(O.param(eps_acc=1e-3), c, G, h, np.zeros((0, n)), [])
@@ -106,8 +116,9 @@ def test_fused_loop_on_csr_matches_dense(T, schedule):
     sparse.destroy()
 
 
-def test_fused_loop_sparse_socp_iterates_vs_oracle(T):
-    # sparse SOCP blocks (90 % zeros): iterates of the CSR fused loop against the dense f64 oracle
+@pytest.mark.parametrize("schedule,two_copies", [("carried", True), ("carried", False), ("sweep", False), ("fused", False)])
+def test_fused_loop_sparse_socp_iterates_vs_oracle(T, schedule, two_copies):
+    # sparse SOCP blocks (90 % zeros): iterates of the sparse fused loop against the dense f64 oracle
     from problems import random_socp
     n, cones = 40, [6, 25, 0, 11]
     f, Gs, hs, cs, d = random_socp(n, cones, seed=7)
@@ -122,7 +133,7 @@ def test_fused_loop_sparse_socp_iterates_vs_oracle(T):
                              snap_iters=[0, 9, 49], trace_cap=64)
     p = T.SolverParam()
     p.eps_acc = 0.0
-    fs = T.FusedSolver(n, m, sp.csr_matrix(A), b, f, seg_t, seg_l, p, "carried")
+    fs = T.FusedSolver(n, m, sp.csr_matrix(A), b, f, seg_t, seg_l, p, schedule, sparse_two_copies=two_copies)
     N = n + 2 * m + 1
     done = 0
     for q, (it, tol) in enumerate(zip([0, 9, 49], [3e-5, 2e-4, 2e-3])):
@@ -133,6 +144,88 @@ def test_fused_loop_sparse_socp_iterates_vs_oracle(T):
         assert np.abs(x - rx).max() <= tol * max(np.abs(rx).max(), 1e-6)
         assert np.abs(y - ry).max() <= tol * max(np.abs(ry).max(), 1e-6)
     fs.destroy()
+
+
+def _iterates_vs_oracle(T, A, b, c, seg_t, seg_l, iters, tols, schedule="sweep"):
+    """iterates of the fused loop on the tiled sparse copy of A against the f64 oracle on the dense-ified A"""
+    m, n = A.shape
+    Ad = np.asfortranarray(A.toarray().astype(np.float32)).ravel(order="F")
+    ro = O.solve_matop_cones(O.param(max_iter=iters[-1] + 2, eps_acc=1e-300), c, Ad, b, seg_t, seg_l, snap_iters=list(iters),
+                             trace_cap=64)
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    fs = T.FusedSolver(n, m, A, b, c, seg_t, seg_l, p, schedule)
+    assert fs.schedule_in_use() == schedule
+    N = n + 2 * m + 1
+    done = 0
+    for q, (it, tol) in enumerate(zip(iters, tols)):
+        fs.run(it + 1 - done, poll_every=64)
+        done = it + 1
+        x, y = fs.iterate()
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        assert np.abs(x - rx).max() <= tol * max(np.abs(rx).max(), 1e-6), (it, np.abs(x - rx).max(), np.abs(rx).max())
+        assert np.abs(y - ry).max() <= tol * max(np.abs(ry).max(), 1e-6), (it, np.abs(y - ry).max(), np.abs(ry).max())
+    fs.destroy()
+
+
+@pytest.mark.parametrize("schedule", ["sweep", "carried"])
+def test_sparse_lp_workload_iterates_vs_oracle(T, schedule):
+    # bench.py --workload sparse-lp at a size the oracle holds dense: the l1reg_lp construction (examples/l1reg_lp/src/main.rs:50-116)
+    # with l = 1500 samples -- m = 6000 (two row blocks), n = 4501 (two column blocks), the 3000 x 1500 kernel block dense --
+    # iterates 0, 1, 2, 9 against the f64 oracle on the dense-ified matrix
+    c, G, h = l1reg_lp(1500, seed=3)
+    A = sp.csc_matrix(G.astype(np.float32))
+    assert A.nnz < 0.2 * G.size
+    _iterates_vs_oracle(T, A, h.astype(np.float32), c.astype(np.float32), [1], [h.size], [0, 1, 2, 9], [3e-5, 6e-5, 1e-4, 3e-4], schedule)
+
+
+@pytest.mark.parametrize("schedule", ["sweep", "carried"])
+def test_sparse_sdp_workload_iterates_vs_oracle(T, schedule):
+    # bench.py --workload sparse-sdp at a size the oracle holds dense: the partitioning_sdp construction
+    # (examples/partitioning_sdp/src/main.rs:45-78) on a 6 x 5 grid -- PSD order 30, n = sk = 465, one -1 (or -sqrt 2) per column of
+    # the PSD rows and one 1 per equality row -- through ProbSDP's stacking, iterates 0, 1, 2, 9 against the oracle
+    from problems import partitioning_sdp
+    from test_gpu_solver import _mb
+    w, syms_f, mat_a, vec_b = partitioning_sdp(6, 5, seed=2)
+    l, n = 30, w.size
+    sdp = T.ProbSDP(_mb(T, T.MatType.General(n, 1)).set_array(w.reshape(-1, 1)),
+                    [_mb(T, T.MatType.SymPack(l)).set_array(s_) for s_ in syms_f],
+                    _mb(T, T.MatType.General(l, n)).set_array(mat_a), _mb(T, T.MatType.General(l, 1)).set_array(vec_b.reshape(-1, 1)),
+                    1e-12)
+    d = sdp.dense()
+    A = sp.csc_matrix(np.asarray(d.mat_a).reshape((d.m, d.n), order="F"))
+    assert A.nnz <= d.n + l + 1
+    _iterates_vs_oracle(T, A, np.asarray(d.vec_b, np.float32), np.asarray(d.vec_c, np.float32), d.seg_type, d.seg_len,
+                        [0, 1, 2, 9], [3e-5, 6e-5, 1e-4, 3e-4], schedule)
+    sdp.drop()
+
+
+def test_sparse_sweep_converges_to_the_dense_answer_multi_tile(T):
+    # a sparse LP spanning 3 x 2 tiles (benchmark_lp's construction with 97 % of the random block dropped): the one-pass recurrence
+    # on the tiled copy stops within a few iterations of the dense one-pass / carried solve, at the same objective
+    rng = np.random.default_rng(5)
+    nn = 4200
+    R = sp.random(2 * nn, nn, density=0.03, format="csc", random_state=rng, dtype=np.float64)
+    R.data = rng.uniform(0, 1, R.nnz)
+    G = sp.vstack([-sp.identity(nn), R]).tocsc().astype(np.float32)
+    c = -rng.uniform(0, 1, nn).astype(np.float32)
+    h = np.concatenate([np.zeros(nn), rng.uniform(0, 1, 2 * nn)]).astype(np.float32)
+    m, n = G.shape
+    p = T.SolverParam()
+    p.eps_acc = 1e-3
+    dense = T.FusedSolver(n, m, np.asfortranarray(G.toarray()).ravel(order="F"), h, c, [1], [m], p, "carried")
+    xd, _ = dense.solve()
+    it_d = dense.status().iters
+    dense.destroy()
+    for sched in ("sweep", "carried"):
+        fs = T.FusedSolver(n, m, G, h, c, [1], [m], p, sched)
+        xs, _ = fs.solve()
+        assert abs(fs.status().iters - it_d) <= max(5, 0.02 * it_d), (sched, fs.status().iters, it_d)
+        od, os_ = float(c.astype(np.float64) @ xd), float(c.astype(np.float64) @ xs)
+        assert abs(od - os_) <= 1e-3 * (1 + abs(od))
+        passes, bpp = fs.passes()
+        assert passes == (2 if sched == "sweep" else 4) and bpp >= 8 * G.nnz
+        fs.destroy()
 
 
 class _DiffOp:

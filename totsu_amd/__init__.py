@@ -12,9 +12,9 @@ from .matbuild import MatBuild
 from .problem import ProbLP, ProbSOCP, ProbSDP, ProbQP, ProbQCQP
 from .fused import FusedSolver, DeviceBuffer, Bf16Matrix
 from .parallel import ShardedSolver, TorchComm, shard_segments
-from .sparse import SparseMatOp
+from .sparse import SparseMatOp, SpTile
 
 __all__ = ["MatOp", "MatType", "Solver", "SolverError", "SolverParam", "F32HIP", "F32HIPSlice", "splitm",
            "ConeZero", "ConeRPos", "ConeSOC", "ConeRotSOC", "ConePSD", "MatBuild", "ProbLP", "ProbSOCP",
            "ProbSDP", "ProbQP", "ProbQCQP", "FusedSolver", "DeviceBuffer", "Bf16Matrix", "ShardedSolver", "TorchComm",
-           "shard_segments", "SparseMatOp"]
+           "shard_segments", "SparseMatOp", "SpTile"]

@@ -90,6 +90,11 @@ PROTOTYPES = {
     "thip_transform_ge_f16": (_i, [_i, _sz, _sz, _f, _vp, _sz, _vp, _vp, _f, _vp]),
     "thip_transform_ge_bf16": (_i, [_i, _sz, _sz, _f, _vp, _sz, _vp, _f, _vp]),
     "thip_spmv_csr": (_i, [_sz, _sz, _sz, _vp, _vp, _vp, _f, _vp, _f, _vp, _i]),
+    "thip_sptile_create": (_i, [_sz, _sz, _sz, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "thip_sptile_destroy": (_i, [_vp]),
+    "thip_sptile_mv": (_i, [_vp, _i, _f, _vp, _f, _vp, _i]),
+    "thip_sptile_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                              C.POINTER(_sz)]),
     "thip_map_eig_worklen": (_sz, [_sz]),
     "thip_map_eig": (_i, [_sz, _vp, _i, _f, _f, _vp, _sz, _i]),
     "thip_eig_decompose": (_i, [_sz, _vp, _i, _f, _f, _vp, _sz, fp]),
@@ -127,6 +132,7 @@ PROTOTYPES = {
     "thip_solver_set_lda_pad": (_i, [_vp, _i]),
     "thip_solver_create": (_i, [C.POINTER(Problem), C.POINTER(Param), _i, C.POINTER(_vp)]),
     "thip_solver_set_csr": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "thip_solver_set_sptile": (_i, [_vp, _vp]),
     "thip_solver_set_allreduce": (_i, [_vp, ALLREDUCE_FN, _vp]),
     "thip_solver_set_overlap": (_i, [_vp, _i]),
     "thip_solver_overlap_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz)]),

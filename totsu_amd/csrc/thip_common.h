@@ -269,6 +269,17 @@ size_t sweep_gran_words(const SweepGeom &g);
 int sweep_census_dry_run(hipStream_t st, unsigned *census, unsigned seq);
 int sweep_launch(hipStream_t st, const SweepGeom &g, const SweepArgs &a);
 
+// thip_sptile.hip: a sparse operator stored once in 4096 x 4096 tiles; both products scatter into LDS accumulators and leave the
+// slices' shares part[slice][2][pad] (pad = the out-vector's length rounded to 64)
+size_t sptile_part_floats(const thip_sptile *M, bool tphase);
+int sptile_slices(const thip_sptile *M, bool tphase);
+size_t sptile_pad(const thip_sptile *M, bool tphase);
+size_t sptile_bytes_per_pass(const thip_sptile *M);
+void sptile_dims(const thip_sptile *M, size_t *m, size_t *n, size_t *nnz);
+int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const float *in0, const float *in1, float *part,
+                   int abs_mode, const int *stop);
+int sptile_colupdate(hipStream_t st, const thip_sptile *M, const SweepArgs &a, const float *partT);
+
 // thip_oneshot.hip: the hook thip_solver_use_oneshot installs and the device address of its error word (NULL: not set up)
 thip_allreduce_fn oneshot_hook();
 const unsigned *oneshot_error_word();

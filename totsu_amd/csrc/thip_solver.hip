@@ -1038,6 +1038,9 @@ struct thip_solver {
     const int64_t *rp = nullptr, *trp = nullptr;
     const int32_t *ci = nullptr, *tci = nullptr;
     const float *sv = nullptr, *tsv = nullptr;
+    // ... or ONE tiled copy serving both products (thip_sptile.hip; thip_solver_set_sptile): the slices' shares of the N
+    // products go to sw_partH (the buffer the one-pass schedule's m-tail reads), those of the T products to sw_partT
+    thip_sptile *spt = nullptr; float *sw_partT = nullptr;
 
     // cone structure
     std::vector<int32_t> seg_type;
@@ -1230,6 +1233,20 @@ int products(thip_solver *s, const float *xn, const float *xt, GemvPartials *gp,
     const int *stop = &s->dst->stop;
     gp->partN = gp->partT = nullptr; gp->nN = gp->nT = 0; gp->strideN = gp->strideT = 0;
     if (s->m == 0 || s->n == 0) return 0;     // zero-sized operator: products are 0 (matop.rs:83-85)
+    if (s->spt) {
+        // the tiled copy: each product is one pass over the stored entries, its slices added up into a finished vector
+        const size_t mp = sptile_pad(s->spt, false), np_ = sptile_pad(s->spt, true);
+        prof_begin(st);
+        THIP_RC(sptile_product(st, s->spt, false, xn, nullptr, s->sw_partH, 0, stop));
+        prof_end(st);
+        THIP_RC(finalize_partials(st, s->m, s->sw_partH, sptile_slices(s->spt, false), 2 * mp, 1.0f, 0.0f, hN, nullptr));
+        prof_begin(st);
+        THIP_RC(sptile_product(st, s->spt, true, xt, nullptr, s->sw_partT, 0, stop));
+        prof_end(st);
+        THIP_RC(finalize_partials(st, s->n, s->sw_partT, sptile_slices(s->spt, true), 2 * np_, 1.0f, 0.0f, gT, nullptr));
+        gp->nN = gp->nT = -1;
+        return 0;
+    }
     if (s->sparse) {
         // hN = A xn and gT = A^T xt as finished vectors (gathers over the CSR of A and of A^T); nN = nT = -1 tells
         // post_k to take them as they are.  The stop flag is honoured by the consumers (a stray product is harmless).
@@ -1686,8 +1703,45 @@ int rebuild_carried(thip_solver *s)
 // placement census came out as 8 x 32 in a dry run.  Examined once per (re)initialisation.
 int sweep_pass(thip_solver *s, int first, int np_m = 0);
 
+// the partial-sum buffers of a solver on the tiled sparse copy (zeroed once: a block without entries is never written) and the
+// words the sweep schedule's host side reads (error word, block partials)
+int spt_buffers(thip_solver *s)
+{
+    hipStream_t st = ctx().stream;
+    if (!s->sw_partT) {
+        const size_t fh = std::max<size_t>(sptile_part_floats(s->spt, false), 64), ft = std::max<size_t>(sptile_part_floats(s->spt, true), 64);
+        if (s->sw_partH) { THIP_TRY(hipFree(s->sw_partH)); s->sw_partH = nullptr; }
+        THIP_TRY(hipMalloc((void **)&s->sw_partH, fh * sizeof(float)));
+        THIP_TRY(hipMalloc((void **)&s->sw_partT, ft * sizeof(float)));
+        THIP_TRY(hipMemsetAsync(s->sw_partH, 0, fh * sizeof(float), st));
+        THIP_TRY(hipMemsetAsync(s->sw_partT, 0, ft * sizeof(float), st));
+    }
+    if (!s->sw_census) {
+        THIP_TRY(hipMalloc((void **)&s->sw_census, 64 * sizeof(unsigned)));
+        THIP_TRY(hipMalloc((void **)&s->sw_part, 12 * EG * sizeof(float)));
+        THIP_TRY(hipMemsetAsync(s->sw_census, 0, 64 * sizeof(unsigned), st));
+        THIP_TRY(hipMemsetAsync(s->sw_part, 0, 12 * EG * sizeof(float), st));
+    }
+    return 0;
+}
+
 int sweep_prepare(thip_solver *s)
 {
+    if (s->spt) {
+        // the tiled sparse copy: no persistent kernel, no placement census, no geometry to time -- the one-pass recurrence
+        // in three launches (sweep_pass) whenever it was asked for on one GPU
+        THIP_RC(spt_buffers(s));
+        if (s->schedule != THIP_SCHED_SWEEP || s->allreduce != nullptr || s->col_shard || s->m == 0 || s->n == 0) return 0;
+        if (s->sweep_state != 0) return 0;
+        s->sw_first = true;
+        s->sgeom = SweepGeom{};
+        s->sgeom.ngroups = sptile_slices(s->spt, false);
+        s->sgeom.mpad = sptile_pad(s->spt, false);
+        s->sgeom.m_eff = (int)s->m;
+        s->sw_plan_ms = 0.0f;
+        s->sweep_state = 1;
+        return 0;
+    }
     if (s->schedule != THIP_SCHED_SWEEP) return 0;
     if ((s->allreduce != nullptr) != s->col_shard) return 0;      // row shards run the carried schedule; column shards need the hook
     if (s->sparse || s->m == 0 || s->n == 0) return 0;      // not now (may change)
@@ -1820,6 +1874,7 @@ int sweep_prepare(thip_solver *s)
 
 bool sweep_active(const thip_solver *s)
 {
+    if (s->spt) return s->schedule == THIP_SCHED_SWEEP && s->sweep_state == 1 && s->allreduce == nullptr && !s->col_shard;
     if (!(s->schedule == THIP_SCHED_SWEEP && s->sweep_state == 1 && (s->allreduce != nullptr) == s->col_shard && !s->sparse
           && s->sgeom.elem == s->a_kind)) return false;       // (planned for the stored form of A in use now)
     // planned on the padded copy (m not a multiple of the rows per slot): only while that copy is the matrix in use
@@ -1866,6 +1921,17 @@ int sweep_pass(thip_solver *s, int first, int np_m)
     a.fault = 0;
     if (!first && s->fault_kind == 2 && s->fault_after >= 0 && s->fault_after-- == 0) { a.fault = 1; s->fault_kind = 0; }
     if (!first && s->fault_kind == 7 && (s->fault_after < 0 || s->fault_after-- <= 0)) { a.fault = 1; s->fault_after = -1; }      // every sweep from then on
+    if (s->spt) {
+        // A^T [v x_y] -> per column: u_k[j], x_x_{k+1}[j], kappa, the sums over n -> A [u_k x_x_{k+1}] as the slices' shares
+        prof_begin(st);
+        THIP_RC(sptile_product(st, s->spt, true, a.v, a.xy, s->sw_partT, 0, a.stop));
+        prof_end(st);
+        THIP_RC(sptile_colupdate(st, s->spt, a, s->sw_partT));
+        prof_begin(st);
+        THIP_RC(sptile_product(st, s->spt, false, a.u, a.xx_out, s->sw_partH, 0, a.stop));
+        prof_end(st);
+        return 0;
+    }
     prof_begin(st);
     THIP_RC(sweep_launch(st, g, a));
     prof_end(st);
@@ -2259,6 +2325,17 @@ int thip_solver_set_csr(thip_solver *s, size_t nnz, const int64_t *dev_rowptr, c
     return 0;
 }
 
+int thip_solver_set_sptile(thip_solver *s, thip_sptile *mat)
+{
+    if (!s || !mat) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    if (s->inited) return fail(THIP_E_INVALID, "thip_solver_set_sptile comes before thip_solver_init", __FILE__, __LINE__);
+    size_t m = 0, n = 0, nnz = 0;
+    sptile_dims(mat, &m, &n, &nnz);
+    if (m != s->m || n != s->n) return fail(THIP_E_INVALID, "the sparse operator's shape is not the problem's m x n", __FILE__, __LINE__);
+    s->sparse = true; s->nnz = nnz; s->spt = mat;
+    return 0;
+}
+
 int thip_solver_set_allreduce(thip_solver *s, thip_allreduce_fn fn, void *c)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
@@ -2328,7 +2405,12 @@ int thip_solver_init(thip_solver *s)
 
     // |A| column sums (sharded partial -> all-reduce with the two scalars in the tail) and row sums
     float *colabs = s->g1, *rowabs = s->h1;
-    if (n && m && s->sparse) {
+    if (n && m && s->spt) {
+        THIP_RC(sptile_product(st, s->spt, false, s->c, nullptr, s->sw_partH, 1, nullptr));
+        THIP_RC(finalize_partials(st, m, s->sw_partH, sptile_slices(s->spt, false), 2 * sptile_pad(s->spt, false), 1.0f, 0.0f, rowabs, nullptr));
+        THIP_RC(sptile_product(st, s->spt, true, s->c, nullptr, s->sw_partT, 1, nullptr));
+        THIP_RC(finalize_partials(st, n, s->sw_partT, sptile_slices(s->spt, true), 2 * sptile_pad(s->spt, true), 1.0f, 0.0f, colabs, nullptr));
+    } else if (n && m && s->sparse) {
         THIP_RC(thip_spmv_csr(m, n, s->nnz, s->rp, s->ci, s->sv, 1.0f, s->sv, 0.0f, rowabs, 1));
         THIP_RC(thip_spmv_csr(n, m, s->nnz, s->trp, s->tci, s->tsv, 1.0f, s->tsv, 0.0f, colabs, 1));
     } else if (n && m) {
@@ -2624,6 +2706,12 @@ int thip_solver_resume(thip_solver *s)
 int thip_solver_passes(const thip_solver *s, int *host_passes, size_t *host_bytes_per_pass)
 {
     if (!s) return fail(THIP_E_INVALID, "null solver", __FILE__, __LINE__);
+    if (s->spt) {
+        // every product is one pass over the stored entries (8 bytes each): two per stage
+        if (host_passes) *host_passes = (s->schedule == THIP_SCHED_REFERENCE || s->schedule == THIP_SCHED_FUSED) ? 6 : (sweep_active(s) ? 2 : 4);
+        if (host_bytes_per_pass) *host_bytes_per_pass = sptile_bytes_per_pass(s->spt);
+        return 0;
+    }
     if (host_passes) *host_passes = s->schedule == THIP_SCHED_REFERENCE ? 6 : (s->schedule == THIP_SCHED_FUSED ? 3 : (sweep_active(s) ? 1 : 2));
     // the algorithmic bytes of a pass (4 m n, or 2 m n for a 16-bit A); the padding rows of a library-owned
     // copy (at most 15 per column) are zeros that the kernel never loads
@@ -2808,6 +2896,7 @@ int thip_solver_destroy(thip_solver *s)
     for (auto &g : s->psd_groups) hipFree(g.dev_offs);
     hipFree(s->grp_beg); hipFree(s->grp_end); hipFree(s->psd_work); hipFree(s->arena); hipFree(s->part);
     hipFree(s->gemv_scr); hipFree(s->dst); hipFree(s->Apad); if (s->A16_owned) hipFree(s->A16); if (s->inv_s_owned) hipFree(s->inv_s);
+    hipFree(s->sw_partT);
     hipFree(s->sw_partH); hipFree(s->sw_gran); hipFree(s->sw_census); hipFree(s->sw_part); hipFree(s->cs_buf);
     if (s->hst) hipHostFree(s->hst);
     if (s->hflags) hipHostFree(s->hflags);

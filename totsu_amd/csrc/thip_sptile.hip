@@ -1,0 +1,479 @@
+// thip_sptile.hip -- sparse operators held ONCE on the device, serving both A x and A^T y (the reference's
+// example matrices -- l1reg_lp, partitioning_sdp, toruscompl_socp -- are mostly zeros; user operators follow
+// examples/imgnr_udef/src/prob_op_a.rs:33-120).
+//
+// Why this format.  tools/scatter_probe.hip (profiles/r06_sparse_scatter_probe.txt) priced the alternatives on this part: per stored
+// entry (4 B value + 4 B index, 16-byte loads) two GATHERS run at 4.0 TB/s of entries for contiguous indices and 0.3 - 1.0 TB/s for
+// random ones, two global float ATOMICS at 0.30 / 0.085 TB/s whatever their scope (agent, or workgroup scope into one accumulator
+// per XCD): a column-major one-pass sweep whose axpys are global scatters is 13x slower than two gather passes.  An index-only
+// transpose (values once, a permutation for the other direction) stores 4 bytes of permutation where the second copy stores 4
+// bytes of value -- it saves nothing and adds a dependent random load.  So: ONE copy of the values in 2-D TILES of 4096 x 4096
+// (row block, column block), entry = {f32 value, u32 (local row | local column << 16)}, tiles ordered by (row block, column
+// block), entries inside a tile in the caller's CSC order (column, then row), every tile padded to whole 16-byte quads.  Both
+// products stream the same 8 bytes per entry with 16-byte loads; the scatter side of either product goes to an accumulator of
+// one block (2 x 4096 floats) in LDS (ds_add_f32: no global atomic anywhere), the gather side reads the in-vector's block from
+// LDS (staged once per tile visit) or, for a visit of fewer than 2048 entries, straight from L2.
+//   N product (A [x0 x1]): a workgroup owns (row block, slice): walks that row block's tiles -- contiguous in memory --, in = the
+//       column block's slice of x, out = the row block's accumulators; entries of one column hit distinct rows: conflict-free.
+//   T product (A^T [y0 y1]): a workgroup owns (column block, slice): walks the tiles of its column block (a list: one per row
+//       block), in = the row block's slice of y, out = the column block's accumulators.  Entries are sorted by column, so a
+//       wave's 256 entries mostly share ONE column: the lane adds its four products first, a wave whose entries all belong to one
+//       column adds them up over the DPP network and issues one ds_add -- a 64-way same-address LDS atomic would serialise.
+// Every (block, slice) writes its 2 x 4096 partial sums to part[slice][2][pad] when it is done; the consumer (the m-tail
+// kernels of the one-pass schedule, sp_col_k below, finalize_partials) adds the slices in a fixed order.  Slices exist so
+// that a matrix with few blocks still fills 256 CUs: ~1024 items per product, at most nnz / (16 dim) slices (the partials'
+// traffic stays under 1/16 of the entries').  The order in which the waves of ONE workgroup reach an LDS accumulator is not fixed:
+// sums differ in the last bits from run to run (the dense schedules are bitwise reproducible; this one is not, and its tests
+// compare to tolerances).
+//
+// The conic loop on this format (THIP_SCHED_SWEEP with thip_solver_set_sptile) is the dense one-pass schedule's recurrence in
+// three launches: T product with [v, x_y] -> sp_col_k (per column: the two scalar updates of thip_sweep_kernel.h's service wave,
+// kappa, the sums over n) -> N product with [u, x_x'] into the groups' shares the m-tail reads.  16 bytes per stored entry and
+// iteration; the two-copy CSR gathers of round 5 (thip_sparse.hip, carried schedule) read 32.
+#include "thip_common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace thip;
+
+namespace thip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SPT_TB = 4096;            // rows / columns per block
+constexpr int SPT_THREADS = 512;
+constexpr int SPT_STAGE_MIN = 2048;     // entries of a tile visit from which the in-vector's block is staged in LDS
+
+struct SptTile { long long e0; int cnt, rb, cw, pad_; };                                   // entries [e0, e0 + cnt), cnt % 4 == 0
+struct SptItem { int out_block, slice, ref0, ref1; long long e_first, e_last; };           // tile refs [ref0, ref1)
+
+struct SptArgs {
+    const f32x4 *vals; const i32x4 *idx; const SptTile *tiles; const int *order; const SptItem *items;
+    const float *in0, *in1;             // in1 == NULL: one right-hand side
+    int in_len;
+    float *part; size_t opad;           // [slice][2][opad]
+    int abs_mode; const int *stop;
+};
+
+template <bool TPH>
+__global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
+{
+    __shared__ float2 lin[SPT_TB];
+    __shared__ float lo0[SPT_TB], lo1[SPT_TB];
+    if (*a.stop != 0) return;
+    const SptItem it = a.items[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool two = a.in1 != nullptr;
+    for (int i = tid; i < SPT_TB; i += SPT_THREADS) { lo0[i] = 0.0f; lo1[i] = 0.0f; }
+    bool prev_staged = true;            // (the zeroing above is ordered by the first visit's barrier)
+    for (int ref = it.ref0; ref < it.ref1; ++ref) {
+        const int t = a.order ? a.order[ref] : ref;
+        const SptTile tl = a.tiles[t];
+        long long e0 = tl.e0, e1 = tl.e0 + tl.cnt;
+        if (ref == it.ref0) e0 = it.e_first;
+        if (ref == it.ref1 - 1) e1 = it.e_last;
+        const int inb = TPH ? tl.rb : tl.cw;
+        const bool staged = (e1 - e0) >= SPT_STAGE_MIN && !a.abs_mode;
+        if (staged || prev_staged) __syncthreads();
+        const float *in0b = a.in0 + (size_t)inb * SPT_TB;
+        const float *in1b = (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB;
+        if (staged) {
+            const int lim = a.in_len - inb * SPT_TB;
+            for (int i = tid; i < SPT_TB; i += SPT_THREADS) lin[i] = i < lim ? make_float2(in0b[i], in1b[i]) : make_float2(0.0f, 0.0f);
+            __syncthreads();
+        }
+        prev_staged = staged;
+        const long long q1 = e1 >> 2;
+        for (long long qb = e0 >> 2; qb < q1; qb += 2 * SPT_THREADS) {
+            f32x4 av[2]; i32x4 iv[2]; bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long long q = qb + tid + u * SPT_THREADS;
+                ok[u] = q < q1;
+                const long long qq = ok[u] ? q : q1 - 1;
+                av[u] = __builtin_nontemporal_load(a.vals + qq);
+                iv[u] = __builtin_nontemporal_load(a.idx + qq);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float p0[4], p1[4]; int oi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned id = (unsigned)iv[u][e];
+                    const int lr = (int)(id & 0xffffu), lc = (int)(id >> 16);
+                    const int ii = TPH ? lr : lc;
+                    oi[e] = TPH ? lc : lr;
+                    float v = ok[u] ? av[u][e] : 0.0f;
+                    float2 x;
+                    if (a.abs_mode) { v = fabsf(v); x = make_float2(1.0f, 1.0f); }
+                    else if (staged) x = lin[ii];
+                    else x = make_float2(in0b[ii], in1b[ii]);
+                    p0[e] = v * x.x; p1[e] = v * x.y;
+                }
+                if (TPH) {
+                    // entries are sorted by column: a lane's four mostly share it, and so does the wave
+                    const bool same = oi[0] == oi[3];
+                    const float s0 = (p0[0] + p0[1]) + (p0[2] + p0[3]), s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+                    const int first = __builtin_amdgcn_readfirstlane(oi[0]);
+                    if (__all(ok[u] && same && oi[0] == first)) {
+                        const float w0 = wave_sum_dpp(s0), w1 = two ? wave_sum_dpp(s1) : 0.0f;
+                        if (lane == 0) { atomicAdd(&lo0[first], w0); if (two) atomicAdd(&lo1[first], w1); }
+                    } else if (ok[u]) {
+                        if (same) { atomicAdd(&lo0[oi[0]], s0); if (two) atomicAdd(&lo1[oi[0]], s1); }
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { atomicAdd(&lo0[oi[e]], p0[e]); if (two) atomicAdd(&lo1[oi[e]], p1[e]); }
+                        }
+                    }
+                } else if (ok[u]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { atomicAdd(&lo0[oi[e]], p0[e]); if (two) atomicAdd(&lo1[oi[e]], p1[e]); }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const size_t r0 = (size_t)it.out_block * SPT_TB;
+    float *o0 = a.part + (size_t)it.slice * 2 * a.opad + r0, *o1 = o0 + a.opad;
+    for (int i = tid; i < SPT_TB; i += SPT_THREADS)
+        if (r0 + i < a.opad) { o0[i] = lo0[i]; if (two) o1[i] = lo1[i]; }
+}
+
+// The per-column step of the one-pass recurrence (the arithmetic of sweep_k's service wave, thip_sweep_kernel.h): gT / g3 = the
+// slices' shares of A^T v and A^T x_y added up, then u_k[j], x_x_{k+1}[j], gP[j], and this workgroup's share of the sums over n.
+struct SpColArgs { SweepArgs a; const float *partT; int nsl; size_t npad; };
+
+__global__ __launch_bounds__(256) void sp_col_k(const SpColArgs ca)
+{
+    const SweepArgs &a = ca.a;
+    __shared__ double shd[16];
+    __shared__ float shf[16];
+    if (*a.stop != 0) return;
+    const int tid = threadIdx.x;
+    float kappa = *a.kappa_p;
+    const bool kupd = a.kappa_out != nullptr && !a.first;
+    if (kupd) {
+        // kappa_k (solver.rs:566-567): every workgroup forms it from the same partials in the same order
+        double dc = 0.0, db = 0.0;
+        for (int k = tid; k < a.pn_count; k += 256) dc += (double)a.pn_in[3 * a.pn_in_stride + k];
+        for (int k = tid; k < a.np_m; k += 256) db += (double)a.pm_brx[k];
+        dc = block_sum_d(dc, shd);
+        db = block_sum_d(db, shd);
+        kappa = fminf(kappa + *a.skappa_p * ((float)dc + (float)db), 0.0f);
+        if (blockIdx.x == 0 && tid == 0) *a.kappa_out = kappa;
+    }
+    const float rtau = *a.rtau_p, tau = *a.tau_p;
+    const bool conv = tau > a.eps_zero;
+    const float rt = conv ? 1.0f / tau : 1.0f;
+    const bool comp_u = a.ku != nullptr, comp_x = a.kx_in != nullptr;
+    const int cpb = (a.n + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int j0 = blockIdx.x * cpb, j1 = min(a.n, j0 + cpb);
+    float sdd = 0.0f, scx = 0.0f, scu = 0.0f, scrx = 0.0f;
+    for (int j = j0 + tid; j < j1; j += 256) {
+        float gT = 0.0f, g3 = 0.0f;
+        for (int s = 0; s < ca.nsl; ++s) {
+            gT += ca.partT[((size_t)s * 2 + 0) * ca.npad + j];
+            g3 += ca.partT[((size_t)s * 2 + 1) * ca.npad + j];
+        }
+        const float cj = a.c[j], uj = a.u[j], xxj = a.xx_in[j];
+        float kuj = comp_u ? a.ku[j] : 0.0f, kxj = comp_x ? a.kx_in[j] : 0.0f;
+        float u_new = uj;
+        if (!a.first) {
+            const float g2 = a.gP[j] - 2.0f * g3;
+            const float inc = a.Su[j] * (-g2 - cj * rtau);
+            if (comp_u) { const float y = inc - kuj; const float t = uj + y; kuj = (t - uj) - y; u_new = t; }
+            else u_new = uj + inc;
+            a.u[j] = u_new;
+            if (comp_u) a.ku[j] = kuj;
+        }
+        float x_new;
+        {
+            const float inc = a.Tx[j] * (gT + cj * kappa);
+            if (comp_x) { const float y = inc - kxj; const float t = xxj + y; kxj = (t - xxj) - y; x_new = t; }
+            else x_new = xxj + inc;
+        }
+        a.xx_out[j] = x_new;
+        if (comp_x) a.kx_out[j] = kxj;
+        a.gP[j] = g3;
+        const float dj = conv ? fmaf(rt, g3, cj) : g3;          // solver.rs:596-597 / 634
+        sdd = fmaf(dj, dj, sdd);
+        scx = fmaf(cj, xxj, scx);
+        scu = fmaf(cj, u_new, scu);
+        scrx = fmaf(cj, xxj - 2.0f * x_new, scrx);
+    }
+    if (a.pn != nullptr) {
+        sdd = block_sum(sdd, shf); scx = block_sum(scx, shf); scu = block_sum(scu, shf); scrx = block_sum(scrx, shf);
+        if (tid == 0) {
+            float *o = a.pn + blockIdx.x;
+            o[0] = sdd; o[a.pn_stride] = scx; o[2 * a.pn_stride] = scu; o[3 * a.pn_stride] = scrx;
+        }
+    }
+}
+
+}  // namespace thip
+
+// ---------------------------------------------------------------------------------------------------
+// the matrix object
+// ---------------------------------------------------------------------------------------------------
+struct thip_sptile {
+    size_t m = 0, n = 0, nnz = 0, nnz_pad = 0;
+    int nrb = 0, ncw = 0, ntiles = 0, nN = 0, nT = 0, slN = 1, slT = 1;
+    size_t mpad = 0, npad = 0;
+    f32x4 *vals = nullptr; i32x4 *idx = nullptr; SptTile *tiles = nullptr; int *order = nullptr;
+    SptItem *itemsN = nullptr, *itemsT = nullptr;
+    // partial sums of the trait-level products (thip_sptile_mv), made on first use
+    float *partN = nullptr, *partT = nullptr;
+};
+
+namespace thip {
+
+size_t sptile_part_floats(const thip_sptile *M, bool tphase) { return tphase ? (size_t)M->slT * 2 * M->npad : (size_t)M->slN * 2 * M->mpad; }
+int sptile_slices(const thip_sptile *M, bool tphase) { return tphase ? M->slT : M->slN; }
+size_t sptile_pad(const thip_sptile *M, bool tphase) { return tphase ? M->npad : M->mpad; }
+size_t sptile_bytes_per_pass(const thip_sptile *M) { return M->nnz_pad * 8; }
+void sptile_dims(const thip_sptile *M, size_t *m, size_t *n, size_t *nnz) { *m = M->m; *n = M->n; *nnz = M->nnz; }
+
+// part[slice][2][pad] <- the slices' shares of A [in0 in1] (tphase: of A^T [in0 in1]); in1 == NULL: one right-hand side (the
+// second half of every slice is then left alone); abs_mode: |A| times ones.  `part` must have been zeroed once after its
+// allocation: a (block, slice) without entries is never written.
+int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const float *in0, const float *in1, float *part,
+                   int abs_mode, const int *stop)
+{
+    const int items = tphase ? M->nT : M->nN;
+    if (items == 0) return 0;
+    SptArgs a;
+    a.vals = M->vals; a.idx = M->idx; a.tiles = M->tiles;
+    a.order = tphase ? M->order : nullptr; a.items = tphase ? M->itemsT : M->itemsN;
+    a.in0 = in0; a.in1 = in1; a.in_len = (int)(tphase ? M->m : M->n);
+    a.part = part; a.opad = tphase ? M->npad : M->mpad;
+    a.abs_mode = abs_mode; a.stop = stop ? stop : ctx().never_stop;
+    if (tphase) hipLaunchKernelGGL(sp_tile_k<true>, dim3(items), dim3(SPT_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(sp_tile_k<false>, dim3(items), dim3(SPT_THREADS), 0, st, a);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+int sptile_colupdate(hipStream_t st, const thip_sptile *M, const SweepArgs &a, const float *partT)
+{
+    SpColArgs ca;
+    ca.a = a; ca.partT = partT; ca.nsl = M->slT; ca.npad = M->npad;
+    hipLaunchKernelGGL(sp_col_k, dim3(256), dim3(256), 0, st, ca);
+    THIP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace thip
+
+namespace {
+
+template <class T>
+int upload(const std::vector<T> &h, T **d)
+{
+    *d = nullptr;
+    const size_t bytes = (h.empty() ? 1 : h.size()) * sizeof(T);
+    THIP_TRY(hipMalloc((void **)d, bytes));
+    if (!h.empty()) THIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr, const int32_t *rowidx, const float *vals)
+{
+    M->m = m; M->n = n; M->nnz = nnz;
+    M->mpad = (m + 63) / 64 * 64; M->npad = (n + 63) / 64 * 64;
+    const size_t nrb = (m + SPT_TB - 1) / SPT_TB, ncw = (n + SPT_TB - 1) / SPT_TB;
+    if (m >= ((size_t)1 << 31) || n >= ((size_t)1 << 31) || nrb * ncw > ((size_t)1 << 27))
+        return fail(THIP_E_INVALID, "sparse operator too large for the tile directory", __FILE__, __LINE__);
+    M->nrb = (int)nrb; M->ncw = (int)ncw;
+    if (nnz && (!colptr || !rowidx || !vals)) return fail(THIP_E_INVALID, "null CSC arrays", __FILE__, __LINE__);
+    if (n && colptr && (colptr[0] != 0 || (size_t)colptr[n] != nnz)) return fail(THIP_E_INVALID, "column pointers do not span nnz", __FILE__, __LINE__);
+    // entries per (row block, column block)
+    std::vector<int64_t> cnt(nrb * ncw ? nrb * ncw : 1, 0);
+    for (size_t j = 0; j < n; ++j) {
+        if (colptr[j + 1] < colptr[j]) return fail(THIP_E_INVALID, "column pointers decrease", __FILE__, __LINE__);
+        int64_t *crow = cnt.data() + j / SPT_TB;
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+            const int32_t r = rowidx[k];
+            if (r < 0 || (size_t)r >= m) return fail(THIP_E_INVALID, "row index out of range", __FILE__, __LINE__);
+            ++crow[(size_t)(r / SPT_TB) * ncw];
+        }
+    }
+    std::vector<SptTile> tiles;
+    std::vector<int64_t> cur(cnt.size(), -1);       // write cursor of a tile; -1: empty
+    std::vector<int> tile_of(cnt.size(), -1);
+    int64_t e = 0;
+    for (size_t rb = 0; rb < nrb; ++rb)
+        for (size_t cw = 0; cw < ncw; ++cw) {
+            const int64_t c = cnt[rb * ncw + cw];
+            if (c == 0) continue;
+            SptTile t; t.e0 = e; t.cnt = (int)((c + 3) / 4 * 4); t.rb = (int)rb; t.cw = (int)cw; t.pad_ = 0;
+            if ((c + 3) / 4 * 4 > 0x7fffffff) return fail(THIP_E_INVALID, "a tile holds more than 2^31 entries", __FILE__, __LINE__);
+            tile_of[rb * ncw + cw] = (int)tiles.size();
+            cur[rb * ncw + cw] = e;
+            tiles.push_back(t);
+            e += t.cnt;
+        }
+    M->ntiles = (int)tiles.size();
+    M->nnz_pad = (size_t)e;
+    std::vector<float> hv(M->nnz_pad ? M->nnz_pad : 4, 0.0f);
+    std::vector<int32_t> hi(M->nnz_pad ? M->nnz_pad : 4, 0);
+    for (size_t j = 0; j < n; ++j) {
+        const size_t cw = j / SPT_TB;
+        const uint32_t lc = (uint32_t)(j % SPT_TB) << 16;
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+            const size_t r = (size_t)rowidx[k];
+            int64_t &c = cur[(r / SPT_TB) * ncw + cw];
+            hv[c] = vals[k];
+            hi[c] = (int32_t)((uint32_t)(r % SPT_TB) | lc);
+            ++c;
+        }
+    }
+    for (const SptTile &t : tiles) {
+        const int64_t real_end = cur[(size_t)t.rb * ncw + t.cw];
+        for (int64_t k = real_end; k < t.e0 + t.cnt; ++k) { hv[k] = 0.0f; hi[k] = hi[real_end - 1]; }
+    }
+    // the tiles of a column block, for the T product
+    std::vector<int> order;
+    order.reserve(tiles.size());
+    for (size_t cw = 0; cw < ncw; ++cw)
+        for (size_t rb = 0; rb < nrb; ++rb)
+            if (tile_of[rb * ncw + cw] >= 0) order.push_back(tile_of[rb * ncw + cw]);
+    // items: ~1024 per product, at least 32 768 entries each, at most nnz / (16 dim) (<= 256) slices per block
+    const int64_t per_item = std::max<int64_t>((int64_t)(M->nnz_pad / 1024), 32768);
+    auto cap_of = [&](size_t dim) { return (int)std::min<size_t>(256, std::max<size_t>(1, M->nnz_pad / (16 * std::max<size_t>(dim, 1)))); };
+    const int capN = cap_of(m), capT = cap_of(n);
+    std::vector<SptItem> itN, itT;
+    M->slN = 1; M->slT = 1;
+    {
+        size_t t0 = 0;
+        while (t0 < tiles.size()) {
+            size_t t1 = t0;
+            while (t1 < tiles.size() && tiles[t1].rb == tiles[t0].rb) ++t1;
+            const int64_t E0 = tiles[t0].e0, E1 = tiles[t1 - 1].e0 + tiles[t1 - 1].cnt, len = E1 - E0;
+            const int S = (int)std::min<int64_t>(capN, std::max<int64_t>(1, (len + per_item - 1) / per_item));
+            M->slN = std::max(M->slN, S);
+            size_t tr = t0;
+            for (int s = 0; s < S; ++s) {
+                const int64_t a0 = E0 + (len / 4 * s / S) * 4, a1 = s + 1 == S ? E1 : E0 + (len / 4 * (s + 1) / S) * 4;
+                if (a1 <= a0) {     // (cannot happen: len >= 4 S is not guaranteed for tiny blocks -- keep the slice, empty)
+                    SptItem it_{ tiles[t0].rb, s, (int)t0, (int)t0, a0, a0 };
+                    itN.push_back(it_);
+                    continue;
+                }
+                while (tiles[tr].e0 + tiles[tr].cnt <= a0) ++tr;
+                size_t tl = tr;
+                while (tiles[tl].e0 + tiles[tl].cnt < a1) ++tl;
+                SptItem it_{ tiles[t0].rb, s, (int)tr, (int)tl + 1, a0, a1 };
+                itN.push_back(it_);
+            }
+            t0 = t1;
+        }
+    }
+    {
+        size_t p0 = 0;
+        while (p0 < order.size()) {
+            size_t p1 = p0;
+            while (p1 < order.size() && tiles[order[p1]].cw == tiles[order[p0]].cw) ++p1;
+            std::vector<int64_t> cum(p1 - p0 + 1, 0);
+            for (size_t p = p0; p < p1; ++p) cum[p - p0 + 1] = cum[p - p0] + tiles[order[p]].cnt;
+            const int64_t len = cum.back();
+            const int S = (int)std::min<int64_t>(capT, std::max<int64_t>(1, (len + per_item - 1) / per_item));
+            M->slT = std::max(M->slT, S);
+            size_t pr = 0;
+            for (int s = 0; s < S; ++s) {
+                const int64_t a0 = (len / 4 * s / S) * 4, a1 = s + 1 == S ? len : (len / 4 * (s + 1) / S) * 4;
+                if (a1 <= a0) {
+                    SptItem it_{ tiles[order[p0]].cw, s, (int)p0, (int)p0, 0, 0 };
+                    itT.push_back(it_);
+                    continue;
+                }
+                while (cum[pr + 1] <= a0) ++pr;
+                size_t pl = pr;
+                while (cum[pl + 1] < a1) ++pl;
+                SptItem it_{ tiles[order[p0]].cw, s, (int)(p0 + pr), (int)(p0 + pl) + 1,
+                             tiles[order[p0 + pr]].e0 + (a0 - cum[pr]), tiles[order[p0 + pl]].e0 + (a1 - cum[pl]) };
+                itT.push_back(it_);
+            }
+            p0 = p1;
+        }
+    }
+    M->nN = (int)itN.size(); M->nT = (int)itT.size();
+    THIP_TRY(hipMalloc((void **)&M->vals, hv.size() * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&M->idx, hi.size() * sizeof(int32_t)));
+    THIP_TRY(hipMemcpy(M->vals, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+    THIP_TRY(hipMemcpy(M->idx, hi.data(), hi.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    THIP_RC(upload(tiles, &M->tiles));
+    THIP_RC(upload(order, &M->order));
+    THIP_RC(upload(itN, &M->itemsN));
+    THIP_RC(upload(itT, &M->itemsT));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int thip_sptile_create(size_t n_row, size_t n_col, size_t nnz, const int64_t *host_colptr, const int32_t *host_rowidx,
+                       const float *host_vals, thip_sptile **out)
+{
+    THIP_NEED_INIT();
+    if (!out) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    *out = nullptr;
+    thip_sptile *M = new thip_sptile();
+    const int rc = build(M, n_row, n_col, nnz, host_colptr, host_rowidx, host_vals);
+    if (rc != 0) { thip_sptile_destroy(M); return rc; }
+    *out = M;
+    return 0;
+}
+
+int thip_sptile_destroy(thip_sptile *M)
+{
+    if (!M) return 0;
+    if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
+    for (void *p : { (void *)M->vals, (void *)M->idx, (void *)M->tiles, (void *)M->order, (void *)M->itemsN, (void *)M->itemsT,
+                     (void *)M->partN, (void *)M->partT })
+        if (p) (void)hipFree(p);
+    delete M;
+    return 0;
+}
+
+int thip_sptile_info(const thip_sptile *M, size_t *host_nnz_stored, int *host_tiles, int *host_items_n, int *host_items_t,
+                     int *host_slices_n, int *host_slices_t, size_t *host_bytes)
+{
+    if (!M) return fail(THIP_E_INVALID, "null matrix", __FILE__, __LINE__);
+    if (host_nnz_stored) *host_nnz_stored = M->nnz_pad;
+    if (host_tiles) *host_tiles = M->ntiles;
+    if (host_items_n) *host_items_n = M->nN;
+    if (host_items_t) *host_items_t = M->nT;
+    if (host_slices_n) *host_slices_n = M->slN;
+    if (host_slices_t) *host_slices_t = M->slT;
+    if (host_bytes) *host_bytes = M->nnz_pad * 8 + (size_t)M->ntiles * (sizeof(SptTile) + sizeof(int))
+                                  + (size_t)(M->nN + M->nT) * sizeof(SptItem);
+    return 0;
+}
+
+// y = alpha * A x + beta * y (transpose != 0: A^T x); abs_mode != 0: |A| and x = 1 (MatOp::absadd_*, matop.rs:98-117).
+// Replaces the reference's dense transform_ge call of MatOp::op_impl (matop.rs:76-86) for an operator held sparse.
+int thip_sptile_mv(thip_sptile *M, int transpose, float alpha, const float *x, float beta, float *y, int abs_mode)
+{
+    THIP_NEED_INIT();
+    if (!M) return fail(THIP_E_INVALID, "null matrix", __FILE__, __LINE__);
+    hipStream_t st = ctx().stream;
+    const bool t = transpose != 0;
+    const size_t len = t ? M->n : M->m;
+    if (len == 0) return 0;
+    float *&part = t ? M->partT : M->partN;
+    if (!part) {
+        const size_t fl = sptile_part_floats(M, t);
+        THIP_TRY(hipMalloc((void **)&part, fl * sizeof(float)));
+        THIP_TRY(hipMemsetAsync(part, 0, fl * sizeof(float), st));
+    }
+    THIP_RC(sptile_product(st, M, t, abs_mode ? (const float *)M->vals : x, nullptr, part, abs_mode, nullptr));
+    return finalize_partials(st, len, part, sptile_slices(M, t), 2 * sptile_pad(M, t), alpha, beta, y, nullptr);
+}
+
+}  // extern "C"

@@ -121,7 +121,7 @@ class FusedResult:
 class FusedSolver:
     def __init__(self, n, m, mat_a, vec_b, vec_c, seg_type, seg_len, param=None, schedule="fused",
                  vec_b_rowabs=None, allreduce=None, a_storage="f32", overlap=None, gemv_autotune=None, lda_pad=None,
-                 sweep_min_bytes=None, col_shard=False):
+                 sweep_min_bytes=None, col_shard=False, sparse_two_copies=False):
         """mat_a / vec_b / vec_c / vec_b_rowabs: DeviceBuffer or host arrays (uploaded).
         a_storage: "f32" (the matrix as given), "bf16" or "f16" (a rounded 16-bit copy streamed at half the bytes; f16
         is column-scaled and rounds 8x finer; see set_a_storage / include/totsu_f32hip.h).
@@ -131,10 +131,24 @@ class FusedSolver:
         self.n, self.m = int(n), int(m)
         self._owned = []
         self._csr = None
-        if hasattr(mat_a, "tocsr"):                       # scipy.sparse matrix: the fused loop runs on CSR gathers
-            from .sparse import _Csr
+        self._spt = None
+        self._spt_owned = False
+        from .sparse import SpTile
+        if isinstance(mat_a, SpTile):                     # a tiled sparse operator built by the caller (kept by the caller)
             assert mat_a.shape == (self.m, self.n)
-            self._csr = (_Csr(mat_a), _Csr(mat_a.T))
+            self._spt = mat_a
+            mat_a = DeviceBuffer(1)
+            self._owned.append(mat_a)
+        elif hasattr(mat_a, "tocsr"):
+            # scipy.sparse matrix: ONE tiled copy serving both products (thip_sptile.hip); sparse_two_copies=True: the round-5
+            # form, CSR of A and of A^T under the 2-pass schedules
+            assert mat_a.shape == (self.m, self.n)
+            if sparse_two_copies:
+                from .sparse import _Csr
+                self._csr = (_Csr(mat_a), _Csr(mat_a.T))
+            else:
+                self._spt = SpTile(mat_a)
+                self._spt_owned = True
             mat_a = DeviceBuffer(1)
             self._owned.append(mat_a)
         self._a16 = mat_a if isinstance(mat_a, Bf16Matrix) else None
@@ -142,7 +156,7 @@ class FusedSolver:
             assert (mat_a.m, mat_a.n) == (self.m, self.n)
             mat_a = DeviceBuffer(1)                       # no f32 matrix: thip_problem.mat_a is not read
             self._owned.append(mat_a)
-        self.mat_a = self._dev(mat_a, 1 if (self._csr or self._a16 is not None) else self.n * self.m)
+        self.mat_a = self._dev(mat_a, 1 if (self._csr or self._spt or self._a16 is not None) else self.n * self.m)
         self.vec_b = self._dev(vec_b, self.m)
         self.vec_c = self._dev(vec_c, self.n)
         self.vec_b_rowabs = None if vec_b_rowabs is None else self._dev(vec_b_rowabs, self.m)
@@ -162,6 +176,8 @@ class FusedSolver:
             a, at = self._csr
             lib.thip_solver_set_csr(self.h, a.nnz, a.rowptr.ptr, a.colidx.ptr, a.vals.ptr, at.rowptr.ptr, at.colidx.ptr,
                                     at.vals.ptr)
+        if self._spt is not None:
+            lib.thip_solver_set_sptile(self.h, self._spt.h)
         self._cb = None
         if allreduce == "rccl":
             lib.thip_solver_use_rccl(self.h)            # native RCCL on the library's stream (thip_comm_init first)
@@ -339,6 +355,9 @@ class FusedSolver:
             for c in self._csr:
                 c.free()
             self._csr = None
+        if getattr(self, "_spt", None) is not None and self._spt_owned:
+            self._spt.free()
+        self._spt = None
 
 
 def comm_init(rank, world, broadcast_bytes):
