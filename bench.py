@@ -30,7 +30,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="socp", choices=["socp", "lp", "sdp"])
+    ap.add_argument("--workload", default="socp", choices=["socp", "lp", "sdp", "sparse-lp", "sparse-sdp"],
+                    help="sparse-lp: the l1reg_lp construction (examples/l1reg_lp/src/main.rs:50-116) with --n samples (default "
+                         "16384: 2.1 GB of non-zeros), A held sparse ONCE on the device (thip_sptile); sparse-sdp: the partitioning_sdp "
+                         "construction (examples/partitioning_sdp/src/main.rs:45-78) with a PSD cone of order --k, n = k (k + 1) / 2")
+    ap.add_argument("--no-two-copy", action="store_true",
+                    help="sparse workloads: skip the A/B leg that iterates the same instance on round 5's two CSR copies")
     ap.add_argument("--k", type=int, default=500, help="PSD order of the sdp workload")
     ap.add_argument("--n", "--size", dest="n", type=int, default=None, help="number of variables (use --size under torchrun: --n is an ambiguous prefix there)")
     ap.add_argument("--cones", type=int, default=1000)
@@ -483,6 +488,300 @@ def eig_record(k, ms_per_pair, spans, ms_per_iter):
     return rec
 
 
+# ---------------------------------------------------------------------------------------------------
+# sparse workloads: the reference's own example constructions, A held sparse once on the device
+# ---------------------------------------------------------------------------------------------------
+def sparse_lp_instance(l, seed=0, lam=0.2):
+    """examples/l1reg_lp/src/main.rs:50-116 with l samples (the example: 20): n = 3 l + 1, m = 4 l, G = the dense 2 l x l Gaussian-kernel
+    block [K ; -K] (sigma^2 = 1 / 8) between +-1 diagonals and one dense column -- nnz = 2 l^2 + 8 l of 12 l^2 + 4 l entries (1 / 6).
+    Sample points from numpy's generator (the reference's Xoshiro stream is not reproducible here).  CSC arrays on the host."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 1, (2, l))
+    y = np.cos(5.0 * x[0]) * np.cos(7.0 * x[1])
+    n, m = 3 * l + 1, 4 * l
+    nnz = 2 * l * l + 8 * l
+    vals = np.empty(nnz, np.float32)
+    rows = np.empty(nnz, np.int32)
+    colptr = np.empty(n + 1, np.int64)
+    ar = np.arange(l, dtype=np.int32)
+    # columns 0 .. l - 1 (z): -1 at rows i and l + i
+    vals[:2 * l] = -1.0
+    rows[0:2 * l:2] = ar
+    rows[1:2 * l:2] = l + ar
+    colptr[:l] = 2 * np.arange(l, dtype=np.int64)
+    pos = 2 * l
+    # columns l .. 2 l - 1 (alpha): K[:, c], -K[:, c], +1 at 2 l + c, -1 at 3 l + c
+    w = 2 * l + 2
+    bv = vals[pos:pos + l * w].reshape(l, w)
+    br = rows[pos:pos + l * w].reshape(l, w)
+    x0, x1 = x[0].astype(np.float32), x[1].astype(np.float32)
+    for c0 in range(0, l, 2048):
+        c1 = min(l, c0 + 2048)
+        d2 = (x0[c0:c1, None] - x0[None, :]) ** 2 + (x1[c0:c1, None] - x1[None, :]) ** 2
+        k = np.exp(-8.0 * d2, dtype=np.float32)
+        bv[c0:c1, :l] = k
+        bv[c0:c1, l:2 * l] = -k
+    bv[:, 2 * l] = 1.0
+    bv[:, 2 * l + 1] = -1.0
+    br[:, :2 * l] = np.arange(2 * l, dtype=np.int32)[None, :]
+    br[:, 2 * l] = 2 * l + ar
+    br[:, 2 * l + 1] = 3 * l + ar
+    colptr[l:2 * l] = pos + w * np.arange(l, dtype=np.int64)
+    pos += l * w
+    # columns 2 l .. 3 l - 1 (beta): -1 at rows 2 l + c and 3 l + c
+    vals[pos:pos + 2 * l] = -1.0
+    rows[pos:pos + 2 * l:2] = 2 * l + ar
+    rows[pos + 1:pos + 2 * l:2] = 3 * l + ar
+    colptr[2 * l:3 * l] = pos + 2 * np.arange(l, dtype=np.int64)
+    pos += 2 * l
+    # column 3 l (bias): +1 at rows 0 .. l - 1, -1 at rows l .. 2 l - 1
+    vals[pos:pos + l] = 1.0
+    vals[pos + l:pos + 2 * l] = -1.0
+    rows[pos:pos + 2 * l] = np.arange(2 * l, dtype=np.int32)
+    colptr[3 * l] = pos
+    pos += 2 * l
+    colptr[n] = pos
+    assert pos == nnz
+    c = np.zeros(n, np.float32)
+    c[:l] = 1.0
+    c[2 * l:3 * l] = lam
+    h = np.zeros(m, np.float32)
+    h[:l] = y
+    h[l:2 * l] = -y
+    return {"n": n, "m": m, "colptr": colptr, "rowidx": rows, "vals": vals, "b": h, "c": c, "seg_type": [1], "seg_len": [m],
+            "what": "l1reg_lp construction (examples/l1reg_lp/src/main.rs:50-116) with l = %d samples: sparse LP n=%d m=%d, nnz=%d "
+                    "(%.1f %% of m n; the 2l x l kernel block dense), f32" % (l, n, m, nnz, 100.0 * nnz / (float(m) * n))}
+
+
+def sparse_sdp_instance(k, seed=0):
+    """examples/partitioning_sdp/src/main.rs:21-79 on a grid graph of k nodes: n = sk = k (k + 1) / 2 packed entries of X, minimise
+    sum W_ij X_ij, X >= 0 (F_kk = -E_ij: one entry per column of the PSD rows, -1 on the diagonal, -sqrt 2 off it after ProbSDP's
+    scale_nondiag, sdp.rs:271-274), diag X = 1 (one 1 per equality row).  The example's dense symmat_f is sk x sk (62.7 GB at
+    k = 500); held sparse it is sk + k entries."""
+    x_num = max(d for d in range(1, int(math.isqrt(k)) + 1) if k % d == 0)
+    y_num = k // x_num
+    rng = np.random.default_rng(seed)
+    sk = k * (k + 1) // 2
+    n, m = sk, sk + k
+    jj = np.repeat(np.arange(k), np.arange(1, k + 1))                  # column j of the packed entry
+    ii = np.arange(sk) - jj * (jj + 1) // 2                            # its row i <= j
+    diag = ii == jj
+    cnt = 1 + diag.astype(np.int64)
+    colptr = np.zeros(n + 1, np.int64)
+    np.cumsum(cnt, out=colptr[1:])
+    nnz = int(colptr[n])
+    rows = np.empty(nnz, np.int32)
+    vals = np.empty(nnz, np.float32)
+    first = colptr[:-1]
+    rows[first] = np.arange(sk, dtype=np.int32)
+    vals[first] = np.where(diag, -1.0, -math.sqrt(2.0)).astype(np.float32)
+    dcols = np.nonzero(diag)[0]
+    rows[first[dcols] + 1] = sk + jj[dcols]
+    vals[first[dcols] + 1] = 1.0
+    w = np.zeros(n, np.float32)
+    for i in range(k):
+        gx, gy = divmod(i, y_num)
+        if gx < x_num - 1:
+            j = i + y_num
+            w[j * (j + 1) // 2 + i] = rng.standard_normal()
+        if gy < y_num - 1:
+            j = i + 1
+            w[j * (j + 1) // 2 + i] = rng.standard_normal()
+    b = np.concatenate([np.zeros(sk, np.float32), np.ones(k, np.float32)])
+    return {"n": n, "m": m, "colptr": colptr, "rowidx": rows, "vals": vals, "b": b, "c": w, "seg_type": [4, 0], "seg_len": [sk, k],
+            "what": "partitioning_sdp construction (examples/partitioning_sdp/src/main.rs:45-78) on a %d x %d grid: sparse SDP, one PSD "
+                    "cone of order %d (sk=%d), n=%d m=%d, nnz=%d, f32" % (x_num, y_num, k, sk, n, m, nnz)}
+
+
+def cpu_baseline_sparse(inst, budget_s=25.0):
+    """the f64 oracle (C, OpenMP) through its sparse user-operator (oracle/totsu_oracle.c oc_solve_csc_cones: the pattern of
+    examples/imgnr_udef/src/prob_op_a.rs) on the SAME instance, a few iterations"""
+    import oracle as O
+    v64 = inst["vals"].astype(np.float64)
+
+    def run(k):
+        par = O.param(max_iter=k, eps_acc=1e-300)
+        t0 = time.perf_counter()
+        O.solve_csc_cones(par, inst["c"], inst["colptr"], inst["rowidx"], v64, inst["b"], inst["seg_type"], inst["seg_len"], use_ql=True)
+        return time.perf_counter() - t0
+
+    t1 = run(2)
+    k2 = int(max(3, min(200, budget_s / 3.0 / max(t1 / 4.0, 1e-3))))
+    rates = []
+    for _ in range(3):
+        t2 = run(2 + k2)
+        rates.append(k2 / (t2 - t1) if t2 > 1.05 * t1 else (2 + k2) / max(t2, 1e-9))
+    rates.sort()
+    return {"value": rates[1], "unit": "iter/s", "cores": O.num_threads(), "kind": "port",
+            "sample": "oracle (C, f64, OpenMP %d threads) with A as a sparse user-defined Operator (CSC + its row-major mirror) on the "
+                      "WHOLE instance, median of 3 timings of %d iterations (min %.3f, max %.3f iter/s); init %.2f s subtracted"
+                      % (O.num_threads(), k2, rates[0], rates[2], t1),
+            "spread_iter_per_s": [rates[0], rates[2]], "host_cpu_count": os.cpu_count()}
+
+
+def run_sparse(a, rank, T, lib, _lib):
+    import ctypes as C
+    from totsu_amd.sparse import SpTile
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "the sparse workloads run on one GPU"
+    t_gen0 = time.perf_counter()
+    if a.workload == "sparse-lp":
+        inst = sparse_lp_instance(a.n or 16384)
+    else:
+        inst = sparse_sdp_instance(a.k)
+    n, m = inst["n"], inst["m"]
+    t_host = time.perf_counter() - t_gen0
+    t0 = time.perf_counter()
+    spt = SpTile.from_csc_arrays(m, n, inst["colptr"], inst["rowidx"], inst["vals"])
+    lib.thip_sync()
+    t_build = time.perf_counter() - t0
+    info = spt.info()
+    p = T.SolverParam()
+    p.max_iter = None
+    p.eps_acc = 0.0
+    p.eps_inf = 0.0
+    p.state_arith = a.state
+    fs = T.FusedSolver(n, m, spt, inst["b"], inst["c"], inst["seg_type"], inst["seg_len"], p, a.schedule)
+    # what THIS box streams: a bare read of as many bytes as one product reads
+    box_read = None
+    nbytes = min(8 * info["nnz_stored"], 20_000_000_000) // 16 * 16
+    if nbytes >= 1 << 20:
+        scratch = T.DeviceBuffer(nbytes // 4)
+        pb, pa = C.c_float(), C.c_float()
+        lib.thip_stream_probe(scratch.ptr, nbytes, 5, C.byref(pb), C.byref(pa))
+        scratch.free()
+        box_read = {"bytes": nbytes, "best_GBps": nbytes / (pb.value * 1e-3) / 1e9, "avg_GBps": nbytes / (pa.value * 1e-3) / 1e9}
+    import torch
+    fs.run(a.warmup, poll_every=max(a.warmup, 1))
+    torch.cuda.synchronize()
+    prof_period = max(1, a.steps // 32)
+    lib.thip_prof_enable(0 if os.environ.get("THIP_BENCH_NO_PROF") else prof_period)
+    t0 = time.perf_counter()
+    r = fs.run(a.steps, poll_every=a.steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    nl, tot_ms = C.c_int64(), C.c_double()
+    lib.thip_prof_read(C.byref(nl), C.byref(tot_ms))
+    npsd, psd_ms = C.c_int64(), C.c_double()
+    lib.thip_prof_read_psd(C.byref(npsd), C.byref(psd_ms))
+    lib.thip_prof_enable(0)
+    assert r.state == _lib.ST_RUNNING and r.iters == a.warmup + a.steps, (r.state, r.iters)
+    # (tau may sit at its clamp 0 for a while -- this LP's does from iteration 5 on, on every schedule and on the dense matrix
+    # alike -- and the convergence criteria are then reported as inf: solver.rs:573-656 evaluates the infeasibility pair instead)
+    xi, yi = fs.iterate()
+    assert math.isfinite(r.tau) and np.isfinite(xi).all() and np.isfinite(yi).all(), "iterate blew up"
+    passes, bytes_per_pass = fs.passes()
+    # one product = one launch over the stored entries: 8 B each + its in-vectors (2 per product) and the slices' partial sums
+    vec_T = 4 * (2 * m + 2 * info["slices_t"] * n)
+    vec_N = 4 * (2 * n + 2 * info["slices_n"] * m)
+    bytes_per_launch = bytes_per_pass + 0.5 * (vec_T + vec_N)
+    avg_ms = tot_ms.value / max(nl.value, 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if nl.value else 0.0
+    iters_per_s = a.steps / elapsed
+    roofline = {
+        "bound": "hbm",
+        "kernel": "sp_tile_k<T> / sp_tile_k<N> (thip_sptile.hip): A^T [v x_y] and A [u x_x'] from the ONE tiled copy, 16-byte loads of "
+                  "{value, local row | local column} entries, LDS accumulators; averaged over both launches of an iteration",
+        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None, "traffic_source": None,
+        "timer": "hip_events on the launch stream around both product launches of every %s iteration of the timed region (thip_prof_*)"
+                 % ("" if prof_period == 1 else "%d-th" % prof_period),
+        "bytes_per_launch": bytes_per_launch, "bytes_of_entries_per_launch": bytes_per_pass,
+        "vector_bytes_per_launch": 0.5 * (vec_T + vec_N),
+        "avg_launch_ms": avg_ms, "launches_timed": nl.value, "passes_over_A_per_iter": passes,
+        "bytes_per_stored_entry_and_iteration": 8 * passes,
+        "box_read_GBps": box_read["best_GBps"] if box_read else None,
+        "frac_of_box_read": (achieved / box_read["best_GBps"]) if (box_read and nl.value) else None,
+    }
+    prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(prof):
+        try:
+            tr = json.load(open(prof))
+            key = "%s_n%d_m%d_%s" % (a.workload, n, m, fs.schedule_in_use())
+            if key in tr:
+                roofline["traffic"] = tr[key]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = ("stored PMC run (profiles/hbm_traffic.json: %s), not a counter of this run"
+                                              % tr[key].get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE"))
+        except Exception:
+            pass
+    roofline_eig = None
+    if a.workload == "sparse-sdp" and npsd.value:
+        roofline_eig = eig_record(a.k, psd_ms.value / npsd.value, npsd.value, 1e3 * elapsed / a.steps)
+    out = {
+        "metric": "solver iterations/sec, %s" % ("sparse LP (l1reg_lp construction)" if a.workload == "sparse-lp"
+                                                 else "sparse SDP (partitioning_sdp construction)"),
+        "value": iters_per_s, "unit": "iter/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (the reference example's construction, sample points / edge weights from numpy's generator, seed 0)",
+        "state_arith": a.state,
+        "config": {"workload": inst["what"], "schedule": fs.schedule_in_use(), "schedule_asked": a.schedule,
+                   "passes_over_A_per_iter": passes, "storage": "one tiled copy (thip_sptile): 4096 x 4096 tiles, 8 B per entry",
+                   "sptile": info, "host_gen_seconds": round(t_host, 2), "tile_build_and_upload_seconds": round(t_build, 2),
+                   "parallelism": "none: one GPU"},
+        "roofline": roofline, "roofline_eig": roofline_eig,
+        "objective_gate": {"tolerance": 1e-4, "this_run": None,
+                           "asserted_in_tests": "tests/test_gpu_sparse.py::test_sparse_%s_workload_iterates_vs_oracle (iterates 0, 1, 2, 9 "
+                                                "of this construction against the f64 oracle on the dense-ified matrix), "
+                                                "::test_sparse_sweep_converges_to_the_dense_answer_multi_tile"
+                                                % ("lp" if a.workload == "sparse-lp" else "sdp")},
+    }
+    fs.destroy()
+    # ---- time to eps (default 1e-3: the eps_acc the reference runs its f32 backend at, benchmark_lp/src/main.rs:62-65) ----
+    to_eps = 1e-3 if (a.to_eps is None and not a.no_to_eps) else a.to_eps
+    if to_eps is not None and not a.no_to_eps:
+        p2 = T.SolverParam()
+        p2.eps_acc = to_eps
+        p2.state_arith = a.state
+        budget = min(a.to_eps_budget, 240.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fs3 = T.FusedSolver(n, m, spt, inst["b"], inst["c"], inst["seg_type"], inst["seg_len"], p2, a.schedule)
+        while True:
+            r2 = fs3.run(5000, poll_every=100)
+            sys.stderr.write("to-eps[%s]: iter %d state %d cri %.3e %.3e %.3e t %.1f s\n"
+                             % (a.workload, r2.iters + 1, r2.state, r2.cri[0], r2.cri[1], r2.cri[2], time.perf_counter() - t0))
+            if r2.state != _lib.ST_RUNNING or time.perf_counter() - t0 > budget:
+                break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        done = r2.state != _lib.ST_RUNNING
+        rec = {"eps_acc": to_eps, "seconds": dt, "iterations": int(r2.iters) + 1, "state": int(r2.state) if done else -1,
+               "budget_seconds": budget, "criteria": [float(v) for v in r2.cri], "iters_per_s": (int(r2.iters) + 1) / dt}
+        if r2.state == _lib.ST_OK:
+            xs, ys = fs3.solution()
+            pobj = float(inst["c"].astype(np.float64) @ xs.astype(np.float64))
+            dobj = -float(inst["b"].astype(np.float64) @ ys.astype(np.float64))
+            rec["primal_objective"], rec["dual_objective"] = pobj, dobj
+            out["objective_gate"]["this_run"] = {"what": "primal vs dual objective of THIS run's answer (f64 dot products on the host)",
+                                                 "rel_gap": abs(pobj - dobj) / max(1.0, abs(pobj))}
+        out["time_to_eps"] = rec
+        fs3.destroy()
+    # ---- A/B: the same instance on round 5's two CSR copies (carried schedule: 2 dual gathers per iteration) ----
+    if not a.no_two_copy:
+        try:
+            import scipy.sparse as sp
+            t0 = time.perf_counter()
+            A = sp.csc_matrix((inst["vals"], inst["rowidx"], inst["colptr"]), shape=(m, n))
+            fs2 = T.FusedSolver(n, m, A, inst["b"], inst["c"], inst["seg_type"], inst["seg_len"], p, "carried", sparse_two_copies=True)
+            t_conv = time.perf_counter() - t0
+            del A
+            fs2.run(a.warmup, poll_every=max(a.warmup, 1))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fs2.run(a.steps, poll_every=a.steps)
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t0
+            out["two_copy_csr"] = {"value": a.steps / e2, "unit": "iter/s", "ms_per_step": 1e3 * e2 / a.steps,
+                                   "what": "round 5's form on the same instance: CSR of A and CSR of A^T (two copies of the values), carried "
+                                           "schedule, 32 B per stored entry and iteration (thip_spmv_csr); host conversion + upload %.1f s" % t_conv,
+                                   "speedup_of_the_tiled_copy": iters_per_s / (a.steps / e2)}
+            fs2.destroy()
+        except Exception as e:              # the optional leg never costs the line
+            out["two_copy_csr"] = {"error": repr(e)}
+    spt.free()
+    out["cpu_baseline"] = None if a.no_cpu else cpu_baseline_sparse(inst)
+    return out, rank, (lambda: None)
+
+
 def run_trait(a, inst, n, wl, t_gen, rank):
     """--path trait: iterations/sec of the trait-level drop-in (no fused loop, no alias types) on the same instance"""
     import ctypes as C
@@ -769,6 +1068,8 @@ def run(a):
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
+    if a.workload in ("sparse-lp", "sparse-sdp"):
+        return run_sparse(a, rank, T, lib, _lib)
     t_gen0 = time.perf_counter()
     cols = (use_dist or emu) and a.path == "fused" and a.workload in ("socp", "lp") and a.a_storage == "f32" \
         and (a.shard == "cols" or (a.shard == "auto" and a.schedule == "sweep")) and not (a.bf16_direct or a.f16_direct)

@@ -160,6 +160,27 @@ def solve_matop_cones(par, vec_c, mat_a, vec_b, seg_type, seg_len, use_ql=False,
     return _finish(rc, x, y, t, keep)
 
 
+def solve_csc_cones(par, vec_c, colptr, rowidx, vals, vec_b, seg_type, seg_len, use_ql=False, trace_cap=0, snap_iters=None):
+    """A given sparse by columns (scipy's csc arrays: indptr / indices / data) as a user-defined Operator."""
+    vec_c, pc = _d(vec_c)
+    vec_b, pb = _d(vec_b)
+    n, m = vec_c.size, vec_b.size
+    cp = np.ascontiguousarray(colptr, dtype=np.int64)
+    ri = np.ascontiguousarray(rowidx, dtype=np.int32)
+    vals, pv = _d(vals)
+    assert cp.size == n + 1 and ri.size == vals.size == int(cp[-1])
+    st = np.ascontiguousarray(seg_type, dtype=np.int32)
+    sl = np.ascontiguousarray(seg_len, dtype=np.int64)
+    x = np.zeros(n)
+    y = np.zeros(m)
+    t, keep = _mk_trace(trace_cap, snap_iters, (n + 2 * m + 1) + (n + m + 1))
+    rc = lib().oc_solve_csc_cones(C.byref(par), _sz(n), _sz(m), pc, cp.ctypes.data_as(C.POINTER(C.c_int64)),
+                                  ri.ctypes.data_as(C.POINTER(C.c_int32)), pv, pb, _sz(len(st)),
+                                  st.ctypes.data_as(C.POINTER(C.c_int32)), sl.ctypes.data_as(C.POINTER(C.c_int64)),
+                                  C.c_int(int(use_ql)), x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), C.byref(t))
+    return _finish(rc, x, y, t, keep)
+
+
 def _colmaj(a, nr, nc):
     a = np.asarray(a, dtype=np.float64)
     if a.ndim == 2:

@@ -967,6 +967,84 @@ int oc_solve_matop_cones(const oc_param *par, size_t n, size_t m,
 }
 
 /* ======================================================================================
+ * A sparse user-defined Operator (the trait: totsu_core/src/solver/operator.rs:11-156; the pattern of a caller's own
+ * operator: examples/imgnr_udef/src/prob_op_a.rs:33-120).  The matrix comes in compressed-sparse-column form; op walks a
+ * row-major mirror built here, trans_op the columns -- both are gathers, so both parallelise over their outputs.  This is the
+ * CPU baseline of bench.py's sparse workloads and the oracle of their parity tests; tests/test_oracle_golden.py pins it
+ * to the dense MatOp path (same iterates on the dense-ified matrix).
+ * ==================================================================================== */
+typedef struct {
+    size_t m, n;
+    const int64_t *cp; const int32_t *ri; const double *cv;      /* by columns (the caller's) */
+    int64_t *rp; int32_t *ci; double *rv;                        /* by rows (built here) */
+} csc_op;
+
+static void csc_size(void *ctx, size_t *nr, size_t *nc) { csc_op *o = ctx; *nr = o->m; *nc = o->n; }
+/* y = alpha A x + beta y (operator.rs:40-57) */
+static void csc_opf(void *ctx, double alpha, const double *x, double beta, double *y)
+{
+    csc_op *o = ctx;
+    #pragma omp parallel for schedule(dynamic, 256)
+    for (size_t r = 0; r < o->m; ++r) {
+        double s = 0.0;
+        for (int64_t k = o->rp[r]; k < o->rp[r + 1]; ++k) s += o->rv[k] * x[o->ci[k]];
+        y[r] = alpha * s + beta * y[r];
+    }
+}
+/* y = alpha A^T x + beta y (operator.rs:59-75) */
+static void csc_top(void *ctx, double alpha, const double *x, double beta, double *y)
+{
+    csc_op *o = ctx;
+    #pragma omp parallel for schedule(dynamic, 256)
+    for (size_t c = 0; c < o->n; ++c) {
+        double s = 0.0;
+        for (int64_t k = o->cp[c]; k < o->cp[c + 1]; ++k) s += o->cv[k] * x[o->ri[k]];
+        y[c] = alpha * s + beta * y[c];
+    }
+}
+/* tau[c] += sum_r |A(r,c)| (operator.rs:82-113) ; sigma[r] += sum_c |A(r,c)| (operator.rs:123-154) */
+static void csc_ac(void *ctx, double *tau)
+{
+    csc_op *o = ctx;
+    for (size_t c = 0; c < o->n; ++c) { double s = 0.0; for (int64_t k = o->cp[c]; k < o->cp[c + 1]; ++k) s += fabs(o->cv[k]); tau[c] += s; }
+}
+static void csc_ar(void *ctx, double *sigma)
+{
+    csc_op *o = ctx;
+    for (size_t r = 0; r < o->m; ++r) { double s = 0.0; for (int64_t k = o->rp[r]; k < o->rp[r + 1]; ++k) s += fabs(o->rv[k]); sigma[r] += s; }
+}
+
+int oc_solve_csc_cones(const oc_param *par, size_t n, size_t m, const double *vec_c,
+                       const int64_t *colptr, const int32_t *rowidx, const double *vals, const double *vec_b,
+                       size_t n_seg, const int32_t *seg_type, const int64_t *seg_len,
+                       int use_ql, double *out_x, double *out_y, oc_trace *trace)
+{
+    csc_op o = { m, n, colptr, rowidx, vals, NULL, NULL, NULL };
+    const int64_t nnz = n ? colptr[n] : 0;
+    o.rp = (int64_t *)calloc(m + 2, sizeof(int64_t));
+    o.ci = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    o.rv = (double *)malloc(sizeof(double) * (size_t)(nnz ? nnz : 1));
+    for (int64_t k = 0; k < nnz; ++k) o.rp[rowidx[k] + 2]++;
+    for (size_t r = 0; r < m; ++r) o.rp[r + 2] += o.rp[r + 1];            /* rp[r + 1] = start of row r while filling */
+    for (size_t c = 0; c < n; ++c)
+        for (int64_t k = colptr[c]; k < colptr[c + 1]; ++k) {
+            const int64_t d = o.rp[rowidx[k] + 1]++;
+            o.ci[d] = (int32_t)c; o.rv[d] = vals[k];
+        }
+    oc_matop mc = { OC_MAT_GENERAL, n, 1, vec_c };
+    oc_matop mb = { OC_MAT_GENERAL, m, 1, vec_b };
+    oc_operator oc = oc_matop_as_operator(&mc), ob = oc_matop_as_operator(&mb);
+    oc_operator oa = { &o, csc_size, csc_opf, csc_top, csc_ac, csc_ar };
+    seg_cone sc;
+    seg_cone_init(&sc, n_seg, seg_type, seg_len, par->eps_zero, use_ql);
+    oc_cone cone = { &sc, seg_proj, seg_group };
+    const int rc = run_and_extract(par, &oc, &oa, &ob, &cone, n, m, out_x, out_y, trace);
+    free(sc.psd_work);
+    free(o.rp); free(o.ci); free(o.rv);
+    return rc;
+}
+
+/* ======================================================================================
  * ProbLP (totsu/src/problem/lp.rs)
  * ==================================================================================== */
 typedef struct { oc_matop g, a; } lp_opa;      /* lp.rs:50-54 */

@@ -130,6 +130,13 @@ int oc_solve_matop_cones(const oc_param *par, size_t n, size_t m,
                          size_t n_seg, const int32_t *seg_type, const int64_t *seg_len,
                          int use_ql, double *out_x, double *out_y, oc_trace *trace);
 
+/* the same with A given sparse, by columns (int64 column pointers, int32 row indices, f64 values): a user-defined
+ * Operator in the pattern of examples/imgnr_udef/src/prob_op_a.rs:33-120 (operator.rs:11-156) */
+int oc_solve_csc_cones(const oc_param *par, size_t n, size_t m, const double *vec_c,
+                       const int64_t *colptr, const int32_t *rowidx, const double *vals, const double *vec_b,
+                       size_t n_seg, const int32_t *seg_type, const int64_t *seg_len,
+                       int use_ql, double *out_x, double *out_y, oc_trace *trace);
+
 /* ProbLP (totsu/src/problem/lp.rs) */
 int oc_solve_lp(const oc_param *par, size_t n, size_t m, size_t p,
                 const double *vec_c, const double *mat_g, const double *vec_h,

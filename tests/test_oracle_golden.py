@@ -289,3 +289,35 @@ def test_toruscompl_socp_construction_on_oracle():
     assert abs(float(q["length"] @ x) / (0.2 * q["length"].sum()) - 1.0) < 5e-3          # the volume bound is active
     assert np.abs(q["mat_a"] @ r.x - q["vec_b"]).max() < 1e-2                               # force balance at every free node
     assert np.all(2.0 * w * x + 1e-2 >= q["length"] * qf * qf)                               # w_i x_i >= v_i q_i^2 / 2
+
+
+def test_sparse_operator_oracle_is_the_dense_oracle():
+    # the CSC user-operator of the oracle (the CPU baseline and checker of the sparse workloads; pattern:
+    # examples/imgnr_udef/src/prob_op_a.rs:33-120) against the MatOp path that the golden vectors pin: same iterates, same trace,
+    # same preconditioner on the dense-ified matrix -- an LP (l1reg_lp construction) and an SOCP with sparse blocks
+    import scipy.sparse as sp
+    from problems import l1reg_lp, random_socp
+    c, G, h = l1reg_lp(40, seed=2)
+    A = sp.csc_matrix(G)
+    par = O.param(max_iter=60, eps_acc=1e-300)
+    rd = O.solve_matop_cones(par, c, G, h, [O.CONE_RPOS], [h.size], snap_iters=[0, 9, 59], trace_cap=64)
+    rs = O.solve_csc_cones(par, c, A.indptr, A.indices, A.data, h, [O.CONE_RPOS], [h.size], snap_iters=[0, 9, 59], trace_cap=64)
+    for a, b in zip(rd.snaps, rs.snaps):
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-13)
+    n, cones = 30, [5, 12, 0, 7]
+    f, Gs, hs, cs, d = random_socp(n, cones, seed=4)
+    rng = np.random.default_rng(1)
+    Gs = [g * (rng.uniform(0, 1, g.shape) < 0.2) for g in Gs]
+    Ad = np.vstack([np.vstack([-c_.reshape(1, n), -g]) for g, c_ in zip(Gs, cs)]).astype(np.float64)
+    b = np.concatenate([np.concatenate([[dd], h_]) for dd, h_ in zip(d, hs)]).astype(np.float64)
+    seg_t, seg_l = [O.CONE_SOC] * len(cones), [1 + k for k in cones]
+    As = sp.csc_matrix(Ad)
+    rd = O.solve_matop_cones(O.param(eps_acc=1e-6, max_iter=200000), f, Ad, b, seg_t, seg_l)
+    rs = O.solve_csc_cones(O.param(eps_acc=1e-6, max_iter=200000), f, As.indptr, As.indices, As.data, b, seg_t, seg_l)
+    # (dropping entries of G after f was formed loses the construction's boundedness: both paths must say so at the same iteration)
+    assert rd.status == rs.status and abs(rd.iters - rs.iters) <= 1
+    assert np.allclose(rd.x, rs.x, rtol=1e-9, atol=1e-11)
+    rd = O.solve_matop_cones(O.param(eps_acc=1e-5, max_iter=400000), c, G, h, [O.CONE_RPOS], [h.size])
+    rs = O.solve_csc_cones(O.param(eps_acc=1e-5, max_iter=400000), c, A.indptr, A.indices, A.data, h, [O.CONE_RPOS], [h.size])
+    assert rd.status == rs.status == O.OK and abs(rd.iters - rs.iters) <= 1
+    assert np.allclose(rd.x, rs.x, rtol=1e-9, atol=1e-11)

@@ -1143,8 +1143,12 @@ size_t pad64(size_t v) { return (v + 63) / 64 * 64; }
 // launch stream around every GEMV kernel of products()
 struct Prof {
     bool on = false;
-    int period = 1;                 // every period-th span is timed (an event pair costs the stream 3-5 us: 9 % of a 0.14 ms iteration)
-    long long seen = 0;             // spans begun since thip_prof_enable
+    int period = 1;                 // the spans of every period-th ITERATION are timed (an event pair costs the stream 3-5 us: 9 % of
+                                    // a 0.14 ms iteration).  By iteration, not by span: a schedule with two kinds of span per iteration
+                                    // (A^T pass then A pass; the two half-launches of the column split; the two products of the tiled
+                                    // sparse copy) would otherwise, with an even period, only ever time one kind
+    long long seen = 0;             // iterations begun since thip_prof_enable
+    bool iter_open = true;          // the spans of the current iteration are timed
     bool open = false;              // the current span is one of the timed ones
     std::vector<hipEvent_t> ev;     // pairs
     size_t used = 0;
@@ -1155,12 +1159,18 @@ struct Prof {
 void prof_begin(hipStream_t st, Prof &p = g_prof)
 {
     if (!p.on) return;
-    p.open = (p.seen++ % p.period) == 0;
+    p.open = p.iter_open;
     if (!p.open) return;
     if (p.used + 2 > p.ev.size()) {
         for (int i = 0; i < 64; ++i) { hipEvent_t e; hipEventCreate(&e); p.ev.push_back(e); }
     }
     hipEventRecord(p.ev[p.used], st);
+}
+// once per iteration of thip_solver_run
+void prof_tick()
+{
+    for (Prof *p : { &g_prof, &g_prof_psd })
+        if (p->on) p->iter_open = (p->seen++ % p->period) == 0;
 }
 void prof_end(hipStream_t st, Prof &p = g_prof)
 {
@@ -2510,8 +2520,10 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
     while (s->hst->state == THIP_ST_RUNNING && (max_steps < 0 || done < max_steps)) {
         int64_t batch = poll_every;
         if (max_steps >= 0 && done + batch > max_steps) batch = max_steps - done;
-        for (int64_t k = 0; k < batch; ++k)
+        for (int64_t k = 0; k < batch; ++k) {
+            prof_tick();
             THIP_RC(sweep ? one_iteration_sweep(s, k + 1 == batch) : (split ? one_iteration_split(s) : one_iteration(s)));
+        }
         if (s->tail_pending) THIP_RC(split_tail(s));       // drain the pipeline before the host looks
         // every bounded device-side wait of the batch: did one run out?
         unsigned sw_err = 0, peer_fault = 0;
@@ -2850,7 +2862,7 @@ int thip_prof_enable(int on)
     for (Prof *p : { &g_prof, &g_prof_psd }) {
         p->on = on > 0;
         p->period = on > 0 ? on : 1;
-        p->seen = 0; p->open = false;
+        p->seen = 0; p->open = false; p->iter_open = true;
         p->used = 0; p->total_ms = 0.0; p->launches = 0;
     }
     return 0;

@@ -52,6 +52,13 @@ constexpr int SPT_STAGE_MIN = 2048;     // entries of a tile visit from which th
 struct SptTile { long long e0; int cnt, rb, cw, pad_; };                                   // entries [e0, e0 + cnt), cnt % 4 == 0
 struct SptItem { int out_block, slice, ref0, ref1; long long e_first, e_last; };           // tile refs [ref0, ref1)
 
+// where element i of a block lives in its LDS array: a lane's four entries are four CONSECUTIVE rows of a dense column (a
+// dwordx4 of the stream), so instruction e of a wave touches rows 4 t + e -- a stride of four words, eight lanes per bank.
+// De-interleaved by i mod 4 the same instruction touches 64 consecutive words (the first N-product kernel ran at 0.8 TB/s of
+// entries with the plain layout: profiles/r06_sparse_lp_kernel_stats_first.txt)
+__device__ __forceinline__ int spt_slot(int i) { return ((i & 3) << 10) | (i >> 2); }
+static_assert(SPT_TB == 4096, "spt_slot de-interleaves a block of 4096");
+
 struct SptArgs {
     const f32x4 *vals; const i32x4 *idx; const SptTile *tiles; const int *order; const SptItem *items;
     const float *in0, *in1;             // in1 == NULL: one right-hand side
@@ -71,6 +78,13 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
     const bool two = a.in1 != nullptr;
     for (int i = tid; i < SPT_TB; i += SPT_THREADS) { lo0[i] = 0.0f; lo1[i] = 0.0f; }
     bool prev_staged = true;            // (the zeroing above is ordered by the first visit's barrier)
+    // N product: ds_add_f32 is slow on this part (two per entry bound the first kernel at 0.8 TB/s of entries whatever the bank
+    // layout), and in a dense column block it is not needed: a column of a full tile is 1024 quads -- exactly one step of this
+    // loop -- so a lane meets the SAME four rows in every step.  The lane keeps the sums of "its" rows in registers for as long
+    // as the rows of its next quad are the ones it holds, and pays the LDS adds only when they change (every step, for a
+    // scattered pattern: the old cost plus a compare).
+    int hold[2][4] = { { -1, -1, -1, -1 }, { -1, -1, -1, -1 } };
+    float h0[2][4] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } }, h1[2][4] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } };
     for (int ref = it.ref0; ref < it.ref1; ++ref) {
         const int t = a.order ? a.order[ref] : ref;
         const SptTile tl = a.tiles[t];
@@ -84,7 +98,7 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
         const float *in1b = (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB;
         if (staged) {
             const int lim = a.in_len - inb * SPT_TB;
-            for (int i = tid; i < SPT_TB; i += SPT_THREADS) lin[i] = i < lim ? make_float2(in0b[i], in1b[i]) : make_float2(0.0f, 0.0f);
+            for (int i = tid; i < SPT_TB; i += SPT_THREADS) lin[spt_slot(i)] = i < lim ? make_float2(in0b[i], in1b[i]) : make_float2(0.0f, 0.0f);
             __syncthreads();
         }
         prev_staged = staged;
@@ -107,11 +121,11 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
                     const unsigned id = (unsigned)iv[u][e];
                     const int lr = (int)(id & 0xffffu), lc = (int)(id >> 16);
                     const int ii = TPH ? lr : lc;
-                    oi[e] = TPH ? lc : lr;
+                    oi[e] = spt_slot(TPH ? lc : lr);
                     float v = ok[u] ? av[u][e] : 0.0f;
                     float2 x;
                     if (a.abs_mode) { v = fabsf(v); x = make_float2(1.0f, 1.0f); }
-                    else if (staged) x = lin[ii];
+                    else if (staged) x = lin[spt_slot(ii)];
                     else x = make_float2(in0b[ii], in1b[ii]);
                     p0[e] = v * x.x; p1[e] = v * x.y;
                 }
@@ -131,17 +145,32 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
                         }
                     }
                 } else if (ok[u]) {
+                    const bool keep = oi[0] == hold[u][0] && oi[1] == hold[u][1] && oi[2] == hold[u][2] && oi[3] == hold[u][3];
+                    if (!keep) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { atomicAdd(&lo0[oi[e]], p0[e]); if (two) atomicAdd(&lo1[oi[e]], p1[e]); }
+                        for (int e = 0; e < 4; ++e) {
+                            if (hold[u][e] >= 0) { atomicAdd(&lo0[hold[u][e]], h0[u][e]); if (two) atomicAdd(&lo1[hold[u][e]], h1[u][e]); }
+                            hold[u][e] = oi[e]; h0[u][e] = 0.0f; h1[u][e] = 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h0[u][e] += p0[e]; h1[u][e] += p1[e]; }
                 }
             }
         }
+    }
+    if (!TPH) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (hold[u][e] >= 0) { atomicAdd(&lo0[hold[u][e]], h0[u][e]); if (two) atomicAdd(&lo1[hold[u][e]], h1[u][e]); }
     }
     __syncthreads();
     const size_t r0 = (size_t)it.out_block * SPT_TB;
     float *o0 = a.part + (size_t)it.slice * 2 * a.opad + r0, *o1 = o0 + a.opad;
     for (int i = tid; i < SPT_TB; i += SPT_THREADS)
-        if (r0 + i < a.opad) { o0[i] = lo0[i]; if (two) o1[i] = lo1[i]; }
+        if (r0 + i < a.opad) { o0[i] = lo0[spt_slot(i)]; if (two) o1[i] = lo1[spt_slot(i)]; }
 }
 
 // The per-column step of the one-pass recurrence (the arithmetic of sweep_k's service wave, thip_sweep_kernel.h): gT / g3 = the
@@ -175,10 +204,26 @@ __global__ __launch_bounds__(256) void sp_col_k(const SpColArgs ca)
     const int j0 = blockIdx.x * cpb, j1 = min(a.n, j0 + cpb);
     float sdd = 0.0f, scx = 0.0f, scu = 0.0f, scrx = 0.0f;
     for (int j = j0 + tid; j < j1; j += 256) {
+        // (eight slices in flight per lane: the sum over up to 256 slices is a latency chain, not a bandwidth problem)
         float gT = 0.0f, g3 = 0.0f;
-        for (int s = 0; s < ca.nsl; ++s) {
-            gT += ca.partT[((size_t)s * 2 + 0) * ca.npad + j];
-            g3 += ca.partT[((size_t)s * 2 + 1) * ca.npad + j];
+        {
+            float t8[8], g8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t8[u] = 0.0f; g8[u] = 0.0f; }
+            int sl = 0;
+            for (; sl + 8 <= ca.nsl; sl += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    t8[u] += ca.partT[((size_t)(sl + u) * 2 + 0) * ca.npad + j];
+                    g8[u] += ca.partT[((size_t)(sl + u) * 2 + 1) * ca.npad + j];
+                }
+            }
+            for (; sl < ca.nsl; ++sl) {
+                t8[0] += ca.partT[((size_t)sl * 2 + 0) * ca.npad + j];
+                g8[0] += ca.partT[((size_t)sl * 2 + 1) * ca.npad + j];
+            }
+            gT = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
+            g3 = ((g8[0] + g8[1]) + (g8[2] + g8[3])) + ((g8[4] + g8[5]) + (g8[6] + g8[7]));
         }
         const float cj = a.c[j], uj = a.u[j], xxj = a.xx_in[j];
         float kuj = comp_u ? a.ku[j] : 0.0f, kxj = comp_x ? a.kx_in[j] : 0.0f;
