@@ -86,6 +86,10 @@ int thip_test_gemm_dual(int kernel, int n, int ld, int nb, const float *A, const
  * 5: one tile per workgroup, general, one item; 6-8: the two-product kernel (two products / one with averaged diagonal tiles /
  * one with the packed output); 9: mode 0 with averaged diagonal tiles */
 int thip_test_chain_probe(int mode, int ld, int reps, float *host_us);
+/* timing probe of the tiled sparse products (tools/sptile_rate.py): `reps` launches each of A^T [y0 y1] and A [x0 x1] on `mat`
+ * (vectors of ones, two right-hand sides as in the one-pass recurrence); host_ms[0] / [1] = best milliseconds per launch of the
+ * T / N product, host_ms[2] / [3] their averages */
+int thip_test_sptile_time(thip_sptile *mat, int reps, float *host_ms);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,29 @@ def pmc(fetch_db, write_db, key):
             rows[label][short] = (calls, val, dur / 1e3)
         print()
 
+    if key.startswith("sparse"):
+        # the tiled sparse products: two instances per iteration (sp_tile_k<true> = A^T [v x_y], <false> = A [u x_x']); bench.py's
+        # roofline averages both launches, and so does the stored traffic
+        per, tot_rd, tot_wr, k_ = {}, 0.0, 0.0, 0
+        for inst in ("thip::sp_tile_k<true>", "thip::sp_tile_k<false>"):
+            f_, w_ = rows["FETCH_SIZE"].get(inst), rows["WRITE_SIZE"].get(inst)
+            if f_ is None:
+                continue
+            rd, wr = 2.0 * f_[1] * 1024.0, (w_[1] if w_ else 0.0) * 1024.0
+            per[inst] = {"launches_fetch_pass": f_[0], "fetch_size_KiB_raw": f_[1], "write_size_KiB_raw": w_[1] if w_ else None,
+                         "read_bytes_corrected_x2": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "avg_us_fetch_pass": f_[2]}
+            tot_rd += rd; tot_wr += wr; k_ += 1
+        if not k_:
+            print("# %s: no sp_tile_k in the FETCH pass" % key)
+            return
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hbm_traffic.json")
+        d = json.load(open(path)) if os.path.exists(path) else {}
+        d[key] = {"kernel": "sp_tile_k<true> and sp_tile_k<false>, mean of the two launches of an iteration", "instances": per,
+                  "hbm_bytes_per_launch": (tot_rd + tot_wr) / k_}
+        json.dump(d, open(path, "w"), indent=1)
+        print("# %s: corrected HBM bytes per launch (mean of both products) = %.4g" % (key, (tot_rd + tot_wr) / k_))
+        return
+
     def wanted(short):
         if key.endswith("_sweep"):
             return "sweep_k<" in short

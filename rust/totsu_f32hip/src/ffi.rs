@@ -206,6 +206,7 @@ extern "C" {
     pub fn thip_test_gemm_chain(shape: c_int, kernel: c_int, n: c_int, ld: c_int, nb: c_int, alpha: f32, x: *const f32,
                                 y: *const f32, beta: f32, d: *const f32, gamma: f32, c: *mut f32) -> c_int;
     pub fn thip_test_chain_probe(mode: c_int, ld: c_int, reps: c_int, host_us: *mut f32) -> c_int;
+    pub fn thip_test_sptile_time(mat: *mut thip_sptile, reps: c_int, host_ms: *mut f32) -> c_int;
     pub fn thip_test_gemm_dual(kernel: c_int, n: c_int, ld: c_int, nb: c_int, a: *const f32, b0: *const f32, b1: *const f32,
                                coef: *const f32, o0: *mut f32, o1: *mut f32) -> c_int;
 }

@@ -164,6 +164,7 @@ PROTOTYPES = {
     "thip_test_gemm_sym": (_i, [_i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_test_gemm_chain": (_i, [_i, _i, _i, _i, _i, _f, _vp, _vp, _f, _vp, _f, _vp]),
     "thip_test_chain_probe": (_i, [_i, _i, _i, C.POINTER(_f)]),
+    "thip_test_sptile_time": (_i, [_vp, _i, C.POINTER(_f)]),
     "thip_test_gemm_dual": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "thip_solver_gemv_plan": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f)]),
     "thip_prof_enable": (_i, [_i]),

@@ -12,7 +12,7 @@
 // block), entries inside a tile in the caller's CSC order (column, then row), every tile padded to whole 16-byte quads.  Both
 // products stream the same 8 bytes per entry with 16-byte loads; the scatter side of either product goes to an accumulator of
 // one block (2 x 4096 floats) in LDS (ds_add_f32: no global atomic anywhere), the gather side reads the in-vector's block from
-// LDS (staged once per tile visit) or, for a visit of fewer than 2048 entries, straight from L2.
+// LDS (staged once per tile visit) or, for a visit of fewer than 8192 entries, straight from L2.
 //   N product (A [x0 x1]): a workgroup owns (row block, slice): walks that row block's tiles -- contiguous in memory --, in = the
 //       column block's slice of x, out = the row block's accumulators; entries of one column hit distinct rows: conflict-free.
 //   T product (A^T [y0 y1]): a workgroup owns (column block, slice): walks the tiles of its column block (a list: one per row
@@ -47,7 +47,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SPT_TB = 4096;            // rows / columns per block
 constexpr int SPT_THREADS = 512;
-constexpr int SPT_STAGE_MIN = 2048;     // entries of a tile visit from which the in-vector's block is staged in LDS
+constexpr int SPT_STAGE_MIN = 8192;     // entries of a tile visit from which the in-vector's block is staged in LDS
 
 struct SptTile { long long e0; int cnt, rb, cw, pad_; };                                   // entries [e0, e0 + cnt), cnt % 4 == 0
 struct SptItem { int out_block, slice, ref0, ref1; long long e_first, e_last; };           // tile refs [ref0, ref1)
@@ -65,6 +65,7 @@ struct SptArgs {
     int in_len;
     float *part; size_t opad;           // [slice][2][opad]
     int abs_mode; const int *stop;
+    int stage_min;                      // entries of a tile visit from which the in-vector's block is staged in LDS
 };
 
 template <bool TPH>
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
         if (ref == it.ref0) e0 = it.e_first;
         if (ref == it.ref1 - 1) e1 = it.e_last;
         const int inb = TPH ? tl.rb : tl.cw;
-        const bool staged = (e1 - e0) >= SPT_STAGE_MIN && !a.abs_mode;
+        const bool staged = (e1 - e0) >= a.stage_min && !a.abs_mode;
         if (staged || prev_staged) __syncthreads();
         const float *in0b = a.in0 + (size_t)inb * SPT_TB;
         const float *in1b = (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB;
@@ -137,12 +138,31 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
                     if (__all(ok[u] && same && oi[0] == first)) {
                         const float w0 = wave_sum_dpp(s0), w1 = two ? wave_sum_dpp(s1) : 0.0f;
                         if (lane == 0) { atomicAdd(&lo0[first], w0); if (two) atomicAdd(&lo1[first], w1); }
-                    } else if (ok[u]) {
-                        if (same) { atomicAdd(&lo0[oi[0]], s0); if (two) atomicAdd(&lo1[oi[0]], s1); }
-                        else {
+                    } else {
+                        // several columns in the wave: a segmented sum over the lanes (keys ascend with the lane: the stream is
+                        // column-sorted), one LDS add per column and wave instead of one per entry.  A lane whose quad straddles
+                        // columns joins the segment of its LAST column and adds its earlier entries itself; a lane past the end
+                        // carries the largest key and nothing.
+                        int key = ok[u] ? oi[3] : 0x7fffffff;
+                        float a0 = 0.0f, a1 = 0.0f;
+                        if (ok[u]) {
+                            if (same) { a0 = s0; a1 = s1; }
+                            else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { atomicAdd(&lo0[oi[e]], p0[e]); if (two) atomicAdd(&lo1[oi[e]], p1[e]); }
+                                for (int e = 0; e < 4; ++e) {
+                                    if (oi[e] == key) { a0 += p0[e]; a1 += p1[e]; }
+                                    else { atomicAdd(&lo0[oi[e]], p0[e]); if (two) atomicAdd(&lo1[oi[e]], p1[e]); }
+                                }
+                            }
                         }
+#pragma unroll
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const int kk = __shfl_up(key, d, 64);
+                            const float t0 = __shfl_up(a0, d, 64), t1 = __shfl_up(a1, d, 64);
+                            if (lane >= d && kk == key) { a0 += t0; a1 += t1; }
+                        }
+                        const int kn = __shfl_down(key, 1, 64);
+                        if ((lane == 63 || kn != key) && key != 0x7fffffff) { atomicAdd(&lo0[key], a0); if (two) atomicAdd(&lo1[key], a1); }
                     }
                 } else if (ok[u]) {
                     const bool keep = oi[0] == hold[u][0] && oi[1] == hold[u][1] && oi[2] == hold[u][2] && oi[3] == hold[u][3];
@@ -297,6 +317,8 @@ int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const floa
     a.in0 = in0; a.in1 = in1; a.in_len = (int)(tphase ? M->m : M->n);
     a.part = part; a.opad = tphase ? M->npad : M->mpad;
     a.abs_mode = abs_mode; a.stop = stop ? stop : ctx().never_stop;
+    static const int stage_min = getenv("THIP_SPT_STAGE_MIN") ? atoi(getenv("THIP_SPT_STAGE_MIN")) : SPT_STAGE_MIN;
+    a.stage_min = stage_min;
     if (tphase) hipLaunchKernelGGL(sp_tile_k<true>, dim3(items), dim3(SPT_THREADS), 0, st, a);
     else hipLaunchKernelGGL(sp_tile_k<false>, dim3(items), dim3(SPT_THREADS), 0, st, a);
     THIP_LAUNCH_CHECK();
@@ -519,6 +541,41 @@ int thip_sptile_mv(thip_sptile *M, int transpose, float alpha, const float *x, f
     }
     THIP_RC(sptile_product(st, M, t, abs_mode ? (const float *)M->vals : x, nullptr, part, abs_mode, nullptr));
     return finalize_partials(st, len, part, sptile_slices(M, t), 2 * sptile_pad(M, t), alpha, beta, y, nullptr);
+}
+
+
+int thip_test_sptile_time(thip_sptile *M, int reps, float *host_ms)
+{
+    THIP_NEED_INIT();
+    if (!M || !host_ms) return fail(THIP_E_INVALID, "null argument", __FILE__, __LINE__);
+    hipStream_t st = ctx().stream;
+    const size_t nv = std::max(M->mpad, M->npad) + 64;
+    float *ones = nullptr, *pt = nullptr, *pn = nullptr;
+    THIP_TRY(hipMalloc((void **)&ones, 2 * nv * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&pt, std::max<size_t>(sptile_part_floats(M, true), 64) * sizeof(float)));
+    THIP_TRY(hipMalloc((void **)&pn, std::max<size_t>(sptile_part_floats(M, false), 64) * sizeof(float)));
+    std::vector<float> h(2 * nv, 1.0f);
+    THIP_TRY(hipMemcpy(ones, h.data(), 2 * nv * sizeof(float), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    THIP_TRY(hipEventCreate(&e0)); THIP_TRY(hipEventCreate(&e1));
+    if (reps < 1) reps = 1;
+    for (int ph = 0; ph < 2; ++ph) {
+        float best = 1e30f, tot = 0.0f;
+        for (int r = 0; r <= reps; ++r) {
+            THIP_TRY(hipEventRecord(e0, st));
+            THIP_RC(sptile_product(st, M, ph == 0, ones, ones + nv, ph == 0 ? pt : pn, 0, nullptr));
+            THIP_TRY(hipEventRecord(e1, st));
+            THIP_TRY(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            THIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+            if (r == 0) continue;
+            tot += ms; if (ms < best) best = ms;
+        }
+        host_ms[ph] = best; host_ms[2 + ph] = tot / reps;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(ones); hipFree(pt); hipFree(pn);
+    return 0;
 }
 
 }  // extern "C"
