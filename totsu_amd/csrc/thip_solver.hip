@@ -1711,7 +1711,7 @@ int rebuild_carried(thip_solver *s)
 // ---------------------------------------------------------------------------------------------------
 // Can the next run use the one-pass kernel?  Dense f32 A on one GPU in a shape sweep_plan() takes, on a device whose
 // placement census came out as 8 x 32 in a dry run.  Examined once per (re)initialisation.
-int sweep_pass(thip_solver *s, int first, int np_m = 0);
+int sweep_pass(thip_solver *s, int first, int np_m = 0, bool timing = false);
 
 // the partial-sum buffers of a solver on the tiled sparse copy (zeroed once: a block without entries is never written) and the
 // words the sweep schedule's host side reads (error word, block partials)
@@ -1811,16 +1811,16 @@ int sweep_prepare(thip_solver *s)
         hipEvent_t e0, e1;
         THIP_TRY(hipEventCreate(&e0));
         THIP_TRY(hipEventCreate(&e1));
-        constexpr int REP = 5;
+        constexpr int REP = 7;
         float med[6], spread[6], cost[6];
         for (int c = 0; c < nc; ++c) {
             s->sgeom = cand[c];
             THIP_TRY(hipMemsetAsync(s->sw_gran, 0, maxG * sizeof(unsigned long long), st));
-            THIP_RC(sweep_pass(s, 1));
+            THIP_RC(sweep_pass(s, 1, 0, true));
             float t[REP];
             for (int r = 0; r < REP; ++r) {
                 THIP_TRY(hipEventRecord(e0, st));
-                THIP_RC(sweep_pass(s, 1));
+                THIP_RC(sweep_pass(s, 1, 0, true));
                 THIP_TRY(hipEventRecord(e1, st));
                 THIP_TRY(hipEventSynchronize(e1));
                 THIP_TRY(hipEventElapsedTime(&t[r], e0, e1));
@@ -1892,7 +1892,7 @@ bool sweep_active(const thip_solver *s)
     return s->is16() ? (s->A16_owned && s->ld16 >= (size_t)s->sgeom.m_eff) : (s->Apad != nullptr && s->ldpad >= (size_t)s->sgeom.m_eff);
 }
 
-int sweep_pass(thip_solver *s, int first, int np_m)
+int sweep_pass(thip_solver *s, int first, int np_m, bool timing)
 {
     hipStream_t st = ctx().stream;
     const SweepGeom &g = s->sgeom;
@@ -1917,7 +1917,14 @@ int sweep_pass(thip_solver *s, int first, int np_m)
     const int par = s->pn_par ^ 1;
     a.pn = s->sw_part + (size_t)par * 2 * EG; a.pn_stride = 256;
     a.pn_in = s->sw_part + (size_t)s->pn_par * 2 * EG; a.pn_in_stride = 256;
-    if (!first) {
+    if (timing) {
+        // a REGULAR sweep's instruction stream and memory traffic (the u update, its Kahan term, five column stores per turn)
+        // that changes nothing of the iterate: u / ku go to scratch n-vectors, kappa stays.  The geometries are timed like this:
+        // timed as first = 1 sweeps (no u update) the plan autotune picked the 16-bit geometry that is 4 % slower in the loop
+        // about every other run (two columns per panel: 1.56 ms as timed, 1.63 in the loop; four: 1.58 / 1.55)
+        a.first = 0;
+        a.u = s->g1; a.ku = s->comp() ? s->g2 : nullptr;
+    } else if (!first) {
         // the sweep of a regular step opens with the kappa update: c.rx_x from the previous sweep's partials, b.rx_y from sw_vm_k
         const unsigned gm_ = np_m > 0 ? (unsigned)np_m : egrid(s->m);      // block partials per sum over m (the m-kernel's grid)
         a.kappa_p = &s->dst->kappa_in; a.kappa_out = &s->dst->kappa;

@@ -116,6 +116,12 @@ static int sweep_plan_one(size_t m, size_t n, size_t lda, const void *mat, int W
 int sweep_plan(size_t m, size_t n, size_t lda, const void *mat, SweepGeom *g, int elem)
 {
     if (elem) {
+        // THIP_SWEEP16_GEOM = "W:gmul" pins the 16-bit geometry (experiments; with THIP_SWEEP_CLASS set so that the solver does not
+        // time the candidates)
+        if (const char *e = getenv("THIP_SWEEP16_GEOM")) {
+            int w = 1, gm = 1;
+            if (sscanf(e, "%d:%d", &w, &gm) == 2 && sweep_plan_one(m, n, lda, mat, w, gm, g, 0, elem) == 0) return 0;
+        }
         if (sweep_plan_one(m, n, lda, mat, 2, 1, g, 0, elem) == 0) return 0;
         return sweep_plan_one(m, n, lda, mat, 1, 1, g, 0, elem);
     }
