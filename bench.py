@@ -464,12 +464,12 @@ def eig_record(k, ms_per_pair, spans, ms_per_iter):
     ld = (k + 63) // 64 * 64
     nt = ld // 32
     tri = nt * (nt + 1) // 2
-    if 20 < k <= 512 and os.environ.get("THIP_PSD_CHAIN", "7") == "7":
-        tiles = 11 * (tri + 2 * tri + tri) + 2 * tri + tri      # 11 degree-7 steps (S S; {Y Y, Y S}; U V), {NS, M S}, T R
-        launches, products, chain = 11 * 3 + 2 + 2, 11 * 4 + 3, "all-symmetric degree-7 polar steps (round 5)"
-    else:
-        tiles = 14 * (2 * tri + nt * nt) + tri + 2 * nt * nt
-        launches, products, chain = 14 * 3 + 3 + 3, 45, "quintic polar steps, general T S products (round 4)"
+    while ld > 512 and (ld // 64) % ((ld + 511) // 512) != 0:    # thip_eig.hip np_of: whole K chunks above order 512
+        ld += 64
+    nt = ld // 32
+    tri = nt * (nt + 1) // 2
+    tiles = 11 * (tri + 2 * tri + tri) + 2 * tri + tri      # 11 degree-7 steps (S S; {Y Y, Y S}; U V), {NS, M S}, T R
+    launches, products, chain = 11 * 3 + 2 + 2, 11 * 4 + 3, "all-symmetric degree-7 polar steps (round 5; orders above 512: round 6)"
     flops_pair = 2.0 * tiles * (2.0 * 32 * 32 * ld)             # both blocks
     tf = flops_pair / (ms_per_pair * 1e-3) / 1e12
     rec = {"bound": "mfma", "kernel": "gemm_pre2_k / polar_dual_k (v_mfma_f32_32x32x2_f32): the PSD projection chain of x_y and x_s",

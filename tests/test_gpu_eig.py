@@ -36,9 +36,10 @@ def _rand_sym(k, seed, rank_def=False):
     return s
 
 
-# (<= 64: one workgroup; 65 .. 512: the all-symmetric degree-7 chain; 600: the round-4 chain, which serves orders above 512)
-@pytest.mark.parametrize("k", [1, 2, 3, 5, 6, 9, 20, 21, 32, 33, 48, 63, 64, 65, 100, 200, 500, 512, 600])
-@pytest.mark.parametrize("rank_def", [False, True])
+# (<= 64: one workgroup; above: the all-symmetric degree-7 chain -- one K chunk up to order 512, two at 513 .. 1024 (600 -> ld 640,
+# 700 -> 768, 1000 -> 1024), three at 1100 (ld 1152) and 1300 (1344), four at 2000 (2048): every K width of a wave, 80 .. 128)
+@pytest.mark.parametrize("k,rank_def", [(k, r) for k in [1, 2, 3, 5, 6, 9, 20, 21, 32, 33, 48, 63, 64, 65, 100, 200, 500, 512, 600, 700]
+                                        for r in (False, True)] + [(1000, True), (1100, False), (1300, True), (2000, False)])
 def test_psd_projection(L, k, rank_def):
     from totsu_amd import ConePSD
     s = _rand_sym(k, k + 17 * rank_def, rank_def)

@@ -35,7 +35,14 @@ constexpr int POLAR_SMALL_MIN_N = 1; // orders 1 .. 64: the polar chain inside o
                                      // 200 at 16 -- and not scale invariant: its column products underflow for entries of 1e-18)
 constexpr int MAX_SWEEPS = 18;
 
-__host__ __device__ inline size_t np_of(size_t n) { return (n + 63) / 64 * 64; }
+// ld of an order-n operand: n rounded up to 64; above 512 the chain's kernels walk K in nch = ceil(ld / 512) chunks of
+// 4 waves x KW (KW a multiple of 16, <= 128), so ld / 64 must be a multiple of nch (704 -> 768, 1088 -> 1152, 1600 -> 1792)
+__host__ __device__ inline size_t np_of(size_t n)
+{
+    size_t ld = (n + 63) / 64 * 64;
+    while (ld > 512 && (ld / 64) % ((ld + 511) / 512) != 0) ld += 64;
+    return ld;
+}
 // row pitch of the ld x ld operands of the polar chain.  A power-of-two pitch (2 KB at ld = 512) looked 6 % slower than
 // 544 or 576 floats in the one-tile probe of round 2 (tools/gemm_phases.hip); built in round 3 and measured in the
 // production chain (32 x 64 blocks, dwordx2 loads of operand b): pads of 0 .. 160 floats all give 0.350-0.355 ms per k = 500
@@ -515,7 +522,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_pre_k(int n, int ld, float alpha
 // part in the epilogue (four accumulator registers each).  Per element the order of every sum is that of gemm_pre_k:
 // the results are bitwise the same.  SYM: the block covers tiles (bi, 2p) and (bi, 2p + 1) of the lower triangle; in
 // the last block of an even row the second tile lies above the diagonal and is computed but not stored.
-template <bool GEN, int KW, bool SYM>
+// MC (round 6, orders above 512): K = ld is walked in ld / (4 KW) chunks of 4 waves x KW, each chunk the one-chunk kernel's body
+// (its own slab registers, its own first DEP slabs up front).  MC = false is the kernel as it was: the same bits.
+template <bool GEN, int KW, bool SYM, bool MC = false>
 __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, const float *__restrict__ X,
                                                    const float *__restrict__ Y, float beta, const float *D, float gamma,
                                                    float *C, const int *__restrict__ stop, size_t ws, int pitch, int dsym)
@@ -551,34 +560,41 @@ __global__ __launch_bounds__(256) void gemm_pre2_k(int n, int ld, float alpha, c
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     constexpr int NQ = KW / 8;
     constexpr int DEP = (GEN ? 12 : 8) < NQ ? (GEN ? 12 : 8) : NQ;
-    f32x4_t av[NQ];
-    f32x2_t bv[NQ][4];
-    auto load = [&](const int q) {
-        if constexpr (GEN) av[q] = *reinterpret_cast<const f32x4_t *>(pa + 8 * q);
-        else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) av[q][t] = pa[(size_t)(8 * q + t) * pitch];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bv[q][t] = *reinterpret_cast<const f32x2_t *>(pb + (size_t)(8 * q + t) * pitch);
-    };
-#pragma unroll
-    for (int q = 0; q < DEP; ++q) load(q);
+    static_assert(!MC || !GEN, "the chunked form is the symmetric one");
     f32x16 acce, acco;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acce[r] = acco[r] = 0.0f;
-    // nothing may cross these points: left alone the scheduler sinks every load to its first use
-    __builtin_amdgcn_sched_barrier(0);
+    const int nch = MC ? ld / (4 * KW) : 1;
+    for (int ch = 0; ch < nch; ++ch) {
+        // (the slabs are this scope's: a chunk is the one-chunk kernel's body, its first DEP slabs a round trip that the
+        // CU's other workgroup covers with its MFMAs -- carried across chunks the slab arrays went to scratch memory)
+        f32x4_t av[NQ];
+        f32x2_t bv[NQ][4];
+        auto load = [&](const int q) {
+            if constexpr (GEN) av[q] = *reinterpret_cast<const f32x4_t *>(pa + 8 * q);
+            else {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+                for (int t = 0; t < 4; ++t) av[q][t] = pa[(size_t)(8 * q + t) * pitch];
+            }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acce = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][0], acce, 0, 0, 0);
-            acco = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][1], acco, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) bv[q][t] = *reinterpret_cast<const f32x2_t *>(pb + (size_t)(8 * q + t) * pitch);
+        };
+#pragma unroll
+        for (int q = 0; q < DEP; ++q) load(q);
+        // nothing may cross these points: left alone the scheduler sinks every load to its first use
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acce = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][0], acce, 0, 0, 0);
+                acco = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][t][1], acco, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + DEP < NQ) load(q + DEP);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (q + DEP < NQ) load(q + DEP);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MC) { pa += (size_t)(4 * KW) * pitch; pb += (size_t)(4 * KW) * pitch; }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { red[wave][0][r][lane] = acce[r]; red[wave][1][r][lane] = acco[r]; }
@@ -686,7 +702,7 @@ __host__ __device__ inline int dual_groups(int nt, int nprod, int NT)
     return g;
 }
 
-template <int KW, int NT>
+template <int KW, int NT, bool MC = false>
 __global__ __launch_bounds__(256) void polar_dual_k(const DualArgs a)
 {
     const int halted = *a.stop;                 // looked at before the first store (see gemm_pre_k)
@@ -759,51 +775,62 @@ __global__ __launch_bounds__(256) void polar_dual_k(const DualArgs a)
     constexpr int PER = 4 * (NT + 1);                              // load instructions per slab of 8 k
     constexpr int DEP0 = 64 / PER < 1 ? 1 : 64 / PER;              // as many slabs ahead as fit the 64 loads a wave may have in flight
     constexpr int DEP = DEP0 < NQ ? DEP0 : NQ;
-    float av[NQ][4], bv[NQ][NT][4];
-    // load number x of slab q: x < 4: A row 8 q + x; else panel (x - 4) / 4, row 8 q + (x - 4) % 4
-    auto load1 = [&](const int q, const int x) {
-        if (x < 4) av[q][x] = *reinterpret_cast<const float *>(pa + (size_t)((8 * q + x) * rowb) + lo);
-        else {
-            const int u = (x - 4) >> 2, t = (x - 4) & 3;
-            bv[q][u][t] = *reinterpret_cast<const float *>(pb[u] + (size_t)((8 * q + t) * rowb) + lo);
-        }
-    };
-#pragma unroll
-    for (int q = 0; q < DEP; ++q) {
-#pragma unroll
-        for (int x = 0; x < PER; ++x) load1(q, x);
-    }
-    // the beta * B_p term of the epilogue: this lane's four elements of every tile, fetched now instead of after the sums
     float dv[NT][4];
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-            dv[u][rr] = a.B[pr[u]][zo + (size_t)(i0 + rr + 8 * wave + 4 * h) * pitch + bj[u] * GT + li];
-    }
     f32x16 acc[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[u][r] = 0.0f;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // slab q's 4 NT MFMAs with slab q + DEP's PER loads dealt out between them (an MFMA holds the pipe for 64 cycles: the
-    // loads issue in its shadow; in blocks after the MFMAs they cost the wave a quarter of the MFMAs' time again)
+    const int nch = MC ? a.ld / (4 * KW) : 1;
+    for (int ch = 0; ch < nch; ++ch) {
+        // (MC: a chunk of 4 KW rows of K is the one-chunk kernel's body with slab registers of its own -- see gemm_pre2_k)
+        float av[NQ][4], bv[NQ][NT][4];
+        // load number x of slab q: x < 4: A row 8 q + x; else panel (x - 4) / 4, row 8 q + (x - 4) % 4
+        auto load1 = [&](const int q, const int x) {
+            if (x < 4) av[q][x] = *reinterpret_cast<const float *>(pa + (size_t)((8 * q + x) * rowb) + lo);
+            else {
+                const int u = (x - 4) >> 2, t = (x - 4) & 3;
+                bv[q][u][t] = *reinterpret_cast<const float *>(pb[u] + (size_t)((8 * q + t) * rowb) + lo);
+            }
+        };
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        int x = 0;
+        for (int q = 0; q < DEP; ++q) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+            for (int x = 0; x < PER; ++x) load1(q, x);
+        }
+        if (ch == 0) {
+            // the beta * B_p term of the epilogue: this lane's four elements of every tile, fetched now instead of after the sums
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][u][t], acc[u], 0, 0, 0);
-                if (q + DEP < NQ) {
-                    const int upto = ((t * NT + u + 1) * PER + 4 * NT - 1) / (4 * NT);
-                    for (; x < upto && x < PER; ++x) load1(q + DEP, x);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+                    dv[u][rr] = a.B[pr[u]][zo + (size_t)(i0 + rr + 8 * wave + 4 * h) * pitch + bj[u] * GT + li];
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // slab q's 4 NT MFMAs with slab q + DEP's PER loads dealt out between them (an MFMA holds the pipe for 64 cycles: the
+        // loads issue in its shadow; in blocks after the MFMAs they cost the wave a quarter of the MFMAs' time again)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            int x = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][t], bv[q][u][t], acc[u], 0, 0, 0);
+                    if (q + DEP < NQ) {
+                        const int upto = ((t * NT + u + 1) * PER + 4 * NT - 1) / (4 * NT);
+                        for (; x < upto && x < PER; ++x) load1(q + DEP, x);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if constexpr (MC) {
+            pa += (size_t)(4 * KW) * rowb;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) pb[u] += (size_t)(4 * KW) * rowb;
         }
     }
 #pragma unroll
@@ -902,12 +929,33 @@ static dim3 dual_grid(DualArgs &a, int nt, int NT, int nb)
     return dim3((unsigned)gp, 1, (unsigned)nb);
 }
 
+// K chunks of an ld above 512 and the K range of a wave in each (np_of guarantees that the division is exact)
+static inline int chunks_of(int ld) { return (ld + 511) / 512; }
+static inline int kw_of(int ld) { return ld / (4 * chunks_of(ld)); }
+
 template <int NT>
 static int launch_dual(hipStream_t st, const DualArgs &a_in, int nb)
 {
     const int nt = a_in.ld / GT;
     DualArgs a = a_in;
     const dim3 g = dual_grid(a, nt, NT, nb);
+    if (a.ld > 512) {
+        if constexpr (NT == 3) {
+#define THIP_DUAL_MC(KW) hipLaunchKernelGGL((polar_dual_k<KW, 3, true>), g, dim3(256), 0, st, a)
+            switch (kw_of(a.ld)) {
+            case 80: THIP_DUAL_MC(80); break;
+            case 96: THIP_DUAL_MC(96); break;
+            case 112: THIP_DUAL_MC(112); break;
+            case 128: THIP_DUAL_MC(128); break;
+            default: return fail(THIP_E_INVALID, "dual: ld is not one np_of() gives", __FILE__, __LINE__);
+            }
+#undef THIP_DUAL_MC
+            THIP_LAUNCH_CHECK();
+            return 0;
+        } else {
+            return fail(THIP_E_INVALID, "dual: orders above 512 run three tile-jobs per workgroup", __FILE__, __LINE__);
+        }
+    }
 #define THIP_DUAL(KW) hipLaunchKernelGGL((polar_dual_k<KW, NT>), g, dim3(256), 0, st, a)
     switch (a.ld / 4) {
     case 16: THIP_DUAL(16); break;
@@ -933,7 +981,7 @@ static int launch_dual(hipStream_t st, const DualArgs &a_in, int nb)
 // the smallest NT whose grid fits one workgroup per CU
 static int dual(hipStream_t st, DualArgs a, int nb)
 {
-    if (a.ld > 512 || a.ld % 64 != 0) return fail(THIP_E_INVALID, "dual: ld <= 512", __FILE__, __LINE__);
+    if (a.ld % 64 != 0 || (a.ld > 512 && (a.ld / 64) % chunks_of(a.ld) != 0)) return fail(THIP_E_INVALID, "dual: ld is not one np_of() gives", __FILE__, __LINE__);
     if (a.stop == nullptr) a.stop = ctx().never_stop;
     const int nt = a.ld / GT;
     static const int force_nt = getenv("THIP_PSD_DUAL_NT") ? atoi(getenv("THIP_PSD_DUAL_NT")) : 0;
@@ -954,6 +1002,7 @@ static int dual(hipStream_t st, DualArgs a, int nb)
     };
     while (NT < 3 && too_many(NT)) ++NT;
     if (force_nt >= 1 && force_nt <= 3) NT = force_nt;
+    if (a.ld > 512) NT = 3;
     return NT == 1 ? launch_dual<1>(st, a, nb) : NT == 2 ? launch_dual<2>(st, a, nb) : launch_dual<3>(st, a, nb);
 }
 
@@ -993,7 +1042,7 @@ __global__ void pack_half_k(int n, int ld, const float *__restrict__ M, const fl
 }
 
 // The whole PSD projection of a matrix of order n <= 64 in ONE workgroup, one launch for a batch (blockIdx.x = item):
-// unpack, Frobenius norm, the 45-product polar chain of polar_project() below and the symmetrised pack, all operands in
+// unpack, Frobenius norm, a 45-product quintic polar chain (the schedule rounds 1-4 ran as launches) and the symmetrised pack, all operands in
 // LDS.  At these orders the chain of launches is nothing but launch boundaries (45 x 4.4 us = 0.2 ms at any n <= 128;
 // the reference's own SDP example, partitioning_sdp, has order 48), while the products themselves are (n / 2) MFMAs per
 // wave: four waves, one 32 x 32 quadrant of the result each (one MFMA wave per SIMD), K runs over the
@@ -1074,7 +1123,7 @@ __global__ __launch_bounds__(256) void polar_small_k(int n, float *__restrict__ 
     for (int e = tid; e < PSN * PSN; e += 256) S0[e >> 6][e & 63] = fro > 0.0f ? M[e >> 6][e & 63] / fro : 0.0f;
     __syncthreads();
     ps_mat *S = &S0, *Z = &S1;
-    // the schedule of polar_project(): 11 lifting quintics (the first on 1.7 x), 3 minimax quintics, 1 Newton-Schulz
+    // 11 lifting quintics (the first on 1.7 x; band [0.3, 1.7], gain 3.94), 3 minimax quintics, 1 Newton-Schulz
     const float LIFT[3] = { 4.02942496f, -3.82532605f, 0.95951948f };
     const float TAILC[3][3] = {
         { 2.647997920f, -1.945904487f, 0.440483961f },
@@ -1133,7 +1182,8 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
         else if (gen) hipLaunchKernelGGL((gemm_pre_k<true, KW, 4, false>), g, dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch, dsym);  \
         else     hipLaunchKernelGGL((gemm_pre_k<false, KW, 4, true>), dim3(nt * (nt + 1) / 2, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch, dsym); \
     } while (0)
-    if (mode >= 2 && ld <= 512) {
+    // (a dsym product exists in the block kernels only: THIP_GEMM_MODE < 2 -- a debug setting -- does not apply to it)
+    if ((mode >= 2 || dsym != 0) && ld <= 512) {
         switch (ld / 4) {
         case 16: THIP_GEMM_PRE4(16); break;
         case 32: THIP_GEMM_PRE4(32); break;
@@ -1145,7 +1195,18 @@ int gemm(hipStream_t st, bool gen, int n, int ld, float alpha, const float *X, c
         default: THIP_GEMM_PRE4(128); break;
         }
     }
-    else if (pitch != ld || dsym != 0) return fail(THIP_E_INVALID, "gemm: a padded pitch / dsym needs ld <= 512", __FILE__, __LINE__);
+    else if ((mode >= 2 || dsym != 0) && !gen && nt % 2 == 0 && (ld / 64) % chunks_of(ld) == 0 && kw_of(ld) >= 80 && kw_of(ld) % 16 == 0) {
+        // orders above 512, symmetric result: the 32 x 64 block kernel walking K in chunks
+#define THIP_GEMM_MC(KW) hipLaunchKernelGGL((gemm_pre2_k<false, KW, true, true>), dim3(npair, 1, nb), dim3(256), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws, pitch, dsym)
+        switch (kw_of(ld)) {
+        case 80: THIP_GEMM_MC(80); break;
+        case 96: THIP_GEMM_MC(96); break;
+        case 112: THIP_GEMM_MC(112); break;
+        default: THIP_GEMM_MC(128); break;
+        }
+#undef THIP_GEMM_MC
+    }
+    else if (pitch != ld || dsym != 0) return fail(THIP_E_INVALID, "gemm: a padded pitch / dsym needs the block kernels (THIP_GEMM_MODE >= 2, a symmetric product)", __FILE__, __LINE__);
     else if (gen) hipLaunchKernelGGL(gemm_k<true>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
     else     hipLaunchKernelGGL(gemm_k<false>, g, dim3(GNW * 64), 0, st, n, ld, alpha, X, Y, beta, D, gamma, C, stop, ws);
 #undef THIP_GEMM_PRE4
@@ -2223,66 +2284,21 @@ int rebuild(hipStream_t st, size_t n, float *packed, int has_scale, float scale,
     return 0;
 }
 
-// P = (M + M sign(M)) / 2 through the matrix cores; nb items per launch (work regions ws floats apart, packed
-// vectors ps floats apart): the chain is launch-bound (8.7 us per 512^3 GEMM on 256 workgroups), so the x_y and x_s
-// projections of one iteration share its 50+ launches
-int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop,
-                  int nb, size_t ws, ptrdiff_t ps, float *rx, ptrdiff_t rps)
-{
-    const int ni = (int)n, ld = (int)np_of(n), pitch = (int)pitch_of((size_t)ld);
-    const size_t tot = (size_t)pitch * ld;
-    const unsigned g = grid_for(tot, BLK, 512);
-    float *M = k.G, *S = k.S, *Y = k.Y, *Z = k.Z, *T = k.V;
-    hipLaunchKernelGGL(unpack_k, dim3(g, 1, nb), dim3(BLK), 0, st, ni, ld, packed, has_scale, scale, M, (float *)nullptr,
-                       k.part, stop, ws, ps, pitch);
-    hipLaunchKernelGGL(scale_by_fro_k, dim3(g, 1, nb), dim3(BLK), 0, st, tot, M, k.part, (int)g, S, stop, ws, 1.0f);
-    // sign(M) = the polar factor of S = M / ||M||_F by the polar iteration S <- p_k(S S^T) S with odd quintics
-    // p_k(x) = a x + b x^3 + c x^5.  Three GEMMs per step, the polynomial folded into the second one's epilogue:
-    //   Y = S S^T ;  T = c Y Y^T + b Y + a I ;  S <- T S
-    // Phase 1 (lifting, 11 steps): ONE polynomial, the LP solution of "maximise the gain s subject to p(x) >= s x on
-    // [0, lo / s], lo <= p(x) <= hi on [lo / s, hi]" for the band [lo, hi] = [0.3, 1.7]: every singular value below the
-    // band grows by s per step and a value inside the band STAYS inside (tools/polar_coeffs.py).  Step 0 takes
-    // x <= 1 and may scale its argument by 1.7.  Relative eigenvalues >= 1e-7 are inside the band after 11 steps.
-    // The polynomial ACCEPTS (0, 1.7] and RETURNS [0.305, 1.68] (gain s = 3.94 below 0.3): with "returns <= 1.7" the LP
-    // solution has p(1.7) = 1.7, a fixed point with p' = 11 -- a singular value that reaches the interior maximum
-    // lands on it and round-off decides which way it leaves; upwards is an overflow within seven steps (it happened:
-    // a 20 x 20 iterate of test_synth_sdp_converges_to_oracle_objective, through the one-workgroup kernel's order of sums).
-    // (The unconstrained minimax composition -- "Polar Express", Amsel et al. 2025 -- is two steps shorter, but its
-    // early polynomials equioscillate between ~0 and 2: an already-large eigenvalue can be thrown back to 1e-6, below
-    // the absolute round-off of the evaluation.  Measured: 3e-5 |X| error on rank-deficient inputs instead of 2e-8.)
-    // Phase 2 (3 steps): minimax polynomials of 1 on [0.3, 1.7] -> [0.73, 1.27] -> [0.985, 1.015] -> 1 +- 2e-5.
-    // Phase 3: one Newton-Schulz step x (3 - x^2) / 2 squares the remaining error.  14 x 3 + 2 = 44 GEMMs (round 1: 13
-    // steps of 3.4445 x - 4.7750 x^3 + 2.0315 x^5, band [0.7, 1.2], and 5 Newton-Schulz steps = 49).
-    static const float LIFT[3] = { 4.02942496f, -3.82532605f, 0.95951948f };
-    static const float TAILC[3][3] = {
-        { 2.647997920f, -1.945904487f, 0.440483961f },
-        { 1.967564378f, -1.351306898f, 0.386705679f },
-        { 1.884943743f, -1.269148602f, 0.384197480f },
-    };
-    for (int it = 0; it < 14; ++it) {
-        float a, b, c;
-        if (it == 0) { a = LIFT[0] * 1.7f; b = LIFT[1] * 4.913f; c = LIFT[2] * 14.19857f; }     // p(1.7 x)
-        else if (it < 11) { a = LIFT[0]; b = LIFT[1]; c = LIFT[2]; }
-        else { a = TAILC[it - 11][0]; b = TAILC[it - 11][1]; c = TAILC[it - 11][2]; }
-        THIP_RC(gemm(st, false, ni, ld, 1.0f, S, S, 0.0f, nullptr, 0.0f, Y, stop, nb, ws, pitch));
-        THIP_RC(gemm(st, false, ni, ld, c, Y, Y, b, Y, a, T, stop, nb, ws, pitch));
-        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws, pitch));
-        float *tmp = S; S = Z; Z = tmp;
-    }
-    // Newton-Schulz x (3 - x^2) / 2:  T = -0.5 S S^T + 1.5 I ;  S <- T S
-    {
-        THIP_RC(gemm(st, false, ni, ld, -0.5f, S, S, 0.0f, nullptr, 1.5f, T, stop, nb, ws, pitch));
-        THIP_RC(gemm(st, true, ni, ld, 1.0f, T, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws, pitch));
-        float *tmp = S; S = Z; Z = tmp;
-    }
-    THIP_RC(gemm(st, true, ni, ld, 1.0f, M, S, 0.0f, nullptr, 0.0f, Z, stop, nb, ws, pitch));      // M sign(M)
-    dim3 gp((unsigned)((n + BLK - 1) / BLK), (unsigned)n, nb);
-    hipLaunchKernelGGL(pack_half_k, gp, dim3(BLK), 0, st, ni, ld, M, Z, has_scale, scale, packed, stop, ws, ps, rx, rps, pitch);
-    THIP_LAUNCH_CHECK();
-    return 0;
-}
-
-
+// P = (M + M sign(M)) / 2 through the matrix cores; nb items per launch (work regions ws floats apart, packed vectors ps floats
+// apart): the chain is launch-bound at k = 500, so the x_y and x_s projections of one iteration share its launches.
+// sign(M) = the polar factor of S = M / ||M||_F by the polar iteration S <- p(S^2) S with odd polynomials: only GEMMs.
+//   Lifting phase: ONE polynomial, the LP solution of "maximise the gain s subject to p(x) >= s x below the band, lo <= p(x) <= hi
+//   on the band" (tools/polar_coeffs.py): every singular value below the band grows by s per step and a value inside the band STAYS
+//   inside.  The polynomial ACCEPTS (0, hi] and RETURNS slightly inside the band: with "returns <= hi" the LP solution has
+//   p(hi) = hi, a fixed point with p' >> 1 -- a singular value that reaches the interior maximum lands on it and round-off decides
+//   which way it leaves; upwards is an overflow within a few steps (it happened in round 2: a 20 x 20 iterate of
+//   test_synth_sdp_converges_to_oracle_objective; tests/golden/psd_k20_band_edge_iterate.npy).  The unconstrained minimax
+//   composition ("Polar Express", Amsel et al. 2025) is two steps shorter, but its early polynomials equioscillate between ~0 and
+//   2: an already-large eigenvalue can be thrown back to 1e-6, below the absolute round-off of the evaluation (measured: 3e-5 |X|
+//   error on rank-deficient inputs instead of 2e-8).
+//   Then minimax polynomials of 1 on the band, and one Newton-Schulz step x (3 - x^2) / 2 that squares the remaining error.
+// (Rounds 1-4 ran quintic steps with general T S products, 48 launches; removed in round 6 when the degree-7 chain below learnt
+// orders above 512.)
 // Round 5: the same projection with every product SYMMETRIC and degree-7 steps -- 37 launches instead of 48.
 //   * S is kept bitwise symmetric: T S is computed like S S^T (lower triangle of tiles, mirrored; diagonal tiles averaged
 //     with their transpose, `dsym`), which turns the antisymmetric round-off of a step into a symmetric perturbation of
@@ -2297,7 +2313,7 @@ int polar_project(hipStream_t st, size_t n, float *packed, int has_scale, float 
 //     steps bring relative eigenvalues >= 1e-7 into the band (5.644^8 = 1.03e6; S_0 = 1.85 M / ||M||_F), 3 minimax
 //     steps take the band to 1 +- 8e-7, and the Newton-Schulz step shares a launch with M S:
 //       {T = 1.5 I - 0.5 S S, R = M S}  ->  M sign(M) = T R, packed by the last launch itself.
-// THIP_PSD_CHAIN=5 keeps the round-4 chain (quintic steps, general T S products).
+// Orders above 512 (round 6): the same chain, its kernels walking K in chunks of 512 (gemm_pre2_k / polar_dual_k, MC = true).
 int polar_project7(hipStream_t st, size_t n, float *packed, int has_scale, float scale, const Work &k, const int *stop,
                    int nb, size_t ws, ptrdiff_t ps, float *rx, ptrdiff_t rps)
 {
@@ -2398,11 +2414,8 @@ int eig_psd_project(hipStream_t st, size_t n, float *packed, int has_scale, floa
         return eig_psd_project_small(st, n, packed, nullptr, 1, has_scale, scale_diag, stop, nbatch, pstride, rx, rx_stride);
     }
     if (map_kind == 0 && n > POLAR_MIN_N) {
-        // orders up to 512 (ld <= 512): the all-symmetric degree-7 chain; above, or THIP_PSD_CHAIN=5: the round-4 quintic chain
-        static const int chain = getenv("THIP_PSD_CHAIN") ? atoi(getenv("THIP_PSD_CHAIN")) : 7;
-        if (chain == 7 && np_of(n) <= 512 && pitch_of(np_of(n)) % 4 == 0)
-            return polar_project7(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride, rx, rx_stride);
-        return polar_project(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride, rx, rx_stride);
+        if (pitch_of(np_of(n)) % 4 != 0) return fail(THIP_E_INVALID, "THIP_PSD_PITCH_PAD must be a multiple of 4 floats", __FILE__, __LINE__);
+        return polar_project7(st, n, packed, has_scale, scale_diag, k, stop, nbatch, ws, pstride, rx, rx_stride);
     }
     for (int z = 0; z < nbatch; ++z) {          // the Jacobi engine works on one matrix at a time
         THIP_RC(decompose(st, n, packed + z * pstride, has_scale, scale_diag, k, map_kind, stop));
