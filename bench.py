@@ -218,6 +218,7 @@ def cpu_baseline(n, n_cones_full, ni, seed, cones_sub, budget_s=25.0):
     # The reference's own f64 backend spends its iteration in 3 + 3 dgemv calls (f64lapack.rs:123-146, MKL there):
     # the same six products through numpy's BLAS on the same sub-matrix bound its iteration rate from above.
     blas = None
+    At = None
     try:
         At = np.asarray(A).reshape(n, m)            # column-major (m x n) seen row-major is A^T
         xv, yv = np.ones(n), np.ones(m)
@@ -243,7 +244,7 @@ def cpu_baseline(n, n_cones_full, ni, seed, cones_sub, budget_s=25.0):
                 "what": "3 x (A x) + 3 x (A^T y) in f64 through numpy's BLAS on the same sub-matrix, scaled by rows"}
     except Exception as e:                          # never let the optional leg break the bench line
         blas = {"error": repr(e)}
-    return {
+    sub = {
         "value": rate_sub * cones_sub / n_cones_full,
         "unit": "iter/s",
         "cores": O.num_threads(),
@@ -258,6 +259,39 @@ def cpu_baseline(n, n_cones_full, ni, seed, cones_sub, budget_s=25.0):
         "host_cpu_count": os.cpu_count(),
         "blas_gemv_bound": blas,
     }
+    A = At = None                        # (At: the BLAS leg's view of the same 13 GB)
+    # The CONFIG itself, not a sample: all n_cones_full cones (A 40 GB of f64 at the headline size), 3 + 3 iterations -- when the
+    # host can hold it; the sub-instance figure above stays beside it as the cross-check
+    full = None
+    try:
+        import psutil
+        need = 8.0 * n * n_cones_full * rows
+        if cones_sub < n_cones_full and psutil.virtual_memory().available > 1.5 * need:
+            t0 = time.perf_counter()
+            f2, A2, b2, st2, sl2 = oracle_sub_instance(n, n_cones_full, ni, seed, n_cones_full)
+            t_gen = time.perf_counter() - t0
+
+            def run_full(k):
+                t0 = time.perf_counter()
+                O.solve_matop_cones(O.param(max_iter=k, eps_acc=1e-300), f2, A2, b2, st2, sl2)
+                return time.perf_counter() - t0
+            ta, tb = run_full(3), run_full(6)
+            rate_full = 3.0 / (tb - ta)
+            full = {"value": rate_full, "unit": "iter/s", "iterations": "3 + 3 (two solves from x = 0, the second three iterations longer)",
+                    "seconds": [ta, tb], "gen_seconds": t_gen,
+                    "what": "oracle (C, f64, OpenMP %d threads) on the WHOLE instance: %d cones, A %d x %d f64 = %.0f GB"
+                            % (O.num_threads(), n_cones_full, n_cones_full * rows, n, need / 1e9)}
+            del A2
+    except Exception as e:              # the optional leg never costs the line
+        full = {"error": repr(e)}
+    if full and "value" in full:
+        out = dict(sub)
+        out.update({"value": full["value"], "sample": full["what"] + ", 3 + 3 iterations: %.3f iter/s (sub-instance of %d cones scaled by rows: %.3f)"
+                    % (full["value"], cones_sub, sub["value"]), "full_instance": full,
+                    "sub_instance": {k: sub[k] for k in ("value", "sample", "measured_sub_instance_iter_per_s", "spread_iter_per_s")}})
+        return out
+    sub["full_instance"] = full
+    return sub
 
 
 def kkt_f64(inst, x, y_local, allreduce_host, block_cones=50):
@@ -925,6 +959,10 @@ def dry_run(a, rank, world, dist, allreduce_host, cols, emu, mixed_leg):
                       "schedule_asked": a.schedule, "rows_per_gpu": plan["rows"], "cols_per_gpu": plan["cols"],
                       "parallelism": ("column-sharded A x%d" % world) if cols else ("row-sharded A x%d" % world if world > 1 else "none"),
                       "collective": "gloo (dry run)", "hbm_plan": plans},
+           "value_partitioning": ("column-sharded (one-pass schedule, one all-reduce of 2 m floats per iteration)" if cols
+                                  else ("none (one GPU)" if world == 1 else "row-sharded (north_star's form: cone-aligned row blocks, "
+                                        "2-pass schedule, all-reduce of A^T y per transposed product)")),
+           "value_column_sharded": None, "value_row_sharded": None,
            "roofline": None, "cpu_baseline": None, "objective_gate": None,
            "row_sharded": ({"rows_per_gpu": plan.get("row_leg_rows"), "value": None} if plan["row_leg_bytes"] else None),
            "time_to_eps": None}
@@ -1365,6 +1403,13 @@ def run(a):
                    "overlap_mode_run": ovi["mode"], "overlap_split_col": ovi["split_col"], "overlap_autotune_ms_per_iter": overlap_times,
                    "gen_seconds": round(t_gen, 3), "gemv_plan": fs.gemv_plan(), "sweep_plan": fs.sweep_plan(), "a_storage": a.a_storage,
                    "hbm_plan": plan},
+        # N > 1: which partitioning produced `value`, and BOTH rates at top level, so that a SCALE record cannot be read as
+        # north_star's row form when it is the column form (the other one is filled by the row_sharded leg below)
+        "value_partitioning": ("column-sharded (one-pass schedule, one all-reduce of 2 m floats per iteration)" if cols
+                               else ("none (one GPU)" if hook is None else "row-sharded (north_star's form: cone-aligned row blocks, "
+                                     "2-pass schedule, all-reduce of A^T y per transposed product)")),
+        "value_column_sharded": iters_per_s if cols else None,
+        "value_row_sharded": iters_per_s if (hook is not None and not cols) else None,
         "roofline": roofline,
         "roofline_eig": roofline_eig,
         # north_star: "same primal/dual objective as the f64 CPU reference within 1e-4 relative".  The f64 oracle runs the
@@ -1436,6 +1481,7 @@ def run(a):
                                   "overlap_autotune_ms_per_iter": times_r,
                                   "parallelism": "row-sharded A x%d (cone-aligned row blocks), all-reduce of A^T y per transposed "
                                                  "product: the partitioning north_star and configs[4] name" % world}
+            out["value_row_sharded"] = out["row_sharded"]["value"]
         except Exception as e:          # the extra leg must never cost the line
             out["row_sharded"] = {"error": repr(e), "stage": stage}
         finally:

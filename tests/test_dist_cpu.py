@@ -192,6 +192,9 @@ def test_bench_gpus_8_control_path_at_the_real_shapes_without_a_gpu():
     assert all(p["row_leg_bytes"] == 4 * 12_500 * 50_000 + 4 * 12_512 * 50_000 for p in plans)
     assert all(p["fits"] and p["total_bytes"] < 0.1 * p["hbm_bytes"] for p in plans)
     assert d["row_sharded"]["rows_per_gpu"] == 12_500
+    # the line names the partitioning behind `value` and carries both rates at top level (a SCALE record of the column form
+    # must not read as north_star's row form)
+    assert d["value_partitioning"].startswith("column-sharded") and "value_column_sharded" in d and "value_row_sharded" in d
     assert "bench.py: --gpus 8 without a launcher" in r.stderr
 
 
@@ -212,6 +215,7 @@ def test_bench_gpus_8_configs4_budget_and_a_rank_that_cannot_sweep():
     plans = d["config"]["hbm_plan"]
     assert all(p["partition"] == "rows" and p["rows"] == 50_000 and p["cols"] == 200_000 and p["row_leg_bytes"] == 0 for p in plans)
     assert d["config"]["schedule"] == "carried" and d["row_sharded"] is None
+    assert d["value_partitioning"].startswith("row-sharded")
     assert "row shards, carried schedule" in r.stderr
 
 
