@@ -4,6 +4,8 @@ solver.rs:525-570, evaluated in a skewed order), termination at the same iterati
 stopped iterate, the fall-back to the carried schedule where the kernel cannot take the problem."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -825,6 +827,28 @@ def test_publish_scope_self_test_and_its_fallback(T):
         lib.thip_sweep_publish_selftest(1, C.byref(agent), info)
     assert agent.value == 0 and f0 == 0 and f1 == 0
     assert np.array_equal(x0, x1) and np.array_equal(y0, y1)
+
+
+def test_publish_scope_verdict_is_cached_per_device(T, tmp_path):
+    """the self-test's verdict is kept in a file keyed by device / driver / runtime (THIP_CACHE_DIR): the first process of a box
+    runs the 200 sweeps and writes it, the next one reads it (info[3] == 0 sweeps run) -- 52 ms of every process start otherwise"""
+    import subprocess
+    import sys
+    code = ("import ctypes as C\nfrom totsu_amd import _lib\n_lib.init()\na, i = C.c_int(-1), (C.c_int * 4)()\n"
+            "_lib.lib.thip_sweep_publish_selftest(0, C.byref(a), i)\nprint(a.value, i[0], i[3])\n")
+    env = dict(os.environ, THIP_CACHE_DIR=str(tmp_path / "cache"))
+    env.pop("THIP_SWEEP_PUBLISH", None)
+    env.pop("THIP_NO_CACHE", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([int(v) for v in r.stdout.split()[-3:]])
+    assert outs[0] == [0, 0, 200], outs
+    assert outs[1] == [0, 0, 0], outs
+    files = os.listdir(tmp_path / "cache")
+    assert len(files) == 1 and files[0].startswith("publish_scope_"), files
 
 
 def test_stream_probe_reports_a_plausible_rate(T):

@@ -1139,6 +1139,14 @@ namespace {
 
 size_t pad64(size_t v) { return (v + 63) / 64 * 64; }
 
+// The protocol of a column-sharded run, in ONE place -- thip_solver_run, sweep_prepare, the termination test and col_shard_abort
+// (a rank that cannot plan its kernel and has to mirror its peers' collectives) must agree on it, or ranks end up in all-reduces
+// of different lengths: the all-reduced buffer [A u (mpad) ; A x_x (mpad) ; 4 x EG sums over n ; fault flag + padding (64)] and
+// the number of attempts every rank makes from the same snapshot before all of them return THIP_E_TIMEOUT.
+constexpr int COL_SHARD_ATTEMPTS = 3;
+inline size_t cs_flag_slot(size_t mpad) { return 2 * mpad + 4 * EG; }
+inline size_t cs_floats(size_t mpad) { return cs_flag_slot(mpad) + 64; }
+
 // optional per-launch timing of the dominant kernel (bench.py roofline): HIP event pairs recorded on the
 // launch stream around every GEMV kernel of products()
 struct Prof {
@@ -1769,6 +1777,9 @@ int sweep_prepare(thip_solver *s)
     if (!elem && m_eff % 4 != 0 && s->Apad != nullptr && s->ldpad >= (m_eff + 3) / 4 * 4) m_eff = (m_eff + 3) / 4 * 4;
     if (elem && m_eff % 8 != 0 && s->A16_owned && s->ld16 >= (m_eff + 7) / 8 * 8) m_eff = (m_eff + 7) / 8 * 8;
     if (!s->col_shard && s->m * s->n * esize < s->sweep_min_bytes) return 0;
+    // how the partial dots are published in this process: decided HERE, at plan time (the self-test allocates 64 MB and
+    // synchronises; left to the first sweep_pass it ran in the middle of the first batch when the autotune is off)
+    (void)sweep_publish_default();
     // the geometries the kernel offers for this matrix (group size, columns per panel); THIP_SWEEP_CLASS pins one
     SweepGeom cand[6];
     int nc = 0;
@@ -1868,7 +1879,7 @@ int sweep_prepare(thip_solver *s)
         }
     }
     if (s->col_shard) {
-        const size_t need = 2 * g.mpad + 4 * EG + 64;      // [A u ; A x_x ; 4 x EG sums over n ; "my kernel gave up" flag]
+        const size_t need = cs_floats(g.mpad);            // [A u ; A x_x ; 4 x EG sums over n ; "my kernel gave up" flag]
         if (s->cs_n != need) {
             if (s->cs_buf) { THIP_TRY(hipFree(s->cs_buf)); s->cs_buf = nullptr; }
             THIP_TRY(hipMalloc((void **)&s->cs_buf, need * sizeof(float)));
@@ -2014,7 +2025,7 @@ int one_iteration_sweep(thip_solver *s, bool last)
     // the NEXT step's (first) m-kernel at its head
     auto stat_args = [&](float *pmb) -> StatArgs {
         return StatArgs{ pns, pn_now(), pmb + 2 * gmm, pmb + 3 * gmm, (int)gmm, pn_now() + 2 * pns, pns, pmb, (int)gmm,
-                         cols ? (const float *)(s->cs_buf + 2 * s->sgeom.mpad + 4 * EG) : (const float *)nullptr,
+                         cols ? (const float *)(s->cs_buf + cs_flag_slot(s->sgeom.mpad)) : (const float *)nullptr,
                          s->par.eps_acc, s->par.eps_inf, ez, (long long)s->par.max_iter, s->xbuf };
     };
     const bool foldable = !s->no_fold;
@@ -2480,7 +2491,7 @@ static int col_shard_abort(thip_solver *s, int64_t max_steps, int64_t poll_every
 {
     hipStream_t st = ctx().stream;
     const size_t mpad = pad64(s->m);                  // SweepGeom::mpad of every plan of this m (rows round to 4 or 8, mpad to 64)
-    const size_t need = 2 * mpad + 4 * EG + 64;
+    const size_t need = cs_floats(mpad);
     if (s->cs_n != need) {
         if (s->cs_buf) { THIP_TRY(hipStreamSynchronize(st)); THIP_TRY(hipFree(s->cs_buf)); s->cs_buf = nullptr; }
         THIP_TRY(hipMalloc((void **)&s->cs_buf, need * sizeof(float)));
@@ -2490,11 +2501,11 @@ static int col_shard_abort(thip_solver *s, int64_t max_steps, int64_t poll_every
     if (max_steps >= 0 && batch > max_steps) batch = max_steps;
     const float one = 1.0f;
     bool first = s->sw_first;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < COL_SHARD_ATTEMPTS; ++attempt) {
         const int64_t calls = batch + (first ? 1 : 0);
         for (int64_t k = 0; k < calls; ++k) {
             THIP_TRY(hipMemsetAsync(s->cs_buf, 0, need * sizeof(float), st));
-            THIP_TRY(hipMemcpyAsync(s->cs_buf + 2 * mpad + 4 * EG, &one, sizeof(float), hipMemcpyHostToDevice, st));
+            THIP_TRY(hipMemcpyAsync(s->cs_buf + cs_flag_slot(mpad), &one, sizeof(float), hipMemcpyHostToDevice, st));
             THIP_RC(do_allreduce(s, s->cs_buf, s->cs_n));
         }
         THIP_TRY(hipStreamSynchronize(st));
@@ -2516,6 +2527,11 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
     THIP_RC(sweep_prepare(s));
     bool sweep = sweep_active(s);
     if (s->col_shard && !sweep) {
+        // a column shard that was never going to sweep is a caller's mistake, not a fault to be raised through collectives
+        // (without a hook do_allreduce is a no-op: the "abort" would spin through dummy calls and report a time-out)
+        if (s->allreduce == nullptr) return fail(THIP_E_INVALID, "a column-sharded solver needs an all-reduce (thip_solver_set_allreduce / _use_rccl / _use_oneshot)", __FILE__, __LINE__);
+        if (s->schedule != THIP_SCHED_SWEEP) return fail(THIP_E_INVALID, "a column-sharded solver runs THIP_SCHED_SWEEP only", __FILE__, __LINE__);
+        if (s->sparse) return fail(THIP_E_INVALID, "column shards are for a dense A", __FILE__, __LINE__);
         if (s->hst->state != THIP_ST_RUNNING || max_steps == 0) return 0;      // nothing would run on any rank
         return col_shard_abort(s, max_steps, poll_every);
     }
@@ -2544,10 +2560,12 @@ int thip_solver_run(thip_solver *s, int64_t max_steps, int64_t poll_every, thip_
             if (s->col_shard) {
                 // a column shard has no 2-pass form to fall back to: every rank restores and retries together (a transient --
                 // another process on the GPU for a moment -- passes; a placement that stays wrong fails cleanly everywhere)
-                if (++retries > 2)
+                if (++retries > COL_SHARD_ATTEMPTS - 1)
                     return fail(THIP_E_TIMEOUT, "the one-pass kernel gave up on some rank of a column-sharded run (3 attempts from the same iterate)", __FILE__, __LINE__);
                 THIP_RC(sweep_rearm(s));
-            } else if (++retries <= 1) {
+            } else if (++retries <= 1 && s->sweep_faults < 3) {
+                // (at most three faults per solve: a disturbance that keeps coming back costs a ~2 s spin-out and a re-run batch
+                // each time -- from the third on the rest of the solve runs the 2-pass schedule)
                 // one GPU: a transient (another process on the device for a moment) should not halve the rate of the 100 000
                 // iterations that may follow -- clean census, ring and error word and give the one-pass schedule ONE more batch
                 // from the restored iterate before giving it up

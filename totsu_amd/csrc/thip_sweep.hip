@@ -39,9 +39,15 @@
 // placement is not the expected one.
 #include "thip_sweep_kernel.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <mutex>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
 
 using namespace thip;
 
@@ -313,9 +319,62 @@ extern "C" int thip_test_sweep(const thip_sweep_test *t, float *host_ms, int *ho
 // ---------------------------------------------------------------------------------------------------
 namespace {
 constexpr int SELFTEST_SWEEPS = 200, SELFTEST_SPIN = 50000, SELFTEST_MAX_POLLS = 4096;
-int g_pub_state = -1;              // -1 not run, 0 wavefront-scope publish passed, 1 agent scope (failed, or no 8 x 32 device)
-int g_pub_info[4] = { 0, 0, 0, 0 };   // error word, polls summed, most polls of one gather, sweeps run
+std::atomic<int> g_pub_state{ -1 };   // -1 not run, 0 wavefront-scope publish passed, 1 agent scope (failed, or no 8 x 32 device)
+std::mutex g_pub_mutex;               // solvers on several host threads: one of them runs the self-test, the others wait for it
+int g_pub_info[4] = { 0, 0, 0, 0 };   // error word, polls summed, most polls of one gather, sweeps run (0: verdict read from the cache file)
 int g_pub_force_fail = 0;
+
+// The verdict is a property of (device, driver, runtime): it is kept in a file so that a process does not spend 52 ms (200 sweeps
+// of 252 us: 1.5 % of the k = 500 SDP's 3.5 s time-to-eps) on it at every start.  $THIP_CACHE_DIR, else $XDG_CACHE_HOME/totsu_f32hip,
+// else ~/.cache/totsu_f32hip; the file name carries device name, PCI bus, driver and runtime versions (a driver change under the
+// library is what the test exists for: it changes the key).  A FAILED verdict is trusted for a day only.
+std::string publish_cache_path()
+{
+    const char *dir = getenv("THIP_CACHE_DIR");
+    std::string base;
+    if (dir && *dir) base = dir;
+    else if (getenv("XDG_CACHE_HOME") && *getenv("XDG_CACHE_HOME")) base = std::string(getenv("XDG_CACHE_HOME")) + "/totsu_f32hip";
+    else if (getenv("HOME") && *getenv("HOME")) base = std::string(getenv("HOME")) + "/.cache/totsu_f32hip";
+    else return std::string();
+    hipDeviceProp_t prop;
+    int drv = 0, rt = 0;
+    if (hipGetDeviceProperties(&prop, ctx().device) != hipSuccess) { (void)hipGetLastError(); return std::string(); }
+    (void)hipDriverGetVersion(&drv); (void)hipRuntimeGetVersion(&rt);
+    char name[512];
+    snprintf(name, sizeof(name), "publish_scope_%s_%s_bus%02x_drv%d_rt%d", prop.name, prop.gcnArchName, prop.pciBusID, drv, rt);
+    for (char *c = name; *c; ++c) if (!((*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || (*c >= '0' && *c <= '9') || *c == '_')) *c = '-';
+    (void)mkdir(base.substr(0, base.find_last_of('/')).c_str(), 0755);
+    (void)mkdir(base.c_str(), 0755);
+    return base + "/" + name;
+}
+int publish_cache_read()
+{
+    static const int off = getenv("THIP_NO_CACHE") ? atoi(getenv("THIP_NO_CACHE")) : 0;
+    if (off) return -1;
+    const std::string p = publish_cache_path();
+    if (p.empty()) return -1;
+    FILE *f = fopen(p.c_str(), "r");
+    if (!f) return -1;
+    int verdict = -1; long long when = 0;
+    const int got = fscanf(f, "%d %lld", &verdict, &when);
+    fclose(f);
+    if (got != 2 || (verdict != 0 && verdict != 1)) return -1;
+    if (verdict == 1 && (long long)time(nullptr) - when > 86400) return -1;
+    return verdict;
+}
+void publish_cache_write(int verdict)
+{
+    static const int off = getenv("THIP_NO_CACHE") ? atoi(getenv("THIP_NO_CACHE")) : 0;
+    if (off) return;
+    const std::string p = publish_cache_path();
+    if (p.empty()) return;
+    const std::string tmp = p + ".tmp" + std::to_string((long long)getpid());
+    FILE *f = fopen(tmp.c_str(), "w");
+    if (!f) return;
+    fprintf(f, "%d %lld\n", verdict, (long long)time(nullptr));
+    fclose(f);
+    (void)rename(tmp.c_str(), p.c_str());
+}
 
 int publish_selftest_run()
 {
@@ -326,8 +385,9 @@ int publish_selftest_run()
     const size_t nv = 6 * m + 12 * n;
     if (hipMalloc((void **)&vec, nv * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); hipFree(A); g_pub_state = 1; return 0; }
     hipStream_t st = ctx().stream;
-    THIP_TRY(hipMemsetAsync(A, 0, m * n * sizeof(float), st));
-    THIP_TRY(hipMemsetAsync(vec, 0, nv * sizeof(float), st));
+    if (hipMemsetAsync(A, 0, m * n * sizeof(float), st) != hipSuccess || hipMemsetAsync(vec, 0, nv * sizeof(float), st) != hipSuccess) {
+        (void)hipGetLastError(); hipFree(A); hipFree(vec); g_pub_state = 1; return 0;
+    }
     thip_sweep_test t;
     memset(&t, 0, sizeof(t));
     float *p = vec;
@@ -340,8 +400,9 @@ int publish_selftest_run()
     int info[8] = { 0 };
     float ms[2];
     const int rc = run_test_sweep(&t, SELFTEST_SPIN, ms, info);
-    THIP_TRY(hipStreamSynchronize(st));
+    const hipError_t se = hipStreamSynchronize(st);
     hipFree(A); hipFree(vec);
+    if (se != hipSuccess) { (void)hipGetLastError(); g_pub_state = 1; g_pub_info[0] = -1; return 0; }
     if (rc != 0) { g_pub_state = 1; g_pub_info[0] = -1; return 0; }      // no 8 x 32 placement, or the shape was refused: the documented form
     g_pub_info[0] = info[0]; g_pub_info[1] = info[5]; g_pub_info[2] = info[6]; g_pub_info[3] = SELFTEST_SWEEPS;
     const bool ok = info[0] == 0 && info[6] <= SELFTEST_MAX_POLLS && !g_pub_force_fail;
@@ -354,12 +415,20 @@ namespace thip {
 // 0: partial dots published with plain stores (the self-test passed), 1: at agent scope
 int sweep_publish_default()
 {
-    if (g_pub_state < 0) {
-        static const int env = getenv("THIP_SWEEP_PUBLISH") ? atoi(getenv("THIP_SWEEP_PUBLISH")) : -1;      // 0 / 1: no self-test
-        if (env == 0 || env == 1) g_pub_state = env;
-        else if (publish_selftest_run() != 0) g_pub_state = 1;
+    if (g_pub_state.load() < 0) {
+        std::lock_guard<std::mutex> lock(g_pub_mutex);
+        if (g_pub_state.load() < 0) {
+            static const int env = getenv("THIP_SWEEP_PUBLISH") ? atoi(getenv("THIP_SWEEP_PUBLISH")) : -1;      // 0 / 1: no self-test
+            const int cached = (env == 0 || env == 1) ? -1 : publish_cache_read();
+            if (env == 0 || env == 1) g_pub_state = env;
+            else if (cached >= 0) g_pub_state = cached;
+            else {
+                if (publish_selftest_run() != 0) g_pub_state = 1;
+                publish_cache_write(g_pub_state.load());
+            }
+        }
     }
-    return g_pub_state;
+    return g_pub_state.load();
 }
 }  // namespace thip
 
@@ -368,7 +437,11 @@ extern "C" int thip_sweep_publish_selftest(int mode, int *host_agent_scope, int 
     THIP_NEED_INIT();
     // mode 0: the cached verdict (run now if it has not been); 1: run again; 2: run again and treat it as FAILED (test hook)
     if (mode < 0 || mode > 2) return fail(THIP_E_INVALID, "thip_sweep_publish_selftest: mode 0, 1 or 2", __FILE__, __LINE__);
-    if (mode != 0) { g_pub_force_fail = mode == 2; THIP_RC(publish_selftest_run()); g_pub_force_fail = 0; }
+    if (mode != 0) {
+        // (a forced run is a test's: its verdict does not go to the cache file)
+        std::lock_guard<std::mutex> lock(g_pub_mutex);
+        g_pub_force_fail = mode == 2; THIP_RC(publish_selftest_run()); g_pub_force_fail = 0;
+    }
     const int v = sweep_publish_default();
     if (host_agent_scope) *host_agent_scope = v;
     if (host_info) for (int i = 0; i < 4; ++i) host_info[i] = g_pub_info[i];
