@@ -51,7 +51,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "totsu_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".inc")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "libtotsu_oracle" not in src, f
