@@ -2,7 +2,8 @@
 // the reference's trait-level calling sequence `Solver::solve((op_c, op_a, op_b, cone, work))` in C++, on three
 // known-answer problems: the nostd_cortex-m LP (x = [2, 2]), a second-order-cone problem (x = [-1, -1], the data of
 // totsu/tests/socp.rs test_socp1 in stacked form) and the 2x2 PSD problem of totsu_core/tests/solver.rs (x = -2); then
-// the LP once more through FusedSolver (the device-resident loop) with f16 storage of A and an f32 finish.
+// the LP with op_a as a sparse user Operator (SparseOp), and once more through FusedSolver (the device-resident loop) with f16
+// storage of A and an f32 finish.
 #include <cstdio>
 #include "totsu_f32hip.hpp"
 
@@ -45,6 +46,21 @@ int main()
         DeviceVec w(ConePSD::query_worklen(3));
         ConePSD cone(w.slice(), 1e-12f);
         bad += run("psd", 1, 3, { 1 }, { 0, -1.41421356f, -3 }, { 1, 0, 10 }, cone, { -2 }, 1e-3f);
+    }
+    {   // the LP with op_a as a caller's sparse Operator (SparseOp over thip_sptile_*: the matrix by columns, one copy on the device)
+        ConeRPos cone;
+        DeviceVec dc(std::vector<float>{ -1, 0 }), db(std::vector<float>{ 6, 6, 1 });
+        MatOp op_c(2, 1, dc.slice()), op_b(3, 1, db.slice());
+        SparseOp op_a(3, 2, { 0, 3, 6 }, { 0, 1, 2, 0, 1, 2 }, { 4, -1, -1, -1, 4, -1 });
+        DeviceVec work(Solver::query_worklen(3, 2));
+        Solver s;
+        s.par.max_iter = 100000;
+        s.par.eps_acc = 1e-5f;
+        const SolverError e = s.solve(op_c, op_a, op_b, cone, work.slice());
+        const std::vector<float> w = work.to_host();
+        const bool ok = e == SolverError::Ok && std::fabs(w[0] - 2.f) <= 1e-3f && std::fabs(w[1] - 2.f) <= 1e-3f;
+        printf("%-10s status %d after %lld iterations: x = [%.5f, %.5f]  %s\n", "sparse-lp", (int)e, (long long)s.iters, w[0], w[1], ok ? "OK" : "MISMATCH");
+        bad += ok ? 0 : 1;
     }
     {   // the same LP through the device-resident loop, with the 16-bit storage of A and a resumed finish on f32:
         // f16 passes to eps 1e-4, then thip_solver_set_a_storage(F32) + resume with eps 1e-5 from the same iterate

@@ -88,6 +88,31 @@ struct MatOp : Operator {                      // MatType::General, column-major
     void absadd_rows(Slice sigma) const override { if (nr && nc) chk(thip_absadd_rows(nr, nc, array.p, sigma.p)); }
 };
 
+// A sparse operator held ONCE on the device (thip_sptile_*): a caller's own Operator in the pattern of
+// examples/imgnr_udef/src/prob_op_a.rs:33-120, given by columns (host arrays: int64 column pointers, int32 row indices, f32 values)
+struct SparseOp : Operator {
+    size_t nr, nc;
+    thip_sptile *mat = nullptr;
+    SparseOp(size_t r, size_t c, const std::vector<int64_t> &colptr, const std::vector<int32_t> &rowidx, const std::vector<float> &vals)
+        : nr(r), nc(c)
+    {
+        chk(thip_sptile_create(r, c, vals.size(), colptr.data(), rowidx.data(), vals.data(), &mat));
+    }
+    SparseOp(const SparseOp &) = delete;
+    SparseOp &operator=(const SparseOp &) = delete;
+    ~SparseOp() override { thip_sptile_destroy(mat); }
+    std::pair<size_t, size_t> size() const override { return { nr, nc }; }
+    void impl(bool tr, float alpha, Slice x, float beta, Slice y) const
+    {
+        if (nr > 0 && nc > 0) chk(thip_sptile_mv(mat, tr ? 1 : 0, alpha, x.p, beta, y.p, 0));
+        else F32HIP::scale(beta, y);
+    }
+    void op(float a, Slice x, float b, Slice y) const override { impl(false, a, x, b, y); }                 // operator.rs:40-57
+    void trans_op(float a, Slice x, float b, Slice y) const override { impl(true, a, x, b, y); }            // operator.rs:59-75
+    void absadd_cols(Slice tau) const override { if (nr && nc) chk(thip_sptile_mv(mat, 1, 1.0f, tau.p, 1.0f, tau.p, 1)); }      // operator.rs:82-113
+    void absadd_rows(Slice sigma) const override { if (nr && nc) chk(thip_sptile_mv(mat, 0, 1.0f, sigma.p, 1.0f, sigma.p, 1)); } // operator.rs:123-154
+};
+
 // ---- Cones -----------------------------------------------------------------------------------------------------------
 struct Cone {
     virtual ~Cone() {}

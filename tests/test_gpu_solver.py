@@ -553,7 +553,7 @@ def test_cpp_trait_mirror_host():
         g.build()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("OK") == 4 and "fused-lp" in r.stdout
+    assert r.stdout.count("OK") == 5 and "fused-lp" in r.stdout and "sparse-lp" in r.stdout
 
 
 @pytest.mark.parametrize("grid", [(2, 3), (3, 4), (8, 6)])       # (8, 6): the size of the reference's example, PSD order 48

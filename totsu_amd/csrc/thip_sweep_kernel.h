@@ -4,6 +4,8 @@
 #pragma once
 #include "thip_common.h"
 
+#include <type_traits>
+
 namespace thip {
 
 constexpr int SW_THREADS = 512;            // 7 streaming waves + 1 service wave
@@ -221,9 +223,17 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         float vv[NSLOT][EPV], yv[NSLOT][EPV], acc1[NSLOT][EPV], acc2[NSLOT][EPV];
         int roff[NSLOT];
         bool valid[NSLOT];
+        // 16-bit storage (round 6): streaming wave 3 shares its SIMD with the service wave, whose chain takes most of a ~0.9 us
+        // interval at priority 3 -- wave 3 is the one the barrier waits for.  A member's rows rarely fill the last slot (12 500 rows
+        // of bf16: 219 of its 448 lanes), so in the LAST slot the waves take their 64-lane pieces in the order 0 1 2 4 5 6 3, and
+        // a wave whose piece lies behind the member's rows runs the body with one slot less (no loads, no dots, no axpy for it).
+        // Wave 3 then carries 3 slots of 4 at BASELINE configs[2].  The f32 instances are untouched (ELEM == 0: vt = tid, one body).
+        const int pos_last = ELEM != 0 ? (wave == 3 ? SW_CW - 1 : (wave > 3 ? wave - 1 : wave)) : wave;
+        const int vt_last = pos_last * 64 + lane;
+        const bool last_live = ELEM == 0 || NSLOT == 1 || row0 + EPV * (pos_last * 64 + SW_CT * (NSLOT - 1)) + EPV <= row1;
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
-            const int r = row0 + EPV * (tid + SW_CT * sl);
+            const int r = row0 + EPV * ((sl == NSLOT - 1 ? vt_last : tid) + SW_CT * sl);
             valid[sl] = r + EPV <= row1;
             roff[sl] = valid[sl] ? r : (row0 + EPV <= a.m ? row0 : 0);
 #pragma unroll
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
                 const int j = min(c0 + (P) * W + q, jmax);                                                     \
                 const char *colp = reinterpret_cast<const char *>(a.A) + (size_t)j * a.lda * ESIZE;            \
-                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl)                                           \
+                _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl)                                           \
                     stg[S][q][sl] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(colp + (size_t)roff[sl] * ESIZE)); \
             }                                                                                                  \
         } while (0)
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             float p_[2 * W];                                                                                   \
             _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
                 float d1 = 0.0f, d2 = 0.0f;                                                                    \
-                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl) {                                         \
+                _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) {                                         \
                     float e_[EPV];                                                                             \
                     sw_unpack<ELEM>(stg[S][q][sl], e_);                                                        \
                     _Pragma("unroll") for (int k = 0; k < EPV; ++k) {                                          \
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             if (SW_DBG(a) & 16) { asm volatile("" :: "v"(stg[S][0][0][1]), "v"(stg[S][W - 1][NSLOT - 1][2])); break; } \
             _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
                 const float s1 = scal[(P) & 1][q], s2 = scal[(P) & 1][W + q];                                  \
-                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl) {                                         \
+                _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) {                                         \
                     float e_[EPV];                                                                             \
                     sw_unpack<ELEM>(stg[S][q][sl], e_);                                                        \
                     _Pragma("unroll") for (int k = 0; k < EPV; ++k) {                                          \
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             }                                                                                                  \
             /* pin the sums here: the optimiser otherwise sinks the axpys of all NS intervals to the end of the */ \
             /* unrolled block and keeps every stage and every interval's scalars alive until then */           \
-            _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl)                                               \
+            _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl)                                               \
                 _Pragma("unroll") for (int k = 0; k < EPV; ++k) {                                              \
                     asm volatile("" : "+v"(acc1[sl][k]));                                                      \
                     asm volatile("" : "+v"(acc2[sl][k]));                                                      \
@@ -301,14 +311,14 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         do {                                                                                                   \
             f32x4 *slot_ = sw_lds + (size_t)((P) % LS) * (W * NSLOT * SW_CT) + tid;                            \
             _Pragma("unroll") for (int q = 0; q < W; ++q)                                                      \
-                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl) slot_[(q * NSLOT + sl) * SW_CT] = stg[S][q][sl]; \
+                _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) slot_[(q * NSLOT + sl) * SW_CT] = stg[S][q][sl]; \
         } while (0)
 #define SW_AXPY_LDS(P)                                                                                         \
         do {                                                                                                   \
             const f32x4 *slot_ = sw_lds + (size_t)((P) % LS) * (W * NSLOT * SW_CT) + tid;                      \
             _Pragma("unroll") for (int q = 0; q < W; ++q) {                                                    \
                 const float s1 = scal[(P) & 1][q], s2 = scal[(P) & 1][W + q];                                  \
-                _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl) {                                         \
+                _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl) {                                         \
                     const f32x4 d_ = slot_[(q * NSLOT + sl) * SW_CT];                                          \
                     float e_[EPV];                                                                             \
                     sw_unpack<ELEM>(d_, e_);                                                                   \
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
                     }                                                                                          \
                 }                                                                                              \
             }                                                                                                  \
-            _Pragma("unroll") for (int sl = 0; sl < NSLOT; ++sl)                                               \
+            _Pragma("unroll") for (int sl = 0; sl < NSL; ++sl)                                               \
                 _Pragma("unroll") for (int k = 0; k < EPV; ++k) {                                              \
                     asm volatile("" : "+v"(acc1[sl][k]));                                                      \
                     asm volatile("" : "+v"(acc2[sl][k]));                                                      \
@@ -339,24 +349,33 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         }
         // fill (one block of NS intervals: LAGL < NS), steady state, drain -- three loops, so that the stage registers
         // have one assignment per loop (two forms of the body inside ONE loop doubled them)
-        int it0 = 0;
-        for (; it0 < LAGT; it0 += NS) { SW_GUARDED_BLOCK(it0); }
-        SW_PHASE(2);
-        for (; it0 + NS <= npan; it0 += NS) {
-            // every phase active, no guards: the waits on the loads are counted, not drained
+        auto stream = [&](auto nsl_c) {
+            constexpr int NSL = decltype(nsl_c)::value;           // slots this wave streams: NSLOT, or NSLOT - 1 (see last_live)
+            int it0 = 0;
+            for (; it0 < LAGT; it0 += NS) { SW_GUARDED_BLOCK(it0); }
+            SW_PHASE(2);
+            for (; it0 + NS <= npan; it0 += NS) {
+                // every phase active, no guards: the waits on the loads are counted, not drained
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int it = it0 + s;
-                SW_LOADS(s, it);
-                SW_DOTS((s + NS - DLAG) % NS, it - DLAG);
-                sw_barrier_dbg(SW_DBG(a));
-                if constexpr (LS == 0) { SW_AXPY((s + 1) % NS, it - LAGL); }
-                else { SW_AXPY_LDS(it - LAGT); SW_SPILL((s + 1) % NS, it - LAGL); }
+                for (int s = 0; s < NS; ++s) {
+                    const int it = it0 + s;
+                    SW_LOADS(s, it);
+                    SW_DOTS((s + NS - DLAG) % NS, it - DLAG);
+                    sw_barrier_dbg(SW_DBG(a));
+                    if constexpr (LS == 0) { SW_AXPY((s + 1) % NS, it - LAGL); }
+                    else { SW_AXPY_LDS(it - LAGT); SW_SPILL((s + 1) % NS, it - LAGL); }
+                }
             }
+            SW_PHASE(3);
+            for (; it0 < total; it0 += NS) { SW_GUARDED_BLOCK(it0); }
+            SW_PHASE(4);
+        };
+        if constexpr (ELEM != 0 && NSLOT > 1) {
+            if (last_live) stream(std::integral_constant<int, NSLOT>{});
+            else stream(std::integral_constant<int, NSLOT - 1>{});
+        } else {
+            stream(std::integral_constant<int, NSLOT>{});
         }
-        SW_PHASE(3);
-        for (; it0 < total; it0 += NS) { SW_GUARDED_BLOCK(it0); }
-        SW_PHASE(4);
 #undef SW_GUARDED_BLOCK
 #undef SW_LOADS
 #undef SW_DOTS
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl)
             if (valid[sl]) {
-                const int r = row0 + EPV * (tid + SW_CT * sl);
+                const int r = row0 + EPV * ((sl == NSLOT - 1 ? vt_last : tid) + SW_CT * sl);
 #pragma unroll
                 for (int k = 0; k < EPV; k += 4) {
                     *reinterpret_cast<float4 *>(h1 + r + k) = make_float4(acc1[sl][k], acc1[sl][k + 1], acc1[sl][k + 2], acc1[sl][k + 3]);
