@@ -224,16 +224,24 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
         int roff[NSLOT];
         bool valid[NSLOT];
         // 16-bit storage (round 6): streaming wave 3 shares its SIMD with the service wave, whose chain takes most of a ~0.9 us
-        // interval at priority 3 -- wave 3 is the one the barrier waits for.  A member's rows rarely fill the last slot (12 500 rows
-        // of bf16: 219 of its 448 lanes), so in the LAST slot the waves take their 64-lane pieces in the order 0 1 2 4 5 6 3, and
-        // a wave whose piece lies behind the member's rows runs the body with one slot less (no loads, no dots, no axpy for it).
-        // Wave 3 then carries 3 slots of 4 at BASELINE configs[2].  The f32 instances are untouched (ELEM == 0: vt = tid, one body).
-        const int pos_last = ELEM != 0 ? (wave == 3 ? SW_CW - 1 : (wave > 3 ? wave - 1 : wave)) : wave;
-        const int vt_last = pos_last * 64 + lane;
-        const bool last_live = ELEM == 0 || NSLOT == 1 || row0 + EPV * (pos_last * 64 + SW_CT * (NSLOT - 1)) + EPV <= row1;
+        // interval at priority 3 -- wave 3 is the one the barrier waits for.  A member's rows rarely fill its 7 x NSLOT wave-slots
+        // (12 500 rows of bf16: 1563 of 1792 lane-slots), so the rows are dealt out WAVE BY WAVE in the order 0 1 2 4 5 6 3 -- a wave
+        // takes all its slots before the next one starts -- and a wave runs the body with as many slots as it has rows for (no loads,
+        // no dots, no axpy for the others).  Wave 3 then carries what is left: 27 lanes of one slot at BASELINE configs[2].
+        // The f32 instances are untouched (ELEM == 0: slot-major rows, one body).
+        const int pos = ELEM != 0 ? (wave == 3 ? SW_CW - 1 : (wave > 3 ? wave - 1 : wave)) : wave;
+        auto row_of = [&](const int sl) { return ELEM != 0 ? row0 + EPV * (pos * 64 * NSLOT + sl * 64 + lane) : row0 + EPV * (tid + SW_CT * sl); };
+        // slots of this wave that hold a row (wave-uniform: lane 0's row of the slot)
+        int my_slots = NSLOT;
+        if constexpr (ELEM != 0) {
+            my_slots = 0;
+#pragma unroll
+            for (int sl = 0; sl < NSLOT; ++sl) my_slots += (row0 + EPV * (pos * 64 * NSLOT + sl * 64) + EPV <= row1) ? 1 : 0;
+            my_slots = __builtin_amdgcn_readfirstlane(my_slots);
+        }
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
-            const int r = row0 + EPV * ((sl == NSLOT - 1 ? vt_last : tid) + SW_CT * sl);
+            const int r = row_of(sl);
             valid[sl] = r + EPV <= row1;
             roff[sl] = valid[sl] ? r : (row0 + EPV <= a.m ? row0 : 0);
 #pragma unroll
@@ -370,9 +378,13 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
             for (; it0 < total; it0 += NS) { SW_GUARDED_BLOCK(it0); }
             SW_PHASE(4);
         };
-        if constexpr (ELEM != 0 && NSLOT > 1) {
-            if (last_live) stream(std::integral_constant<int, NSLOT>{});
-            else stream(std::integral_constant<int, NSLOT - 1>{});
+        if constexpr (ELEM != 0) {
+            // (NSLOT <= 4 for 16-bit storage: at most five bodies)
+            if (my_slots == NSLOT) stream(std::integral_constant<int, NSLOT>{});
+            else if (NSLOT > 1 && my_slots == NSLOT - 1) stream(std::integral_constant<int, (NSLOT > 1 ? NSLOT - 1 : 0)>{});
+            else if (NSLOT > 2 && my_slots == NSLOT - 2) stream(std::integral_constant<int, (NSLOT > 2 ? NSLOT - 2 : 0)>{});
+            else if (NSLOT > 3 && my_slots == NSLOT - 3) stream(std::integral_constant<int, (NSLOT > 3 ? NSLOT - 3 : 0)>{});
+            else stream(std::integral_constant<int, 0>{});
         } else {
             stream(std::integral_constant<int, NSLOT>{});
         }
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(SW_THREADS) void sweep_k(const SweepArgs a)
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl)
             if (valid[sl]) {
-                const int r = row0 + EPV * ((sl == NSLOT - 1 ? vt_last : tid) + SW_CT * sl);
+                const int r = row_of(sl);
 #pragma unroll
                 for (int k = 0; k < EPV; k += 4) {
                     *reinterpret_cast<float4 *>(h1 + r + k) = make_float4(acc1[sl][k], acc1[sl][k + 1], acc1[sl][k + 2], acc1[sl][k + 3]);
