@@ -799,11 +799,13 @@ def run_sparse(a, rank, T, lib, _lib):
             t_conv = time.perf_counter() - t0
             del A
             fs2.run(a.warmup, poll_every=max(a.warmup, 1))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            fs2.run(a.steps, poll_every=a.steps)
-            torch.cuda.synchronize()
-            e2 = time.perf_counter() - t0
+            e2 = 1e30
+            for _ in range(3):              # (best of three regions: this leg has come out 4x slow on its first region now and then)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fs2.run(a.steps, poll_every=a.steps)
+                torch.cuda.synchronize()
+                e2 = min(e2, time.perf_counter() - t0)
             out["two_copy_csr"] = {"value": a.steps / e2, "unit": "iter/s", "ms_per_step": 1e3 * e2 / a.steps,
                                    "what": "round 5's form on the same instance: CSR of A and CSR of A^T (two copies of the values), carried "
                                            "schedule, 32 B per stored entry and iteration (thip_spmv_csr); host conversion + upload %.1f s" % t_conv,

@@ -78,7 +78,6 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const bool two = a.in1 != nullptr;
     for (int i = tid; i < SPT_TB; i += SPT_THREADS) { lo0[i] = 0.0f; lo1[i] = 0.0f; }
-    bool prev_staged = true;            // (the zeroing above is ordered by the first visit's barrier)
     // N product: ds_add_f32 is slow on this part (two per entry bound the first kernel at 0.8 TB/s of entries whatever the bank
     // layout), and in a dense column block it is not needed: a column of a full tile is 1024 quads -- exactly one step of this
     // loop -- so a lane meets the SAME four rows in every step.  The lane keeps the sums of "its" rows in registers for as long
@@ -86,29 +85,17 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
     // scattered pattern: the old cost plus a compare).
     int hold[2][4] = { { -1, -1, -1, -1 }, { -1, -1, -1, -1 } };
     float h0[2][4] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } }, h1[2][4] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } };
-    for (int ref = it.ref0; ref < it.ref1; ++ref) {
-        const int t = a.order ? a.order[ref] : ref;
-        const SptTile tl = a.tiles[t];
-        long long e0 = tl.e0, e1 = tl.e0 + tl.cnt;
-        if (ref == it.ref0) e0 = it.e_first;
-        if (ref == it.ref1 - 1) e1 = it.e_last;
-        const int inb = TPH ? tl.rb : tl.cw;
-        const bool staged = (e1 - e0) >= a.stage_min && !a.abs_mode;
-        if (staged || prev_staged) __syncthreads();
-        const float *in0b = a.in0 + (size_t)inb * SPT_TB;
-        const float *in1b = (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB;
-        if (staged) {
-            const int lim = a.in_len - inb * SPT_TB;
-            for (int i = tid; i < SPT_TB; i += SPT_THREADS) lin[spt_slot(i)] = i < lim ? make_float2(in0b[i], in1b[i]) : make_float2(0.0f, 0.0f);
-            __syncthreads();
-        }
-        prev_staged = staged;
+    __syncthreads();                    // the accumulators are zero before any wave adds to them
+    // one visit of a tile: entries [e0, e1) streamed by the threads t0, t0 + stride, ... (the whole workgroup: tid / 512; one wave
+    // alone: lane / 64), the in-vector's block from LDS (staged) or straight from L2
+    auto visit = [&](const long long e0, const long long e1, const bool staged, const float *in0b, const float *in1b, const int t0,
+                     const int stride) {
         const long long q1 = e1 >> 2;
-        for (long long qb = e0 >> 2; qb < q1; qb += 2 * SPT_THREADS) {
+        for (long long qb = e0 >> 2; qb < q1; qb += 2 * stride) {
             f32x4 av[2]; i32x4 iv[2]; bool ok[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const long long q = qb + tid + u * SPT_THREADS;
+                const long long q = qb + t0 + u * stride;
                 ok[u] = q < q1;
                 const long long qq = ok[u] ? q : q1 - 1;
                 av[u] = __builtin_nontemporal_load(a.vals + qq);
@@ -178,6 +165,44 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
                 }
             }
         }
+            };
+    auto clip = [&](const int ref, const SptTile &tl, long long &e0, long long &e1) {
+        e0 = tl.e0; e1 = tl.e0 + tl.cnt;
+        if (ref == it.ref0) e0 = it.e_first;
+        if (ref == it.ref1 - 1) e1 = it.e_last;
+    };
+    // (1) the TINY visits (at most one step of a wave: 512 entries), one WAVE each, eight at a time: a visit is a chain of dependent
+    // round trips -- tile record, entries, in-vector -- and an item of a very sparse operator walks dozens of them (the equality rows
+    // of the partitioning SDP: 31 tiles of 16 entries); no barrier, the accumulators take LDS adds from any wave
+    constexpr long long TINY = 2 * 64 * 4;
+    const int wave = tid >> 6;
+    for (int ref = it.ref0 + wave; ref < it.ref1; ref += SPT_THREADS / 64) {
+        const SptTile tl = a.tiles[a.order ? a.order[ref] : ref];
+        long long e0, e1;
+        clip(ref, tl, e0, e1);
+        if (e1 - e0 > TINY) continue;
+        const int inb = TPH ? tl.rb : tl.cw;
+        visit(e0, e1, false, a.in0 + (size_t)inb * SPT_TB, (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB, lane, 64);
+    }
+    // (2) the others, the whole workgroup on each; from stage_min entries on with the in-vector's block staged in LDS
+    bool prev_staged = false;
+    for (int ref = it.ref0; ref < it.ref1; ++ref) {
+        const SptTile tl = a.tiles[a.order ? a.order[ref] : ref];
+        long long e0, e1;
+        clip(ref, tl, e0, e1);
+        if (e1 - e0 <= TINY) continue;
+        const int inb = TPH ? tl.rb : tl.cw;
+        const float *in0b = a.in0 + (size_t)inb * SPT_TB;
+        const float *in1b = (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB;
+        const bool staged = (e1 - e0) >= a.stage_min && !a.abs_mode;
+        if (staged) {
+            if (prev_staged) __syncthreads();           // the previous visit's reads of `lin` are done
+            const int lim = a.in_len - inb * SPT_TB;
+            for (int i = tid; i < SPT_TB; i += SPT_THREADS) lin[spt_slot(i)] = i < lim ? make_float2(in0b[i], in1b[i]) : make_float2(0.0f, 0.0f);
+            __syncthreads();
+            prev_staged = true;
+        }
+        visit(e0, e1, staged, in0b, in1b, tid, SPT_THREADS);
     }
     if (!TPH) {
 #pragma unroll
