@@ -787,6 +787,17 @@ def run_sparse(a, rank, T, lib, _lib):
             rec["primal_objective"], rec["dual_objective"] = pobj, dobj
             out["objective_gate"]["this_run"] = {"what": "primal vs dual objective of THIS run's answer (f64 dot products on the host)",
                                                  "rel_gap": abs(pobj - dobj) / max(1.0, abs(pobj))}
+            # north_star's gate -- the f64 CPU reference's objective within 1e-4 -- where the oracle's answer for this very
+            # instance is on file (tools/sparse_sdp_oracle_objective.py: 10 minutes of 8 CPU threads for k = 500)
+            try:
+                ev = json.load(open(os.path.join(ROOT, "profiles", "r06_sparse_sdp_oracle_objective.json")))
+                if a.workload == "sparse-sdp" and ev["workload"] == inst["what"] and ev["eps_acc"] == to_eps:
+                    out["objective_gate"]["this_run"].update({
+                        "oracle_primal_objective": ev["primal_objective"], "oracle_iterations": ev["iterations"],
+                        "rel_diff_vs_f64_oracle": abs(pobj - ev["primal_objective"]) / max(1.0, abs(ev["primal_objective"])),
+                        "oracle_source": "profiles/r06_sparse_sdp_oracle_objective.json (oracle through its sparse user-operator, same instance, same eps_acc)"})
+            except Exception:
+                pass
         out["time_to_eps"] = rec
         fs3.destroy()
     # ---- A/B: the same instance on round 5's two CSR copies (carried schedule: 2 dual gathers per iteration) ----
