@@ -228,6 +228,71 @@ def test_sparse_sweep_converges_to_the_dense_answer_multi_tile(T):
         fs.destroy()
 
 
+def test_sptile_edge_cases_and_errors_through_the_c_abi(T):
+    # what the boundary must accept (operator.rs: zero-sized operators, a matrix without entries, entries only in the padding of a
+    # quad) and what it must refuse loudly (row index out of range, column pointers that do not span nnz)
+    import ctypes as C
+    from totsu_amd import _lib
+    from totsu_amd._lib import ThipError, E_INVALID, lib
+    from totsu_amd.sparse import SpTile, SparseMatOp
+    L = T.F32HIP
+    # no entries at all: y = beta y, absadd adds nothing
+    z = SparseMatOp(L, sp.csc_matrix((5, 3), dtype=np.float32))
+    x, y = _sl(L, np.ones(3)), _sl(L, np.arange(5.0))
+    z.op(2.0, x, 0.5, y)
+    assert np.allclose(y.get_ref(), 0.5 * np.arange(5.0))
+    t = _sl(L, np.full(3, 7.0))
+    z.absadd_cols(t)
+    assert np.allclose(t.get_ref(), 7.0)
+    z.drop()
+    # zero rows / zero columns (matop.rs:83-85: the product of an empty operator is beta * y)
+    for shape in ((0, 4), (4, 0)):
+        e = SparseMatOp(L, sp.csc_matrix(shape, dtype=np.float32))
+        xs, ys = _sl(L, np.ones(shape[1])), _sl(L, np.full(shape[0], 3.0))
+        e.op(1.0, xs, 2.0, ys)
+        assert np.allclose(ys.get_ref(), 6.0)
+        xt, yt = _sl(L, np.ones(shape[0])), _sl(L, np.full(shape[1], 3.0))
+        e.trans_op(1.0, xt, -1.0, yt)
+        assert np.allclose(yt.get_ref(), -3.0)
+        e.drop()
+    # one entry in the last row and column of a matrix that spans three tiles each way (quads of 1 + 3 padding entries)
+    big = sp.csc_matrix(([2.5], ([9999], [8500])), shape=(10000, 8501), dtype=np.float32)
+    o = SparseMatOp(L, big)
+    assert o.t.info()["tiles"] == 1 and o.t.info()["nnz_stored"] == 4
+    x, y = _sl(L, np.arange(8501.0)), _sl(L, np.zeros(10000))
+    o.op(1.0, x, 0.0, y)
+    yy = y.get_ref()
+    assert yy[9999] == 2.5 * 8500 and not yy[:9999].any()
+    o.drop()
+    # refused: a row index beyond n_row, column pointers that do not end at nnz
+    cp = np.array([0, 1, 2], np.int64)
+    ri = np.array([0, 5], np.int32)
+    va = np.array([1.0, 2.0], np.float32)
+    h = C.c_void_p()
+    with pytest.raises(ThipError) as ei:
+        lib.thip_sptile_create(3, 2, 2, cp.ctypes.data, ri.ctypes.data, va.ctypes.data, C.byref(h))
+    assert ei.value.code == E_INVALID
+    cp2 = np.array([0, 1, 1], np.int64)
+    with pytest.raises(ThipError) as ei:
+        lib.thip_sptile_create(3, 2, 2, cp2.ctypes.data, ri.ctypes.data, va.ctypes.data, C.byref(h))
+    assert ei.value.code == E_INVALID
+    # a sparse operator whose shape is not the problem's is refused by the solver
+    st = SpTile(sp.csc_matrix(np.eye(4, dtype=np.float32)))
+    with pytest.raises(AssertionError):                      # (the Python layer's own check)
+        T.FusedSolver(3, 4, st, np.zeros(4, np.float32), np.zeros(3, np.float32), [1], [4])
+    db, dc = T.DeviceBuffer(4, zero=True), T.DeviceBuffer(3, zero=True)
+    seg_t, seg_l = (C.c_int32 * 1)(1), (C.c_int64 * 1)(4)
+    prob = _lib.Problem(3, 4, None, db.ptr, dc.ptr, None, 1, C.cast(seg_t, C.POINTER(C.c_int32)), C.cast(seg_l, C.POINTER(C.c_int64)))
+    par = T.fused._c_param(T.SolverParam())
+    hs = C.c_void_p()
+    lib.thip_solver_create(C.byref(prob), C.byref(par), _lib.SCHED_SWEEP, C.byref(hs))
+    with pytest.raises(ThipError) as ei:                     # (and the library's)
+        lib.thip_solver_set_sptile(hs, st.h)
+    assert ei.value.code == E_INVALID
+    lib.thip_solver_destroy(hs)
+    st.free()
+
+
 class _DiffOp:
     """A user-defined matrix-free Operator built only from LinAlg primitives, in the pattern of
     examples/imgnr_udef/src/prob_op_a.rs: the (n-1) x n forward-difference matrix D (D x)_i = x_{i+1} - x_i, never

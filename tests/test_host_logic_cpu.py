@@ -376,3 +376,42 @@ def test_bench_f64_gates_for_lp_and_sdp_lines_on_oracle_solutions():
     # and it does tell a wrong answer: y = 0 is feasible for the cone but leaves the residual at ||c||
     g0 = bench.kkt_f64_sdp(inst, ro.x.astype(np.float32), np.zeros(sk, dtype=np.float32))
     assert g0["dual_residual_rel_f64"] > 0.1
+
+
+def test_bench_sparse_workload_constructions_are_the_reference_examples():
+    """bench.py --workload sparse-lp / sparse-sdp build their operators directly in compressed-column form (GB-sized at the default
+    sizes): at small sizes they are, entry for entry, the dense constructions of the reference's examples that tests/problems.py
+    restates (examples/l1reg_lp/src/main.rs:50-116; examples/partitioning_sdp/src/main.rs:45-78 through ProbSDP's stacking,
+    sdp.rs:271-280), and the oracle's sparse user-operator solves them to the dense oracle's answer"""
+    import importlib.util
+    import sys
+    import scipy.sparse as sp
+    from problems import l1reg_lp, partitioning_sdp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    i = bench.sparse_lp_instance(20, seed=0)
+    c, G, h = l1reg_lp(20, seed=0)
+    A = sp.csc_matrix((i["vals"], i["rowidx"], i["colptr"]), shape=(i["m"], i["n"]))
+    assert A.has_sorted_indices or True
+    assert np.abs(A.toarray() - G).max() <= 2e-7 and np.abs(i["c"] - c).max() <= 1e-7 and np.abs(i["b"] - h).max() <= 1e-7
+    assert A.nnz == 2 * 20 * 20 + 8 * 20 and i["seg_type"] == [O.CONE_RPOS] and i["seg_len"] == [80]
+    ro_d = O.solve_lp(O.param(eps_acc=1e-4), c, G, h, np.zeros((0, c.size)), [])
+    ro_s = O.solve_csc_cones(O.param(eps_acc=1e-4), i["c"], i["colptr"], i["rowidx"], i["vals"], i["b"], i["seg_type"], i["seg_len"])
+    assert ro_d.status == ro_s.status == O.OK and abs(ro_d.iters - ro_s.iters) <= max(3, 0.01 * ro_d.iters)
+    assert abs(float(c @ ro_d.x) - float(c @ ro_s.x)) <= 1e-4 * (1 + abs(float(c @ ro_d.x)))
+    # partitioning_sdp on a 5 x 6 grid: the stacked [symmat_f ; mat_a] with -1 / -sqrt 2 entries and the equality rows
+    j = bench.sparse_sdp_instance(30, seed=2)
+    w, syms_f, mat_a, vec_b = partitioning_sdp(5, 6, seed=2)
+    sk = 465
+    A = sp.csc_matrix((j["vals"], j["rowidx"], j["colptr"]), shape=(j["m"], j["n"])).toarray()
+    jj = np.repeat(np.arange(30), np.arange(1, 31))
+    ii = np.arange(sk) - jj * (jj + 1) // 2
+    ref = np.vstack([np.array(syms_f[:-1]).T * np.where(ii == jj, 1.0, np.sqrt(2.0))[:, None], mat_a])
+    assert np.abs(A - ref).max() <= 1e-6 and np.abs(j["c"] - w).max() <= 1e-6
+    assert j["seg_type"] == [O.CONE_PSD, O.CONE_ZERO] and j["seg_len"] == [sk, 30] and np.all(j["b"][sk:] == 1.0) and not j["b"][:sk].any()
