@@ -155,8 +155,9 @@ int thip_spmv_csr(size_t n_row, size_t n_col, size_t nnz, const int64_t *dev_row
  * compressed-sparse-column form (int64 column pointers, int32 row indices, f32 values -- what a MatBuild<General> with its zeros
  * dropped holds, matbuild/mod.rs:22-41) into 4096 x 4096 tiles of {value, local row | local column << 16} entries; both A x and
  * A^T y stream the same 8 bytes per entry with 16-byte loads and scatter into LDS accumulators -- no second copy of the values,
- * no global atomics (thip_sptile.hip has the measurements behind the format).  Sums are not bitwise reproducible from run to run
- * (LDS atomics).  thip_sptile_mv is `Operator::op / trans_op` (operator.rs:40-75) for such an operator: y = alpha A x + beta y,
+ * no global atomics (thip_sptile.hip has the measurements behind the format).  The accumulators are 64-bit fixed-point words fed by
+ * integer LDS adds: the sums are bitwise reproducible from run to run.
+ * thip_sptile_mv is `Operator::op / trans_op` (operator.rs:40-75) for such an operator: y = alpha A x + beta y,
  * transpose != 0: A^T; abs_mode != 0: |A| and x = 1 (absadd_rows / absadd_cols, operator.rs:82-154).  x, y on the device. */
 typedef struct thip_sptile thip_sptile;
 int thip_sptile_create(size_t n_row, size_t n_col, size_t nnz, const int64_t *host_colptr, const int32_t *host_rowidx,

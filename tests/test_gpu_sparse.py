@@ -293,6 +293,43 @@ def test_sptile_edge_cases_and_errors_through_the_c_abi(T):
     st.free()
 
 
+def test_tiled_sparse_products_are_bitwise_reproducible(T):
+    # the LDS accumulators of the tiled products are 64-bit fixed-point words fed by INTEGER adds: whatever order the waves reach
+    # them in, the sums are the same -- two operators built from the same matrix, and two runs of the loop, agree bit for bit
+    from totsu_amd.sparse import SparseMatOp
+    L = T.F32HIP
+    rng = np.random.default_rng(11)
+    a = sp.random(9000, 6000, density=0.01, format="csc", random_state=rng, dtype=np.float64)
+    a.data = rng.standard_normal(a.nnz) * np.exp(rng.uniform(-8, 8, a.nnz))          # 7 decades of magnitudes
+    x = rng.standard_normal(6000).astype(np.float32)
+    yv = rng.standard_normal(9000).astype(np.float32)
+    outs = []
+    for _ in range(3):
+        op = SparseMatOp(L, a)
+        sy, sx = _sl(L, np.zeros(9000)), _sl(L, np.zeros(6000))
+        op.op(1.0, _sl(L, x), 0.0, sy)
+        op.trans_op(1.0, _sl(L, yv), 0.0, sx)
+        outs.append((sy.get_ref().copy(), sx.get_ref().copy()))
+        op.drop()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+    d = a.toarray()
+    assert np.all(np.abs(outs[0][0] - d @ x) <= 1e-5 * (np.abs(d) @ np.abs(x)) + 1e-30)
+    assert np.all(np.abs(outs[0][1] - d.T @ yv) <= 1e-5 * (np.abs(d.T) @ np.abs(yv)) + 1e-30)
+    # the loop: two solvers on the same sparse LP stop at the same iteration with the same bits
+    c, G, h = l1reg_lp(60, seed=4)
+    A = sp.csc_matrix(G.astype(np.float32))
+    p = T.SolverParam()
+    p.eps_acc = 1e-3
+    res = []
+    for _ in range(2):
+        fs = T.FusedSolver(c.size, h.size, A, h.astype(np.float32), c.astype(np.float32), [1], [h.size], p, "sweep")
+        xs, ys = fs.solve()
+        res.append((fs.status().iters, xs, ys))
+        fs.destroy()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
 class _DiffOp:
     """A user-defined matrix-free Operator built only from LinAlg primitives, in the pattern of
     examples/imgnr_udef/src/prob_op_a.rs: the (n-1) x n forward-difference matrix D (D x)_i = x_{i+1} - x_i, never

@@ -11,7 +11,7 @@
 // (row block, column block), entry = {f32 value, u32 (local row | local column << 16)}, tiles ordered by (row block, column
 // block), entries inside a tile in the caller's CSC order (column, then row), every tile padded to whole 16-byte quads.  Both
 // products stream the same 8 bytes per entry with 16-byte loads; the scatter side of either product goes to an accumulator of
-// one block (2 x 4096 floats) in LDS (ds_add_f32: no global atomic anywhere), the gather side reads the in-vector's block from
+// one block (2 x 4096 fixed-point words) in LDS (integer LDS adds: no global atomic anywhere), the gather side reads the in-vector's block from
 // LDS (staged once per tile visit) or, for a visit of fewer than 8192 entries, straight from L2.
 //   N product (A [x0 x1]): a workgroup owns (row block, slice): walks that row block's tiles -- contiguous in memory --, in = the
 //       column block's slice of x, out = the row block's accumulators; entries of one column hit distinct rows: conflict-free.
@@ -22,9 +22,8 @@
 // Every (block, slice) writes its 2 x 4096 partial sums to part[slice][2][pad] when it is done; the consumer (the m-tail
 // kernels of the one-pass schedule, sp_col_k below, finalize_partials) adds the slices in a fixed order.  Slices exist so
 // that a matrix with few blocks still fills 256 CUs: ~1024 items per product, at most nnz / (16 dim) slices (the partials'
-// traffic stays under 1/16 of the entries').  The order in which the waves of ONE workgroup reach an LDS accumulator is not fixed:
-// sums differ in the last bits from run to run (the dense schedules are bitwise reproducible; this one is not, and its tests
-// compare to tolerances).
+// traffic stays under 1/16 of the entries').  The order in which the waves of ONE workgroup reach an LDS accumulator is not fixed,
+// but the accumulators are fixed-point words and the adds integer adds (see sp_tile_k): the sums are bitwise reproducible.
 //
 // The conic loop on this format (THIP_SCHED_SWEEP with thip_solver_set_sptile) is the dense one-pass schedule's recurrence in
 // three launches: T product with [v, x_y] -> sp_col_k (per column: the two scalar updates of thip_sweep_kernel.h's service wave,
@@ -33,7 +32,9 @@
 #include "thip_common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
+#include <limits>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -46,7 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SPT_TB = 4096;            // rows / columns per block
-constexpr int SPT_THREADS = 512;
+constexpr int SPT_THREADS = 1024;          // one workgroup per CU: 96 KB of LDS (two 64-bit accumulator blocks + the staged in-vector block)
 constexpr int SPT_STAGE_MIN = 8192;     // entries of a tile visit from which the in-vector's block is staged in LDS
 
 struct SptTile { long long e0; int cnt, rb, cw, pad_; };                                   // entries [e0, e0 + cnt), cnt % 4 == 0
@@ -66,21 +67,72 @@ struct SptArgs {
     float *part; size_t opad;           // [slice][2][opad]
     int abs_mode; const int *stop;
     int stage_min;                      // entries of a tile visit from which the in-vector's block is staged in LDS
+    // fixed-point accumulation (see sp_tile_k): block maxima of |in0| / |in1| left by sp_absmax_k (nmax each, in1's behind in0's),
+    // the exponent bound of the stored values and the bits of headroom for the longest row (N) / column (T)
+    const float *xmax; int nmax; int a_exp; int head_bits;
 };
+
+constexpr int SPT_NMAX = 256;           // block maxima per in-vector
+
+// block maxima of |x0|, |x1| (x1 may be NULL): part[b], part[SPT_NMAX + b]; every block of the grid writes its slot
+__global__ __launch_bounds__(256) void sp_absmax_k(const float *__restrict__ x0, const float *__restrict__ x1, int len, float *__restrict__ part)
+{
+    __shared__ float sh[16];
+    float m0 = 0.0f, m1 = 0.0f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) {
+        m0 = fmaxf(m0, fabsf(x0[i]));
+        if (x1) m1 = fmaxf(m1, fabsf(x1[i]));
+    }
+    // (max of non-negative floats = max of their bit patterns: block_min on the negated values)
+    m0 = -block_min(-m0, sh);
+    m1 = -block_min(-m1, sh);
+    if (threadIdx.x == 0) { part[blockIdx.x] = m0; part[SPT_NMAX + blockIdx.x] = m1; }
+}
+
+// The accumulators are 64-bit FIXED-POINT words and the LDS adds INTEGER adds (round 6, second half).  tools/lds_atomic_probe.hip:
+// ds_add_f32 runs at 0.33 lane-adds per clock per CU on this part, ds_add_u32 at 7.4, ds_add_u64 at 5.4-6.7 (profiles/
+// r06_lds_atomic_rates.txt) -- the float form was what bounded every scattered pattern (0.64 TB/s of entries).  A product p = a x is
+// added as (int64)(p * 2^k): with |a| < 2^(a_exp + 1) (the matrix's, known at build time), |x| <= xmax (sp_absmax_k, one small launch
+// in front of the product) and at most 2^head_bits terms per out element (the longest row / column), k = 62 - head_bits - (bound of
+// the product's exponent) keeps every partial sum inside 63 bits; the resolution is 2^-(60 - head_bits) of the largest possible
+// product -- finer than an f32 accumulator's.  And integer adds are associative: whatever order the waves reach an accumulator
+// in, the sum is the same -- the products are BITWISE REPRODUCIBLE again (the register sums of the dense path and the wave sums
+// of the T product have a fixed order by construction).
+__device__ __forceinline__ double spt_scale(const float *xm, int nmax, int a_exp, int head_bits, float *sh, double *inv)
+{
+    // every workgroup forms the same maximum from the same block maxima
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < nmax; i += blockDim.x) m = fmaxf(m, xm[i]);
+    m = -block_min(-m, sh);
+    int ex = 0;
+    if (m > 0.0f && m < __builtin_inff()) (void)frexpf(m, &ex);          // m < 2^ex
+    const int k = 62 - head_bits - (a_exp + 1 + ex);
+    *inv = ldexp(1.0, -k);
+    return ldexp(1.0, k);
+}
+__device__ __forceinline__ void spt_add(unsigned long long *acc, float p, double S)
+{
+    atomicAdd(acc, (unsigned long long)(long long)((double)p * S));
+}
 
 template <bool TPH>
 __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
 {
-    __shared__ float2 lin[SPT_TB];
-    __shared__ float lo0[SPT_TB], lo1[SPT_TB];
+    extern __shared__ unsigned long long spt_lds[];
+    unsigned long long *const lo0 = spt_lds, *const lo1 = spt_lds + SPT_TB;
+    float2 *const lin = reinterpret_cast<float2 *>(spt_lds + 2 * SPT_TB);
+    __shared__ float shm[16];
     if (*a.stop != 0) return;
     const SptItem it = a.items[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63;
     const bool two = a.in1 != nullptr;
-    for (int i = tid; i < SPT_TB; i += SPT_THREADS) { lo0[i] = 0.0f; lo1[i] = 0.0f; }
-    // N product: ds_add_f32 is slow on this part (two per entry bound the first kernel at 0.8 TB/s of entries whatever the bank
-    // layout), and in a dense column block it is not needed: a column of a full tile is 1024 quads -- exactly one step of this
-    // loop -- so a lane meets the SAME four rows in every step.  The lane keeps the sums of "its" rows in registers for as long
+    for (int i = tid; i < SPT_TB; i += SPT_THREADS) { lo0[i] = 0ull; lo1[i] = 0ull; }
+    double inv0 = 1.0, inv1 = 1.0;
+    const double S0 = a.abs_mode ? ldexp(1.0, 62 - a.head_bits - (a.a_exp + 2)) : spt_scale(a.xmax, a.nmax, a.a_exp, a.head_bits, shm, &inv0);
+    const double S1 = (two && !a.abs_mode) ? spt_scale(a.xmax + SPT_NMAX, a.nmax, a.a_exp, a.head_bits, shm, &inv1) : 1.0;
+    if (a.abs_mode) inv0 = ldexp(1.0, -(62 - a.head_bits - (a.a_exp + 2)));
+    // N product: in a dense column block no LDS add is needed at all: a column of a full tile is 1024 quads -- one step of this
+    // loop, or half of one -- so a lane meets the SAME four rows in every step.  The lane keeps the sums of "its" rows in registers for as long
     // as the rows of its next quad are the ones it holds, and pays the LDS adds only when they change (every step, for a
     // scattered pattern: the old cost plus a compare).
     int hold[2][4] = { { -1, -1, -1, -1 }, { -1, -1, -1, -1 } };
@@ -124,7 +176,7 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
                     const int first = __builtin_amdgcn_readfirstlane(oi[0]);
                     if (__all(ok[u] && same && oi[0] == first)) {
                         const float w0 = wave_sum_dpp(s0), w1 = two ? wave_sum_dpp(s1) : 0.0f;
-                        if (lane == 0) { atomicAdd(&lo0[first], w0); if (two) atomicAdd(&lo1[first], w1); }
+                        if (lane == 0) { spt_add(&lo0[first], w0, S0); if (two) spt_add(&lo1[first], w1, S1); }
                     } else {
                         // several columns in the wave: a segmented sum over the lanes (keys ascend with the lane: the stream is
                         // column-sorted), one LDS add per column and wave instead of one per entry.  A lane whose quad straddles
@@ -138,7 +190,7 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     if (oi[e] == key) { a0 += p0[e]; a1 += p1[e]; }
-                                    else { atomicAdd(&lo0[oi[e]], p0[e]); if (two) atomicAdd(&lo1[oi[e]], p1[e]); }
+                                    else { spt_add(&lo0[oi[e]], p0[e], S0); if (two) spt_add(&lo1[oi[e]], p1[e], S1); }
                                 }
                             }
                         }
@@ -149,14 +201,14 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
                             if (lane >= d && kk == key) { a0 += t0; a1 += t1; }
                         }
                         const int kn = __shfl_down(key, 1, 64);
-                        if ((lane == 63 || kn != key) && key != 0x7fffffff) { atomicAdd(&lo0[key], a0); if (two) atomicAdd(&lo1[key], a1); }
+                        if ((lane == 63 || kn != key) && key != 0x7fffffff) { spt_add(&lo0[key], a0, S0); if (two) spt_add(&lo1[key], a1, S1); }
                     }
                 } else if (ok[u]) {
                     const bool keep = oi[0] == hold[u][0] && oi[1] == hold[u][1] && oi[2] == hold[u][2] && oi[3] == hold[u][3];
                     if (!keep) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if (hold[u][e] >= 0) { atomicAdd(&lo0[hold[u][e]], h0[u][e]); if (two) atomicAdd(&lo1[hold[u][e]], h1[u][e]); }
+                            if (hold[u][e] >= 0) { spt_add(&lo0[hold[u][e]], h0[u][e], S0); if (two) spt_add(&lo1[hold[u][e]], h1[u][e], S1); }
                             hold[u][e] = oi[e]; h0[u][e] = 0.0f; h1[u][e] = 0.0f;
                         }
                     }
@@ -209,13 +261,16 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (hold[u][e] >= 0) { atomicAdd(&lo0[hold[u][e]], h0[u][e]); if (two) atomicAdd(&lo1[hold[u][e]], h1[u][e]); }
+                if (hold[u][e] >= 0) { spt_add(&lo0[hold[u][e]], h0[u][e], S0); if (two) spt_add(&lo1[hold[u][e]], h1[u][e], S1); }
     }
     __syncthreads();
     const size_t r0 = (size_t)it.out_block * SPT_TB;
     float *o0 = a.part + (size_t)it.slice * 2 * a.opad + r0, *o1 = o0 + a.opad;
     for (int i = tid; i < SPT_TB; i += SPT_THREADS)
-        if (r0 + i < a.opad) { o0[i] = lo0[spt_slot(i)]; if (two) o1[i] = lo1[spt_slot(i)]; }
+        if (r0 + i < a.opad) {
+            o0[i] = (float)((double)(long long)lo0[spt_slot(i)] * inv0);
+            if (two) o1[i] = (float)((double)(long long)lo1[spt_slot(i)] * inv1);
+        }
 }
 
 // The per-column step of the one-pass recurrence (the arithmetic of sweep_k's service wave, thip_sweep_kernel.h): gT / g3 = the
@@ -318,6 +373,10 @@ struct thip_sptile {
     SptItem *itemsN = nullptr, *itemsT = nullptr;
     // partial sums of the trait-level products (thip_sptile_mv), made on first use
     float *partN = nullptr, *partT = nullptr;
+    // fixed-point accumulation: |value| < 2^(a_exp + 1); at most 2^headN / 2^headT entries in a row / column; block maxima of the
+    // in-vectors of the launch in flight (2 x SPT_NMAX floats)
+    int a_exp = 0, headN = 1, headT = 1;
+    float *xmax = nullptr;
 };
 
 namespace thip {
@@ -342,10 +401,23 @@ int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const floa
     a.in0 = in0; a.in1 = in1; a.in_len = (int)(tphase ? M->m : M->n);
     a.part = part; a.opad = tphase ? M->npad : M->mpad;
     a.abs_mode = abs_mode; a.stop = stop ? stop : ctx().never_stop;
+    a.xmax = M->xmax; a.a_exp = M->a_exp; a.head_bits = tphase ? M->headT : M->headN; a.nmax = 1;
+    if (!abs_mode) {
+        const int len = a.in_len;
+        a.nmax = (int)std::min<size_t>(SPT_NMAX, std::max<size_t>(1, ((size_t)len + 1023) / 1024));
+        hipLaunchKernelGGL(sp_absmax_k, dim3(a.nmax), dim3(256), 0, st, in0, in1, len, M->xmax);
+    }
+    constexpr size_t lds = (size_t)SPT_TB * (2 * sizeof(unsigned long long) + sizeof(float2));
+    static bool attr_set = false;
+    if (!attr_set) {
+        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
     static const int stage_min = getenv("THIP_SPT_STAGE_MIN") ? atoi(getenv("THIP_SPT_STAGE_MIN")) : SPT_STAGE_MIN;
     a.stage_min = stage_min;
-    if (tphase) hipLaunchKernelGGL(sp_tile_k<true>, dim3(items), dim3(SPT_THREADS), 0, st, a);
-    else hipLaunchKernelGGL(sp_tile_k<false>, dim3(items), dim3(SPT_THREADS), 0, st, a);
+    if (tphase) hipLaunchKernelGGL(sp_tile_k<true>, dim3(items), dim3(SPT_THREADS), lds, st, a);
+    else hipLaunchKernelGGL(sp_tile_k<false>, dim3(items), dim3(SPT_THREADS), lds, st, a);
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -385,14 +457,30 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
     if (n && colptr && (colptr[0] != 0 || (size_t)colptr[n] != nnz)) return fail(THIP_E_INVALID, "column pointers do not span nnz", __FILE__, __LINE__);
     // entries per (row block, column block)
     std::vector<int64_t> cnt(nrb * ncw ? nrb * ncw : 1, 0);
+    std::vector<int32_t> rowlen(m ? m : 1, 0);
+    int64_t max_col = 0;
+    float amax = 0.0f;
     for (size_t j = 0; j < n; ++j) {
         if (colptr[j + 1] < colptr[j]) return fail(THIP_E_INVALID, "column pointers decrease", __FILE__, __LINE__);
         int64_t *crow = cnt.data() + j / SPT_TB;
+        max_col = std::max<int64_t>(max_col, colptr[j + 1] - colptr[j]);
         for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
             const int32_t r = rowidx[k];
             if (r < 0 || (size_t)r >= m) return fail(THIP_E_INVALID, "row index out of range", __FILE__, __LINE__);
             ++crow[(size_t)(r / SPT_TB) * ncw];
+            ++rowlen[r];
+            const float av = std::fabs(vals[k]);
+            if (av > amax && av < std::numeric_limits<float>::infinity()) amax = av;
         }
+    }
+    {
+        // the fixed-point accumulators' bounds: |value| < 2^(a_exp + 1), at most 2^head terms per out element (+ 1 bit of slack)
+        int ex = 0;
+        if (amax > 0.0f) (void)std::frexp(amax, &ex);           // amax < 2^ex
+        M->a_exp = ex - 1;
+        const int64_t max_row = m ? *std::max_element(rowlen.begin(), rowlen.end()) : 0;
+        auto bits = [](int64_t c) { int b = 0; while (((int64_t)1 << b) < c) ++b; return b + 1; };
+        M->headN = bits(std::max<int64_t>(max_row, 1)); M->headT = bits(std::max<int64_t>(max_col, 1));
     }
     std::vector<SptTile> tiles;
     std::vector<int64_t> cur(cnt.size(), -1);       // write cursor of a tile; -1: empty
@@ -434,8 +522,11 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
     for (size_t cw = 0; cw < ncw; ++cw)
         for (size_t rb = 0; rb < nrb; ++rb)
             if (tile_of[rb * ncw + cw] >= 0) order.push_back(tile_of[rb * ncw + cw]);
-    // items: ~1024 per product, at least 32 768 entries each, at most nnz / (16 dim) (<= 256) slices per block
-    const int64_t per_item = std::max<int64_t>((int64_t)(M->nnz_pad / 1024), 32768);
+    // items: ~512 per product (two per CU: one workgroup of 1024 threads is resident per CU, and every item costs a fill and a drain
+    // of its pipeline -- 1024 items measured 2.5 % slower on the 4.3 GB LP, 768 worse still: a third round with a quarter of the CUs),
+    // at least 32 768 entries each, at most nnz / (16 dim) (<= 256) slices per block
+    static const int items_target = getenv("THIP_SPT_ITEMS") ? std::max(1, atoi(getenv("THIP_SPT_ITEMS"))) : 512;
+    const int64_t per_item = std::max<int64_t>((int64_t)(M->nnz_pad / items_target), 32768);
     auto cap_of = [&](size_t dim) { return (int)std::min<size_t>(256, std::max<size_t>(1, M->nnz_pad / (16 * std::max<size_t>(dim, 1)))); };
     const int capN = cap_of(m), capT = cap_of(n);
     std::vector<SptItem> itN, itT;
@@ -502,6 +593,8 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
     THIP_RC(upload(order, &M->order));
     THIP_RC(upload(itN, &M->itemsN));
     THIP_RC(upload(itT, &M->itemsT));
+    THIP_TRY(hipMalloc((void **)&M->xmax, 2 * SPT_NMAX * sizeof(float)));
+    THIP_TRY(hipMemset(M->xmax, 0, 2 * SPT_NMAX * sizeof(float)));
     return 0;
 }
 
@@ -527,7 +620,7 @@ int thip_sptile_destroy(thip_sptile *M)
     if (!M) return 0;
     if (ctx().inited) (void)hipStreamSynchronize(ctx().stream);
     for (void *p : { (void *)M->vals, (void *)M->idx, (void *)M->tiles, (void *)M->order, (void *)M->itemsN, (void *)M->itemsT,
-                     (void *)M->partN, (void *)M->partT })
+                     (void *)M->partN, (void *)M->partT, (void *)M->xmax })
         if (p) (void)hipFree(p);
     delete M;
     return 0;
