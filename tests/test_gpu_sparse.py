@@ -264,6 +264,24 @@ def test_sptile_edge_cases_and_errors_through_the_c_abi(T):
     yy = y.get_ref()
     assert yy[9999] == 2.5 * 8500 and not yy[:9999].any()
     o.drop()
+    # a non-finite entry in the in-vector is answered with NaN (the fixed-point accumulators cannot carry it: it must not vanish),
+    # and magnitudes far from 1 are as good as near it (the fixed-point scale follows the in-vector's maximum)
+    rng = np.random.default_rng(3)
+    mat = sp.random(300, 200, density=0.05, format="csc", random_state=rng, dtype=np.float64)
+    mat.data = rng.standard_normal(mat.nnz)
+    o = SparseMatOp(L, mat)
+    bad = np.ones(200)
+    bad[17] = np.nan
+    y = _sl(L, np.zeros(300))
+    o.op(1.0, _sl(L, bad), 0.0, y)
+    assert np.isnan(y.get_ref()).all()
+    for scale in (1e-30, 1e25):
+        xv = (rng.standard_normal(200) * scale).astype(np.float32)
+        y = _sl(L, np.zeros(300))
+        o.op(1.0, _sl(L, xv), 0.0, y)
+        d = mat.toarray()
+        assert np.all(np.abs(y.get_ref() - d @ xv.astype(np.float64)) <= 1e-5 * (np.abs(d) @ np.abs(xv.astype(np.float64))) + 1e-44)
+    o.drop()
     # refused: a row index beyond n_row, column pointers that do not end at nnz
     cp = np.array([0, 1, 2], np.int64)
     ri = np.array([0, 5], np.int32)

@@ -80,8 +80,10 @@ __global__ __launch_bounds__(256) void sp_absmax_k(const float *__restrict__ x0,
     __shared__ float sh[16];
     float m0 = 0.0f, m1 = 0.0f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) {
-        m0 = fmaxf(m0, fabsf(x0[i]));
-        if (x1) m1 = fmaxf(m1, fabsf(x1[i]));
+        // (a NaN counts as an infinite entry: the product then answers NaN instead of dropping it -- fmaxf would)
+        const float v0 = fabsf(x0[i]);
+        m0 = fmaxf(m0, v0 == v0 ? v0 : __builtin_inff());
+        if (x1) { const float v1 = fabsf(x1[i]); m1 = fmaxf(m1, v1 == v1 ? v1 : __builtin_inff()); }
     }
     // (max of non-negative floats = max of their bit patterns: block_min on the negated values)
     m0 = -block_min(-m0, sh);
@@ -105,7 +107,8 @@ __device__ __forceinline__ double spt_scale(const float *xm, int nmax, int a_exp
     for (int i = threadIdx.x; i < nmax; i += blockDim.x) m = fmaxf(m, xm[i]);
     m = -block_min(-m, sh);
     int ex = 0;
-    if (m > 0.0f && m < __builtin_inff()) (void)frexpf(m, &ex);          // m < 2^ex
+    if (!(m < __builtin_inff())) { *inv = __builtin_nan(""); return 1.0; }    // an infinite / NaN entry in the in-vector: the product is NaN
+    if (m > 0.0f) (void)frexpf(m, &ex);                                   // m < 2^ex
     const int k = 62 - head_bits - (a_exp + 1 + ex);
     *inv = ldexp(1.0, -k);
     return ldexp(1.0, k);
