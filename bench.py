@@ -765,7 +765,7 @@ def run_sparse(a, rank, T, lib, _lib):
         p2 = T.SolverParam()
         p2.eps_acc = to_eps
         p2.state_arith = a.state
-        budget = min(a.to_eps_budget, 240.0)
+        budget = a.to_eps_budget if a.to_eps is not None else min(a.to_eps_budget, 240.0)      # (the default leg stays short)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         fs3 = T.FusedSolver(n, m, spt, inst["b"], inst["c"], inst["seg_type"], inst["seg_len"], p2, a.schedule)

@@ -48,6 +48,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SPT_TB = 4096;            // rows / columns per block
 constexpr int SPT_THREADS = 1024;          // one workgroup per CU: 96 KB of LDS (two 64-bit accumulator blocks + the staged in-vector block)
+constexpr int SPT_THREADS_LITE = 512;      // an operator without a visit worth staging: no in-vector block, 64 KB, two workgroups per CU
 constexpr int SPT_STAGE_MIN = 8192;     // entries of a tile visit from which the in-vector's block is staged in LDS
 
 struct SptTile { long long e0; int cnt, rb, cw, pad_; };                                   // entries [e0, e0 + cnt), cnt % 4 == 0
@@ -118,12 +119,15 @@ __device__ __forceinline__ void spt_add(unsigned long long *acc, float p, double
     atomicAdd(acc, (unsigned long long)(long long)((double)p * S));
 }
 
-template <bool TPH>
-__global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
+// LITE: every tile visit of the operator is below the staging threshold (a very sparse operator: a stencil, the partitioning SDP) --
+// no staged block, 64 KB of LDS, 512 threads: two workgroups per CU, whose fills and drains overlap
+template <bool TPH, bool LITE = false>
+__global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile_k(const SptArgs a)
 {
+    constexpr int SPT_THREADS = LITE ? thip::SPT_THREADS_LITE : thip::SPT_THREADS;
     extern __shared__ unsigned long long spt_lds[];
     unsigned long long *const lo0 = spt_lds, *const lo1 = spt_lds + SPT_TB;
-    float2 *const lin = reinterpret_cast<float2 *>(spt_lds + 2 * SPT_TB);
+    float2 *const lin = reinterpret_cast<float2 *>(spt_lds + 2 * SPT_TB);      // (LITE: never touched)
     __shared__ float shm[16];
     if (*a.stop != 0) return;
     const SptItem it = a.items[blockIdx.x];
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(SPT_THREADS) void sp_tile_k(const SptArgs a)
         const int inb = TPH ? tl.rb : tl.cw;
         const float *in0b = a.in0 + (size_t)inb * SPT_TB;
         const float *in1b = (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB;
-        const bool staged = (e1 - e0) >= a.stage_min && !a.abs_mode;
+        const bool staged = !LITE && (e1 - e0) >= a.stage_min && !a.abs_mode;
         if (staged) {
             if (prev_staged) __syncthreads();           // the previous visit's reads of `lin` are done
             const int lim = a.in_len - inb * SPT_TB;
@@ -380,6 +384,7 @@ struct thip_sptile {
     // in-vectors of the launch in flight (2 x SPT_NMAX floats)
     int a_exp = 0, headN = 1, headT = 1;
     float *xmax = nullptr;
+    int64_t max_visit = 0;      // entries of the largest tile
 };
 
 namespace thip {
@@ -410,17 +415,27 @@ int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const floa
         a.nmax = (int)std::min<size_t>(SPT_NMAX, std::max<size_t>(1, ((size_t)len + 1023) / 1024));
         hipLaunchKernelGGL(sp_absmax_k, dim3(a.nmax), dim3(256), 0, st, in0, in1, len, M->xmax);
     }
-    constexpr size_t lds = (size_t)SPT_TB * (2 * sizeof(unsigned long long) + sizeof(float2));
+    constexpr size_t lds_full = (size_t)SPT_TB * (2 * sizeof(unsigned long long) + sizeof(float2));
+    constexpr size_t lds_lite = (size_t)SPT_TB * (2 * sizeof(unsigned long long));
     static bool attr_set = false;
     if (!attr_set) {
-        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
+        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
+        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lite));
+        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lite));
         attr_set = true;
     }
+    // (abs mode never stages either)
+    const bool lite = M->max_visit < (int64_t)a.stage_min || abs_mode != 0;
     static const int stage_min = getenv("THIP_SPT_STAGE_MIN") ? atoi(getenv("THIP_SPT_STAGE_MIN")) : SPT_STAGE_MIN;
     a.stage_min = stage_min;
-    if (tphase) hipLaunchKernelGGL(sp_tile_k<true>, dim3(items), dim3(SPT_THREADS), lds, st, a);
-    else hipLaunchKernelGGL(sp_tile_k<false>, dim3(items), dim3(SPT_THREADS), lds, st, a);
+    if (lite) {
+        if (tphase) hipLaunchKernelGGL((sp_tile_k<true, true>), dim3(items), dim3(SPT_THREADS_LITE), lds_lite, st, a);
+        else hipLaunchKernelGGL((sp_tile_k<false, true>), dim3(items), dim3(SPT_THREADS_LITE), lds_lite, st, a);
+    } else {
+        if (tphase) hipLaunchKernelGGL((sp_tile_k<true, false>), dim3(items), dim3(SPT_THREADS), lds_full, st, a);
+        else hipLaunchKernelGGL((sp_tile_k<false, false>), dim3(items), dim3(SPT_THREADS), lds_full, st, a);
+    }
     THIP_LAUNCH_CHECK();
     return 0;
 }
@@ -501,6 +516,7 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
             e += t.cnt;
         }
     M->ntiles = (int)tiles.size();
+    for (const SptTile &t_ : tiles) M->max_visit = std::max<int64_t>(M->max_visit, t_.cnt);
     M->nnz_pad = (size_t)e;
     std::vector<float> hv(M->nnz_pad ? M->nnz_pad : 4, 0.0f);
     std::vector<int32_t> hi(M->nnz_pad ? M->nnz_pad : 4, 0);
