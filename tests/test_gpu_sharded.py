@@ -114,6 +114,34 @@ def test_sharded_socp_matches_unsharded(T, schedule):
     assert abs(float(dense.vec_c.astype(np.float64) @ xa) - pobj) <= 1e-3 * (1 + abs(pobj))
 
 
+@pytest.mark.parametrize("schedule", ["fused", "carried"])
+def test_sharded_sparse_lp_matches_unsharded(T, schedule):
+    """row shards of a SPARSE operator (each rank holds the tiled copy of its row block, thip_solver_set_sptile): the products come
+    back as finished vectors, the all-reduce of A_g^T y_g and the sharded sums are the dense path's -- two emulated ranks reproduce
+    the unsharded sparse solve and the oracle's objective"""
+    import scipy.sparse as sp
+    from problems import l1reg_lp
+    c, G, h = l1reg_lp(30, seed=7)
+    n, m = c.size, h.size
+    A = sp.csr_matrix(G.astype(np.float32))
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 400_000, 1e-3
+    fs = T.FusedSolver(n, m, A, h.astype(np.float32), c.astype(np.float32), [1], [m], p, schedule)
+    x1, y1 = fs.solve()
+    r1 = fs.status()
+    fs.destroy()
+    cut = 70
+    parts = [dict(n=n, m=hi - lo, mat_a=A[lo:hi], vec_b=h[lo:hi].astype(np.float32), vec_c=c.astype(np.float32), seg_type=[1],
+                  seg_len=[hi - lo], rowabs=None) for lo, hi in ((0, cut), (cut, m))]
+    (ra, xa, ya, _), (rb, xb, yb, _) = _run_sharded(T, parts, p, schedule)
+    assert ra.state == rb.state == 0 and ra.iters == rb.iters and abs(ra.iters - r1.iters) <= max(3, 0.02 * r1.iters)
+    assert np.array_equal(xa, xb)
+    ro = O.solve_lp(O.param(eps_acc=1e-3), c, G, h, np.zeros((0, n)), [])
+    pobj = float(c @ ro.x)
+    for x in (x1, xa):
+        assert abs(float(c @ x.astype(np.float64)) - pobj) <= 1e-3 * (1 + abs(pobj))
+
+
 def test_sharded_lp_first_iterates(T):
     c, G, h = benchmark_lp(48, seed=6)
     lp = T.ProbLP(_mb(T, T.MatType.General(48, 1)).set_array(c.reshape(-1, 1)), _mb(T, T.MatType.General(96, 48)).set_array(G),
