@@ -1,3 +1,7 @@
+"""The same sparse LP (bench.py's sparse-lp construction with l samples) through four paths -- the tiled copy under the one-pass and
+the carried schedule, round 5's two CSR copies, the dense-ified matrix -- tau, the first criterion and the sizes of the iterate after
+1, 2, 5, 10, 20, 45 iterations side by side (round 6: this is how "tau sits at its clamp from iteration 5 on" was seen to be the
+problem's, not a path's).      python tools/sparse_paths_compare.py 4096"""
 import sys, numpy as np, scipy.sparse as sp
 sys.path.insert(0, '.')
 import importlib.util
