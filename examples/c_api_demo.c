@@ -44,7 +44,30 @@ int main(void)
     CHK(thip_solver_solution(s, x, yy));
     printf("state %d after %lld iterations: x = [%.5f, %.5f] (expect [2, 2])\n", st.state, (long long)st.iter, x[0], x[1]);
     CHK(thip_solver_destroy(s));
+
+    /* the same LP with A as a sparse operator held once on the device (thip_sptile_*: the matrix by columns, host arrays), through the
+     * one-pass recurrence in three launches */
+    const int64_t colptr[3] = { 0, 3, 6 };
+    const int32_t rowidx[6] = { 0, 1, 2, 0, 1, 2 };
+    thip_sptile *sp = NULL;
+    thip_status st2;
+    float xs[2], ys[3], nrm2 = 0.f;
+    CHK(thip_sptile_create(3, 2, 6, colptr, rowidx, a_h, &sp));
+    CHK(thip_sptile_mv(sp, 0, 1.0f, c, 0.0f, y, 0));                 /* y = A c through the sparse copy */
+    CHK(thip_norm(3, y, &nrm2));
+    thip_problem prob2 = { 2, 3, NULL, b, c, NULL, 1, seg_type, seg_len };
+    CHK(thip_solver_create(&prob2, &par, THIP_SCHED_SWEEP, &s));
+    CHK(thip_solver_set_sptile(s, sp));
+    CHK(thip_solver_init(s));
+    CHK(thip_solver_run(s, -1, 32, &st2));
+    CHK(thip_solver_solution(s, xs, ys));
+    printf("sparse: ||A c|| = %.6f, state %d after %lld iterations: x = [%.5f, %.5f] (expect [2, 2])\n", nrm2, st2.state,
+           (long long)st2.iter, xs[0], xs[1]);
+    CHK(thip_solver_destroy(s));
+    CHK(thip_sptile_destroy(sp));
     CHK(thip_free(a)); CHK(thip_free(b)); CHK(thip_free(c)); CHK(thip_free(y));
     CHK(thip_shutdown());
-    return (st.state == THIP_ST_OK && x[0] > 1.999f && x[0] < 2.001f && x[1] > 1.999f && x[1] < 2.001f) ? 0 : 1;
+    return (st.state == THIP_ST_OK && x[0] > 1.999f && x[0] < 2.001f && x[1] > 1.999f && x[1] < 2.001f
+            && st2.state == THIP_ST_OK && xs[0] > 1.999f && xs[0] < 2.001f && xs[1] > 1.999f && xs[1] < 2.001f
+            && nrm2 > 4.2426f && nrm2 < 4.2427f) ? 0 : 1;
 }

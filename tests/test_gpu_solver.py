@@ -496,6 +496,7 @@ def test_plain_c_host_over_the_abi():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "x = [2.0000" in r.stdout or "x = [1.9999" in r.stdout
+    assert "sparse: ||A c|| = 4.2426" in r.stdout          # the same LP through thip_sptile_* / thip_solver_set_sptile from plain C
 
 
 @pytest.mark.parametrize("path", ["trait", "reference", "fused", "carried"])
