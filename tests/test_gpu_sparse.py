@@ -200,6 +200,42 @@ def test_sparse_sdp_workload_iterates_vs_oracle(T, schedule):
     sdp.drop()
 
 
+def test_toruscompl_socp_example_on_the_sparse_copy(T):
+    # examples/toruscompl_socp/src/main.rs:43-268 (the third mostly-zero example matrix SURVEY.md 8f names: 99 % zeros) stacked by ProbSOCP
+    # and held sparse: 158 cones of 1 + 2 rows, 317 cones of 1 + 0 rows, 112 zero-cone rows -- through the one-pass recurrence and the
+    # carried schedule on the tiled copy, against the f64 oracle at the example's eps_acc
+    from problems import toruscompl_socp
+    from test_gpu_solver import _mb
+    q = toruscompl_socp(9, 7, 0.2)
+    n = q["vec_f"].size
+    ro = O.solve_socp(O.param(max_iter=1_000_000, eps_acc=1e-3), q["vec_f"], q["mats_g"], q["vecs_h"], q["vecs_c"],
+                      q["scls_d"], q["mat_a"], q["vec_b"])
+    assert ro.status == O.OK
+    col = lambda v: np.asarray(v, np.float32).reshape(-1, 1)
+    socp = T.ProbSOCP(_mb(T, T.MatType.General(n, 1)).set_array(col(q["vec_f"])),
+                      [_mb(T, T.MatType.General(G.shape[0], n)).set_array(G) for G in q["mats_g"]],
+                      [_mb(T, T.MatType.General(len(h_), 1)).set_array(col(h_)) for h_ in q["vecs_h"]],
+                      [_mb(T, T.MatType.General(n, 1)).set_array(col(c_)) for c_ in q["vecs_c"]], list(q["scls_d"]),
+                      _mb(T, T.MatType.General(q["vec_b"].size, n)).set_array(q["mat_a"]),
+                      _mb(T, T.MatType.General(q["vec_b"].size, 1)).set_array(col(q["vec_b"])))
+    d = socp.dense()
+    A = sp.csc_matrix(np.asarray(d.mat_a).reshape((d.m, d.n), order="F"))
+    assert A.nnz < 0.02 * d.m * d.n
+    p = T.SolverParam()
+    p.max_iter, p.eps_acc = 1_000_000, 1e-3
+    for sched in ("sweep", "carried"):
+        fs = T.FusedSolver(d.n, d.m, A, np.asarray(d.vec_b, np.float32), np.asarray(d.vec_c, np.float32), d.seg_type, d.seg_len, p, sched,
+                           vec_b_rowabs=d.vec_b_rowabs)
+        assert fs.schedule_in_use() == sched
+        x, _ = fs.solve(poll_every=64)
+        st = fs.status()
+        fs.destroy()
+        assert st.state == 0 and abs(st.iters - ro.iters) <= 0.05 * ro.iters + 5, (sched, st.iters, ro.iters)
+        obj, obj_r = float(q["vec_f"] @ x.astype(np.float64)), float(q["vec_f"] @ ro.x)
+        assert abs(obj - obj_r) <= 1e-3 * (1 + abs(obj_r)), (sched, obj, obj_r)
+    socp.drop()
+
+
 def test_sparse_sweep_converges_to_the_dense_answer_multi_tile(T):
     # a sparse LP spanning 3 x 2 tiles (benchmark_lp's construction with 97 % of the random block dropped): the one-pass recurrence
     # on the tiled copy stops within a few iterations of the dense one-pass / carried solve, at the same objective
