@@ -559,8 +559,18 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
             const int S = (int)std::min<int64_t>(capN, std::max<int64_t>(1, (len + per_item - 1) / per_item));
             M->slN = std::max(M->slN, S);
             size_t tr = t0;
+            // a cut falls on a multiple of 256 entries FROM ITS TILE'S START: a wave streams 64 quads, and in a dense tile (columns of
+            // 4096 entries) no wave then straddles two columns -- a straddling wave of the T product runs the segmented sum
+            auto cutN = [&](int64_t c) -> int64_t {
+                if (c <= E0) return E0;
+                if (c >= E1) return E1;
+                size_t t_ = t0;
+                while (tiles[t_].e0 + tiles[t_].cnt <= c) ++t_;
+                const int64_t r = std::min<int64_t>(((c - tiles[t_].e0 + 128) / 256) * 256, tiles[t_].cnt);
+                return tiles[t_].e0 + r;
+            };
             for (int s = 0; s < S; ++s) {
-                const int64_t a0 = E0 + (len / 4 * s / S) * 4, a1 = s + 1 == S ? E1 : E0 + (len / 4 * (s + 1) / S) * 4;
+                const int64_t a0 = s == 0 ? E0 : cutN(E0 + (len / 4 * s / S) * 4), a1 = s + 1 == S ? E1 : cutN(E0 + (len / 4 * (s + 1) / S) * 4);
                 if (a1 <= a0) {     // (cannot happen: len >= 4 S is not guaranteed for tiny blocks -- keep the slice, empty)
                     SptItem it_{ tiles[t0].rb, s, (int)t0, (int)t0, a0, a0 };
                     itN.push_back(it_);
@@ -586,8 +596,16 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
             const int S = (int)std::min<int64_t>(capT, std::max<int64_t>(1, (len + per_item - 1) / per_item));
             M->slT = std::max(M->slT, S);
             size_t pr = 0;
+            auto cutT = [&](int64_t c) -> int64_t {         // (in the column block's cumulative entry space; see cutN)
+                if (c <= 0) return (int64_t)0;
+                if (c >= len) return len;
+                size_t q_ = 0;
+                while (cum[q_ + 1] <= c) ++q_;
+                const int64_t r = std::min<int64_t>(((c - cum[q_] + 128) / 256) * 256, cum[q_ + 1] - cum[q_]);
+                return cum[q_] + r;
+            };
             for (int s = 0; s < S; ++s) {
-                const int64_t a0 = (len / 4 * s / S) * 4, a1 = s + 1 == S ? len : (len / 4 * (s + 1) / S) * 4;
+                const int64_t a0 = s == 0 ? 0 : cutT((len / 4 * s / S) * 4), a1 = s + 1 == S ? len : cutT((len / 4 * (s + 1) / S) * 4);
                 if (a1 <= a0) {
                     SptItem it_{ tiles[order[p0]].cw, s, (int)p0, (int)p0, 0, 0 };
                     itT.push_back(it_);
