@@ -677,7 +677,7 @@ def run_sparse(a, rank, T, lib, _lib):
     fs = T.FusedSolver(n, m, spt, inst["b"], inst["c"], inst["seg_type"], inst["seg_len"], p, a.schedule)
     # what THIS box streams: a bare read of as many bytes as one product reads
     box_read = None
-    nbytes = min(8 * info["nnz_stored"], 20_000_000_000) // 16 * 16
+    nbytes = min(info["bytes_per_product"], 20_000_000_000) // 16 * 16
     if nbytes >= 1 << 20:
         scratch = T.DeviceBuffer(nbytes // 4)
         pb, pa = C.c_float(), C.c_float()
@@ -704,7 +704,8 @@ def run_sparse(a, rank, T, lib, _lib):
     xi, yi = fs.iterate()
     assert math.isfinite(r.tau) and np.isfinite(xi).all() and np.isfinite(yi).all(), "iterate blew up"
     passes, bytes_per_pass = fs.passes()
-    # one product = one launch over the stored entries: 8 B each + its in-vectors (2 per product) and the slices' partial sums
+    # one product = one launch over the stored entries (8 B each; 4 B in a tile held dense, without indices) + its in-vectors
+    # (2 per product) and the slices' partial sums
     vec_T = 4 * (2 * m + 2 * info["slices_t"] * n)
     vec_N = 4 * (2 * n + 2 * info["slices_n"] * m)
     bytes_per_launch = bytes_per_pass + 0.5 * (vec_T + vec_N)
@@ -714,7 +715,7 @@ def run_sparse(a, rank, T, lib, _lib):
     roofline = {
         "bound": "hbm",
         "kernel": "sp_tile_k<T> / sp_tile_k<N> (thip_sptile.hip): A^T [v x_y] and A [u x_x'] from the ONE tiled copy, 16-byte loads of "
-                  "{value, local row | local column} entries, LDS accumulators; averaged over both launches of an iteration",
+                  "{value, local row | local column} entries (values alone in full tiles), LDS accumulators; averaged over both launches of an iteration",
         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
         "traffic": None, "traffic_source": None,
         "timer": "hip_events on the launch stream around both product launches of every %s iteration of the timed region (thip_prof_*)"
@@ -722,7 +723,9 @@ def run_sparse(a, rank, T, lib, _lib):
         "bytes_per_launch": bytes_per_launch, "bytes_of_entries_per_launch": bytes_per_pass,
         "vector_bytes_per_launch": 0.5 * (vec_T + vec_N),
         "avg_launch_ms": avg_ms, "launches_timed": nl.value, "passes_over_A_per_iter": passes,
-        "bytes_per_stored_entry_and_iteration": 8 * passes,
+        "bytes_per_stored_entry_and_iteration": bytes_per_pass * passes / max(info["nnz_stored"], 1),
+        "dense_tiles": info["dense_tiles"], "tiles": info["tiles"], "indexed_entries": info["indexed_entries"],
+        "stored_entries": info["nnz_stored"],
         "box_read_GBps": box_read["best_GBps"] if box_read else None,
         "frac_of_box_read": (achieved / box_read["best_GBps"]) if (box_read and nl.value) else None,
     }

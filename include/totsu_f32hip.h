@@ -168,6 +168,9 @@ int thip_sptile_mv(thip_sptile *mat, int transpose, float alpha, const float *x,
  * products, bytes on the device */
 int thip_sptile_info(const thip_sptile *mat, size_t *host_nnz_stored, int *host_tiles, int *host_items_n, int *host_items_t,
                      int *host_slices_n, int *host_slices_t, size_t *host_bytes);
+/* how the entries are stored: tiles held without indices (full 4096-row tiles whose every column is full: 4 bytes per entry),
+ * entries that carry an index (8 bytes per entry), and the bytes of entries ONE product streams */
+int thip_sptile_layout(const thip_sptile *mat, int *host_dense_tiles, size_t *host_indexed_entries, size_t *host_bytes_per_product);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-resident variants used by the fused path (no host round trip).  They replace host loops

@@ -105,7 +105,8 @@ def pmc(fetch_db, write_db, key):
         # the tiled sparse products: two instances per iteration (sp_tile_k<true> = A^T [v x_y], <false> = A [u x_x']); bench.py's
         # roofline averages both launches, and so does the stored traffic
         per, tot_rd, tot_wr, k_ = {}, 0.0, 0.0, 0
-        for inst in ("thip::sp_tile_k<true>", "thip::sp_tile_k<false>"):
+        # (the full-size instances: <T, LITE = false>; a LITE instance appears once per solve, for the |A| sums)
+        for inst in ("thip::sp_tile_k<true, false>", "thip::sp_tile_k<false, false>"):
             f_, w_ = rows["FETCH_SIZE"].get(inst), rows["WRITE_SIZE"].get(inst)
             if f_ is None:
                 continue

@@ -134,6 +134,8 @@ extern "C" {
     pub fn thip_sptile_info(mat: *const thip_sptile, host_nnz_stored: *mut usize, host_tiles: *mut c_int,
                             host_items_n: *mut c_int, host_items_t: *mut c_int, host_slices_n: *mut c_int,
                             host_slices_t: *mut c_int, host_bytes: *mut usize) -> c_int;
+    pub fn thip_sptile_layout(mat: *const thip_sptile, host_dense_tiles: *mut c_int, host_indexed_entries: *mut usize,
+                              host_bytes_per_product: *mut usize) -> c_int;
     pub fn thip_to_bf16(n_row: usize, n_col: usize, mat: *const f32, mat16: *mut u16, ld16: usize) -> c_int;
     pub fn thip_transform_ge_bf16(transpose: c_int, n_row: usize, n_col: usize, alpha: f32, mat16: *const u16,
                                   ld16: usize, x: *const f32, beta: f32, y: *mut f32) -> c_int;

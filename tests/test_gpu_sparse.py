@@ -384,6 +384,87 @@ def test_tiled_sparse_products_are_bitwise_reproducible(T):
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
+def _with_full_tiles(rng):
+    """8242 x 4106: tile (0, 0) full, (1, 0) 30 % random, (2, 0) = the last 50 rows, full but not of full height, (0, 1) = 4096 x 10
+    full, (1, 1) empty, (2, 1) one entry"""
+    d = np.zeros((8242, 4106))
+    d[:4096, :4096] = rng.standard_normal((4096, 4096))
+    blk = rng.standard_normal((4096, 4096))
+    blk[rng.uniform(size=blk.shape) > 0.3] = 0.0
+    d[4096:8192, :4096] = blk
+    d[8192:, :4096] = rng.standard_normal((50, 4096))
+    d[:4096, 4096:] = rng.standard_normal((4096, 10))
+    d[8200, 4100] = 2.5
+    return d
+
+
+def test_full_tiles_are_held_without_indices(T):
+    # a tile of full height whose every column holds all 4096 rows stores values only (4 bytes per entry) and runs the dense
+    # routines of sp_tile_k; same contract, same tolerances; a caller whose rows do not ascend gets the indexed form and the same answer
+    from totsu_amd.sparse import SparseMatOp, SpTile
+    L = T.F32HIP
+    rng = np.random.default_rng(21)
+    d = _with_full_tiles(rng)
+    a = sp.csc_matrix(d)
+    a.sort_indices()
+    x = rng.standard_normal(d.shape[1]).astype(np.float32)
+    yv = rng.standard_normal(d.shape[0]).astype(np.float32)
+
+    def products(op):
+        sy, sx = _sl(L, yv.copy()), _sl(L, x.copy())
+        op.op(0.7, _sl(L, x), -0.3, sy)
+        op.trans_op(-1.5, _sl(L, yv), 0.5, sx)
+        st, ss = _sl(L, np.zeros(d.shape[1])), _sl(L, np.zeros(d.shape[0]))
+        op.absadd_cols(st)
+        op.absadd_rows(ss)
+        return sy.get_ref().copy(), sx.get_ref().copy(), st.get_ref().copy(), ss.get_ref().copy()
+
+    op = SparseMatOp(L, a)
+    info = op.t.info()
+    assert info["dense_tiles"] == 2 and info["tiles"] == 5
+    assert info["indexed_entries"] == info["nnz_stored"] - 4096 * 4096 - 4096 * 10
+    assert info["bytes_per_product"] == 4 * info["nnz_stored"] + 4 * info["indexed_entries"]
+    o1 = products(op)
+    op.drop()
+    op = SparseMatOp(L, a)
+    o2 = products(op)
+    op.drop()
+    for u, v in zip(o1, o2):
+        assert np.array_equal(u, v)                                     # bitwise reproducible, as the indexed form
+    ref_n = 0.7 * d @ x - 0.3 * yv
+    ref_t = -1.5 * d.T @ yv + 0.5 * x
+    assert np.all(np.abs(o1[0] - ref_n) <= 1e-5 * (0.7 * np.abs(d) @ np.abs(x) + 0.3 * np.abs(yv) + 1e-6))
+    assert np.all(np.abs(o1[1] - ref_t) <= 1e-5 * (1.5 * np.abs(d.T) @ np.abs(yv) + 0.5 * np.abs(x) + 1e-6))
+    assert np.allclose(o1[2], np.abs(d).sum(axis=0), rtol=1e-5) and np.allclose(o1[3], np.abs(d).sum(axis=1), rtol=1e-5)
+    # rows handed over in DESCENDING order within every column: nothing may be taken for dense
+    cp = a.indptr.astype(np.int64)
+    ri, va = a.indices.copy(), a.data.astype(np.float32)
+    for j in range(d.shape[1]):
+        ri[cp[j]:cp[j + 1]] = ri[cp[j]:cp[j + 1]][::-1]
+        va[cp[j]:cp[j + 1]] = va[cp[j]:cp[j + 1]][::-1]
+    t = SpTile.from_csc_arrays(d.shape[0], d.shape[1], cp, ri.astype(np.int32), va)
+    assert t.info()["dense_tiles"] == 0 and t.info()["indexed_entries"] == t.info()["nnz_stored"]
+    sy, sx = _sl(L, np.zeros(d.shape[0])), _sl(L, np.zeros(d.shape[1]))
+    t.mv(False, 0.7, _sl(L, x), 0.0, sy)
+    t.mv(True, -1.5, _sl(L, yv), 0.0, sx)
+    assert np.all(np.abs(sy.get_ref() - 0.7 * d @ x) <= 1e-5 * (0.7 * np.abs(d) @ np.abs(x) + 1e-6))
+    assert np.all(np.abs(sx.get_ref() + 1.5 * d.T @ yv) <= 1e-5 * (1.5 * np.abs(d.T) @ np.abs(yv) + 1e-6))
+    t.free()
+
+
+def test_sparse_lp_with_full_tiles_iterates_vs_oracle(T):
+    # the l1reg_lp construction at l = 4096: the kernel block [K ; -K] is two full tiles (held without indices), the diagonals
+    # beside it indexed ones -- iterates 0, 1, 2, 9 of the one-pass loop against the f64 oracle on the dense-ified matrix
+    from totsu_amd.sparse import SpTile
+    c, G, h = l1reg_lp(4096, seed=5)
+    A = sp.csc_matrix(G.astype(np.float32))
+    A.sort_indices()
+    t = SpTile(A)
+    assert t.info()["dense_tiles"] == 2
+    t.free()
+    _iterates_vs_oracle(T, A, h.astype(np.float32), c.astype(np.float32), [1], [h.size], [0, 1, 2, 9], [3e-5, 6e-5, 1e-4, 3e-4], "sweep")
+
+
 class _DiffOp:
     """A user-defined matrix-free Operator built only from LinAlg primitives, in the pattern of
     examples/imgnr_udef/src/prob_op_a.rs: the (n-1) x n forward-difference matrix D (D x)_i = x_{i+1} - x_i, never

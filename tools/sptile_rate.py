@@ -65,11 +65,11 @@ def main():
         info = t.info()
         ms = (C.c_float * 4)()
         lib.thip_test_sptile_time(t.h, 5, ms)
-        by = 8.0 * info["nnz_stored"]
+        by = float(info["bytes_per_product"])
         tcsr_n = csr_time(M.tocsr())
         tcsr_t = csr_time(M.T.tocsr())
-        print("%s: nnz %d (stored %d), %d tiles, slices N / T %d / %d" % (name, M.nnz, info["nnz_stored"], info["tiles"],
-                                                                          info["slices_n"], info["slices_t"]))
+        print("%s: nnz %d (stored %d), %d tiles (%d without indices), slices N / T %d / %d, %.3f GB per product"
+              % (name, M.nnz, info["nnz_stored"], info["tiles"], info["dense_tiles"], info["slices_n"], info["slices_t"], by / 1e9))
         print("    tiled copy, two right-hand sides:  T product %8.3f ms = %6.2f TB/s of entries   N product %8.3f ms = %6.2f TB/s"
               % (ms[0], by / ms[0] / 1e9, ms[1], by / ms[1] / 1e9))
         print("    CSR gathers, one right-hand side:  A^T (own copy) %8.3f ms = %6.2f TB/s   A %8.3f ms = %6.2f TB/s"

@@ -95,6 +95,7 @@ PROTOTYPES = {
     "thip_sptile_mv": (_i, [_vp, _i, _f, _vp, _f, _vp, _i]),
     "thip_sptile_info": (_i, [_vp, C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
                               C.POINTER(_sz)]),
+    "thip_sptile_layout": (_i, [_vp, C.POINTER(_i), C.POINTER(_sz), C.POINTER(_sz)]),
     "thip_map_eig_worklen": (_sz, [_sz]),
     "thip_map_eig": (_i, [_sz, _vp, _i, _f, _f, _vp, _sz, _i]),
     "thip_eig_decompose": (_i, [_sz, _vp, _i, _f, _f, _vp, _sz, fp]),

@@ -29,6 +29,11 @@
 // three launches: T product with [v, x_y] -> sp_col_k (per column: the two scalar updates of thip_sweep_kernel.h's service wave,
 // kappa, the sums over n) -> N product with [u, x_x'] into the groups' shares the m-tail reads.  16 bytes per stored entry and
 // iteration; the two-copy CSR gathers of round 5 (thip_sparse.hip, carried schedule) read 32.
+//
+// DENSE tiles.  A tile of full height whose every column holds all 4096 rows (the X / -X blocks of l1reg_lp: 99.98 % of its
+// entries) needs no indices: entry e of the tile is row e mod 4096 of column e / 4096.  Such a tile stores its values only
+// -- 4 bytes per entry, both on the device and per product -- and is streamed by two lean routines (sp_tile_k: dense_n /
+// dense_t) whose sums stay in registers for a whole column (T) or a whole visit (N).
 #include "thip_common.h"
 
 #include <algorithm>
@@ -37,6 +42,8 @@
 #include <limits>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <type_traits>
 #include <vector>
 
 using namespace thip;
@@ -51,7 +58,9 @@ constexpr int SPT_THREADS = 1024;          // one workgroup per CU: 96 KB of LDS
 constexpr int SPT_THREADS_LITE = 512;      // an operator without a visit worth staging: no in-vector block, 64 KB, two workgroups per CU
 constexpr int SPT_STAGE_MIN = 8192;     // entries of a tile visit from which the in-vector's block is staged in LDS
 
-struct SptTile { long long e0; int cnt, rb, cw, pad_; };                                   // entries [e0, e0 + cnt), cnt % 4 == 0
+// entries [e0, e0 + cnt) of `vals`, cnt % 4 == 0; their indices at [i0, i0 + cnt) of `idx` -- or nowhere (dense != 0): the
+// tile is full, entry e0 + k is row k % 4096 of column k / 4096
+struct SptTile { long long e0, i0; int cnt, rb, cw, dense; };
 struct SptItem { int out_block, slice, ref0, ref1; long long e_first, e_last; };           // tile refs [ref0, ref1)
 
 // where element i of a block lives in its LDS array: a lane's four entries are four CONSECUTIVE rows of a dense column (a
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
     __shared__ float shm[16];
     if (*a.stop != 0) return;
     const SptItem it = a.items[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool two = a.in1 != nullptr;
     for (int i = tid; i < SPT_TB; i += SPT_THREADS) { lo0[i] = 0ull; lo1[i] = 0ull; }
     double inv0 = 1.0, inv1 = 1.0;
@@ -147,9 +156,11 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
     __syncthreads();                    // the accumulators are zero before any wave adds to them
     // one visit of a tile: entries [e0, e1) streamed by the threads t0, t0 + stride, ... (the whole workgroup: tid / 512; one wave
     // alone: lane / 64), the in-vector's block from LDS (staged) or straight from L2
-    auto visit = [&](const long long e0, const long long e1, const bool staged, const float *in0b, const float *in1b, const int t0,
-                     const int stride) {
+    auto visit = [&](const SptTile &tl, const long long e0, const long long e1, const bool staged, const float *in0b, const float *in1b,
+                     const int t0, const int stride) {
         const long long q1 = e1 >> 2;
+        const long long dq = (tl.i0 - tl.e0) >> 2;          // quad of `idx` that goes with a quad of `vals`
+        const bool dense = tl.dense != 0;
         for (long long qb = e0 >> 2; qb < q1; qb += 2 * stride) {
             f32x4 av[2]; i32x4 iv[2]; bool ok[2];
 #pragma unroll
@@ -158,7 +169,11 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
                 ok[u] = q < q1;
                 const long long qq = ok[u] ? q : q1 - 1;
                 av[u] = __builtin_nontemporal_load(a.vals + qq);
-                iv[u] = __builtin_nontemporal_load(a.idx + qq);
+                if (dense) {                // (a dense tile away from its fast routines: a clipped end, abs mode, LITE)
+                    const int k = (int)((qq << 2) - tl.e0);
+                    const int w = (k & (SPT_TB - 1)) | ((k >> 12) << 16);
+                    iv[u][0] = w; iv[u][1] = w + 1; iv[u][2] = w + 2; iv[u][3] = w + 3;
+                } else iv[u] = __builtin_nontemporal_load(a.idx + qq + dq);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -225,6 +240,78 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
             }
         }
             };
+    // The fast routines of a DENSE tile (in-vector block staged; [e0, e1) cut on multiples of 256 entries from the tile's start, so a
+    // wave's 64 quads lie in one column).  Four 16-byte loads of VALUES in flight per lane: the bytes in flight of the indexed form.
+    // T product: a wave takes a contiguous run of 64-quad chunks, lanes keep their partial sums for as long as the column lasts:
+    // one wave sum and one LDS add per column and wave.
+    auto dense_t = [&](const SptTile &tl, const long long e0, const long long e1) {
+        constexpr int NW = SPT_THREADS / 64;
+        const long long c0 = (e0 - tl.e0) >> 8, nc = (e1 - e0) >> 8;     // chunks of 64 quads, counted from the tile's start
+        const long long w0 = c0 + nc * wave / NW, w1 = c0 + nc * (wave + 1) / NW;
+        const f32x4 *const tv = a.vals + (tl.e0 >> 2);
+        int cur = -1;
+        float s0 = 0.0f, s1 = 0.0f;
+        auto flush = [&]() {
+            if (cur < 0) return;
+            const float t0 = wave_sum_dpp(s0), t1 = two ? wave_sum_dpp(s1) : 0.0f;
+            if (lane == 0) { spt_add(&lo0[spt_slot(cur)], t0, S0); if (two) spt_add(&lo1[spt_slot(cur)], t1, S1); }
+            s0 = 0.0f; s1 = 0.0f;
+        };
+        for (long long cb = w0; cb < w1; cb += 4) {
+            f32x4 av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long c = cb + u < w1 ? cb + u : w1 - 1;
+                av[u] = __builtin_nontemporal_load(tv + (c << 6) + lane);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (cb + u >= w1) break;                                // (wave-uniform)
+                const int k = (int)((cb + u) << 6);                     // the chunk's first quad within the tile
+                const int col = k >> 10;
+                if (col != cur) { flush(); cur = col; }
+                const int r = (((k & 1023) + lane) << 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 y = lin[spt_slot(r + e)];
+                    s0 = fmaf(av[u][e], y.x, s0); s1 = fmaf(av[u][e], y.y, s1);
+                }
+            }
+        }
+        flush();
+    };
+    // N product: thread t takes the quads t, t + THREADS, ... of the visit -- always the same four rows (a column is 1024 quads) --
+    // and keeps their sums in registers for the whole visit; x of the column is one LDS word for the whole wave.
+    auto dense_n = [&](const SptTile &tl, const long long e0, const long long e1) {
+        static_assert(1024 % SPT_THREADS == 0 || SPT_THREADS % 1024 == 0, "a thread must meet the same rows in every step");
+        constexpr int STEP = SPT_THREADS < 1024 ? 1024 : SPT_THREADS;      // quads between a thread's loads
+        const long long q0 = e0 >> 2, q1 = e1 >> 2, tq0 = tl.e0 >> 2;
+        for (int sub = 0; sub < STEP / SPT_THREADS; ++sub) {
+            const int t = tid + sub * SPT_THREADS;
+            float r0[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, r1[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (long long qb = q0 + t; qb < q1; qb += 4 * STEP) {
+                f32x4 av[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long q = qb + u * STEP;
+                    av[u] = __builtin_nontemporal_load(a.vals + (q < q1 ? q : qb));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long q = qb + u * STEP;
+                    if (q >= q1) break;
+                    const float2 x = lin[spt_slot((int)((q - tq0) >> 10))];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { r0[e] = fmaf(av[u][e], x.x, r0[e]); r1[e] = fmaf(av[u][e], x.y, r1[e]); }
+                }
+            }
+            if (q0 + t < q1) {
+                const int row = (int)(((q0 + t - tq0) & 1023) << 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { spt_add(&lo0[spt_slot(row + e)], r0[e], S0); if (two) spt_add(&lo1[spt_slot(row + e)], r1[e], S1); }
+            }
+        }
+    };
     auto clip = [&](const int ref, const SptTile &tl, long long &e0, long long &e1) {
         e0 = tl.e0; e1 = tl.e0 + tl.cnt;
         if (ref == it.ref0) e0 = it.e_first;
@@ -234,14 +321,13 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
     // round trips -- tile record, entries, in-vector -- and an item of a very sparse operator walks dozens of them (the equality rows
     // of the partitioning SDP: 31 tiles of 16 entries); no barrier, the accumulators take LDS adds from any wave
     constexpr long long TINY = 2 * 64 * 4;
-    const int wave = tid >> 6;
     for (int ref = it.ref0 + wave; ref < it.ref1; ref += SPT_THREADS / 64) {
         const SptTile tl = a.tiles[a.order ? a.order[ref] : ref];
         long long e0, e1;
         clip(ref, tl, e0, e1);
         if (e1 - e0 > TINY) continue;
         const int inb = TPH ? tl.rb : tl.cw;
-        visit(e0, e1, false, a.in0 + (size_t)inb * SPT_TB, (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB, lane, 64);
+        visit(tl, e0, e1, false, a.in0 + (size_t)inb * SPT_TB, (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB, lane, 64);
     }
     // (2) the others, the whole workgroup on each; from stage_min entries on with the in-vector's block staged in LDS
     bool prev_staged = false;
@@ -253,7 +339,8 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
         const int inb = TPH ? tl.rb : tl.cw;
         const float *in0b = a.in0 + (size_t)inb * SPT_TB;
         const float *in1b = (two ? a.in1 : a.in0) + (size_t)inb * SPT_TB;
-        const bool staged = !LITE && (e1 - e0) >= a.stage_min && !a.abs_mode;
+        const bool fast = !LITE && tl.dense != 0 && !a.abs_mode && ((e0 - tl.e0) & 255) == 0 && ((e1 - tl.e0) & 255) == 0;
+        const bool staged = !LITE && ((e1 - e0) >= a.stage_min || fast) && !a.abs_mode;
         if (staged) {
             if (prev_staged) __syncthreads();           // the previous visit's reads of `lin` are done
             const int lim = a.in_len - inb * SPT_TB;
@@ -261,7 +348,9 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
             __syncthreads();
             prev_staged = true;
         }
-        visit(e0, e1, staged, in0b, in1b, tid, SPT_THREADS);
+        if (!LITE && fast) {
+            if (TPH) dense_t(tl, e0, e1); else dense_n(tl, e0, e1);
+        } else visit(tl, e0, e1, staged, in0b, in1b, tid, SPT_THREADS);
     }
     if (!TPH) {
 #pragma unroll
@@ -385,6 +474,8 @@ struct thip_sptile {
     int a_exp = 0, headN = 1, headT = 1;
     float *xmax = nullptr;
     int64_t max_visit = 0;      // entries of the largest tile
+    int ndense = 0;             // tiles stored without indices
+    size_t nidx = 0;            // entries that carry an index
 };
 
 namespace thip {
@@ -392,7 +483,7 @@ namespace thip {
 size_t sptile_part_floats(const thip_sptile *M, bool tphase) { return tphase ? (size_t)M->slT * 2 * M->npad : (size_t)M->slN * 2 * M->mpad; }
 int sptile_slices(const thip_sptile *M, bool tphase) { return tphase ? M->slT : M->slN; }
 size_t sptile_pad(const thip_sptile *M, bool tphase) { return tphase ? M->npad : M->mpad; }
-size_t sptile_bytes_per_pass(const thip_sptile *M) { return M->nnz_pad * 8; }
+size_t sptile_bytes_per_pass(const thip_sptile *M) { return M->nnz_pad * 4 + M->nidx * 4; }
 void sptile_dims(const thip_sptile *M, size_t *m, size_t *n, size_t *nnz) { *m = M->m; *n = M->n; *nnz = M->nnz; }
 
 // part[slice][2][pad] <- the slices' shares of A [in0 in1] (tphase: of A^T [in0 in1]); in1 == NULL: one right-hand side (the
@@ -425,10 +516,10 @@ int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const floa
         THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lite));
         attr_set = true;
     }
-    // (abs mode never stages either)
-    const bool lite = M->max_visit < (int64_t)a.stage_min || abs_mode != 0;
     static const int stage_min = getenv("THIP_SPT_STAGE_MIN") ? atoi(getenv("THIP_SPT_STAGE_MIN")) : SPT_STAGE_MIN;
     a.stage_min = stage_min;
+    // (abs mode never stages either)
+    const bool lite = M->max_visit < (int64_t)a.stage_min || abs_mode != 0;
     if (lite) {
         if (tphase) hipLaunchKernelGGL((sp_tile_k<true, true>), dim3(items), dim3(SPT_THREADS_LITE), lds_lite, st, a);
         else hipLaunchKernelGGL((sp_tile_k<false, true>), dim3(items), dim3(SPT_THREADS_LITE), lds_lite, st, a);
@@ -476,15 +567,20 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
     // entries per (row block, column block)
     std::vector<int64_t> cnt(nrb * ncw ? nrb * ncw : 1, 0);
     std::vector<int32_t> rowlen(m ? m : 1, 0);
+    std::vector<char> unsorted(ncw ? ncw : 1, 0);   // a column block with a column whose rows do not ascend: no dense tiles there
+    static const bool allow_dense = !(getenv("THIP_SPT_DENSE") && atoi(getenv("THIP_SPT_DENSE")) == 0);
     int64_t max_col = 0;
     float amax = 0.0f;
     for (size_t j = 0; j < n; ++j) {
         if (colptr[j + 1] < colptr[j]) return fail(THIP_E_INVALID, "column pointers decrease", __FILE__, __LINE__);
         int64_t *crow = cnt.data() + j / SPT_TB;
         max_col = std::max<int64_t>(max_col, colptr[j + 1] - colptr[j]);
+        int32_t prev = -1;
         for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
             const int32_t r = rowidx[k];
             if (r < 0 || (size_t)r >= m) return fail(THIP_E_INVALID, "row index out of range", __FILE__, __LINE__);
+            if (r <= prev) unsorted[j / SPT_TB] = 1;
+            prev = r;
             ++crow[(size_t)(r / SPT_TB) * ncw];
             ++rowlen[r];
             const float av = std::fabs(vals[k]);
@@ -503,12 +599,17 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
     std::vector<SptTile> tiles;
     std::vector<int64_t> cur(cnt.size(), -1);       // write cursor of a tile; -1: empty
     std::vector<int> tile_of(cnt.size(), -1);
-    int64_t e = 0;
+    int64_t e = 0, ie = 0;
     for (size_t rb = 0; rb < nrb; ++rb)
         for (size_t cw = 0; cw < ncw; ++cw) {
             const int64_t c = cnt[rb * ncw + cw];
             if (c == 0) continue;
-            SptTile t; t.e0 = e; t.cnt = (int)((c + 3) / 4 * 4); t.rb = (int)rb; t.cw = (int)cw; t.pad_ = 0;
+            SptTile t; t.e0 = e; t.cnt = (int)((c + 3) / 4 * 4); t.rb = (int)rb; t.cw = (int)cw;
+            // dense: full height, ascending rows in every column (then 4096 entries per column are all of its rows), at least four columns
+            const int64_t wcols = (int64_t)std::min<size_t>(SPT_TB, n - cw * SPT_TB);
+            t.dense = (allow_dense && !unsorted[cw] && (rb + 1) * SPT_TB <= m && wcols >= 4 && c == wcols * SPT_TB) ? 1 : 0;
+            t.i0 = t.dense ? 0 : ie;
+            if (t.dense) ++M->ndense; else ie += t.cnt;
             if ((c + 3) / 4 * 4 > 0x7fffffff) return fail(THIP_E_INVALID, "a tile holds more than 2^31 entries", __FILE__, __LINE__);
             tile_of[rb * ncw + cw] = (int)tiles.size();
             cur[rb * ncw + cw] = e;
@@ -518,22 +619,25 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
     M->ntiles = (int)tiles.size();
     for (const SptTile &t_ : tiles) M->max_visit = std::max<int64_t>(M->max_visit, t_.cnt);
     M->nnz_pad = (size_t)e;
+    M->nidx = (size_t)ie;
     std::vector<float> hv(M->nnz_pad ? M->nnz_pad : 4, 0.0f);
-    std::vector<int32_t> hi(M->nnz_pad ? M->nnz_pad : 4, 0);
+    std::vector<int32_t> hi(M->nidx ? M->nidx : 4, 0);
     for (size_t j = 0; j < n; ++j) {
         const size_t cw = j / SPT_TB;
         const uint32_t lc = (uint32_t)(j % SPT_TB) << 16;
         for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
             const size_t r = (size_t)rowidx[k];
-            int64_t &c = cur[(r / SPT_TB) * ncw + cw];
+            const size_t ti = (r / SPT_TB) * ncw + cw;
+            int64_t &c = cur[ti];
+            const SptTile &t = tiles[tile_of[ti]];
             hv[c] = vals[k];
-            hi[c] = (int32_t)((uint32_t)(r % SPT_TB) | lc);
+            if (!t.dense) hi[t.i0 + (c - t.e0)] = (int32_t)((uint32_t)(r % SPT_TB) | lc);
             ++c;
         }
     }
     for (const SptTile &t : tiles) {
         const int64_t real_end = cur[(size_t)t.rb * ncw + t.cw];
-        for (int64_t k = real_end; k < t.e0 + t.cnt; ++k) { hv[k] = 0.0f; hi[k] = hi[real_end - 1]; }
+        for (int64_t k = real_end; k < t.e0 + t.cnt; ++k) { hv[k] = 0.0f; hi[t.i0 + (k - t.e0)] = hi[t.i0 + (real_end - 1 - t.e0)]; }
     }
     // the tiles of a column block, for the T product
     std::vector<int> order;
@@ -541,13 +645,56 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
     for (size_t cw = 0; cw < ncw; ++cw)
         for (size_t rb = 0; rb < nrb; ++rb)
             if (tile_of[rb * ncw + cw] >= 0) order.push_back(tile_of[rb * ncw + cw]);
-    // items: ~512 per product (two per CU: one workgroup of 1024 threads is resident per CU, and every item costs a fill and a drain
-    // of its pipeline -- 1024 items measured 2.5 % slower on the 4.3 GB LP, 768 worse still: a third round with a quarter of the CUs),
-    // at least 32 768 entries each, at most nnz / (16 dim) (<= 256) slices per block
-    static const int items_target = getenv("THIP_SPT_ITEMS") ? std::max(1, atoi(getenv("THIP_SPT_ITEMS"))) : 512;
-    const int64_t per_item = std::max<int64_t>((int64_t)(M->nnz_pad / items_target), 32768);
+    // items: a block's entries are cut into S equal slices of about `per_item` entries, at least 32 768, at most nnz / (16 dim)
+    // (<= 256) slices per block.  One workgroup is resident per CU and the workgroups are handed out in launch order, so a product
+    // takes as long as the busiest CU: per_item is the candidate whose items, list-scheduled on 256 CUs at (entries + a fill and a
+    // drain worth 32 768 entries) each, finish first.  (Measured on the l1reg_lp matrix with full tiles: 256 / 384 / 512 / 768 / 1024
+    // items = 0.367 / 0.421 / 0.385 / 0.384 / 0.392 ms per product -- whole rounds win, a round with a few workgroups loses.)
+    // THIP_SPT_ITEMS=k: per_item = stored entries / k, as before.
+    static const int items_target = getenv("THIP_SPT_ITEMS") ? std::max(0, atoi(getenv("THIP_SPT_ITEMS"))) : 0;    // (0: choose)
     auto cap_of = [&](size_t dim) { return (int)std::min<size_t>(256, std::max<size_t>(1, M->nnz_pad / (16 * std::max<size_t>(dim, 1)))); };
     const int capN = cap_of(m), capT = cap_of(n);
+    auto pick_per_item = [&](const std::vector<int64_t> &lens, const int cap) -> int64_t {
+        if (items_target > 0) return std::max<int64_t>((int64_t)(M->nnz_pad / items_target), 32768);
+        constexpr int CUS = 256;
+        constexpr int64_t FIXED = 32768;
+        int64_t best_p = std::max<int64_t>((int64_t)(M->nnz_pad / 512), 32768), best_t = std::numeric_limits<int64_t>::max();
+        std::vector<int64_t> heap;
+        for (int t = 128; t <= 1024; t += 8) {
+            const int64_t P = std::max<int64_t>((int64_t)(M->nnz_pad / t), 32768);
+            heap.assign(CUS, 0);            // (a min-heap of the CUs' finish times)
+            int64_t span = 0;
+            for (const int64_t len : lens) {
+                const int S = (int)std::min<int64_t>(cap, std::max<int64_t>(1, (len + P - 1) / P));
+                const int64_t cost = (len + S - 1) / S + FIXED;
+                for (int k = 0; k < S; ++k) {
+                    std::pop_heap(heap.begin(), heap.end(), std::greater<int64_t>());
+                    heap.back() += cost;
+                    span = std::max(span, heap.back());
+                    std::push_heap(heap.begin(), heap.end(), std::greater<int64_t>());
+                }
+            }
+            if (span < best_t) { best_t = span; best_p = P; }
+            if (P == 32768) break;
+        }
+        return best_p;
+    };
+    std::vector<int64_t> lensN, lensT;
+    for (size_t t0 = 0; t0 < tiles.size();) {
+        size_t t1 = t0;
+        int64_t len = 0;
+        while (t1 < tiles.size() && tiles[t1].rb == tiles[t0].rb) len += tiles[t1++].cnt;
+        lensN.push_back(len);
+        t0 = t1;
+    }
+    for (size_t p0 = 0; p0 < order.size();) {
+        size_t p1 = p0;
+        int64_t len = 0;
+        while (p1 < order.size() && tiles[order[p1]].cw == tiles[order[p0]].cw) len += tiles[order[p1++]].cnt;
+        lensT.push_back(len);
+        p0 = p1;
+    }
+    const int64_t per_itemN = pick_per_item(lensN, capN), per_itemT = pick_per_item(lensT, capT);
     std::vector<SptItem> itN, itT;
     M->slN = 1; M->slT = 1;
     {
@@ -556,7 +703,7 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
             size_t t1 = t0;
             while (t1 < tiles.size() && tiles[t1].rb == tiles[t0].rb) ++t1;
             const int64_t E0 = tiles[t0].e0, E1 = tiles[t1 - 1].e0 + tiles[t1 - 1].cnt, len = E1 - E0;
-            const int S = (int)std::min<int64_t>(capN, std::max<int64_t>(1, (len + per_item - 1) / per_item));
+            const int S = (int)std::min<int64_t>(capN, std::max<int64_t>(1, (len + per_itemN - 1) / per_itemN));
             M->slN = std::max(M->slN, S);
             size_t tr = t0;
             // a cut falls on a multiple of 256 entries FROM ITS TILE'S START: a wave streams 64 quads, and in a dense tile (columns of
@@ -593,7 +740,7 @@ int build(thip_sptile *M, size_t m, size_t n, size_t nnz, const int64_t *colptr,
             std::vector<int64_t> cum(p1 - p0 + 1, 0);
             for (size_t p = p0; p < p1; ++p) cum[p - p0 + 1] = cum[p - p0] + tiles[order[p]].cnt;
             const int64_t len = cum.back();
-            const int S = (int)std::min<int64_t>(capT, std::max<int64_t>(1, (len + per_item - 1) / per_item));
+            const int S = (int)std::min<int64_t>(capT, std::max<int64_t>(1, (len + per_itemT - 1) / per_itemT));
             M->slT = std::max(M->slT, S);
             size_t pr = 0;
             auto cutT = [&](int64_t c) -> int64_t {         // (in the column block's cumulative entry space; see cutN)
@@ -673,8 +820,17 @@ int thip_sptile_info(const thip_sptile *M, size_t *host_nnz_stored, int *host_ti
     if (host_items_t) *host_items_t = M->nT;
     if (host_slices_n) *host_slices_n = M->slN;
     if (host_slices_t) *host_slices_t = M->slT;
-    if (host_bytes) *host_bytes = M->nnz_pad * 8 + (size_t)M->ntiles * (sizeof(SptTile) + sizeof(int))
+    if (host_bytes) *host_bytes = M->nnz_pad * 4 + M->nidx * 4 + (size_t)M->ntiles * (sizeof(SptTile) + sizeof(int))
                                   + (size_t)(M->nN + M->nT) * sizeof(SptItem);
+    return 0;
+}
+
+int thip_sptile_layout(const thip_sptile *M, int *host_dense_tiles, size_t *host_indexed_entries, size_t *host_bytes_per_product)
+{
+    if (!M) return fail(THIP_E_INVALID, "null matrix", __FILE__, __LINE__);
+    if (host_dense_tiles) *host_dense_tiles = M->ndense;
+    if (host_indexed_entries) *host_indexed_entries = M->nidx;
+    if (host_bytes_per_product) *host_bytes_per_product = sptile_bytes_per_pass(M);
     return 0;
 }
 

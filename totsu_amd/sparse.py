@@ -92,8 +92,11 @@ class SpTile:
         nz, by = C.c_size_t(), C.c_size_t()
         t, i_n, i_t, s_n, s_t = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
         lib.thip_sptile_info(self.h, C.byref(nz), C.byref(t), C.byref(i_n), C.byref(i_t), C.byref(s_n), C.byref(s_t), C.byref(by))
+        nd, ni, bp = C.c_int(), C.c_size_t(), C.c_size_t()
+        lib.thip_sptile_layout(self.h, C.byref(nd), C.byref(ni), C.byref(bp))
         return {"nnz": self.nnz, "nnz_stored": nz.value, "tiles": t.value, "items_n": i_n.value, "items_t": i_t.value,
-                "slices_n": s_n.value, "slices_t": s_t.value, "device_bytes": by.value}
+                "slices_n": s_n.value, "slices_t": s_t.value, "device_bytes": by.value,
+                "dense_tiles": nd.value, "indexed_entries": ni.value, "bytes_per_product": bp.value}
 
     def free(self):
         if getattr(self, "h", None) is not None:
