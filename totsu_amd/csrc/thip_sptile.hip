@@ -177,8 +177,78 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
     int hold[2][4] = { { -1, -1, -1, -1 }, { -1, -1, -1, -1 } };
     float h0[2][4] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } }, h1[2][4] = { { 0.0f, 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f, 0.0f } };
     __syncthreads();                    // the accumulators are zero before any wave adds to them
-    // one visit of a tile: entries [e0, e1) streamed by the threads t0, t0 + stride, ... (the whole workgroup: tid / 512; one wave
-    // alone: lane / 64), the in-vector's block from LDS (staged) or straight from L2
+    // one quad of the stream (slot u of the lane's two in flight): four entries `av` with their index words `iv`, the in-vector's
+    // block from LDS (staged) or straight from L2 (in0b / in1b); `tag` tells the visits of one wave apart (the flat walk of LITE)
+    auto process = [&](const int u, const f32x4 av, const i32x4 iv, const bool ok, const bool staged, const float *in0b, const float *in1b,
+                       const int tag) {
+                float p0[4], p1[4]; int oi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned id = (unsigned)iv[e];
+                    const int lr = (int)(id & 0xffffu), lc = (int)(id >> 16);
+                    const int ii = TPH ? lr : lc;
+                    oi[e] = spt_slot(TPH ? lc : lr);
+                    float v = ok ? av[e] : 0.0f;
+                    float2 x;
+                    if (a.abs_mode) { v = fabsf(v); x = make_float2(1.0f, 1.0f); }
+                    else if (staged) x = lin[spt_slot(ii)];
+                    else x = make_float2(in0b[ii], in1b[ii]);
+                    p0[e] = v * x.x; p1[e] = v * x.y;
+                }
+                if (TPH) {
+                    // entries are sorted by column: a lane's four mostly share it, and so does the wave
+                    const bool same = oi[0] == oi[3];
+                    const float s0 = (p0[0] + p0[1]) + (p0[2] + p0[3]), s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+                    const int tg = tag << 12;           // (a slot is 12 bits)
+                    const int first = __builtin_amdgcn_readfirstlane(oi[0] | tg);
+                    if (__all(ok && same && (oi[0] | tg) == first)) {
+                        const float w0 = wave_sum_dpp(s0), w1 = two ? wave_sum_dpp(s1) : 0.0f;
+                        if (lane == 0) { spt_add(&lo0[first & 0xfff], w0, S0); if (two) spt_add(&lo1[first & 0xfff], w1, S1); }
+                    } else {
+                        // several columns in the wave: a segmented sum over the lanes (keys ascend with the lane: the stream is
+                        // column-sorted), one LDS add per column and wave instead of one per entry.  A lane whose quad straddles
+                        // columns joins the segment of its LAST column and adds its earlier entries itself; a lane past the end
+                        // carries the largest key and nothing.
+                        // (equal keys are neighbours also where two visits meet inside a wave: the key carries the visit's tag)
+                        const int key = ok ? (oi[3] | tg) : 0x7fffffff;
+                        float a0 = 0.0f, a1 = 0.0f;
+                        if (ok) {
+                            if (same) { a0 = s0; a1 = s1; }
+                            else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (oi[e] == oi[3]) { a0 += p0[e]; a1 += p1[e]; }
+                                    else { spt_add(&lo0[oi[e]], p0[e], S0); if (two) spt_add(&lo1[oi[e]], p1[e], S1); }
+                                }
+                            }
+                        }
+                        seg_scan_dpp(key, a0, a1);
+                        const int kn = __builtin_amdgcn_update_dpp(-2, key, 0x130, 0xf, 0xf, false);     // the next lane's key (wave shift left)
+                        if (kn != key && key != 0x7fffffff) { spt_add(&lo0[key & 0xfff], a0, S0); if (two) spt_add(&lo1[key & 0xfff], a1, S1); }
+                    }
+                } else if (ok) {
+                    const bool keep = oi[0] == hold[u][0] && oi[1] == hold[u][1] && oi[2] == hold[u][2] && oi[3] == hold[u][3];
+                    if (!keep) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (hold[u][e] >= 0) { spt_add(&lo0[hold[u][e]], h0[u][e], S0); if (two) spt_add(&lo1[hold[u][e]], h1[u][e], S1); }
+                            hold[u][e] = oi[e]; h0[u][e] = 0.0f; h1[u][e] = 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h0[u][e] += p0[e]; h1[u][e] += p1[e]; }
+                }
+    };
+    // (a dense tile away from its fast routines -- a clipped end, abs mode, LITE -- computes the index words it does not store)
+    auto dense_idx = [&](const long long qq, const long long tile_e0) {
+        const int k = (int)((qq << 2) - tile_e0);
+        const int w = (k & (SPT_TB - 1)) | ((k >> 12) << 16);
+        i32x4 iv;
+        iv[0] = w; iv[1] = w + 1; iv[2] = w + 2; iv[3] = w + 3;
+        return iv;
+    };
+    // one visit of a tile: entries [e0, e1) streamed by the threads t0, t0 + stride, ... (the whole workgroup: tid / THREADS; one wave
+    // alone: lane / 64)
     auto visit = [&](const SptTile &tl, const long long e0, const long long e1, const bool staged, const float *in0b, const float *in1b,
                      const int t0, const int stride) {
         const long long q1 = e1 >> 2;
@@ -192,72 +262,13 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
                 ok[u] = q < q1;
                 const long long qq = ok[u] ? q : q1 - 1;
                 av[u] = __builtin_nontemporal_load(a.vals + qq);
-                if (dense) {                // (a dense tile away from its fast routines: a clipped end, abs mode, LITE)
-                    const int k = (int)((qq << 2) - tl.e0);
-                    const int w = (k & (SPT_TB - 1)) | ((k >> 12) << 16);
-                    iv[u][0] = w; iv[u][1] = w + 1; iv[u][2] = w + 2; iv[u][3] = w + 3;
-                } else iv[u] = __builtin_nontemporal_load(a.idx + qq + dq);
+                if (dense) iv[u] = dense_idx(qq, tl.e0);
+                else iv[u] = __builtin_nontemporal_load(a.idx + qq + dq);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float p0[4], p1[4]; int oi[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned id = (unsigned)iv[u][e];
-                    const int lr = (int)(id & 0xffffu), lc = (int)(id >> 16);
-                    const int ii = TPH ? lr : lc;
-                    oi[e] = spt_slot(TPH ? lc : lr);
-                    float v = ok[u] ? av[u][e] : 0.0f;
-                    float2 x;
-                    if (a.abs_mode) { v = fabsf(v); x = make_float2(1.0f, 1.0f); }
-                    else if (staged) x = lin[spt_slot(ii)];
-                    else x = make_float2(in0b[ii], in1b[ii]);
-                    p0[e] = v * x.x; p1[e] = v * x.y;
-                }
-                if (TPH) {
-                    // entries are sorted by column: a lane's four mostly share it, and so does the wave
-                    const bool same = oi[0] == oi[3];
-                    const float s0 = (p0[0] + p0[1]) + (p0[2] + p0[3]), s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
-                    const int first = __builtin_amdgcn_readfirstlane(oi[0]);
-                    if (__all(ok[u] && same && oi[0] == first)) {
-                        const float w0 = wave_sum_dpp(s0), w1 = two ? wave_sum_dpp(s1) : 0.0f;
-                        if (lane == 0) { spt_add(&lo0[first], w0, S0); if (two) spt_add(&lo1[first], w1, S1); }
-                    } else {
-                        // several columns in the wave: a segmented sum over the lanes (keys ascend with the lane: the stream is
-                        // column-sorted), one LDS add per column and wave instead of one per entry.  A lane whose quad straddles
-                        // columns joins the segment of its LAST column and adds its earlier entries itself; a lane past the end
-                        // carries the largest key and nothing.
-                        int key = ok[u] ? oi[3] : 0x7fffffff;
-                        float a0 = 0.0f, a1 = 0.0f;
-                        if (ok[u]) {
-                            if (same) { a0 = s0; a1 = s1; }
-                            else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    if (oi[e] == key) { a0 += p0[e]; a1 += p1[e]; }
-                                    else { spt_add(&lo0[oi[e]], p0[e], S0); if (two) spt_add(&lo1[oi[e]], p1[e], S1); }
-                                }
-                            }
-                        }
-                        seg_scan_dpp(key, a0, a1);
-                        const int kn = __builtin_amdgcn_update_dpp(-2, key, 0x130, 0xf, 0xf, false);     // the next lane's key (wave shift left)
-                        if (kn != key && key != 0x7fffffff) { spt_add(&lo0[key], a0, S0); if (two) spt_add(&lo1[key], a1, S1); }
-                    }
-                } else if (ok[u]) {
-                    const bool keep = oi[0] == hold[u][0] && oi[1] == hold[u][1] && oi[2] == hold[u][2] && oi[3] == hold[u][3];
-                    if (!keep) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (hold[u][e] >= 0) { spt_add(&lo0[hold[u][e]], h0[u][e], S0); if (two) spt_add(&lo1[hold[u][e]], h1[u][e], S1); }
-                            hold[u][e] = oi[e]; h0[u][e] = 0.0f; h1[u][e] = 0.0f;
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { h0[u][e] += p0[e]; h1[u][e] += p1[e]; }
-                }
-            }
+            for (int u = 0; u < 2; ++u) process(u, av[u], iv[u], ok[u], staged, in0b, in1b, 0);
         }
-            };
+    };
     // The fast routines of a DENSE tile (in-vector block staged; [e0, e1) cut on multiples of 256 entries from the tile's start, so a
     // wave's 64 quads lie in one column).  Four 16-byte loads of VALUES in flight per lane: the bytes in flight of the indexed form.
     // T product: a wave takes a contiguous run of 64-quad chunks, lanes keep their partial sums for as long as the column lasts:
@@ -335,6 +346,58 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
         if (ref == it.ref0) e0 = it.e_first;
         if (ref == it.ref1 - 1) e1 = it.e_last;
     };
+    if constexpr (LITE) {
+        // LITE walks its item FLAT: the visits' records are fetched together (one lane each) into a table, their quad counts scanned,
+        // and the workgroup streams the concatenation -- every load of the item is in flight at once instead of one chain of dependent
+        // round trips (tile record, entries, in-vector) per visit.  A very sparse operator's item is a handful of small visits
+        // (a stencil: 3 of ~7 000 entries; the partitioning SDP's equality rows: 31 of 16).
+        constexpr int MAXV = 64;
+        __shared__ long long v_pre[MAXV + 1], v_q0[MAXV], v_dq[MAXV], v_te0[MAXV];
+        __shared__ int v_inb[MAXV];
+        for (int base = it.ref0; base < it.ref1; base += MAXV) {
+            const int nv = min(MAXV, it.ref1 - base);
+            if (base != it.ref0) __syncthreads();           // the previous table is no longer read
+            if (wave == 0) {
+                long long c = 0;
+                if (lane < nv) {
+                    const int ref = base + lane;
+                    const SptTile tl = a.tiles[a.order ? a.order[ref] : ref];
+                    long long e0, e1;
+                    clip(ref, tl, e0, e1);
+                    v_q0[lane] = e0 >> 2; v_dq[lane] = (tl.i0 - tl.e0) >> 2; v_te0[lane] = tl.e0;
+                    v_inb[lane] = (TPH ? tl.rb : tl.cw) | (tl.dense ? 1 << 30 : 0);
+                    c = (e1 - e0) >> 2;
+                }
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const long long t = __shfl_up(c, d, 64); if (lane >= d) c += t; }
+                v_pre[lane + 1] = c;
+                if (lane == 0) v_pre[0] = 0;
+            }
+            __syncthreads();
+            const long long total = v_pre[nv];
+            int v = 0;
+            for (long long gb = 0; gb < total; gb += 2 * SPT_THREADS) {
+                f32x4 av[2]; i32x4 iv[2]; bool ok[2]; int vv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const long long g = gb + tid + u * SPT_THREADS;
+                    ok[u] = g < total;
+                    const long long gc = ok[u] ? g : total - 1;
+                    while (gc >= v_pre[v + 1]) ++v;             // (a lane's quads ascend: v only moves forward)
+                    vv[u] = v;
+                    const long long qq = v_q0[v] + (gc - v_pre[v]);
+                    av[u] = __builtin_nontemporal_load(a.vals + qq);
+                    if (v_inb[v] >> 30) iv[u] = dense_idx(qq, v_te0[v]);
+                    else iv[u] = __builtin_nontemporal_load(a.idx + qq + v_dq[v]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const size_t inb = (size_t)(v_inb[vv[u]] & 0x3fffffff) * SPT_TB;
+                    process(u, av[u], iv[u], ok[u], false, a.in0 + inb, (two ? a.in1 : a.in0) + inb, vv[u] + 1);
+                }
+            }
+        }
+    } else {
     // (1) the TINY visits (at most one step of a wave: 512 entries), one WAVE each, eight at a time: a visit is a chain of dependent
     // round trips -- tile record, entries, in-vector -- and an item of a very sparse operator walks dozens of them (the equality rows
     // of the partitioning SDP: 31 tiles of 16 entries); no barrier, the accumulators take LDS adds from any wave
@@ -369,6 +432,7 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
         if (!LITE && fast) {
             if (TPH) dense_t(tl, e0, e1); else dense_n(tl, e0, e1);
         } else visit(tl, e0, e1, staged, in0b, in1b, tid, SPT_THREADS);
+    }
     }
     if (!TPH) {
 #pragma unroll
