@@ -29,7 +29,9 @@ def _sl(L, a):
                                            ((64, 64), 0.9), ((7, 2000), 0.5), ((2000, 3), 0.4),
                                            # several 4096 x 4096 tiles; tall dense columns (a wave's entries share a column);
                                            # an empty row block in the middle; a visit below the LDS-staging threshold
-                                           ((9000, 5000), 0.01), ((13000, 70), 0.9), ((300, 20000), 0.02), ((12500, 4097), 0.0008)])
+                                           ((9000, 5000), 0.01), ((13000, 70), 0.9), ((300, 20000), 0.02), ((12500, 4097), 0.0008),
+                                           # one item of 74 small tiles: the flat walk of the LITE instance refills its table of 64
+                                           ((64, 300000), 0.0015), ((300000, 64), 0.0015)])
 def test_sparse_operator_contract(T, shape, density, two_copies):
     from totsu_amd.sparse import SparseMatOp
     L = T.F32HIP
