@@ -40,6 +40,7 @@
 #include <cmath>
 #include <cstdio>
 #include <limits>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -590,14 +591,20 @@ int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const floa
     }
     constexpr size_t lds_full = (size_t)SPT_TB * (2 * sizeof(unsigned long long) + sizeof(float2));
     constexpr size_t lds_lite = (size_t)SPT_TB * (2 * sizeof(unsigned long long));
-    static bool attr_set = false;
-    if (!attr_set) {
-        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
-        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
-        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lite));
-        THIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&sp_tile_k<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lite));
-        attr_set = true;
-    }
+    // (once per process, whichever thread comes first; a failure is reported to every caller)
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [&]() {
+        auto set = [&](const void *f, size_t bytes) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
+        };
+        set(reinterpret_cast<const void *>(&sp_tile_k<true, false>), lds_full);
+        set(reinterpret_cast<const void *>(&sp_tile_k<false, false>), lds_full);
+        set(reinterpret_cast<const void *>(&sp_tile_k<true, true>), lds_lite);
+        set(reinterpret_cast<const void *>(&sp_tile_k<false, true>), lds_lite);
+    });
+    THIP_TRY(attr_err);
     static const int stage_min = getenv("THIP_SPT_STAGE_MIN") ? atoi(getenv("THIP_SPT_STAGE_MIN")) : SPT_STAGE_MIN;
     a.stage_min = stage_min;
     // (abs mode never stages either)
