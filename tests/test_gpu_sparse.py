@@ -467,6 +467,38 @@ def test_sparse_lp_with_full_tiles_iterates_vs_oracle(T):
     _iterates_vs_oracle(T, A, h.astype(np.float32), c.astype(np.float32), [1], [h.size], [0, 1, 2, 9], [3e-5, 6e-5, 1e-4, 3e-4], "sweep")
 
 
+def test_stencil_lp_with_long_vectors_iterates_vs_sparse_oracle(T):
+    # a 5-point Laplacian on an 800 x 800 grid as the inequality matrix of an LP: m = n = 640 000 -- long enough for the wide-block
+    # forms of the O(m + n) kernels of the sparse one-pass loop (sw_xm_k<., FLAT>, sp_col_k, sp_absmax_k with 1024 threads) --
+    # iterates 0, 1, 2, 9 against the f64 oracle running the same matrix through its sparse user-operator
+    g = 800
+    e = np.ones(g, np.float32)
+    L1 = sp.diags([-e[:-1], 2 * e, -e[:-1]], [-1, 0, 1], format="csc")
+    A = (sp.kron(sp.identity(g, dtype=np.float32), L1) + sp.kron(L1, sp.identity(g, dtype=np.float32))).tocsc().astype(np.float32)
+    A.sort_indices()
+    m, n = A.shape
+    rng = np.random.default_rng(8)
+    b = rng.uniform(0.5, 1.5, m).astype(np.float32)
+    c = rng.standard_normal(n).astype(np.float32)
+    iters, tols = [0, 1, 2, 9], [3e-5, 6e-5, 1e-4, 3e-4]
+    ro = O.solve_csc_cones(O.param(max_iter=iters[-1] + 2, eps_acc=1e-300), c, A.indptr, A.indices, A.data, b, [1], [m],
+                           snap_iters=list(iters), trace_cap=64)
+    p = T.SolverParam()
+    p.eps_acc = 0.0
+    fs = T.FusedSolver(n, m, A, b, c, [1], [m], p, "sweep")
+    assert fs.schedule_in_use() == "sweep"
+    N = n + 2 * m + 1
+    done = 0
+    for q, (it, tol) in enumerate(zip(iters, tols)):
+        fs.run(it + 1 - done, poll_every=64)
+        done = it + 1
+        x, y = fs.iterate()
+        rx, ry = ro.snaps[q][:N], ro.snaps[q][N:]
+        assert np.abs(x - rx).max() <= tol * max(np.abs(rx).max(), 1e-6), (it, np.abs(x - rx).max(), np.abs(rx).max())
+        assert np.abs(y - ry).max() <= tol * max(np.abs(ry).max(), 1e-6), (it, np.abs(y - ry).max(), np.abs(ry).max())
+    fs.destroy()
+
+
 class _DiffOp:
     """A user-defined matrix-free Operator built only from LinAlg primitives, in the pattern of
     examples/imgnr_udef/src/prob_op_a.rs: the (n-1) x n forward-difference matrix D (D x)_i = x_{i+1} - x_i, never

@@ -86,11 +86,12 @@ struct SptArgs {
 constexpr int SPT_NMAX = 256;           // block maxima per in-vector
 
 // block maxima of |x0|, |x1| (x1 may be NULL): part[b], part[SPT_NMAX + b]; every block of the grid writes its slot
-__global__ __launch_bounds__(256) void sp_absmax_k(const float *__restrict__ x0, const float *__restrict__ x1, int len, float *__restrict__ part)
+// (256 or 1024 threads: at most SPT_NMAX blocks, so a long vector -- a stencil's 9 M -- needs the wider block to keep the loads in flight)
+__global__ __launch_bounds__(1024) void sp_absmax_k(const float *__restrict__ x0, const float *__restrict__ x1, int len, float *__restrict__ part)
 {
     __shared__ float sh[16];
     float m0 = 0.0f, m1 = 0.0f;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
         // (a NaN counts as an infinite entry: the product then answers NaN instead of dropping it -- fmaxf would)
         const float v0 = fabsf(x0[i]);
         m0 = fmaxf(m0, v0 == v0 ? v0 : __builtin_inff());
@@ -456,7 +457,8 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
 // slices' shares of A^T v and A^T x_y added up, then u_k[j], x_x_{k+1}[j], gP[j], and this workgroup's share of the sums over n.
 struct SpColArgs { SweepArgs a; const float *partT; int nsl; size_t npad; };
 
-__global__ __launch_bounds__(256) void sp_col_k(const SpColArgs ca)
+// (256 blocks of 256 threads, or of 1024 when a block has more than 1024 columns)
+__global__ __launch_bounds__(1024) void sp_col_k(const SpColArgs ca)
 {
     const SweepArgs &a = ca.a;
     __shared__ double shd[16];
@@ -468,8 +470,8 @@ __global__ __launch_bounds__(256) void sp_col_k(const SpColArgs ca)
     if (kupd) {
         // kappa_k (solver.rs:566-567): every workgroup forms it from the same partials in the same order
         double dc = 0.0, db = 0.0;
-        for (int k = tid; k < a.pn_count; k += 256) dc += (double)a.pn_in[3 * a.pn_in_stride + k];
-        for (int k = tid; k < a.np_m; k += 256) db += (double)a.pm_brx[k];
+        for (int k = tid; k < a.pn_count; k += (int)blockDim.x) dc += (double)a.pn_in[3 * a.pn_in_stride + k];
+        for (int k = tid; k < a.np_m; k += (int)blockDim.x) db += (double)a.pm_brx[k];
         dc = block_sum_d(dc, shd);
         db = block_sum_d(db, shd);
         kappa = fminf(kappa + *a.skappa_p * ((float)dc + (float)db), 0.0f);
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void sp_col_k(const SpColArgs ca)
     const int cpb = (a.n + (int)gridDim.x - 1) / (int)gridDim.x;
     const int j0 = blockIdx.x * cpb, j1 = min(a.n, j0 + cpb);
     float sdd = 0.0f, scx = 0.0f, scu = 0.0f, scrx = 0.0f;
-    for (int j = j0 + tid; j < j1; j += 256) {
+    for (int j = j0 + tid; j < j1; j += (int)blockDim.x) {
         // (eight slices in flight per lane: the sum over up to 256 slices is a latency chain, not a bandwidth problem)
         float gT = 0.0f, g3 = 0.0f;
         {
@@ -587,7 +589,7 @@ int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const floa
     if (!abs_mode) {
         const int len = a.in_len;
         a.nmax = (int)std::min<size_t>(SPT_NMAX, std::max<size_t>(1, ((size_t)len + 1023) / 1024));
-        hipLaunchKernelGGL(sp_absmax_k, dim3(a.nmax), dim3(256), 0, st, in0, in1, len, M->xmax);
+        hipLaunchKernelGGL(sp_absmax_k, dim3(a.nmax), dim3(len > SPT_NMAX * 1024 ? 1024 : 256), 0, st, in0, in1, len, M->xmax);
     }
     constexpr size_t lds_full = (size_t)SPT_TB * (2 * sizeof(unsigned long long) + sizeof(float2));
     constexpr size_t lds_lite = (size_t)SPT_TB * (2 * sizeof(unsigned long long));
@@ -624,7 +626,7 @@ int sptile_colupdate(hipStream_t st, const thip_sptile *M, const SweepArgs &a, c
 {
     SpColArgs ca;
     ca.a = a; ca.partT = partT; ca.nsl = M->slT; ca.npad = M->npad;
-    hipLaunchKernelGGL(sp_col_k, dim3(256), dim3(256), 0, st, ca);
+    hipLaunchKernelGGL(sp_col_k, dim3(256), dim3(M->n > (size_t)256 * 1024 ? 1024 : 256), 0, st, ca);
     THIP_LAUNCH_CHECK();
     return 0;
 }
