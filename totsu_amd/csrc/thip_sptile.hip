@@ -12,7 +12,7 @@
 // block), entries inside a tile in the caller's CSC order (column, then row), every tile padded to whole 16-byte quads.  Both
 // products stream the same 8 bytes per entry with 16-byte loads; the scatter side of either product goes to an accumulator of
 // one block (2 x 4096 fixed-point words) in LDS (integer LDS adds: no global atomic anywhere), the gather side reads the in-vector's block from
-// LDS (staged once per tile visit) or, for a visit of fewer than 8192 entries, straight from L2.
+// LDS (staged once per tile visit) or, for a visit of fewer than 24 576 entries, straight from L2.
 //   N product (A [x0 x1]): a workgroup owns (row block, slice): walks that row block's tiles -- contiguous in memory --, in = the
 //       column block's slice of x, out = the row block's accumulators; entries of one column hit distinct rows: conflict-free.
 //   T product (A^T [y0 y1]): a workgroup owns (column block, slice): walks the tiles of its column block (a list: one per row
@@ -57,7 +57,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int SPT_TB = 4096;            // rows / columns per block
 constexpr int SPT_THREADS = 1024;          // one workgroup per CU: 96 KB of LDS (two 64-bit accumulator blocks + the staged in-vector block)
 constexpr int SPT_THREADS_LITE = 512;      // an operator without a visit worth staging: no in-vector block, 64 KB, two workgroups per CU
-constexpr int SPT_STAGE_MIN = 8192;     // entries of a tile visit from which the in-vector's block is staged in LDS
+// entries of a tile visit from which the in-vector's block (32 KB) is staged in LDS.  8192 until the LITE instance walked its items
+// flat: a 5-point Laplacian's diagonal tiles hold ~20 K entries, and with the threshold above them the operator runs LITE
+// (T / N 0.230 / 0.203 -> 0.169 / 0.148 ms = 2.1 / 2.4 TB/s of entries; the random 1 % matrix, tiles of 162 K entries, is unmoved;
+// at 65 536 its T product loses 8 %)
+constexpr int SPT_STAGE_MIN = 24576;
 
 // entries [e0, e0 + cnt) of `vals`, cnt % 4 == 0; their indices at [i0, i0 + cnt) of `idx` -- or nowhere (dense != 0): the
 // tile is full, entry e0 + k is row k % 4096 of column k / 4096
