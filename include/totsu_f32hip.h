@@ -156,7 +156,9 @@ int thip_spmv_csr(size_t n_row, size_t n_col, size_t nnz, const int64_t *dev_row
  * dropped holds, matbuild/mod.rs:22-41) into 4096 x 4096 tiles of {value, local row | local column << 16} entries; both A x and
  * A^T y stream the same 8 bytes per entry with 16-byte loads and scatter into LDS accumulators -- no second copy of the values,
  * no global atomics (thip_sptile.hip has the measurements behind the format).  The accumulators are 64-bit fixed-point words fed by
- * integer LDS adds: the sums are bitwise reproducible from run to run.
+ * integer LDS adds: the sums are bitwise reproducible from run to run.  Rows inside a column may come in any order; where they ascend,
+ * a tile of full height whose every column holds all 4096 rows (a dense block of the matrix) is stored WITHOUT its index words -- 4 bytes
+ * per entry on the device and per product (thip_sptile_layout reports how many).
  * thip_sptile_mv is `Operator::op / trans_op` (operator.rs:40-75) for such an operator: y = alpha A x + beta y,
  * transpose != 0: A^T; abs_mode != 0: |A| and x = 1 (absadd_rows / absadd_cols, operator.rs:82-154).  x, y on the device. */
 typedef struct thip_sptile thip_sptile;
