@@ -21,7 +21,7 @@
 //       column adds them up over the DPP network and issues one ds_add -- a 64-way same-address LDS atomic would serialise.
 // Every (block, slice) writes its 2 x 4096 partial sums to part[slice][2][pad] when it is done; the consumer (the m-tail
 // kernels of the one-pass schedule, sp_col_k below, finalize_partials) adds the slices in a fixed order.  Slices exist so
-// that a matrix with few blocks still fills 256 CUs: ~1024 items per product, at most nnz / (16 dim) slices (the partials'
+// that a matrix with few blocks still fills 256 CUs: the items are chosen by list-scheduling (build()), at most nnz / (16 dim) slices (the partials'
 // traffic stays under 1/16 of the entries').  The order in which the waves of ONE workgroup reach an LDS accumulator is not fixed,
 // but the accumulators are fixed-point words and the adds integer adds (see sp_tile_k): the sums are bitwise reproducible.
 //
