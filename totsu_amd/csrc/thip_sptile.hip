@@ -87,6 +87,7 @@ struct SptArgs {
     const float *xmax; int nmax; int a_exp; int head_bits;
 };
 
+constexpr int SPT_FIX_BITS = 50;        // bits of a fixed-point partial sum below the sign (see spt_add)
 constexpr int SPT_NMAX = 256;           // block maxima per in-vector
 
 // block maxima of |x0|, |x1| (x1 may be NULL): part[b], part[SPT_NMAX + b]; every block of the grid writes its slot
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(1024) void sp_absmax_k(const float *__restrict__ x0
 // ds_add_f32 runs at 0.33 lane-adds per clock per CU on this part, ds_add_u32 at 7.4, ds_add_u64 at 5.4-6.7 (profiles/
 // r06_lds_atomic_rates.txt) -- the float form was what bounded every scattered pattern (0.64 TB/s of entries).  A product p = a x is
 // added as (int64)(p * 2^k): with |a| < 2^(a_exp + 1) (the matrix's, known at build time), |x| <= xmax (sp_absmax_k, one small launch
-// in front of the product) and at most 2^head_bits terms per out element (the longest row / column), k = 62 - head_bits - (bound of
-// the product's exponent) keeps every partial sum inside 63 bits; the resolution is 2^-(60 - head_bits) of the largest possible
+// in front of the product) and at most 2^head_bits terms per out element (the longest row / column), k = 50 - head_bits - (bound of
+// the product's exponent) keeps every partial sum below 2^50 (so that a term converts with one f64 fma, spt_add); the resolution is 2^-(48 - head_bits) of the largest possible
 // product -- finer than an f32 accumulator's.  And integer adds are associative: whatever order the waves reach an accumulator
 // in, the sum is the same -- the products are BITWISE REPRODUCIBLE again (the register sums of the dense path and the wave sums
 // of the T product have a fixed order by construction).
@@ -125,15 +126,20 @@ __device__ __forceinline__ double spt_scale(const float *xm, int nmax, int a_exp
     int ex = 0;
     if (!(m < __builtin_inff())) { *inv = __builtin_nan(""); return 1.0; }    // an infinite / NaN entry in the in-vector: the product is NaN
     if (m > 0.0f) (void)frexpf(m, &ex);                                   // m < 2^ex
-    const int k = 62 - head_bits - (a_exp + 1 + ex);
+    const int k = SPT_FIX_BITS - head_bits - (a_exp + 1 + ex);
     *inv = ldexp(1.0, -k);
     return ldexp(1.0, k);
 }
-// (An integer-only conversion -- frexp, a 24-bit mantissa, a 64-bit shift into place -- measured SLOWER than this f64 form on the
-// scattered patterns: N 0.37 -> 0.43 ms, T 0.41 -> 0.46 on the random 1 % matrix.)
+// The conversion is ONE f64 fma: |p S| < 2^51, so p S + 1.5 2^52 lies in [2^52, 2^53) and the low bits of its mantissa are
+// round(p S) in two's complement -- the word to add is the difference of the bit patterns.  (long long)((double)p * S) -- f64 -> i64
+// has no instruction: a dozen f64 operations -- made the scattered patterns VALU-bound: PMC on the random 1 % matrix, VALUBusy 73 %
+// (T product) / 65 % with 33 % LDS bank conflicts (N), profiles/r06_sparse_patterns_pmc_counters.txt; an integer-only form (frexp,
+// 24-bit mantissa, 64-bit shift) measured slower still.  The price: 50 instead of 62 bits below the sign.
 __device__ __forceinline__ void spt_add(unsigned long long *acc, float p, double S)
 {
-    atomicAdd(acc, (unsigned long long)(long long)((double)p * S));
+    constexpr double M = 6755399441055744.0;        // 1.5 * 2^52
+    const double d = fma((double)p, S, M);
+    atomicAdd(acc, (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(M)));
 }
 
 // Inclusive SEGMENTED sums over the lanes of a wave on the DPP network: keys ascend with the lane (equal keys are neighbours), every
@@ -173,9 +179,9 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
     const bool two = a.in1 != nullptr;
     for (int i = tid; i < SPT_TB; i += SPT_THREADS) { lo0[i] = 0ull; lo1[i] = 0ull; }
     double inv0 = 1.0, inv1 = 1.0;
-    const double S0 = a.abs_mode ? ldexp(1.0, 62 - a.head_bits - (a.a_exp + 2)) : spt_scale(a.xmax, a.nmax, a.a_exp, a.head_bits, shm, &inv0);
+    const double S0 = a.abs_mode ? ldexp(1.0, SPT_FIX_BITS - a.head_bits - (a.a_exp + 2)) : spt_scale(a.xmax, a.nmax, a.a_exp, a.head_bits, shm, &inv0);
     const double S1 = (two && !a.abs_mode) ? spt_scale(a.xmax + SPT_NMAX, a.nmax, a.a_exp, a.head_bits, shm, &inv1) : 1.0;
-    if (a.abs_mode) inv0 = ldexp(1.0, -(62 - a.head_bits - (a.a_exp + 2)));
+    if (a.abs_mode) inv0 = ldexp(1.0, -(SPT_FIX_BITS - a.head_bits - (a.a_exp + 2)));
     // N product: in a dense column block no LDS add is needed at all: a column of a full tile is 1024 quads -- one step of this
     // loop, or half of one -- so a lane meets the SAME four rows in every step.  The lane keeps the sums of "its" rows in registers for as long
     // as the rows of its next quad are the ones it holds, and pays the LDS adds only when they change (every step, for a
