@@ -277,7 +277,7 @@ size_t sptile_pad(const thip_sptile *M, bool tphase);
 size_t sptile_bytes_per_pass(const thip_sptile *M);
 void sptile_dims(const thip_sptile *M, size_t *m, size_t *n, size_t *nnz);
 int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const float *in0, const float *in1, float *part,
-                   int abs_mode, const int *stop);
+                   int abs_mode, const int *stop, bool xmax_ready = false);
 int sptile_colupdate(hipStream_t st, const thip_sptile *M, const SweepArgs &a, const float *partT);
 
 // thip_oneshot.hip: the hook thip_solver_use_oneshot installs and the device address of its error word (NULL: not set up)

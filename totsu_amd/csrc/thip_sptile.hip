@@ -465,7 +465,7 @@ __global__ __launch_bounds__(LITE ? SPT_THREADS_LITE : SPT_THREADS) void sp_tile
 
 // The per-column step of the one-pass recurrence (the arithmetic of sweep_k's service wave, thip_sweep_kernel.h): gT / g3 = the
 // slices' shares of A^T v and A^T x_y added up, then u_k[j], x_x_{k+1}[j], gP[j], and this workgroup's share of the sums over n.
-struct SpColArgs { SweepArgs a; const float *partT; int nsl; size_t npad; };
+struct SpColArgs { SweepArgs a; const float *partT; int nsl; size_t npad; float *xmax; };   // xmax: block maxima of |u_k|, |x_x_{k+1}| (the N product's in-vectors)
 
 // (256 blocks of 256 threads, or of 1024 when a block has more than 1024 columns)
 __global__ __launch_bounds__(1024) void sp_col_k(const SpColArgs ca)
@@ -494,6 +494,7 @@ __global__ __launch_bounds__(1024) void sp_col_k(const SpColArgs ca)
     const int cpb = (a.n + (int)gridDim.x - 1) / (int)gridDim.x;
     const int j0 = blockIdx.x * cpb, j1 = min(a.n, j0 + cpb);
     float sdd = 0.0f, scx = 0.0f, scu = 0.0f, scrx = 0.0f;
+    float mu = 0.0f, mx = 0.0f;         // sp_absmax_k's maxima of the two vectors this kernel writes, over this block's columns
     for (int j = j0 + tid; j < j1; j += (int)blockDim.x) {
         // (eight slices in flight per lane: the sum over up to 256 slices is a latency chain, not a bandwidth problem)
         float gT = 0.0f, g3 = 0.0f;
@@ -535,12 +536,22 @@ __global__ __launch_bounds__(1024) void sp_col_k(const SpColArgs ca)
         }
         a.xx_out[j] = x_new;
         if (comp_x) a.kx_out[j] = kxj;
+        {
+            const float au = fabsf(u_new), ax = fabsf(x_new);
+            mu = fmaxf(mu, au == au ? au : __builtin_inff());
+            mx = fmaxf(mx, ax == ax ? ax : __builtin_inff());
+        }
         a.gP[j] = g3;
         const float dj = conv ? fmaf(rt, g3, cj) : g3;          // solver.rs:596-597 / 634
         sdd = fmaf(dj, dj, sdd);
         scx = fmaf(cj, xxj, scx);
         scu = fmaf(cj, u_new, scu);
         scrx = fmaf(cj, xxj - 2.0f * x_new, scrx);
+    }
+    if (ca.xmax != nullptr) {           // (gridDim.x == SPT_NMAX: every slot is written)
+        mu = -block_min(-mu, shf);
+        mx = -block_min(-mx, shf);
+        if (tid == 0) { ca.xmax[blockIdx.x] = mu; ca.xmax[SPT_NMAX + blockIdx.x] = mx; }
     }
     if (a.pn != nullptr) {
         sdd = block_sum(sdd, shf); scx = block_sum(scx, shf); scu = block_sum(scu, shf); scrx = block_sum(scrx, shf);
@@ -584,8 +595,10 @@ void sptile_dims(const thip_sptile *M, size_t *m, size_t *n, size_t *nnz) { *m =
 // part[slice][2][pad] <- the slices' shares of A [in0 in1] (tphase: of A^T [in0 in1]); in1 == NULL: one right-hand side (the
 // second half of every slice is then left alone); abs_mode: |A| times ones.  `part` must have been zeroed once after its
 // allocation: a (block, slice) without entries is never written.
+// xmax_ready: the kernel that produced in0 / in1 left their block maxima in M->xmax (all SPT_NMAX slots of each: sp_col_k does, for
+// the N product of the one-pass loop) -- no sp_absmax_k launch.
 int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const float *in0, const float *in1, float *part,
-                   int abs_mode, const int *stop)
+                   int abs_mode, const int *stop, bool xmax_ready)
 {
     const int items = tphase ? M->nT : M->nN;
     if (items == 0) return 0;
@@ -596,7 +609,8 @@ int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const floa
     a.part = part; a.opad = tphase ? M->npad : M->mpad;
     a.abs_mode = abs_mode; a.stop = stop ? stop : ctx().never_stop;
     a.xmax = M->xmax; a.a_exp = M->a_exp; a.head_bits = tphase ? M->headT : M->headN; a.nmax = 1;
-    if (!abs_mode) {
+    if (!abs_mode && xmax_ready) a.nmax = SPT_NMAX;
+    else if (!abs_mode) {
         const int len = a.in_len;
         a.nmax = (int)std::min<size_t>(SPT_NMAX, std::max<size_t>(1, ((size_t)len + 1023) / 1024));
         hipLaunchKernelGGL(sp_absmax_k, dim3(a.nmax), dim3(len > SPT_NMAX * 1024 ? 1024 : 256), 0, st, in0, in1, len, M->xmax);
@@ -635,7 +649,8 @@ int sptile_product(hipStream_t st, const thip_sptile *M, bool tphase, const floa
 int sptile_colupdate(hipStream_t st, const thip_sptile *M, const SweepArgs &a, const float *partT)
 {
     SpColArgs ca;
-    ca.a = a; ca.partT = partT; ca.nsl = M->slT; ca.npad = M->npad;
+    ca.a = a; ca.partT = partT; ca.nsl = M->slT; ca.npad = M->npad; ca.xmax = M->xmax;
+    static_assert(SPT_NMAX == 256, "sp_col_k's grid fills every slot of the block maxima");
     hipLaunchKernelGGL(sp_col_k, dim3(256), dim3(M->n > (size_t)256 * 1024 ? 1024 : 256), 0, st, ca);
     THIP_LAUNCH_CHECK();
     return 0;
