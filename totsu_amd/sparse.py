@@ -1,7 +1,7 @@
 """`SparseMatOp`: a sparse matrix as a linear `Operator` (totsu_core/src/solver/operator.rs:11-156) for the trait-level
 `Solver(F32HIP)` -- the user-defined-operator pattern of examples/imgnr_udef/src/prob_op_a.rs with the matrix kept
 sparse on the device.  Default: ONE tiled copy serving `op` and `trans_op` (`SpTile`, thip_sptile_*); `two_copies=True`
-keeps the round-5 form, CSR of A and of A^T (the faster one for stencil-like patterns with a handful of entries per column).
+keeps the round-5 form, CSR of A and of A^T (one right-hand side per call; the A/B leg of bench.py's sparse workloads).
 Both forms give bitwise reproducible sums."""
 import ctypes as C
 
